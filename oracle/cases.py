@@ -1,0 +1,97 @@
+"""Seeded test cases shared by oracle/make_goldens.py (reference side, build container)
+and tests/ (oracle + HIP side).  Test infrastructure.
+
+Each case is (config, state-dict seed, inputs) built only from `seeded.uniform`, so a
+fixture stores just the expected outputs.
+"""
+import torch
+
+from . import seeded
+from .lisa import LisaCfg
+from .llama import LlamaCfg
+from .sam_encoder import SamCfg
+from .vit import VitCfg
+
+V = 32004
+SEG, IM_START, IM_END, IMG = 32000, 32001, 32002, -200
+
+
+def sam_small_cfg():
+    # 2 heads x hd 80; one windowed (14, zero-padding 30->42 exercised) + one global block
+    return SamCfg(img=480, patch=16, dim=160, depth=2, heads=2, window=14, global_idx=(1,), out_chans=256)
+
+
+def sam_small_case(batch=1):
+    cfg = sam_small_cfg()
+    sd = seeded.fill_state_dict(seeded.sam_shapes(cfg, pfx=""), 11)
+    img = seeded.uniform((batch, 3, cfg.img, cfg.img), 12, -2, 2)
+    return cfg, sd, img
+
+
+def tiny_lisa_cfg(backbone="dinov2", lora_r=0):
+    return LisaCfg(
+        llama=LlamaCfg(hidden=256, inter=512, layers=2, heads=2, vocab=V, lora_r=lora_r),
+        clip=VitCfg(dim=64, layers=3, heads=2, mlp=128, patch=14, img=224, eps=1e-5),
+        dino=VitCfg(dim=1024, layers=2, heads=16, mlp=4096, patch=14, img=518, eps=1e-6),
+        sam=SamCfg(depth=0) if backbone == "dinov2" else SamCfg(dim=160, depth=2, heads=2, global_idx=(1,)),
+        backbone=backbone, seg_token_idx=SEG)
+
+
+def tiny_lisa_state(cfg, seed=3):
+    return seeded.fill_state_dict(seeded.lisa_shapes(cfg), seed)
+
+
+def prompt_ids(n_seq, L, seed, seg_pos=None):
+    ids = seeded.uniform((n_seq, L), seed, 3, 31999).long()
+    ids[:, 0], ids[:, 1], ids[:, 2], ids[:, 3] = 1, IM_START, IMG, IM_END
+    ids[:, (L - 5) if seg_pos is None else seg_pos] = SEG
+    return ids
+
+
+def tiny_lisa_batch(img_size=896, K=16, L=24):
+    """2 images, 3 conversations (offset [0,2,3]), one right-padded sequence."""
+    B = 2
+    ids = prompt_ids(3, L, 21)
+    labels = ids.clone()
+    labels[:, :10] = -100
+    am = torch.ones(3, L, dtype=torch.bool)
+    am[1, L - 2:] = False
+    return dict(
+        images=seeded.uniform((B, 3, img_size, img_size), 22, -2, 2),
+        images_clip=seeded.uniform((B, 3, 224, 224), 23, -2, 2),
+        input_ids=ids, labels=labels, attention_masks=am, offset=torch.tensor([0, 2, 3]),
+        sam_segs_list=[(seeded.uniform((K, 256, 256), 24 + b) > 0.4).float() for b in range(B)],
+        sam_ious_list=[seeded.uniform((c, K), 30 + b, 0, 1).double() for b, c in enumerate([2, 1])],
+        sam_iops_list=[seeded.uniform((c, K), 40 + b, 0, 1).double() for b, c in enumerate([2, 1])])
+
+
+def first_image_inference(batch):
+    """The validation shape (LISA.py:268-290): one image, one conversation."""
+    return dict(images=batch["images"][:1], images_clip=batch["images_clip"][:1], input_ids=batch["input_ids"][:1],
+                labels=None, attention_masks=batch["attention_masks"][:1], offset=torch.tensor([0, 1]),
+                sam_segs_list=batch["sam_segs_list"][:1])
+
+
+def loss_inputs():
+    return dict(P=seeded.uniform((256, 256), 1), t=seeded.uniform((1, 256), 2), iou=seeded.uniform((256, 1), 3, 0, 1),
+                pr=seeded.uniform((256, 1), 4, 0, 1), x=seeded.uniform((3, 64, 64), 5, -3, 3),
+                y=(seeded.uniform((3, 64, 64), 6) > 0).float())
+
+
+def head_case(C=2, K=256, D=256):
+    sd = seeded.fill_state_dict(seeded.head_shapes(512, D), 51)
+    pooled = seeded.uniform((K, D), 52, -1, 1)
+    text = seeded.uniform((C, D), 53, -1, 1)
+    return sd, pooled, text
+
+
+def iou_metric_cases():
+    out = []
+    for i, (p_thr, ign) in enumerate([(0.0, False), (0.3, True), (2.0, False)]):   # last: empty prediction
+        pred = (seeded.uniform((64, 64), 60 + i) > p_thr).long()
+        tgt = (seeded.uniform((64, 64), 70 + i) > 0.2).long()
+        if ign:
+            tgt[seeded.uniform((64, 64), 80 + i) > 0.8] = 255
+        out.append((pred, tgt))
+    out.append((torch.zeros(64, 64, dtype=torch.long), torch.zeros(64, 64, dtype=torch.long)))   # empty union
+    return out

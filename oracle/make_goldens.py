@@ -1,0 +1,171 @@
+"""Generate tests/golden/* by running the imported reference.  BUILD CONTAINER ONLY
+(`python -m oracle.make_goldens`; needs /root/reference).  Test infrastructure.
+
+For every case: run the reference module on seeded inputs + seeded weights, assert the
+oracle restatement reproduces it (fp32, tight), then store the reference outputs.
+Fixtures hold data only (expected outputs + the case parameters), never reference code.
+"""
+import os
+import sys
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from . import cases, lisa, losses, mask_head, ref_harness as rh, sam_encoder, seeded
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+TOL = 2e-5
+
+
+def _check(name, ref, mine, tol=TOL):
+    d = (ref.float() - mine.float()).abs().max().item()
+    s = ref.float().abs().max().item()
+    print(f"  {name}: max|ref-oracle| = {d:.3e} (|ref|max {s:.3e})")
+    assert d <= tol * max(1.0, s), name
+
+
+def gold_losses():
+    import model.loss as RL
+    i = cases.loss_inputs()
+    ref = dict(align=RL.softmax_align_loss(i["P"], i["t"], i["iou"]), reg=RL.iou_regression_loss(i["pr"], i["iou"]),
+               dice=RL.dice_loss(i["x"], i["y"], 3), bce=RL.sigmoid_ce_loss(i["x"], i["y"], 3))
+    mine = dict(align=losses.softmax_align(i["P"], i["t"], i["iou"]), reg=losses.iop_regression(i["pr"], i["iou"]),
+                dice=losses.dice(i["x"], i["y"], 3), bce=losses.sigmoid_ce(i["x"], i["y"], 3))
+    for k in ref:
+        _check("loss." + k, ref[k], mine[k], 1e-6)
+    # gradients of the two live losses w.r.t. their inputs (for the backward kernels)
+    P = i["P"].clone().requires_grad_(True); t = i["t"].clone().requires_grad_(True)
+    RL.softmax_align_loss(P, t, i["iou"]).backward()
+    pr = i["pr"].clone().requires_grad_(True)
+    RL.iou_regression_loss(pr, i["iou"]).backward()
+    torch.save({**{k: v.detach() for k, v in ref.items()}, "dP": P.grad, "dt": t.grad, "dpr": pr.grad},
+               os.path.join(OUT, "losses.pt"))
+
+
+def gold_iou_metric():
+    sys.modules.setdefault("cv2", sys.modules.get("cv2"))
+    from utils.utils import intersectionAndUnionGPU
+    exp = []
+    for pred, tgt in cases.iou_metric_cases():
+        ri, ru, rt = intersectionAndUnionGPU(pred.clone().float(), tgt.clone().float(), 2, ignore_index=255)
+        mi, mu, mt = losses.intersection_and_union(pred, tgt, 2, 255)
+        _check("iou.I", ri, mi, 0); _check("iou.U", ru, mu, 0)
+        exp.append(torch.stack([ri, ru, rt]))
+    torch.save({"IUT": torch.stack(exp)}, os.path.join(OUT, "iou_metric.pt"))
+
+
+def gold_sam_small():
+    from model.segment_anything.modeling.image_encoder import ImageEncoderViT
+    cfg, sd, img = cases.sam_small_case(batch=1)
+    ref = ImageEncoderViT(depth=cfg.depth, embed_dim=cfg.dim, img_size=cfg.img, mlp_ratio=4,
+                          norm_layer=partial(nn.LayerNorm, eps=1e-6), num_heads=cfg.heads, patch_size=cfg.patch,
+                          qkv_bias=True, use_rel_pos=True, global_attn_indexes=list(cfg.global_idx),
+                          window_size=cfg.window, out_chans=cfg.out_chans).eval()
+    ref.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        a = ref(img)
+        b = sam_encoder.sam_image_encoder(sd, "", img, cfg)
+        # per-block activations, useful when bisecting a kernel mismatch
+        x = ref.patch_embed(img) + ref.pos_embed
+        blk = []
+        for bl in ref.blocks:
+            x = bl(x)
+            blk.append(x.clone())
+    _check("sam_small.out", a, b)
+    torch.save({"out": a, "block0": blk[0], "block1": blk[1]}, os.path.join(OUT, "sam_encoder_small.pt"))
+
+
+def gold_head():
+    from model.transformer import Attention, LISA_TwoWayAttentionBlock
+    sd, pooled, text = cases.head_case()
+    layers = nn.ModuleList([LISA_TwoWayAttentionBlock(256, 8, 2048, attention_downsample_rate=1) for _ in range(2)])
+    fin, nrm = Attention(256, 8, downsample_rate=1), nn.LayerNorm(256)
+    iou_h = nn.Sequential(nn.Linear(256, 128), nn.ReLU(), nn.Linear(128, 1), nn.Sigmoid())
+    emb_h = nn.Sequential(nn.Linear(256, 2048), nn.ReLU(), nn.Linear(2048, 256))
+    mods = {"lisa_attention_layers": layers, "lisa_final_attn": fin, "lisa_norm_final_attn": nrm,
+            "lisa_iou_head": iou_h, "lisa_embedding_head": emb_h}
+    for n, m in mods.items():
+        m.load_state_dict({k[len("model." + n) + 1:]: v for k, v in sd.items() if k.startswith("model." + n + ".")},
+                          strict=True)
+    with torch.no_grad():
+        C = text.shape[0]
+        s, t = pooled.unsqueeze(0).expand(C, -1, -1), text.unsqueeze(1)       # LISA.py:363-372
+        for l in layers:
+            s, t = l(queries=s, keys=t)
+        s = nrm(s + fin(q=s, k=t, v=t))
+        r_iou, r_emb = iou_h(s), emb_h(s)
+        m_iou, m_emb = mask_head.mask_head(sd, "model.", pooled, text)
+    _check("head.iou", r_iou, m_iou); _check("head.emb", r_emb, m_emb)
+    torch.save({"iou": r_iou, "emb": r_emb}, os.path.join(OUT, "mask_head.pt"))
+
+
+def gold_lisa_tiny():
+    cfg = cases.tiny_lisa_cfg()
+    rh.setup(clip_cfg_kwargs=dict(hidden_size=cfg.clip.dim, intermediate_size=cfg.clip.mlp,
+                                  num_hidden_layers=cfg.clip.layers, num_attention_heads=cfg.clip.heads),
+             dino_cfg_kwargs=dict(num_hidden_layers=cfg.dino.layers))
+    m = rh.build_lisa(dict(hidden_size=cfg.llama.hidden, intermediate_size=cfg.llama.inter,
+                           num_hidden_layers=cfg.llama.layers, num_attention_heads=cfg.llama.heads,
+                           num_key_value_heads=cfg.llama.heads, vocab_size=cfg.llama.vocab,
+                           max_position_embeddings=2048, rms_norm_eps=cfg.llama.eps), seg_token_idx=cfg.seg_token_idx)
+    sd = cases.tiny_lisa_state(cfg)
+    ref_sd = {}
+    for k, v in sd.items():
+        if k.startswith("model.visual_model_dinov2.") or k.startswith("model.visual_model."):
+            continue
+        ref_sd[k.replace("vision_tower.vision_tower.vision_model.", "vision_tower.vision_tower.hf.")] = v
+    ref_sd.update(rh.hub_to_hf_dino_names(sd, "model.visual_model_dinov2.", "model.visual_model_dinov2.m.", cfg.dino.layers))
+    res = m.load_state_dict(ref_sd, strict=False)
+    assert not res.unexpected_keys and all(k.startswith("model.visual_model.") for k in res.missing_keys), res
+
+    batch = cases.tiny_lisa_batch()
+    extra = dict(masks_list=[None, None], label_list=[None, None], resize_list=[None, None])
+    m.train()
+    for p in m.parameters():
+        p.requires_grad_(True)
+    out = m(**batch, **extra, inference=False)
+    with torch.no_grad():
+        mine = lisa.model_forward(sd, cfg, **batch, inference=False, return_aux=True)
+    for k in ("loss", "ce_loss", "align_loss", "regression_loss"):
+        _check("lisa.train." + k, out[k].detach(), torch.as_tensor(mine[k]), 1e-5)
+    out["loss"].backward()
+    gn = {"text_fc2_w": m.model.text_hidden_fcs[0][2].weight.grad,
+          "lm_head_rows": m.lm_head.weight.grad[::1000].clone(),
+          "iou_head0_w": m.model.lisa_iou_head[0].weight.grad,
+          "q_proj_l1": m.model.layers[1].self_attn.q_proj.weight.grad,
+          "final_attn_q_w": m.model.lisa_final_attn.q_proj.weight.grad}
+    m.eval()
+    inf = cases.first_image_inference(batch)
+    with torch.no_grad():
+        r = m(**inf, masks_list=[None], label_list=[None], resize_list=[None], sam_ious_list=None,
+              sam_iops_list=None, inference=True)
+        o = lisa.model_forward(sd, cfg, **inf, inference=True, return_aux=True)
+        ro = super(type(m), m).forward(images=inf["images_clip"], attention_mask=inf["attention_masks"],
+                                       input_ids=inf["input_ids"], output_hidden_states=True)
+    _check("lisa.inf.sim", r["pred_similarity"][0], o["pred_similarity"][0], 1e-5)
+    _check("lisa.inf.iou", r["pred_iou"][0], o["pred_iou"][0], 1e-5)
+    _check("lisa.inf.logits", ro.logits, o["logits"], 1e-4)
+    _check("lisa.inf.hidden", ro.hidden_states, o["hidden"], 1e-4)
+    torch.save({"train": {k: out[k].detach() for k in ("loss", "ce_loss", "align_loss", "regression_loss")},
+                "grads": gn,
+                "pred_similarity": r["pred_similarity"][0], "pred_iou": r["pred_iou"][0],
+                "logits_sample": ro.logits[0, ::7, ::997].clone(), "hidden": ro.hidden_states[0].clone(),
+                "feats_sample": o["feats"][0, ::8, ::4, ::4].clone()}, os.path.join(OUT, "lisa_tiny.pt"))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    cfg = cases.tiny_lisa_cfg()
+    rh.setup(clip_cfg_kwargs=dict(hidden_size=cfg.clip.dim, intermediate_size=cfg.clip.mlp,
+                                  num_hidden_layers=cfg.clip.layers, num_attention_heads=cfg.clip.heads),
+             dino_cfg_kwargs=dict(num_hidden_layers=cfg.dino.layers))
+    for f in (gold_losses, gold_iou_metric, gold_sam_small, gold_head, gold_lisa_tiny):
+        print(f.__name__)
+        f()
+    print("wrote", sorted(os.listdir(OUT)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,76 @@
+"""Oracle: mask-selection head (test infrastructure).
+
+Follows reference `model/transformer.py` (Attention :286-341,
+LISA_TwoWayAttentionBlock :215-283, MLPBlock :13-26) and the head wiring in
+`model/LISA.py` (:91-121 construction, :201-218 mask_pooling, :350-391 per-image
+flow, :394-408 inference scoring).  Pinned against the imported reference.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _lin(sd, name, x):
+    return F.linear(x, sd[name + ".weight"], sd[name + ".bias"])
+
+
+def _ln(sd, name, x, eps=1e-5):
+    return F.layer_norm(x, (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], eps)
+
+
+def mh_attention(sd, p, q, k, v, heads=8):
+    """transformer.py:319-341 (downsample_rate=1)."""
+    q, k, v = _lin(sd, p + "q_proj", q), _lin(sd, p + "k_proj", k), _lin(sd, p + "v_proj", v)
+    B, Nq, D = q.shape
+    hd = D // heads
+    sp = lambda t: t.view(B, t.shape[1], heads, hd).transpose(1, 2)
+    q, k, v = sp(q), sp(k), sp(v)
+    a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), -1)
+    o = (a @ v).transpose(1, 2).reshape(B, Nq, D)
+    return _lin(sd, p + "out_proj", o)
+
+
+def two_way_block(sd, p, queries, keys):
+    """transformer.py:255-283: post-LN; queries = mask feats [C,K,D], keys = text [C,1,D]."""
+    queries = _ln(sd, p + "norm1", queries + mh_attention(sd, p + "self_attn.", queries, queries, queries))
+    queries = _ln(sd, p + "norm2", queries + mh_attention(sd, p + "cross_attn_token_to_image.", queries, keys, keys))
+    m = _lin(sd, p + "mlp.lin2", F.relu(_lin(sd, p + "mlp.lin1", queries)))
+    queries = _ln(sd, p + "norm3", queries + m)
+    keys = _ln(sd, p + "norm4", keys + mh_attention(sd, p + "cross_attn_image_to_token.", keys, queries, queries))
+    return queries, keys
+
+
+def upsample_feats(feats, size=256):
+    """LISA.py:350-354: fp32 bilinear (align_corners=False) then back to the input dtype."""
+    dt = feats.dtype
+    return F.interpolate(feats.float(), size=(size, size), mode="bilinear", align_corners=False).to(dt)
+
+
+def mask_pooling(feats_chw, segs):
+    """LISA.py:201-218: feats [D,h,w], segs [K,h,w] -> [K,D]."""
+    e, w = feats_chw.flatten(1), segs.flatten(1)
+    return (w @ e.t()) / (w.sum(-1, keepdim=True) + 1e-8)
+
+
+def mask_head(sd, pfx, segs_feature, text_feature):
+    """LISA.py:363-391.  segs_feature [K,D], text_feature [C,D] ->
+    (pred_iou [C,K,1], seg embeddings [C,K,D])."""
+    C = text_feature.shape[0]
+    t = text_feature.unsqueeze(1)
+    s = segs_feature.unsqueeze(0)
+    if C > 0:
+        s = s.expand(C, -1, -1)
+    for i in range(2):
+        s, t = two_way_block(sd, f"{pfx}lisa_attention_layers.{i}.", s, t)
+    s = _ln(sd, pfx + "lisa_norm_final_attn", s + mh_attention(sd, pfx + "lisa_final_attn.", s, t, t))
+    iou = torch.sigmoid(_lin(sd, pfx + "lisa_iou_head.2", F.relu(_lin(sd, pfx + "lisa_iou_head.0", s))))
+    emb = _lin(sd, pfx + "lisa_embedding_head.2", F.relu(_lin(sd, pfx + "lisa_embedding_head.0", s)))
+    return iou, emb
+
+
+def cosine_scores(pred_embedding, seg_emb):
+    """LISA.py:398-403: pred_embedding [1,D], seg_emb [K,D] -> [1,K]."""
+    a = pred_embedding / pred_embedding.norm(dim=-1, keepdim=True)
+    b = seg_emb / seg_emb.norm(dim=-1, keepdim=True)
+    return a @ b.t()
