@@ -1,0 +1,153 @@
+/* libllmseg_hip.so -- C ABI of the MI355X (gfx950) kernels behind LLM-Seg's `model_forward` hot path.
+ *
+ * The reference (wangjunchi/LLMSeg) has no FFI boundary: its path is PyTorch eager ops
+ * (SURVEY.md §8b).  Each entry point below replaces the eager op sequence cited next to it
+ * (paths relative to the reference tree).  All pointers are DEVICE pointers owned by the caller
+ * (PyTorch's caching allocator); kernels never allocate, never synchronise, and launch on the
+ * `stream` argument (a hipStream_t passed as void*).  bf16 tensors are raw uint16 storage.
+ * Every function returns 0 on success or a negative LLMSEG_E* code; llmseg_last_error() gives text.
+ * Rows of every bf16 matrix must be 16-byte aligned (pointer and leading dimension % 8 == 0)
+ * unless stated otherwise.
+ */
+#ifndef LLMSEG_HIP_H
+#define LLMSEG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LLMSEG_OK 0
+#define LLMSEG_EINVAL (-1)
+#define LLMSEG_ELAUNCH (-2)
+
+/* epilogue activation */
+enum { LLMSEG_ACT_NONE = 0, LLMSEG_ACT_RELU = 1, LLMSEG_ACT_GELU = 2, LLMSEG_ACT_QUICKGELU = 3, LLMSEG_ACT_SILU = 4,
+       LLMSEG_ACT_SIGMOID = 5 };
+
+int llmseg_version(void);
+const char* llmseg_last_error(void);
+
+/* ---- GEMM ------------------------------------------------------------------------------------
+ * C[b][m][n] = epi( alpha * sum_k A[b][m][k] * W[b][n][k] ),  A,W bf16 (K contiguous), fp32 accumulate on MFMA.
+ * epi(v) = residual[m][n] + gamma[n] * act(v + bias[n])   (each term optional, NULL = absent).
+ * Replaces every nn.Linear / 1x1 conv / patch-embed conv on the path: HF LlamaAttention/LlamaMLP projections and
+ * lm_head (model/llava/model/language_model/llava_llama.py:93-105), SAM qkv/proj/mlp
+ * (model/segment_anything/modeling/image_encoder.py:238-258, common.py:25-26), neck convs (:92-108),
+ * mm_projector (model/llava/model/llava_arch.py:93-96), text_hidden_fcs / lisa_* heads (model/LISA.py:54-121).
+ * out_f32 != 0 writes fp32 C (ldc in elements of the output type).  batch/strides (in elements) give a strided-batched GEMM.
+ */
+typedef struct {
+  const void* A; const void* W; void* C;
+  const void* bias;      /* bf16 [N] or NULL */
+  const void* gamma;     /* bf16 [N] or NULL (DINOv2 LayerScale) */
+  const void* residual;  /* bf16 [M][ldr] or NULL */
+  int64_t M, N, K;
+  int64_t lda, ldw, ldc, ldr;
+  int64_t batch, strideA, strideW, strideC;
+  float alpha;
+  int act;
+  int out_f32;
+} llmseg_gemm_args;
+int llmseg_gemm_bf16(const llmseg_gemm_args* args, void* stream);
+
+/* ---- fused attention forward -----------------------------------------------------------------
+ * O[b][h][q][:] = softmax_k( scale * Q.K^T + bias + mask ) V, online softmax in fp32, bf16 MFMA.
+ * Q/K/V/O are addressed as base + b*stride_b + h*stride_h + row*stride_row (elements); head_dim in {32,64,80,128}.
+ *  - causal + key_mask: HF LlamaAttention eager path (transformers 4.29; call site llava_llama.py:93-102)
+ *  - rel_h/rel_w: SAM decomposed relative position (image_encoder.py:244-251, 354-392):
+ *      bias(q,k) = rel_h[b][h][q][qh-kh+grid_h-1] + rel_w[b][h][q][qw-kw+grid_w-1], q=(qh,qw), k=(kh,kw) on a grid_h x grid_w grid,
+ *      rel_* are fp32 [batch][heads][Nq][rel_ld] (the q . R^T products, produced by llmseg_gemm_bf16 with out_f32)
+ *  - plain: CLIP / DINOv2 ViT attention, mask-selection head attention (model/transformer.py:319-341)
+ * o_row_map (int32 [batch][Nq] or NULL): output row for query (b,q) inside O (rows of stride o_stride_row, ignoring
+ * o_stride_b); negative = skip.  Used to fold SAM's window_unpartition + crop (image_encoder.py:291-318) into the store.
+ */
+typedef struct {
+  const void* Q; const void* K; const void* V; void* O;
+  int64_t q_stride_b, q_stride_h, q_stride_row;
+  int64_t k_stride_b, k_stride_h, k_stride_row;
+  int64_t v_stride_b, v_stride_h, v_stride_row;
+  int64_t o_stride_b, o_stride_h, o_stride_row;
+  int32_t batch, heads, Nq, Nk, head_dim;
+  float scale;
+  int32_t causal;
+  const uint8_t* key_mask;   /* [batch][Nk] 1 = attend, or NULL */
+  const float* rel_h; const float* rel_w; int32_t rel_ld, grid_h, grid_w;
+  const int32_t* o_row_map;
+} llmseg_attn_args;
+int llmseg_attn_fwd(const llmseg_attn_args* args, void* stream);
+
+/* ---- row-wise normalisation ------------------------------------------------------------------
+ * y[row_map ? row_map[r] : r][:] = norm(x[r][:]) * w (+ b); statistics in fp32.
+ * rms != 0: HF LlamaRMSNorm (variance over x^2, no mean, no bias).  Otherwise nn.LayerNorm / SAM LayerNorm2d in
+ * channels-last form (common.py:31-43).  row_map folds SAM's window_partition (image_encoder.py:263-288) into the store
+ * (padding rows of y are left untouched -- the caller zero-fills them once).
+ */
+int llmseg_norm(const void* x, const void* w, const void* b, void* y, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy,
+                float eps, int rms, const int32_t* row_map, void* stream);
+
+/* RoPE, rotate-half form, applied in place to `heads` heads of width head_dim starting at x (row stride ld):
+ * positions = row % T (HF LlamaRotaryEmbedding, position_ids = arange(T)); cos/sin fp32 [T][head_dim/2]. */
+int llmseg_rope(void* x, const float* cos, const float* sin, int64_t rows, int64_t T, int32_t heads, int32_t head_dim,
+                int64_t ld, void* stream);
+
+/* out[r][c] = silu(gu[r][c]) * gu[r][I + c]   (HF LlamaMLP: down(silu(gate(x)) * up(x)); gu = x.[Wgate;Wup]^T) */
+int llmseg_swiglu(const void* gu, void* out, int64_t rows, int64_t I, int64_t ldgu, int64_t ldo, void* stream);
+
+/* y[r][:] = x[r][:] + add[(r % add_rows)][:]  (positional embeddings; x may alias y) */
+int llmseg_add_rows(const void* x, const void* add, void* y, int64_t rows, int64_t cols, int64_t add_rows, void* stream);
+
+/* im2col for stride==kernel patch embedding: img bf16 [B][3][H][W] -> cols bf16 [B*gh*gw][ldo], column = c*p*p + i*p + j,
+ * zero-filled up to ldo.  (PatchEmbed image_encoder.py:395-426; CLIP/DINOv2 patch convs.)  out_row_offset/out_rows_per_img
+ * let the caller leave a CLS row at the front of each image's block. */
+int llmseg_patchify(const void* img, void* cols, int32_t B, int32_t H, int32_t W, int32_t p, int64_t ldo,
+                    int64_t out_rows_per_img, int64_t out_row_offset, void* stream);
+
+/* 3x3 / pad 1 im2col on a channels-last map: x bf16 [B][H][W][C] -> cols [B*H*W][9*C], column = (ky*3+kx)*C + c
+ * (SAM neck conv, image_encoder.py:100-106; the weight is re-laid-out to match at load time). */
+int llmseg_im2col3x3(const void* x, void* cols, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* LLaVA splice (llava_arch.py:185-208): out[n][t][:] = embed[ids] for text positions, img_feats[n][t-img_pos] inside the
+ * image span.  ids int64 [N][L] with exactly one IMAGE token (-200) per row; out [N][L-1+P][H]. */
+int llmseg_embed_splice(const int64_t* ids, const void* embed, const void* img_feats, void* out, int32_t N, int32_t L,
+                        int32_t P, int32_t H, int64_t vocab, void* stream);
+
+/* gather rows: out[i][:] = x[idx[i]][:] (bf16, cols % 8 == 0) -- [SEG] hidden-state gather (LISA.py:322-323) */
+int llmseg_gather_rows(const void* x, const int64_t* idx, void* out, int64_t n, int64_t cols, int64_t ldx, void* stream);
+
+/* Fused bilinear-upsample + mask pooling (LISA.py:350-361, 201-218):
+ * pooled[k][c] = sum_p segs[k][p] * Up(feat)[c][p] / (sum_p segs[k][p] + 1e-8), Up = F.interpolate(size=S, bilinear,
+ * align_corners=False) of the channels-last bf16 map feat [g*g][C].  Computed as (segs . U) . feat, i.e. the mask is
+ * pulled back through the adjoint of the interpolation, so the [C][S][S] upsampled tensor is never materialised and
+ * `segs` (K*S*S bf16, the only large operand) is read from HBM exactly once.  feat bf16 [g*g][C]; pooled bf16 [K][C]. */
+int llmseg_upsample_maskpool(const void* feat, const void* segs, void* pooled, int32_t K, int32_t C, int32_t g, int32_t S,
+                             void* stream);
+
+/* Cosine scoring (LISA.py:398-403): sim[k] = <t,e_k> / (|t||e_k|); t bf16 [D], e bf16 [K][D]; sim fp32 [K]. */
+int llmseg_cosine_scores(const void* t, const void* e, float* sim, int32_t K, int32_t D, void* stream);
+
+/* softmax_align_loss + iou_regression_loss (model/loss.py:50-94), one (image, round) per call, fp32 results:
+ * out[0] = KL(softmax(gt_iou/tau) || softmax(cos(e_k,t)/tau)) summed; out[1] = mean((p-g)^2 exp(g-1)) * 50.
+ * Optional gradients: d_e fp32 [K][D], d_t fp32 [D], d_pred fp32 [K] (of out[0] resp. out[1]; NULL = skip). */
+int llmseg_align_reg_loss(const void* e, const void* t, const float* gt_iou, const void* pred_iou, const float* gt_iop,
+                          float* out, float* d_e, float* d_t, float* d_pred, int32_t K, int32_t D, float tau, void* stream);
+
+/* dice_loss + sigmoid_ce_loss (model/loss.py:4-47; named by the north_star, no caller in the reference):
+ * logits bf16/fp32-as-float [M][HW] given as fp32, targets fp32; out[0] = dice (scale 1000, eps 1e-6), out[1] = bce,
+ * both summed over masks / (num_masks + 1e-8).  out must be zeroed by the caller. */
+int llmseg_dice_bce(const float* logits, const float* targets, float* out, int32_t M, int64_t HW, float num_masks, void* stream);
+
+/* Shifted cross-entropy over bf16 logits (llava_llama.py:108-118): rows = N*T positions, labels int64 [N][T] already in
+ * spliced form; position (n,t) is scored against labels[n][t+1]; ignore_index -100.  acc fp32[2] += {sum nll, count}. */
+int llmseg_ce_loss(const void* logits, const int64_t* labels, float* acc, int32_t N, int32_t T, int64_t V, int64_t ldl,
+                   void* stream);
+
+/* ---- per-kernel timing (bench roofline): HIP events recorded around every GEMM launch on its own stream ---------- */
+int llmseg_prof_enable(int on);                 /* 1 = record events around GEMM launches */
+int llmseg_prof_collect(double* total_ms, double* total_flops, int64_t* launches);  /* syncs events, resets */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,85 @@
+"""ctypes binding of libllmseg_hip.so (C ABI declared in include/llmseg_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a symbol is
+absent, importing/using the ops raises.  Build with `llmseg_amd/csrc/build.sh`
+(`__graft_entry__.build()` does that).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libllmseg_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SILU, ACT_SIGMOID = range(6)
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p),
+                ("bias", C.c_void_p), ("gamma", C.c_void_p), ("residual", C.c_void_p),
+                ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
+                ("lda", C.c_int64), ("ldw", C.c_int64), ("ldc", C.c_int64), ("ldr", C.c_int64),
+                ("batch", C.c_int64), ("strideA", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64),
+                ("alpha", C.c_float), ("act", C.c_int), ("out_f32", C.c_int)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p),
+                ("q_stride_b", C.c_int64), ("q_stride_h", C.c_int64), ("q_stride_row", C.c_int64),
+                ("k_stride_b", C.c_int64), ("k_stride_h", C.c_int64), ("k_stride_row", C.c_int64),
+                ("v_stride_b", C.c_int64), ("v_stride_h", C.c_int64), ("v_stride_row", C.c_int64),
+                ("o_stride_b", C.c_int64), ("o_stride_h", C.c_int64), ("o_stride_row", C.c_int64),
+                ("batch", C.c_int32), ("heads", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("head_dim", C.c_int32),
+                ("scale", C.c_float), ("causal", C.c_int32),
+                ("key_mask", C.c_void_p), ("rel_h", C.c_void_p), ("rel_w", C.c_void_p),
+                ("rel_ld", C.c_int32), ("grid_h", C.c_int32), ("grid_w", C.c_int32),
+                ("o_row_map", C.c_void_p)]
+
+
+_i64, _i32, _f32, _p = C.c_int64, C.c_int32, C.c_float, C.c_void_p
+
+# name -> argtypes (restype is int unless noted); must list EVERY symbol of include/llmseg_hip.h
+SIGNATURES = {
+    "llmseg_version": [],
+    "llmseg_last_error": [],
+    "llmseg_gemm_bf16": [C.POINTER(GemmArgs), _p],
+    "llmseg_attn_fwd": [C.POINTER(AttnArgs), _p],
+    "llmseg_norm": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _f32, C.c_int, _p, _p],
+    "llmseg_rope": [_p, _p, _p, _i64, _i64, _i32, _i32, _i64, _p],
+    "llmseg_swiglu": [_p, _p, _i64, _i64, _i64, _i64, _p],
+    "llmseg_add_rows": [_p, _p, _p, _i64, _i64, _i64, _p],
+    "llmseg_patchify": [_p, _p, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _p],
+    "llmseg_im2col3x3": [_p, _p, _i32, _i32, _i32, _i32, _p],
+    "llmseg_embed_splice": [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i64, _p],
+    "llmseg_gather_rows": [_p, _p, _p, _i64, _i64, _i64, _p],
+    "llmseg_upsample_maskpool": [_p, _p, _p, _i32, _i32, _i32, _i32, _p],
+    "llmseg_cosine_scores": [_p, _p, _p, _i32, _i32, _p],
+    "llmseg_align_reg_loss": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _f32, _p],
+    "llmseg_dice_bce": [_p, _p, _p, _i32, _i64, _f32, _p],
+    "llmseg_ce_loss": [_p, _p, _p, _i32, _i32, _i64, _i64, _p],
+    "llmseg_prof_enable": [C.c_int],
+    "llmseg_prof_collect": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library and bind every declared symbol (raises if anything is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: the HIP extension is not built "
+                           f"(run llmseg_amd/csrc/build.sh); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == "llmseg_last_error" else C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {load().llmseg_last_error().decode()}")

@@ -1,0 +1,316 @@
+// Fused attention forward for gfx950 (flash-style: online softmax, scores never leave the CU).
+//
+// One kernel template covers the four attention shapes on the LLM-Seg hot path (include/llmseg_hip.h):
+//   Llama causal + key-padding (hd 128), CLIP/DINOv2 ViT global (hd 64), SAM ViT-H windowed/global with
+//   decomposed relative position (hd 80), mask-selection head (hd 32).
+//
+// CDNA4 mapping: workgroup = 4 wave64 = 128 query rows; each wave owns 32 queries and walks K/V in tiles of 64
+// keys staged through LDS.  Scores are computed TRANSPOSED, S^T = K . Q^T, with v_mfma_f32_32x32x16_bf16
+// (A = K fragment from LDS, B = Q fragment held in registers for the whole kernel), so that every lane owns
+// one query column: the online-softmax max/sum are in-lane reductions plus ONE cross-half exchange, and
+// the O rescale is a per-lane scalar.  The exponentiated scores are packed to bf16 in registers and fed back
+// as the B operand of O^T = V^T . P^T; the k-slot order of that MFMA is chosen to be exactly the order the
+// S^T accumulator registers already have, so P never moves between lanes.  V is transposed while it is staged
+// (global rows -> 4x8 register transpose -> 8-byte LDS writes), K is stored row-major with a one-chunk pad
+// (conflict-free ds_read_b128 on gfx950's 16-lane service groups).
+#include "common.h"
+#include "llmseg_hip.h"
+
+namespace {
+
+constexpr int BQ = 128, BKV = 64, NT = 256;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float NEG = -1.0e30f;
+
+struct AttnP {
+  const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O;
+  long qsb, qsh, qsr, ksb, ksh, ksr, vsb, vsh, vsr, osb, osh, osr;
+  int batch, heads, Nq, Nk;
+  float scale_log2;
+  int causal;
+  const uint8_t* key_mask;
+  const float* rel_h; const float* rel_w; int rel_ld, gh, gw;
+  const int32_t* o_row_map;
+};
+
+__device__ __forceinline__ uint32_t perm_lo(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }
+__device__ __forceinline__ uint32_t perm_hi(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xffff0000u); }
+
+// REL: 0 = no bias, 1 = generic grid, 2 = grid_w == BKV (a K tile is exactly one key row: kh uniform, kw = offset)
+template <int HD, int REL>
+__global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(AttnP p) {
+  constexpr int KS = HD / 16;                 // k-steps of QK^T
+  constexpr int DT = (HD + 31) / 32;          // 32-row blocks of O^T
+  constexpr int CH = HD / 8;                  // 16-byte chunks per row
+  constexpr int PK = (HD + 8) * 2;            // K_lds row pitch (bytes): CH+1 chunks -> odd
+  constexpr int PV = (BKV + 4) * 2;           // Vt row pitch (bytes) = 136 = 8 * 17
+  __shared__ __attribute__((aligned(16))) char smem[BKV * PK + DT * 32 * PV + BKV * 4];
+  char* Ks = smem;
+  char* Vt = smem + BKV * PK;
+  uint32_t* lut = reinterpret_cast<uint32_t*>(smem + BKV * PK + DT * 32 * PV);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, half = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * BQ;
+  const int q = q0 + wave * 32 + ql;
+  const int qc = min(q, p.Nq - 1);
+
+  const bf16_t* Qg = p.Q + (long)b * p.qsb + (long)h * p.qsh;
+  const bf16_t* Kg = p.K + (long)b * p.ksb + (long)h * p.ksh;
+  const bf16_t* Vg = p.V + (long)b * p.vsb + (long)h * p.vsh;
+
+  // ---- Q fragments (B operand): col = query, k-slots = 8 consecutive d ------------------------------------------
+  bf16x8_t qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    qf[ks] = *reinterpret_cast<const bf16x8_t*>(Qg + (long)qc * p.qsr + ks * 16 + half * 8);
+
+  // ---- relative-position setup -----------------------------------------------------------------------------------
+  int qh = 0, qw = 0;
+  const float* relh_row = nullptr;
+  const float* relw_row = nullptr;
+  float bw_cache[REL == 2 ? 32 : 1];
+  if (REL != 0) {
+    qh = qc / p.gw; qw = qc - qh * p.gw;
+    const long rrow = ((long)(b * p.heads + h) * p.Nq + qc) * p.rel_ld;
+    relh_row = p.rel_h + rrow;
+    relw_row = p.rel_w + rrow;
+    if (REL == 2) {
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kw = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          bw_cache[jb * 16 + r] = relw_row[qw - kw + p.gw - 1] * LOG2E;
+        }
+    }
+  }
+
+  int kv_len = p.Nk;
+  if (p.causal) kv_len = min(p.Nk, q0 + BQ);
+  const int ntiles = (kv_len + BKV - 1) / BKV;
+
+  // ---- staging registers (explicit scalars: arrays captured by the staging code end up in scratch) ---------------
+  constexpr int KIT = (BKV * CH + NT - 1) / NT;        // K items (16B chunks) per thread, <= 4
+  static_assert(KIT <= 4 && 16 * CH <= NT, "staging map assumes head_dim <= 128");
+  uint4 kreg0 = make_uint4(0, 0, 0, 0), kreg1 = kreg0, kreg2 = kreg0, kreg3 = kreg0;
+  uint4 vreg0 = kreg0, vreg1 = kreg0, vreg2 = kreg0, vreg3 = kreg0;
+  const int v_kq = tid & 15, v_c = tid >> 4;
+  const bool v_on = tid < 16 * CH;
+
+#define LL_K_LOAD(IT, REG)                                                                          \
+  if constexpr (KIT > IT) {                                                                         \
+    const int idx = tid + IT * NT;                                                                  \
+    if ((IT + 1) * NT <= BKV * CH || idx < BKV * CH) {                                              \
+      const int key = idx / CH, c = idx - key * CH;                                                 \
+      REG = *reinterpret_cast<const uint4*>(Kg + (long)min(k0s + key, p.Nk - 1) * p.ksr + c * 8);   \
+    }                                                                                               \
+  }
+#define LL_K_STORE(IT, REG)                                                                         \
+  if constexpr (KIT > IT) {                                                                         \
+    const int idx = tid + IT * NT;                                                                  \
+    if ((IT + 1) * NT <= BKV * CH || idx < BKV * CH) {                                              \
+      const int key = idx / CH, c = idx - key * CH;                                                 \
+      *reinterpret_cast<uint4*>(Ks + key * PK + c * 16) = REG;                                      \
+    }                                                                                               \
+  }
+#define LL_STAGE_LOAD(T)                                                                            \
+  {                                                                                                 \
+    const int k0s = (T) * BKV;                                                                      \
+    LL_K_LOAD(0, kreg0) LL_K_LOAD(1, kreg1) LL_K_LOAD(2, kreg2) LL_K_LOAD(3, kreg3)                 \
+    if (v_on) {                                                                                     \
+      const bf16_t* vp = Vg + v_c * 8;                                                              \
+      vreg0 = *reinterpret_cast<const uint4*>(vp + (long)min(k0s + 4 * v_kq + 0, p.Nk - 1) * p.vsr); \
+      vreg1 = *reinterpret_cast<const uint4*>(vp + (long)min(k0s + 4 * v_kq + 1, p.Nk - 1) * p.vsr); \
+      vreg2 = *reinterpret_cast<const uint4*>(vp + (long)min(k0s + 4 * v_kq + 2, p.Nk - 1) * p.vsr); \
+      vreg3 = *reinterpret_cast<const uint4*>(vp + (long)min(k0s + 4 * v_kq + 3, p.Nk - 1) * p.vsr); \
+    }                                                                                               \
+  }
+  // V: 4 keys x 8 d per thread, 4x8 register transpose, 8-byte writes Vt[8c + d][4kq .. 4kq+3]
+#define LL_STAGE_STORE(T)                                                                           \
+  {                                                                                                 \
+    LL_K_STORE(0, kreg0) LL_K_STORE(1, kreg1) LL_K_STORE(2, kreg2) LL_K_STORE(3, kreg3)             \
+    if (v_on) {                                                                                     \
+      char* dst = Vt + (8 * v_c) * PV + 8 * v_kq;                                                   \
+      *reinterpret_cast<uint2*>(dst + 0 * PV) = make_uint2(perm_lo(vreg0.x, vreg1.x), perm_lo(vreg2.x, vreg3.x)); \
+      *reinterpret_cast<uint2*>(dst + 1 * PV) = make_uint2(perm_hi(vreg0.x, vreg1.x), perm_hi(vreg2.x, vreg3.x)); \
+      *reinterpret_cast<uint2*>(dst + 2 * PV) = make_uint2(perm_lo(vreg0.y, vreg1.y), perm_lo(vreg2.y, vreg3.y)); \
+      *reinterpret_cast<uint2*>(dst + 3 * PV) = make_uint2(perm_hi(vreg0.y, vreg1.y), perm_hi(vreg2.y, vreg3.y)); \
+      *reinterpret_cast<uint2*>(dst + 4 * PV) = make_uint2(perm_lo(vreg0.z, vreg1.z), perm_lo(vreg2.z, vreg3.z)); \
+      *reinterpret_cast<uint2*>(dst + 5 * PV) = make_uint2(perm_hi(vreg0.z, vreg1.z), perm_hi(vreg2.z, vreg3.z)); \
+      *reinterpret_cast<uint2*>(dst + 6 * PV) = make_uint2(perm_lo(vreg0.w, vreg1.w), perm_lo(vreg2.w, vreg3.w)); \
+      *reinterpret_cast<uint2*>(dst + 7 * PV) = make_uint2(perm_hi(vreg0.w, vreg1.w), perm_hi(vreg2.w, vreg3.w)); \
+    }                                                                                               \
+    if (REL == 1 && tid < BKV) {                                                                    \
+      const int key = min((T) * BKV + tid, p.Nk - 1);                                               \
+      const int kh = key / p.gw;                                                                    \
+      lut[tid] = ((uint32_t)kh << 16) | (uint32_t)(key - kh * p.gw);                                \
+    }                                                                                               \
+  }
+
+  f32x16_t o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+  float m_run = NEG, l_run = 0.f;
+
+  LL_STAGE_LOAD(0)
+  LL_STAGE_STORE(0)
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) LL_STAGE_LOAD(t + 1)
+    const int k0 = t * BKV;
+
+    // ---- S^T = K . Q^T : two 32-key blocks ------------------------------------------------------------------------
+    f32x16_t s[2];
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[jb][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (jb * 32 + ql) * PK + (2 * ks + half) * 16);
+        s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[jb], 0, 0, 0);
+      }
+    }
+
+    // ---- scale, bias, masks (log2 domain) ---------------------------------------------------------------------------
+    float bh_tile = 0.f;
+    if (REL == 2) bh_tile = relh_row[qh - t + p.gh - 1] * LOG2E;      // tile t == key row kh
+    float mx = NEG;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int koff = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int key = k0 + koff;
+        float v = s[jb][r] * p.scale_log2;
+        if (REL == 2) v += bh_tile + bw_cache[jb * 16 + r];
+        if (REL == 1) {
+          const uint32_t kk = lut[koff];
+          const int kh = (int)(kk >> 16), kw = (int)(kk & 0xffffu);
+          v += (relh_row[qh - kh + p.gh - 1] + relw_row[qw - kw + p.gw - 1]) * LOG2E;
+        }
+        bool ok = key < p.Nk;
+        if (p.causal) ok = ok && (key <= q);
+        if (p.key_mask) ok = ok && (p.key_mask[(long)b * p.Nk + min(key, p.Nk - 1)] != 0);
+        v = ok ? v : NEG;
+        s[jb][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float lsum = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(s[jb][r] - m_new);
+        s[jb][r] = pv;
+        lsum += pv;
+      }
+    l_run = l_run * alpha + lsum;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+
+    // ---- O^T += V^T . P^T : 4 k-steps of 16 keys; P fragment for step ss = accumulator regs 8*(ss&1)..+7 of block ss>>1
+#pragma unroll
+    for (int ss = 0; ss < 4; ++ss) {
+      const int jb = ss >> 1, rb = 8 * (ss & 1);
+      const uint4 pu = make_uint4(pack2bf(s[jb][rb + 0], s[jb][rb + 1]), pack2bf(s[jb][rb + 2], s[jb][rb + 3]),
+                                  pack2bf(s[jb][rb + 4], s[jb][rb + 5]), pack2bf(s[jb][rb + 6], s[jb][rb + 7]));
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const char* vrow = Vt + (d * 32 + ql) * PV + (16 * ss + 4 * half) * 2;
+        const uint2 va = *reinterpret_cast<const uint2*>(vrow);
+        const uint2 vb = *reinterpret_cast<const uint2*>(vrow + 16);
+        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(va.x, va.y, vb.x, vb.y));
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+      }
+    }
+
+    __syncthreads();
+    if (t + 1 < ntiles) LL_STAGE_STORE(t + 1)
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane holds O[q][d..d+3] groups ------------------------------------------------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_tot;
+  if (q < p.Nq) {
+    bf16_t* orow;
+    bool skip = false;
+    if (p.o_row_map) {
+      const int row = p.o_row_map[(long)b * p.Nq + q];
+      skip = row < 0;
+      orow = p.O + (long)h * p.osh + (long)(skip ? 0 : row) * p.osr;
+    } else {
+      orow = p.O + (long)b * p.osb + (long)h * p.osh + (long)q * p.osr;
+    }
+    if (!skip) {
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dd = d * 32 + 8 * g + 4 * half;
+          if (dd < HD)
+            *reinterpret_cast<uint2*>(orow + dd) =
+                make_uint2(pack2bf(o[d][4 * g] * inv, o[d][4 * g + 1] * inv), pack2bf(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv));
+        }
+    }
+  }
+}
+
+template <int HD>
+int launch_hd(const AttnP& p, hipStream_t s) {
+  dim3 grid((p.Nq + BQ - 1) / BQ, p.heads, p.batch);
+  if (p.rel_h == nullptr) hipLaunchKernelGGL((attn_fwd_kernel<HD, 0>), grid, dim3(NT), 0, s, p);
+  else if (p.gw == BKV && (p.Nk % BKV) == 0) hipLaunchKernelGGL((attn_fwd_kernel<HD, 2>), grid, dim3(NT), 0, s, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<HD, 1>), grid, dim3(NT), 0, s, p);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int llmseg_attn_fwd(const llmseg_attn_args* a, void* stream) {
+  LL_CHECK(a && a->Q && a->K && a->V && a->O, "attn: null pointer");
+  LL_CHECK(a->batch > 0 && a->heads > 0 && a->Nq > 0 && a->Nk > 0, "attn: bad sizes");
+  LL_CHECK(a->head_dim == 32 || a->head_dim == 64 || a->head_dim == 80 || a->head_dim == 128, "attn: head_dim %d unsupported", a->head_dim);
+  LL_CHECK(((a->q_stride_row | a->k_stride_row | a->v_stride_row | a->q_stride_h | a->k_stride_h | a->v_stride_h |
+             a->q_stride_b | a->k_stride_b | a->v_stride_b) & 7) == 0, "attn: Q/K/V strides must be multiples of 8 elements");
+  LL_CHECK(((a->o_stride_row | a->o_stride_h | a->o_stride_b) & 3) == 0, "attn: O strides must be multiples of 4 elements");
+  LL_CHECK((((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V) & 15) == 0 && (((uintptr_t)a->O) & 7) == 0, "attn: misaligned pointer");
+  if (a->rel_h || a->rel_w) {
+    LL_CHECK(a->rel_h && a->rel_w && a->grid_h > 0 && a->grid_w > 0 && a->grid_h * a->grid_w == a->Nk && a->Nq == a->Nk &&
+             a->rel_ld >= 2 * (a->grid_h > a->grid_w ? a->grid_h : a->grid_w) - 1, "attn: bad relative-position arguments");
+    LL_CHECK(a->grid_h < 65536 && a->grid_w < 65536, "attn: grid too large");
+  }
+  AttnP p;
+  p.Q = (const bf16_t*)a->Q; p.K = (const bf16_t*)a->K; p.V = (const bf16_t*)a->V; p.O = (bf16_t*)a->O;
+  p.qsb = a->q_stride_b; p.qsh = a->q_stride_h; p.qsr = a->q_stride_row;
+  p.ksb = a->k_stride_b; p.ksh = a->k_stride_h; p.ksr = a->k_stride_row;
+  p.vsb = a->v_stride_b; p.vsh = a->v_stride_h; p.vsr = a->v_stride_row;
+  p.osb = a->o_stride_b; p.osh = a->o_stride_h; p.osr = a->o_stride_row;
+  p.batch = a->batch; p.heads = a->heads; p.Nq = a->Nq; p.Nk = a->Nk;
+  p.scale_log2 = a->scale * LOG2E;
+  p.causal = a->causal; p.key_mask = a->key_mask;
+  p.rel_h = a->rel_h; p.rel_w = a->rel_w; p.rel_ld = a->rel_ld; p.gh = a->grid_h; p.gw = a->grid_w;
+  p.o_row_map = a->o_row_map;
+  hipStream_t s = (hipStream_t)stream;
+  switch (a->head_dim) {
+    case 32: launch_hd<32>(p, s); break;
+    case 64: launch_hd<64>(p, s); break;
+    case 80: launch_hd<80>(p, s); break;
+    default: launch_hd<128>(p, s); break;
+  }
+  LL_LAUNCH_CHECK("attn_fwd");
+  return LLMSEG_OK;
+}

@@ -1,0 +1,72 @@
+// C-ABI glue shared by all kernels: error string, version, optional per-GEMM HIP-event timing.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <mutex>
+#include <vector>
+#include "llmseg_hip.h"
+
+static thread_local char g_err[512] = "";
+
+void llmseg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* llmseg_last_error(void) { return g_err; }
+extern "C" int llmseg_version(void) { return 1; }
+
+// ---- GEMM timing: one (start, stop) event pair per launch, recorded on the launch stream -----------------------
+namespace {
+struct ProfRec { hipEvent_t a, b; double flops; };
+std::mutex g_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_recs;
+std::vector<ProfRec> g_pool;
+hipEvent_t g_cur = nullptr;
+}  // namespace
+
+void llmseg_prof_begin(hipStream_t s) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  ProfRec r;
+  if (!g_pool.empty()) { r = g_pool.back(); g_pool.pop_back(); }
+  else { hipEventCreate(&r.a); hipEventCreate(&r.b); }
+  r.flops = 0;
+  hipEventRecord(r.a, s);
+  g_recs.push_back(r);
+}
+
+void llmseg_prof_end(hipStream_t s, double flops) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_recs.empty()) return;
+  g_recs.back().flops = flops;
+  hipEventRecord(g_recs.back().b, s);
+}
+
+extern "C" int llmseg_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_prof_on = on != 0;
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_prof_collect(double* total_ms, double* total_flops, int64_t* launches) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  double ms = 0, fl = 0;
+  for (auto& r : g_recs) {
+    hipEventSynchronize(r.b);
+    float t = 0;
+    hipEventElapsedTime(&t, r.a, r.b);
+    ms += t;
+    fl += r.flops;
+    g_pool.push_back(r);
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = (int64_t)g_recs.size();
+  g_recs.clear();
+  return LLMSEG_OK;
+}

@@ -1,0 +1,208 @@
+// Mask-selection head kernels (HBM-bound): fused upsample+mask-pooling, cosine scoring, the two live losses
+// (softmax-KL align + weighted-MSE IoP regression), the north_star-named dice/BCE losses, and the shifted
+// cross-entropy over the LM logits.  See include/llmseg_hip.h for the reference lines each one replaces.
+#include "common.h"
+#include "llmseg_hip.h"
+
+namespace {
+
+// ---- pooled[k][:] = (segs[k] . U) . feat / (sum segs[k] + 1e-8) -------------------------------------------------------
+// One workgroup per proposal k.  Phase 1 streams the S x S mask once (the only large HBM operand: K*S*S*2 bytes in
+// total) and scatters every non-zero pixel through the ADJOINT of the bilinear interpolation into a g x g fp32
+// accumulator in LDS (ds_add_f32; 4 taps per pixel).  Phase 2 is the small dense product with the L2-resident
+// channels-last feature map.  The [C][S][S] upsampled tensor of the reference is never formed.
+__global__ __launch_bounds__(256) void upsample_maskpool_kernel(const bf16_t* __restrict__ feat, const bf16_t* __restrict__ segs,
+                                                               bf16_t* __restrict__ pooled, int C, int g, int S) {
+  extern __shared__ float acc[];                 // g*g (+16 for reductions)
+  float* red = acc + g * g;
+  const int k = blockIdx.x;
+  for (int i = threadIdx.x; i < g * g; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  const float scale = (float)g / (float)S;
+  const bf16_t* m = segs + (long)k * S * S;
+  float wsum = 0.f;
+  for (int px = threadIdx.x; px < S; px += blockDim.x) {
+    // F.interpolate(bilinear, align_corners=False): src = max(0, (dst + .5) * scale - .5)
+    const float sx = fmaxf(0.f, ((float)px + 0.5f) * scale - 0.5f);
+    const int x0 = (int)sx, x1 = min(x0 + 1, g - 1);
+    const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+    for (int py = 0; py < S; ++py) {
+      const float v = bf2f(m[(long)py * S + px]);
+      if (v != 0.f) {
+        wsum += v;
+        const float sy = fmaxf(0.f, ((float)py + 0.5f) * scale - 0.5f);
+        const int y0 = (int)sy, y1 = min(y0 + 1, g - 1);
+        const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
+        atomicAdd(&acc[y0 * g + x0], v * ly0 * lx0);
+        atomicAdd(&acc[y0 * g + x1], v * ly0 * lx1);
+        atomicAdd(&acc[y1 * g + x0], v * ly1 * lx0);
+        atomicAdd(&acc[y1 * g + x1], v * ly1 * lx1);
+      }
+    }
+  }
+  wsum = block_sum(wsum, red);      // includes the barriers that publish acc[]
+  const float inv = 1.f / (wsum + 1e-8f);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = 0.f;
+    for (int s = 0; s < g * g; ++s) a += acc[s] * bf2f(feat[(long)s * C + c]);
+    pooled[(long)k * C + c] = f2bf(a * inv);
+  }
+}
+
+// ---- cosine scores: one wave per proposal ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cosine_kernel(const bf16_t* __restrict__ t, const bf16_t* __restrict__ e, float* __restrict__ sim, int K, int D) {
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= K) return;
+  float dot = 0.f, ne = 0.f, ntt = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float a = bf2f(t[d]), b = bf2f(e[(long)k * D + d]);
+    dot += a * b; ne += b * b; ntt += a * a;
+  }
+  dot = wave_sum(dot); ne = wave_sum(ne); ntt = wave_sum(ntt);
+  if (lane == 0) sim[k] = dot / (sqrtf(ne) * sqrtf(ntt));
+}
+
+// ---- align (KL) + IoP regression losses for one (image, round); single workgroup --------------------------------------
+__global__ __launch_bounds__(256) void align_reg_kernel(const bf16_t* __restrict__ e, const bf16_t* __restrict__ t, const float* __restrict__ gt_iou,
+                                                       const bf16_t* __restrict__ pred, const float* __restrict__ gt_iop, float* __restrict__ out,
+                                                       float* __restrict__ d_e, float* __restrict__ d_t, float* __restrict__ d_pred, int K, int D,
+                                                       float tau) {
+  extern __shared__ float sm[];                  // cos[K], enorm[K], gsoft[K], red[16]
+  float* cs = sm; float* en = sm + K; float* gs = sm + 2 * K; float* red = sm + 3 * K;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  float tn2 = 0.f;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) { const float a = bf2f(t[d]); tn2 += a * a; }
+  tn2 = block_sum(tn2, red);
+  const float tn = sqrtf(tn2);
+  for (int k = wv; k < K; k += nw) {
+    float dot = 0.f, ne = 0.f;
+    for (int d = lane; d < D; d += 64) { const float a = bf2f(t[d]), b = bf2f(e[(long)k * D + d]); dot += a * b; ne += b * b; }
+    dot = wave_sum(dot); ne = wave_sum(ne);
+    if (lane == 0) { en[k] = sqrtf(ne); cs[k] = dot / (sqrtf(ne) * tn); }
+  }
+  __syncthreads();
+  // softmax over K of cos/tau and gt/tau
+  float mx_s = -1e30f, mx_g = -1e30f;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) { mx_s = fmaxf(mx_s, cs[k] / tau); mx_g = fmaxf(mx_g, gt_iou[k] / tau); }
+  mx_s = block_max(mx_s, red); mx_g = block_max(mx_g, red);
+  float se = 0.f, ge = 0.f;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) { se += __expf(cs[k] / tau - mx_s); ge += __expf(gt_iou[k] / tau - mx_g); }
+  se = block_sum(se, red); ge = block_sum(ge, red);
+  const float lse_s = mx_s + __logf(se), lse_g = mx_g + __logf(ge);
+  float kl = 0.f, rg = 0.f;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const float lg = gt_iou[k] / tau - lse_g, ls = cs[k] / tau - lse_s;
+    const float pg = __expf(lg);
+    gs[k] = pg;
+    kl += pg > 0.f ? pg * (lg - ls) : 0.f;          // F.kl_div(log q, p): p * (log p - log q), 0 where p == 0
+    const float pr = bf2f(pred[k]), g = gt_iop[k];
+    const float w = __expf(g - 1.f);
+    rg += (pr - g) * (pr - g) * w;
+    if (d_pred) d_pred[k] = 2.f * (pr - g) * w * 50.f / (float)K;
+  }
+  kl = block_sum(kl, red); rg = block_sum(rg, red);
+  if (threadIdx.x == 0) { out[0] = kl; out[1] = rg / (float)K * 50.f; }
+  if (d_e || d_t) {
+    // dKL/dcos_k = (softmax_s[k] - softmax_g[k]) / tau;  cos_k = <e_k, t> / (|e_k||t|)
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+      float acc_t = 0.f;
+      const float td = bf2f(t[d]);
+      for (int k = 0; k < K; ++k) {
+        const float gk = (__expf(cs[k] / tau - lse_s) - gs[k]) / tau;
+        const float ed = bf2f(e[(long)k * D + d]);
+        if (d_e) d_e[(long)k * D + d] = gk * (td / (en[k] * tn) - cs[k] * ed / (en[k] * en[k]));
+        acc_t += gk * (ed / (en[k] * tn) - cs[k] * td / (tn * tn));
+      }
+      if (d_t) d_t[d] = acc_t;
+    }
+  }
+}
+
+// ---- dice + BCE-with-logits, one workgroup per mask ----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dice_bce_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, long HW,
+                                                      float num_masks) {
+  __shared__ float red[16];
+  const long m = blockIdx.x;
+  float sxy = 0.f, sx = 0.f, sy = 0.f, bce = 0.f;
+  for (long i = threadIdx.x; i < HW; i += blockDim.x) {
+    const float l = x[m * HW + i], t = y[m * HW + i];
+    const float s = 1.f / (1.f + __expf(-l));
+    sxy += s * t; sx += s; sy += t;
+    bce += fmaxf(l, 0.f) - l * t + log1pf(__expf(-fabsf(l)));
+  }
+  sxy = block_sum(sxy, red); sx = block_sum(sx, red); sy = block_sum(sy, red); bce = block_sum(bce, red);
+  if (threadIdx.x == 0) {
+    const float sc = 1000.f, eps = 1e-6f;
+    const float dice = 1.f - (2.f * sxy / sc + eps) / (sx / sc + sy / sc + eps);
+    atomicAdd(&out[0], dice / (num_masks + 1e-8f));
+    atomicAdd(&out[1], bce / (float)HW / (num_masks + 1e-8f));
+  }
+}
+
+// ---- shifted CE: one workgroup per (n, t) with a valid label -------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logits, const int64_t* __restrict__ labels, float* __restrict__ acc, int T,
+                                                long V, long ldl) {
+  __shared__ float red[16];
+  const int n = blockIdx.x / (T - 1), t = blockIdx.x % (T - 1);
+  const long lab = labels[(long)n * T + t + 1];
+  if (lab < 0 || lab >= V) return;                        // ignore_index (-100)
+  const bf16_t* row = logits + ((long)n * T + t) * ldl;
+  float mx = -1e30f;
+  for (long i = threadIdx.x; i < V; i += blockDim.x) mx = fmaxf(mx, bf2f(row[i]));
+  mx = block_max(mx, red);
+  float s = 0.f;
+  for (long i = threadIdx.x; i < V; i += blockDim.x) s += __expf(bf2f(row[i]) - mx);
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&acc[0], mx + __logf(s) - bf2f(row[lab]));
+    atomicAdd(&acc[1], 1.f);
+  }
+}
+
+}  // namespace
+
+extern "C" int llmseg_upsample_maskpool(const void* feat, const void* segs, void* pooled, int32_t K, int32_t C, int32_t g, int32_t S,
+                                        void* stream) {
+  LL_CHECK(feat && segs && pooled && K > 0 && C > 0 && g > 0 && S >= g, "upsample_maskpool: bad arguments");
+  const size_t lds = ((size_t)g * g + 16) * sizeof(float);
+  LL_CHECK(lds <= 64 * 1024, "upsample_maskpool: feature grid %d too large for LDS", g);
+  hipLaunchKernelGGL(upsample_maskpool_kernel, dim3(K), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)feat, (const bf16_t*)segs,
+                     (bf16_t*)pooled, C, g, S);
+  LL_LAUNCH_CHECK("upsample_maskpool");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_cosine_scores(const void* t, const void* e, float* sim, int32_t K, int32_t D, void* stream) {
+  LL_CHECK(t && e && sim && K > 0 && D > 0, "cosine_scores: bad arguments");
+  hipLaunchKernelGGL(cosine_kernel, dim3((K + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)e, sim, K, D);
+  LL_LAUNCH_CHECK("cosine_scores");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_align_reg_loss(const void* e, const void* t, const float* gt_iou, const void* pred_iou, const float* gt_iop, float* out,
+                                     float* d_e, float* d_t, float* d_pred, int32_t K, int32_t D, float tau, void* stream) {
+  LL_CHECK(e && t && gt_iou && pred_iou && gt_iop && out && K > 0 && D > 0 && tau > 0.f, "align_reg_loss: bad arguments");
+  const size_t lds = ((size_t)3 * K + 16) * sizeof(float);
+  LL_CHECK(lds <= 64 * 1024, "align_reg_loss: K=%d too large", K);
+  hipLaunchKernelGGL(align_reg_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)e, (const bf16_t*)t, gt_iou,
+                     (const bf16_t*)pred_iou, gt_iop, out, d_e, d_t, d_pred, K, D, tau);
+  LL_LAUNCH_CHECK("align_reg_loss");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_dice_bce(const float* logits, const float* targets, float* out, int32_t M, int64_t HW, float num_masks, void* stream) {
+  LL_CHECK(logits && targets && out && M > 0 && HW > 0, "dice_bce: bad arguments");
+  hipLaunchKernelGGL(dice_bce_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, targets, out, (long)HW, num_masks);
+  LL_LAUNCH_CHECK("dice_bce");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_ce_loss(const void* logits, const int64_t* labels, float* acc, int32_t N, int32_t T, int64_t V, int64_t ldl, void* stream) {
+  LL_CHECK(logits && labels && acc && N > 0 && T > 1 && V > 0 && ldl >= V, "ce_loss: bad arguments");
+  hipLaunchKernelGGL(ce_kernel, dim3((unsigned)(N * (T - 1))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, labels, acc, T, (long)V,
+                     (long)ldl);
+  LL_LAUNCH_CHECK("ce_loss");
+  return LLMSEG_OK;
+}

@@ -1,0 +1,272 @@
+// HBM-bound glue kernels for the LLM-Seg hot path on gfx950: row norms, RoPE, SwiGLU, positional adds, im2col,
+// LLaVA embedding splice, row gather.  All are streaming kernels: 16-byte (8 x bf16) accesses per lane, wave64
+// shuffles for row statistics, fp32 math, one rounding to bf16 on store (see include/llmseg_hip.h for the
+// reference ops each one replaces).
+#include "common.h"
+#include "llmseg_hip.h"
+
+namespace {
+
+// ---- LayerNorm / RMSNorm: one wave per row, three L1-resident passes ----------------------------------------------
+__global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                  const bf16_t* __restrict__ bias, bf16_t* __restrict__ y, long rows, int cols,
+                                                  long ldx, long ldy, float eps, int rms, const int32_t* __restrict__ row_map) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * ldx;
+  const int nch = cols >> 3;
+  float f[8];
+  float s = 0.f;
+  if (!rms) {
+    for (int c = lane; c < nch; c += 64) {
+      unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += f[e];
+    }
+    s = wave_sum(s);
+  }
+  const float mean = rms ? 0.f : s / (float)cols;
+  float v = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; v += d * d; }
+  }
+  v = wave_sum(v);
+  const float rstd = rsqrtf(v / (float)cols + eps);
+  long orow = row;
+  if (row_map) { orow = row_map[row]; if (orow < 0) return; }
+  bf16_t* yr = y + orow * ldy;
+  for (int c = lane; c < nch; c += 64) {
+    float g[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
+    unpack8(*reinterpret_cast<const uint4*>(w + c * 8), g);
+    if (rms) {
+      // HF LlamaRMSNorm rounds the normalised value to the activation dtype before the weight multiply
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = g[e] * bf2f(f2bf(f[e] * rstd));
+    } else {
+      float bb[8];
+      if (bias) unpack8(*reinterpret_cast<const uint4*>(bias + c * 8), bb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (f[e] - mean) * rstd * g[e] + (bias ? bb[e] : 0.f);
+    }
+    *reinterpret_cast<uint4*>(yr + c * 8) = pack8(o);
+  }
+}
+
+// ---- RoPE (rotate-half), in place ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ x, const float* __restrict__ cs, const float* __restrict__ sn,
+                                                  long rows, long T, int heads, int hd, long ld) {
+  const int hc = hd >> 4;                       // 8-wide chunks in half a head
+  const long total = rows * heads * hc;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % hc);
+    const long rh = i / hc;
+    const int h = (int)(rh % heads);
+    const long row = rh / heads;
+    const long pos = row % T;
+    bf16_t* p1 = x + row * ld + (long)h * hd + c * 8;
+    bf16_t* p2 = p1 + (hd >> 1);
+    float a[8], b[8], o1[8], o2[8];
+    unpack8(*reinterpret_cast<const uint4*>(p1), a);
+    unpack8(*reinterpret_cast<const uint4*>(p2), b);
+    const float* cp = cs + pos * (hd >> 1) + c * 8;
+    const float* sp = sn + pos * (hd >> 1) + c * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      o1[e] = a[e] * cp[e] - b[e] * sp[e];
+      o2[e] = b[e] * cp[e] + a[e] * sp[e];
+    }
+    *reinterpret_cast<uint4*>(p1) = pack8(o1);
+    *reinterpret_cast<uint4*>(p2) = pack8(o2);
+  }
+}
+
+__global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, long rows, long I,
+                                                    long ldgu, long ldo) {
+  const long ich = I >> 3, total = rows * ich;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / ich, c = i % ich;
+    float g[8], u[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(gu + row * ldgu + c * 8), g);
+    unpack8(*reinterpret_cast<const uint4*>(gu + row * ldgu + I + c * 8), u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = g[e] / (1.f + __expf(-g[e])) * u[e];
+    *reinterpret_cast<uint4*>(out + row * ldo + c * 8) = pack8(o);
+  }
+}
+
+__global__ __launch_bounds__(256) void add_rows_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ add, bf16_t* __restrict__ y,
+                                                      long rows, long cols, long add_rows) {
+  const long nch = cols >> 3, total = rows * nch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / nch, c = i % nch;
+    float a[8], b[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + row * cols + c * 8), a);
+    unpack8(*reinterpret_cast<const uint4*>(add + (row % add_rows) * cols + c * 8), b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += b[e];
+    *reinterpret_cast<uint4*>(y + row * cols + c * 8) = pack8(a);
+  }
+}
+
+// one thread per (patch row, channel, in-patch row): p contiguous pixels; tail threads zero-fill the K padding
+__global__ __launch_bounds__(256) void patchify_kernel(const bf16_t* __restrict__ img, bf16_t* __restrict__ cols, int B, int H, int W, int p,
+                                                      long ldo, long rows_per_img, long row_off) {
+  const int gh = H / p, gw = W / p;
+  const int runs = 3 * p + 1;                   // +1: padding run
+  const long total = (long)B * gh * gw * runs;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int run = (int)(i % runs);
+    const long patch = i / runs;
+    const int px = (int)(patch % gw);
+    const int py = (int)((patch / gw) % gh);
+    const int b = (int)(patch / ((long)gw * gh));
+    bf16_t* dst = cols + ((long)b * rows_per_img + row_off + (long)py * gw + px) * ldo;
+    if (run == 3 * p) {
+      for (long k = 3L * p * p; k < ldo; ++k) dst[k] = 0;
+    } else {
+      const int c = run / p, iy = run % p;
+      const bf16_t* src = img + (((long)b * 3 + c) * H + (long)py * p + iy) * W + (long)px * p;
+      dst += (long)c * p * p + (long)iy * p;
+      for (int j = 0; j < p; ++j) dst[j] = src[j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ cols, int B, int H, int W, int C) {
+  const int cch = C >> 3;
+  const long total = (long)B * H * W * 9 * cch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cch);
+    long r = i / cch;
+    const int tap = (int)(r % 9); r /= 9;
+    const int xx = (int)(r % W); r /= W;
+    const int yy = (int)(r % H);
+    const int b = (int)(r / H);
+    const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = *reinterpret_cast<const uint4*>(x + (((long)b * H + sy) * W + sx) * C + c * 8);
+    *reinterpret_cast<uint4*>(cols + (((long)b * H + yy) * W + xx) * 9L * C + (long)tap * C + c * 8) = v;
+  }
+}
+
+// one block per output position (n, t)
+__global__ __launch_bounds__(256) void embed_splice_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ embed,
+                                                          const bf16_t* __restrict__ feats, bf16_t* __restrict__ out, int N, int L, int P, int Hd,
+                                                          long vocab) {
+  __shared__ int s_pos;
+  const int Tn = L - 1 + P;
+  const int n = blockIdx.x / Tn, t = blockIdx.x % Tn;
+  if (threadIdx.x == 0) s_pos = L;
+  __syncthreads();
+  for (int i = threadIdx.x; i < L; i += blockDim.x)
+    if (ids[(long)n * L + i] == -200) atomicMin(&s_pos, i);
+  __syncthreads();
+  const int ip = s_pos;
+  const bf16_t* src;
+  if (t >= ip && t < ip + P) {
+    src = feats + ((long)n * P + (t - ip)) * Hd;
+  } else {
+    long id = ids[(long)n * L + (t < ip ? t : t - P + 1)];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    src = embed + id * Hd;
+  }
+  bf16_t* dst = out + ((long)n * Tn + t) * Hd;
+  for (int c = threadIdx.x; c < (Hd >> 3); c += blockDim.x)
+    *reinterpret_cast<uint4*>(dst + c * 8) = *reinterpret_cast<const uint4*>(src + c * 8);
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ x, const int64_t* __restrict__ idx, bf16_t* __restrict__ out,
+                                                         long n, long cols, long ldx) {
+  const long nch = cols >> 3, total = n * nch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / nch, c = i % nch;
+    *reinterpret_cast<uint4*>(out + r * cols + c * 8) = *reinterpret_cast<const uint4*>(x + idx[r] * ldx + c * 8);
+  }
+}
+
+inline unsigned grid_for(long total) {
+  long g = (total + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+#define AL16(p) ((((uintptr_t)(p)) & 15) == 0)
+
+extern "C" int llmseg_norm(const void* x, const void* w, const void* b, void* y, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy,
+                           float eps, int rms, const int32_t* row_map, void* stream) {
+  LL_CHECK(x && w && y && rows > 0 && cols > 0, "norm: bad arguments");
+  LL_CHECK((cols & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0, "norm: cols/ld must be multiples of 8");
+  LL_CHECK(AL16(x) && AL16(w) && AL16(y) && (b == nullptr || AL16(b)), "norm: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(norm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w,
+                     (const bf16_t*)b, (bf16_t*)y, (long)rows, (int)cols, (long)ldx, (long)ldy, eps, rms, row_map);
+  LL_LAUNCH_CHECK("norm");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_rope(void* x, const float* cos, const float* sin, int64_t rows, int64_t T, int32_t heads, int32_t head_dim,
+                           int64_t ld, void* stream) {
+  LL_CHECK(x && cos && sin && rows > 0 && T > 0 && heads > 0, "rope: bad arguments");
+  LL_CHECK((head_dim & 15) == 0 && (ld & 7) == 0 && AL16(x), "rope: head_dim %% 16 and 16-byte alignment required");
+  const long total = rows * heads * (head_dim >> 4);
+  hipLaunchKernelGGL(rope_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, cos, sin, (long)rows, (long)T, heads,
+                     head_dim, (long)ld);
+  LL_LAUNCH_CHECK("rope");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_swiglu(const void* gu, void* out, int64_t rows, int64_t I, int64_t ldgu, int64_t ldo, void* stream) {
+  LL_CHECK(gu && out && rows > 0 && I > 0 && (I & 7) == 0 && (ldgu & 7) == 0 && (ldo & 7) == 0 && AL16(gu) && AL16(out), "swiglu: bad arguments");
+  hipLaunchKernelGGL(swiglu_kernel, dim3(grid_for(rows * (I >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gu, (bf16_t*)out,
+                     (long)rows, (long)I, (long)ldgu, (long)ldo);
+  LL_LAUNCH_CHECK("swiglu");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_add_rows(const void* x, const void* add, void* y, int64_t rows, int64_t cols, int64_t add_rows, void* stream) {
+  LL_CHECK(x && add && y && rows > 0 && (cols & 7) == 0 && add_rows > 0 && AL16(x) && AL16(add) && AL16(y), "add_rows: bad arguments");
+  hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(rows * (cols >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)add,
+                     (bf16_t*)y, (long)rows, (long)cols, (long)add_rows);
+  LL_LAUNCH_CHECK("add_rows");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_patchify(const void* img, void* cols, int32_t B, int32_t H, int32_t W, int32_t p, int64_t ldo, int64_t out_rows_per_img,
+                               int64_t out_row_offset, void* stream) {
+  LL_CHECK(img && cols && B > 0 && p > 0 && H % p == 0 && W % p == 0 && ldo >= 3L * p * p, "patchify: bad arguments");
+  const long total = (long)B * (H / p) * (W / p) * (3 * p + 1);
+  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)img, (bf16_t*)cols, B, H, W, p,
+                     (long)ldo, (long)out_rows_per_img, (long)out_row_offset);
+  LL_LAUNCH_CHECK("patchify");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_im2col3x3(const void* x, void* cols, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+  LL_CHECK(x && cols && B > 0 && H > 0 && W > 0 && (C & 7) == 0 && AL16(x) && AL16(cols), "im2col3x3: bad arguments");
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for((long)B * H * W * 9 * (C >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (bf16_t*)cols, B, H, W, C);
+  LL_LAUNCH_CHECK("im2col3x3");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_embed_splice(const int64_t* ids, const void* embed, const void* img_feats, void* out, int32_t N, int32_t L, int32_t P,
+                                   int32_t H, int64_t vocab, void* stream) {
+  LL_CHECK(ids && embed && img_feats && out && N > 0 && L > 0 && P > 0 && (H & 7) == 0 && AL16(embed) && AL16(img_feats) && AL16(out),
+           "embed_splice: bad arguments");
+  hipLaunchKernelGGL(embed_splice_kernel, dim3((unsigned)(N * (L - 1 + P))), dim3(256), 0, (hipStream_t)stream, ids, (const bf16_t*)embed,
+                     (const bf16_t*)img_feats, (bf16_t*)out, N, L, P, H, (long)vocab);
+  LL_LAUNCH_CHECK("embed_splice");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_gather_rows(const void* x, const int64_t* idx, void* out, int64_t n, int64_t cols, int64_t ldx, void* stream) {
+  LL_CHECK(x && idx && out && n > 0 && (cols & 7) == 0 && (ldx & 7) == 0 && AL16(x) && AL16(out), "gather_rows: bad arguments");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n * (cols >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, idx, (bf16_t*)out,
+                     (long)n, (long)cols, (long)ldx);
+  LL_LAUNCH_CHECK("gather_rows");
+  return LLMSEG_OK;
+}

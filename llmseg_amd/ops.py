@@ -1,0 +1,214 @@
+"""Tensor-level wrappers over the C ABI (include/llmseg_hip.h).
+
+PyTorch is plumbing here: it owns device memory (`torch.empty`) and the current HIP stream; every
+arithmetic op below is a kernel of libllmseg_hip.so.  Inputs must be CUDA(HIP) tensors; nothing in
+this module computes on the CPU.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_SIGMOID, ACT_SILU, AttnArgs, GemmArgs)
+
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _req(t, dtype=BF16):
+    assert t.is_cuda and t.dtype == dtype, f"expected cuda {dtype}, got {t.device} {t.dtype}"
+    return t
+
+
+def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alpha=1.0, out_f32=False):
+    """out[M,N] = residual + gamma * act(alpha * a[M,K] @ w[N,K]^T + bias).  a/w: 2-D bf16, last dim contiguous."""
+    _req(a); _req(w)
+    assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1] and a.stride(1) == 1 and w.stride(1) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else BF16)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    g = GemmArgs(A=a.data_ptr(), W=w.data_ptr(), C=out.data_ptr(),
+                 bias=None if bias is None else _req(bias).data_ptr(),
+                 gamma=None if gamma is None else _req(gamma).data_ptr(),
+                 residual=None if residual is None else _req(residual).data_ptr(),
+                 M=M, N=N, K=K, lda=a.stride(0), ldw=w.stride(0), ldc=out.stride(0),
+                 ldr=0 if residual is None else residual.stride(0),
+                 batch=1, strideA=0, strideW=0, strideC=0, alpha=alpha, act=act, out_f32=1 if out_f32 else 0)
+    if residual is not None:
+        assert residual.shape == (M, N) and residual.stride(1) == 1
+    _lib.check(_lib.load().llmseg_gemm_bf16(C.byref(g), _stream()), "gemm")
+    return out
+
+
+def gemm_batched(a, w, out, M, N, K, lda, ldw, ldc, batch, sA, sW, sC, out_f32=True, alpha=1.0):
+    """Strided-batched GEMM on raw strides (elements); used for the per-head q.R^T relative-position products."""
+    g = GemmArgs(A=a.data_ptr(), W=w.data_ptr(), C=out.data_ptr(), bias=None, gamma=None, residual=None,
+                 M=M, N=N, K=K, lda=lda, ldw=ldw, ldc=ldc, ldr=0, batch=batch, strideA=sA, strideW=sW, strideC=sC,
+                 alpha=alpha, act=ACT_NONE, out_f32=1 if out_f32 else 0)
+    _lib.check(_lib.load().llmseg_gemm_bf16(C.byref(g), _stream()), "gemm_batched")
+    return out
+
+
+def attention(q, k, v, out, *, batch, heads, Nq, Nk, head_dim, q_strides, k_strides, v_strides, o_strides, scale=None,
+              causal=False, key_mask=None, rel_h=None, rel_w=None, rel_ld=0, grid_hw=(0, 0), o_row_map=None):
+    """Strided fused attention.  *_strides = (batch, head, row) in elements relative to the given tensors' data_ptr."""
+    a = AttnArgs(Q=q.data_ptr(), K=k.data_ptr(), V=v.data_ptr(), O=out.data_ptr(),
+                 q_stride_b=q_strides[0], q_stride_h=q_strides[1], q_stride_row=q_strides[2],
+                 k_stride_b=k_strides[0], k_stride_h=k_strides[1], k_stride_row=k_strides[2],
+                 v_stride_b=v_strides[0], v_stride_h=v_strides[1], v_stride_row=v_strides[2],
+                 o_stride_b=o_strides[0], o_stride_h=o_strides[1], o_stride_row=o_strides[2],
+                 batch=batch, heads=heads, Nq=Nq, Nk=Nk, head_dim=head_dim,
+                 scale=(1.0 / math.sqrt(head_dim)) if scale is None else scale, causal=1 if causal else 0,
+                 key_mask=None if key_mask is None else key_mask.data_ptr(),
+                 rel_h=None if rel_h is None else rel_h.data_ptr(), rel_w=None if rel_w is None else rel_w.data_ptr(),
+                 rel_ld=rel_ld, grid_h=grid_hw[0], grid_w=grid_hw[1],
+                 o_row_map=None if o_row_map is None else o_row_map.data_ptr())
+    _lib.check(_lib.load().llmseg_attn_fwd(C.byref(a), _stream()), "attn_fwd")
+    return out
+
+
+def attention_packed(qkv, batch, n_tok, heads, head_dim, out=None, **kw):
+    """qkv [batch*n_tok, 3*heads*head_dim] (q|k|v, heads-major inside each) -> out [batch*n_tok, heads*head_dim]."""
+    D = heads * head_dim
+    assert qkv.shape == (batch * n_tok, 3 * D) and qkv.stride(1) == 1
+    ld = qkv.stride(0)
+    if out is None:
+        out = torch.empty((batch * n_tok, D), device=qkv.device, dtype=BF16)
+    st = (n_tok * ld, head_dim, ld)
+    return attention(qkv, qkv[:, D:], qkv[:, 2 * D:], out, batch=batch, heads=heads, Nq=n_tok, Nk=n_tok, head_dim=head_dim,
+                     q_strides=st, k_strides=st, v_strides=st, o_strides=(n_tok * out.stride(0), head_dim, out.stride(0)), **kw)
+
+
+def norm(x, w, b=None, eps=1e-5, rms=False, out=None, row_map=None, out_rows=None):
+    _req(x); _req(w)
+    assert x.dim() == 2 and x.stride(1) == 1
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((rows if out_rows is None else out_rows, cols), device=x.device, dtype=BF16)
+    _lib.check(_lib.load().llmseg_norm(_ptr(x), _ptr(w), _ptr(b), _ptr(out), rows, cols, x.stride(0), out.stride(0), eps,
+                                       1 if rms else 0, _ptr(row_map), _stream()), "norm")
+    return out
+
+
+def rope_(x, cos, sin, rows, T, heads, head_dim, ld):
+    _lib.check(_lib.load().llmseg_rope(_ptr(x), _ptr(cos), _ptr(sin), rows, T, heads, head_dim, ld, _stream()), "rope")
+    return x
+
+
+def swiglu(gu, inter, out=None):
+    rows = gu.shape[0]
+    if out is None:
+        out = torch.empty((rows, inter), device=gu.device, dtype=BF16)
+    _lib.check(_lib.load().llmseg_swiglu(_ptr(gu), _ptr(out), rows, inter, gu.stride(0), out.stride(0), _stream()), "swiglu")
+    return out
+
+
+def add_rows(x, add, out=None):
+    """x [rows, cols] + add[(row % add.shape[0])]."""
+    assert x.is_contiguous() and add.is_contiguous() and x.shape[1] == add.shape[1]
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.load().llmseg_add_rows(_ptr(x), _ptr(add), _ptr(out), x.shape[0], x.shape[1], add.shape[0], _stream()), "add_rows")
+    return out
+
+
+def patchify(img, p, ldo, rows_per_img=None, row_off=0, out=None):
+    _req(img)
+    B, Cc, H, W = img.shape
+    assert Cc == 3 and img.is_contiguous()
+    n = (H // p) * (W // p)
+    rows_per_img = n if rows_per_img is None else rows_per_img
+    if out is None:
+        out = torch.zeros((B * rows_per_img, ldo), device=img.device, dtype=BF16) if row_off else \
+            torch.empty((B * rows_per_img, ldo), device=img.device, dtype=BF16)
+    _lib.check(_lib.load().llmseg_patchify(_ptr(img), _ptr(out), B, H, W, p, ldo, rows_per_img, row_off, _stream()), "patchify")
+    return out
+
+
+def im2col3x3(x, B, H, W, Cc):
+    out = torch.empty((B * H * W, 9 * Cc), device=x.device, dtype=BF16)
+    _lib.check(_lib.load().llmseg_im2col3x3(_ptr(x), _ptr(out), B, H, W, Cc, _stream()), "im2col3x3")
+    return out
+
+
+def embed_splice(ids, embed, img_feats, P):
+    N, L = ids.shape
+    H = embed.shape[1]
+    out = torch.empty((N, L - 1 + P, H), device=embed.device, dtype=BF16)
+    _lib.check(_lib.load().llmseg_embed_splice(_ptr(ids), _ptr(embed), _ptr(img_feats), _ptr(out), N, L, P, H, embed.shape[0],
+                                               _stream()), "embed_splice")
+    return out
+
+
+def gather_rows(x, idx):
+    out = torch.empty((idx.shape[0], x.shape[1]), device=x.device, dtype=BF16)
+    if idx.shape[0] == 0:
+        return out
+    _lib.check(_lib.load().llmseg_gather_rows(_ptr(x), _ptr(idx), _ptr(out), idx.shape[0], x.shape[1], x.stride(0), _stream()),
+               "gather_rows")
+    return out
+
+
+def upsample_maskpool(feat_cl, segs, g, S):
+    """feat_cl bf16 [g*g, C] channels-last, segs bf16 [K, S, S] -> pooled bf16 [K, C]."""
+    _req(feat_cl); _req(segs)
+    assert feat_cl.is_contiguous() and segs.is_contiguous()
+    K, Cc = segs.shape[0], feat_cl.shape[1]
+    out = torch.empty((K, Cc), device=segs.device, dtype=BF16)
+    _lib.check(_lib.load().llmseg_upsample_maskpool(_ptr(feat_cl), _ptr(segs), _ptr(out), K, Cc, g, S, _stream()), "upsample_maskpool")
+    return out
+
+
+def cosine_scores(t, e):
+    K, D = e.shape
+    out = torch.empty((K,), device=e.device, dtype=torch.float32)
+    _lib.check(_lib.load().llmseg_cosine_scores(_ptr(t), _ptr(e), _ptr(out), K, D, _stream()), "cosine_scores")
+    return out
+
+
+def align_reg_loss(e, t, gt_iou, pred_iou, gt_iop, tau=0.05, want_grads=False):
+    """-> out fp32[2] = (align KL, IoP regression) and optionally (d_e [K,D], d_t [D], d_pred [K]) fp32."""
+    K, D = e.shape
+    out = torch.empty((2,), device=e.device, dtype=torch.float32)
+    d_e = torch.empty((K, D), device=e.device, dtype=torch.float32) if want_grads else None
+    d_t = torch.empty((D,), device=e.device, dtype=torch.float32) if want_grads else None
+    d_p = torch.empty((K,), device=e.device, dtype=torch.float32) if want_grads else None
+    _lib.check(_lib.load().llmseg_align_reg_loss(_ptr(e), _ptr(t), _ptr(gt_iou), _ptr(pred_iou), _ptr(gt_iop), _ptr(out), _ptr(d_e),
+                                                 _ptr(d_t), _ptr(d_p), K, D, tau, _stream()), "align_reg_loss")
+    return (out, d_e, d_t, d_p) if want_grads else out
+
+
+def dice_bce(logits, targets, num_masks):
+    M = logits.shape[0]
+    HW = logits[0].numel()
+    out = torch.zeros((2,), device=logits.device, dtype=torch.float32)
+    _lib.check(_lib.load().llmseg_dice_bce(_ptr(logits), _ptr(targets), _ptr(out), M, HW, float(num_masks), _stream()), "dice_bce")
+    return out
+
+
+def ce_loss(logits, labels):
+    """logits bf16 [N,T,V(ld)], labels int64 [N,T] (spliced) -> fp32[2] = (sum nll, count)."""
+    N, T, V = logits.shape
+    acc = torch.zeros((2,), device=logits.device, dtype=torch.float32)
+    _lib.check(_lib.load().llmseg_ce_loss(_ptr(logits), _ptr(labels), _ptr(acc), N, T, V, logits.stride(1), _stream()), "ce_loss")
+    return acc
+
+
+def prof_enable(on):
+    _lib.load().llmseg_prof_enable(1 if on else 0)
+
+
+def prof_collect():
+    ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+    _lib.load().llmseg_prof_collect(C.byref(ms), C.byref(fl), C.byref(n))
+    return ms.value, fl.value, n.value

@@ -1,0 +1,257 @@
+"""Per-kernel parity checks: HIP kernel (through the C ABI) vs a plain fp32 PyTorch/oracle computation on the CPU.
+
+Each check returns a list of (name, max_abs_err, tolerance).  Used by tests/test_kernels_gpu.py (asserts) and
+tools/gpu_diag.py (prints the whole table without stopping at the first failure).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from llmseg_amd import ops
+from oracle import losses as olosses
+from oracle import mask_head as ohead
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def err(got, ref):
+    return (got.detach().float().cpu() - ref.float()).abs().max().item()
+
+
+def tol_bf16(ref, k=1.0):
+    return k * (2.0 ** -7) * max(1.0, ref.float().abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------------------------ GEMM
+def check_gemm():
+    out = []
+    for i, (M, N, K) in enumerate([(256, 256, 256), (319, 4096, 4096), (130, 200, 72), (1000, 1280, 1280), (64, 1, 128),
+                                   (4100, 384, 592)]):
+        a, w = rnd(M, K, seed=10 + i), rnd(N, K, seed=20 + i, scale=1 / math.sqrt(K))
+        ref = a.float() @ w.float().t()
+        got = ops.gemm(a.to(DEV), w.to(DEV))
+        out.append((f"gemm {M}x{N}x{K}", err(got, ref), tol_bf16(ref)))
+    # full epilogue: bias + gelu + LayerScale + residual
+    M, N, K = 300, 520, 256
+    a, w, b, g, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / 16), rnd(N, seed=3), rnd(N, seed=4), rnd(M, N, seed=5)
+    for act, fn in ((ops.ACT_GELU, F.gelu), (ops.ACT_RELU, F.relu), (ops.ACT_SILU, F.silu), (ops.ACT_SIGMOID, torch.sigmoid),
+                    (ops.ACT_QUICKGELU, lambda x: x * torch.sigmoid(1.702 * x))):
+        ref = r.float() + g.float() * fn(a.float() @ w.float().t() + b.float())
+        got = ops.gemm(a.to(DEV), w.to(DEV), bias=b.to(DEV), act=act, residual=r.to(DEV), gamma=g.to(DEV))
+        out.append((f"gemm epilogue act={act}", err(got, ref), tol_bf16(ref, 1.5)))
+    # fp32 output, odd ldc, alpha, strided A (a view into a wider buffer)
+    M, N, K = 200, 27, 80
+    big = rnd(M, 3 * K, seed=6)
+    w = rnd(N, K, seed=7)
+    ref = 0.5 * (big[:, K:2 * K].float() @ w.float().t())
+    bigd = big.to(DEV)
+    got = ops.gemm(bigd[:, K:2 * K], w.to(DEV), alpha=0.5, out_f32=True)
+    out.append(("gemm f32-out strided-A N=27", err(got, ref), 1e-3))
+    # strided-batched (per-head q . R^T as used for SAM rel-pos)
+    heads, hd, rows, R = 2, 80, 196, 27
+    q = rnd(rows, 3 * heads * hd, seed=8)
+    tab = rnd(32, hd, seed=9)
+    qd, tabd = q.to(DEV), tab.to(DEV)
+    o = torch.zeros(heads, rows, 32, device=DEV, dtype=torch.float32)
+    ops.gemm_batched(qd, tabd, o, M=rows, N=R, K=hd, lda=3 * heads * hd, ldw=hd, ldc=32, batch=heads, sA=hd, sW=0, sC=rows * 32)
+    ref = torch.stack([q[:, h * hd:(h + 1) * hd].float() @ tab[:R].float().t() for h in range(heads)])
+    out.append(("gemm batched rel-pos", err(o[:, :, :R], ref), 1e-3))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, scale, bias=None):
+    s = (q.float() @ k.float().transpose(-1, -2)) * scale
+    if bias is not None:
+        s = s + bias
+    return torch.softmax(s, -1) @ v.float()
+
+
+def check_attention():
+    out = []
+    for hd, B, H, N in [(32, 2, 8, 256), (64, 1, 4, 257), (128, 2, 2, 319), (80, 3, 2, 196), (64, 1, 2, 1100)]:
+        D = H * hd
+        qkv = rnd(B * N, 3 * D, seed=hd + N, scale=1.0)
+        o = ops.attention_packed(qkv.to(DEV), B, N, H, hd)
+        x = qkv.view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+        ref = _attn_ref(x[0], x[1], x[2], hd ** -0.5).transpose(1, 2).reshape(B * N, D)
+        out.append((f"attn plain hd={hd} N={N}", err(o, ref), tol_bf16(ref, 2.0)))
+    # causal + key padding (Llama form)
+    hd, B, H, N = 128, 2, 2, 319
+    D = H * hd
+    qkv = rnd(B * N, 3 * D, seed=77)
+    km = torch.ones(B, N, dtype=torch.uint8)
+    km[1, 300:] = 0
+    o = ops.attention_packed(qkv.to(DEV), B, N, H, hd, causal=True, key_mask=km.to(DEV))
+    x = qkv.view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    bias = torch.zeros(B, 1, N, N)
+    bias.masked_fill_(torch.ones(N, N, dtype=torch.bool).triu(1)[None, None], -1e30)
+    bias.masked_fill_((km == 0)[:, None, None, :], -1e30)
+    ref = _attn_ref(x[0], x[1], x[2], hd ** -0.5, bias).transpose(1, 2).reshape(B * N, D)
+    out.append(("attn causal+keymask hd=128", err(o, ref), tol_bf16(ref, 2.0)))
+    # decomposed rel-pos: generic grid (14x14 window) and the tile-aligned 64-wide grid
+    for (gh, gw, B, H) in [(14, 14, 3, 2), (30, 30, 1, 2), (64, 64, 1, 1)]:
+        hd, N = 80, gh * gw
+        D = H * hd
+        qkv = rnd(B * N, 3 * D, seed=gh, scale=0.7)
+        R = 2 * max(gh, gw) - 1
+        ld = (R + 3) // 4 * 4
+        relh = (torch.randn(B, H, N, ld, generator=torch.Generator().manual_seed(gh + 1)) * 0.5)
+        relw = (torch.randn(B, H, N, ld, generator=torch.Generator().manual_seed(gh + 2)) * 0.5)
+        o = ops.attention_packed(qkv.to(DEV), B, N, H, hd, rel_h=relh.to(DEV), rel_w=relw.to(DEV), rel_ld=ld, grid_hw=(gh, gw))
+        x = qkv.view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+        qi = torch.arange(N)
+        qh_, qw_ = qi // gw, qi % gw
+        ih = (qh_[:, None] - qh_[None, :] + gh - 1)       # [Nq, Nk] index into rel_h rows
+        iw = (qw_[:, None] - qw_[None, :] + gw - 1)
+        bias = torch.gather(relh, 3, ih[None, None].expand(B, H, N, N)) + torch.gather(relw, 3, iw[None, None].expand(B, H, N, N))
+        ref = _attn_ref(x[0], x[1], x[2], hd ** -0.5, bias).transpose(1, 2).reshape(B * N, D)
+        out.append((f"attn rel-pos grid {gh}x{gw}", err(o, ref), tol_bf16(ref, 2.0)))
+    # o_row_map: scatter rows (window un-partition): reverse order, skip every 5th query
+    hd, B, H, N = 80, 2, 2, 196
+    D = H * hd
+    qkv = rnd(B * N, 3 * D, seed=5)
+    rm = torch.arange(B * N - 1, -1, -1, dtype=torch.int32)
+    rm[::5] = -1
+    od = torch.zeros(B * N, D, device=DEV, dtype=BF)
+    ops.attention_packed(qkv.to(DEV), B, N, H, hd, out=od, o_row_map=rm.to(DEV))
+    x = qkv.view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    full = _attn_ref(x[0], x[1], x[2], hd ** -0.5).transpose(1, 2).reshape(B * N, D)
+    ref = torch.zeros(B * N, D)
+    keep = rm >= 0
+    ref[rm[keep].long()] = full[keep]
+    out.append(("attn o_row_map", err(od, ref), tol_bf16(ref, 2.0)))
+    # cross attention shape of the head: Nq != Nk (1 query over K keys), separate tensors
+    hd, H, Nq, Nk = 32, 8, 1, 256
+    q, k, v = rnd(Nq, H * hd, seed=1), rnd(Nk, H * hd, seed=2), rnd(Nk, H * hd, seed=3)
+    od = torch.empty(Nq, H * hd, device=DEV, dtype=BF)
+    ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), od, batch=1, heads=H, Nq=Nq, Nk=Nk, head_dim=hd,
+                  q_strides=(0, hd, H * hd), k_strides=(0, hd, H * hd), v_strides=(0, hd, H * hd), o_strides=(0, hd, H * hd))
+    sp = lambda t, n: t.view(n, H, hd).transpose(0, 1)
+    ref = _attn_ref(sp(q, Nq), sp(k, Nk), sp(v, Nk), hd ** -0.5).transpose(0, 1).reshape(Nq, H * hd)
+    out.append(("attn cross 1xK hd=32", err(od, ref), tol_bf16(ref, 2.0)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------- pointwise
+def check_pointwise():
+    out = []
+    x, w, b = rnd(333, 1280, seed=1, scale=2.0), rnd(1280, seed=2), rnd(1280, seed=3)
+    ref = F.layer_norm(x.float(), (1280,), w.float(), b.float(), 1e-6)
+    out.append(("layernorm", err(ops.norm(x.to(DEV), w.to(DEV), b.to(DEV), eps=1e-6), ref), tol_bf16(ref)))
+    x, w = rnd(100, 4096, seed=4, scale=3.0), rnd(4096, seed=5)
+    xf = x.float()
+    ref = w.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(BF).float()
+    out.append(("rmsnorm", err(ops.norm(x.to(DEV), w.to(DEV), None, eps=1e-6, rms=True), ref), tol_bf16(ref)))
+    # row_map (window partition): map row r -> 2r+1, others stay zero
+    x, w, b = rnd(50, 160, seed=6), rnd(160, seed=7), rnd(160, seed=8)
+    rm = (torch.arange(50, dtype=torch.int32) * 2 + 1)
+    y = torch.zeros(101, 160, device=DEV, dtype=BF)
+    ops.norm(x.to(DEV), w.to(DEV), b.to(DEV), eps=1e-6, out=y, row_map=rm.to(DEV))
+    ref = torch.zeros(101, 160)
+    ref[rm.long()] = F.layer_norm(x.float(), (160,), w.float(), b.float(), 1e-6)
+    out.append(("layernorm row_map", err(y, ref), tol_bf16(ref)))
+    # rope on q|k of a packed qkv
+    T, nh, hd, N = 37, 2, 128, 3
+    qkv = rnd(N * T, 3 * nh * hd, seed=9)
+    inv = 1.0 / (10000 ** (torch.arange(0, hd, 2).float() / hd))
+    ang = torch.outer(torch.arange(T).float(), inv)
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    d = qkv.to(DEV).clone()
+    ops.rope_(d, cos.to(DEV), sin.to(DEV), N * T, T, 2 * nh, hd, 3 * nh * hd)
+    xr = qkv.float().view(N, T, 3, nh, hd)
+    c2, s2 = torch.cat([cos, cos], -1)[None, :, None], torch.cat([sin, sin], -1)[None, :, None]
+    rot = lambda t: torch.cat([-t[..., hd // 2:], t[..., :hd // 2]], -1)
+    ref = xr.clone()
+    for j in (0, 1):
+        ref[:, :, j] = xr[:, :, j] * c2 + rot(xr[:, :, j]) * s2
+    out.append(("rope", err(d, ref.view(N * T, -1)), tol_bf16(ref)))
+    gu = rnd(77, 2 * 512, seed=10)
+    ref = F.silu(gu[:, :512].float()) * gu[:, 512:].float()
+    out.append(("swiglu", err(ops.swiglu(gu.to(DEV), 512), ref), tol_bf16(ref)))
+    x, a = rnd(3 * 50, 64, seed=11), rnd(50, 64, seed=12)
+    ref = x.float() + a.float().repeat(3, 1)
+    out.append(("add_rows", err(ops.add_rows(x.to(DEV), a.to(DEV)), ref), tol_bf16(ref)))
+    for p, Hh in ((14, 56), (16, 64)):
+        img = rnd(2, 3, Hh, Hh, seed=p)
+        ld = (3 * p * p + 7) // 8 * 8
+        got = ops.patchify(img.to(DEV), p, ld)
+        ref = F.unfold(img.float(), p, stride=p).transpose(1, 2).reshape(-1, 3 * p * p)
+        out.append((f"patchify p={p}", max(err(got[:, :3 * p * p], ref), got[:, 3 * p * p:].float().abs().max().item()), 0.0))
+    got = ops.patchify(rnd(2, 3, 28, 28, seed=3).to(DEV), 14, 592, rows_per_img=5, row_off=1)
+    ref = torch.zeros(10, 588)
+    ref.view(2, 5, 588)[:, 1:] = F.unfold(rnd(2, 3, 28, 28, seed=3).float(), 14, stride=14).transpose(1, 2)
+    out.append(("patchify cls-offset", err(got[:, :588], ref), 0.0))
+    x = rnd(2, 6, 5, 16, seed=13)
+    got = ops.im2col3x3(x.to(DEV), 2, 6, 5, 16)
+    ref = F.unfold(x.float().permute(0, 3, 1, 2), 3, padding=1)               # [B, C*9, HW], index c*9 + tap
+    ref = ref.view(2, 16, 9, 30).permute(0, 3, 2, 1).reshape(60, 144)         # -> [B*HW, tap*C + c]
+    out.append(("im2col3x3", err(got, ref), 0.0))
+    N, L, P, Hd, V = 3, 12, 5, 64, 100
+    ids = torch.randint(0, V, (N, L), generator=torch.Generator().manual_seed(1))
+    ids[:, 2] = -200
+    ids[1, 2], ids[1, 7] = 5, -200
+    emb, feats = rnd(V, Hd, seed=14), rnd(N, P, Hd, seed=15)
+    got = ops.embed_splice(ids.to(DEV), emb.to(DEV), feats.to(DEV), P)
+    ref = torch.stack([torch.cat([emb[ids[n, :int((ids[n] == -200).nonzero())]], feats[n],
+                                  emb[ids[n, int((ids[n] == -200).nonzero()) + 1:]]]) for n in range(N)])
+    out.append(("embed_splice", err(got, ref), 0.0))
+    x = rnd(40, 256, seed=16)
+    idx = torch.tensor([3, 39, 0, 3], dtype=torch.int64)
+    out.append(("gather_rows", err(ops.gather_rows(x.to(DEV), idx.to(DEV)), x[idx]), 0.0))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------ head
+def check_head():
+    out = []
+    K, Cc, g, S = 16, 256, 64, 256
+    feat = rnd(1, Cc, g, g, seed=1)                                            # reference layout [1,C,g,g]
+    gen = torch.Generator().manual_seed(2)
+    segs = (torch.rand(K, S, S, generator=gen) > 0.7).to(BF)
+    segs[1] = torch.rand(S, S, generator=gen).to(BF)                           # a soft mask
+    segs[2] = 0                                                                # an empty proposal
+    up = ohead.upsample_feats(feat.float(), S)[0]
+    ref = ohead.mask_pooling(up, segs.float())
+    got = ops.upsample_maskpool(feat[0].permute(1, 2, 0).reshape(g * g, Cc).contiguous().to(DEV), segs.to(DEV), g, S)
+    out.append(("upsample_maskpool", err(got, ref), tol_bf16(ref)))
+    Kp, D = 256, 256
+    e, t = rnd(Kp, D, seed=3), rnd(D, seed=4)
+    ref = ohead.cosine_scores(t.float()[None], e.float())[0]
+    out.append(("cosine_scores", err(ops.cosine_scores(t.to(DEV), e.to(DEV)), ref), 2e-4))
+    gen = torch.Generator().manual_seed(5)
+    gi, gp = torch.rand(Kp, generator=gen), torch.rand(Kp, generator=gen)
+    pr = torch.rand(Kp, generator=gen).to(BF)
+    ef, tf, pf = e.float().requires_grad_(True), t.float().requires_grad_(True), pr.float().requires_grad_(True)
+    la = olosses.softmax_align(ef, tf[None], gi[:, None])
+    lr = olosses.iop_regression(pf[:, None], gp[:, None])
+    la.backward(); lr.backward()
+    o, d_e, d_t, d_p = ops.align_reg_loss(e.to(DEV), t.to(DEV), gi.to(DEV), pr.to(DEV), gp.to(DEV), want_grads=True)
+    out.append(("align loss", abs(o[0].item() - la.item()), 1e-3 * max(1.0, abs(la.item()))))
+    out.append(("regression loss", abs(o[1].item() - lr.item()), 1e-3 * max(1.0, abs(lr.item()))))
+    out.append(("align d_e", err(d_e, ef.grad), 1e-3 * max(1e-3, ef.grad.abs().max().item())))
+    out.append(("align d_t", err(d_t, tf.grad), 1e-3 * max(1e-3, tf.grad.abs().max().item())))
+    out.append(("regression d_pred", err(d_p, pf.grad), 1e-3 * max(1e-3, pf.grad.abs().max().item())))
+    x = torch.randn(3, 64, 64, generator=gen) * 3
+    y = (torch.rand(3, 64, 64, generator=gen) > 0.5).float()
+    o = ops.dice_bce(x.to(DEV), y.to(DEV), 3)
+    out.append(("dice", abs(o[0].item() - olosses.dice(x, y, 3).item()), 1e-4))
+    out.append(("bce", abs(o[1].item() - olosses.sigmoid_ce(x, y, 3).item()), 1e-4))
+    N, T, V = 2, 9, 32004
+    logits = rnd(N, T, V, seed=6, scale=2.0)
+    labels = torch.randint(0, V, (N, T), generator=gen)
+    labels[:, :3] = -100
+    acc = ops.ce_loss(logits.to(DEV), labels.to(DEV))
+    ref = F.cross_entropy(logits[:, :-1].float().reshape(-1, V), labels[:, 1:].reshape(-1), ignore_index=-100)
+    out.append(("shifted CE", abs(acc[0].item() / acc[1].item() - ref.item()), 1e-3))
+    return out
+
+
+ALL = [check_gemm, check_attention, check_pointwise, check_head]

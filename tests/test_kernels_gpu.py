@@ -1,0 +1,36 @@
+"""GPU: every HIP kernel, called through the C ABI, against an fp32 PyTorch / oracle computation of the same op."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+
+
+def _run(fn):
+    res = fn()
+    bad = [(n, e, t) for n, e, t in res if not (e <= t)]
+    assert not bad, "kernel parity failures: " + "; ".join(f"{n}: err {e:.3e} > tol {t:.3e}" for n, e, t in bad)
+
+
+def test_gemm():
+    from tests import kernel_checks as kc
+    _run(kc.check_gemm)
+
+
+def test_attention():
+    from tests import kernel_checks as kc
+    _run(kc.check_attention)
+
+
+def test_pointwise():
+    from tests import kernel_checks as kc
+    _run(kc.check_pointwise)
+
+
+def test_head():
+    from tests import kernel_checks as kc
+    _run(kc.check_head)
