@@ -57,8 +57,8 @@ int llmseg_gemm_bf16(const llmseg_gemm_args* args, void* stream);
  * Q/K/V/O are addressed as base + b*stride_b + h*stride_h + row*stride_row (elements); head_dim in {32,64,80,128}.
  *  - causal + key_mask: HF LlamaAttention eager path (transformers 4.29; call site llava_llama.py:93-102)
  *  - rel_h/rel_w: SAM decomposed relative position (image_encoder.py:244-251, 354-392):
- *      bias(q,k) = rel_h[b][h][q][qh-kh+grid_h-1] + rel_w[b][h][q][qw-kw+grid_w-1], q=(qh,qw), k=(kh,kw) on a grid_h x grid_w grid,
- *      rel_* are fp32 [batch][heads][Nq][rel_ld] (the q . R^T products, produced by llmseg_gemm_bf16 with out_f32)
+ *      bias(q,k) = rel_h[h][b][q][qh-kh+grid_h-1] + rel_w[h][b][q][qw-kw+grid_w-1], q=(qh,qw), k=(kh,kw) on a grid_h x grid_w grid,
+ *      rel_* are fp32 [heads][batch*Nq][rel_ld] (the q . R^T products, as the strided-batched llmseg_gemm_bf16 with out_f32 writes them)
  *  - plain: CLIP / DINOv2 ViT attention, mask-selection head attention (model/transformer.py:319-341)
  * o_row_map (int32 [batch][Nq] or NULL): output row for query (b,q) inside O (rows of stride o_stride_row, ignoring
  * o_stride_b); negative = skip.  Used to fold SAM's window_unpartition + crop (image_encoder.py:291-318) into the store.
@@ -109,9 +109,10 @@ int llmseg_patchify(const void* img, void* cols, int32_t B, int32_t H, int32_t W
 int llmseg_im2col3x3(const void* x, void* cols, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 
 /* LLaVA splice (llava_arch.py:185-208): out[n][t][:] = embed[ids] for text positions, img_feats[n][t-img_pos] inside the
- * image span.  ids int64 [N][L] with exactly one IMAGE token (-200) per row; out [N][L-1+P][H]. */
+ * image span.  ids int64 [N][L] with exactly one IMAGE token (-200) per row; out [N][L-1+P][H]; sequence n's P feature
+ * rows start at img_feats + n*feats_stride_n (elements), so a CLS row per image can be skipped in place. */
 int llmseg_embed_splice(const int64_t* ids, const void* embed, const void* img_feats, void* out, int32_t N, int32_t L,
-                        int32_t P, int32_t H, int64_t vocab, void* stream);
+                        int32_t P, int32_t H, int64_t vocab, int64_t feats_stride_n, void* stream);
 
 /* gather rows: out[i][:] = x[idx[i]][:] (bf16, cols % 8 == 0) -- [SEG] hidden-state gather (LISA.py:322-323) */
 int llmseg_gather_rows(const void* x, const int64_t* idx, void* out, int64_t n, int64_t cols, int64_t ldx, void* stream);

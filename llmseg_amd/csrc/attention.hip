@@ -73,7 +73,7 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(AttnP p) {
   float bw_cache[REL == 2 ? 32 : 1];
   if (REL != 0) {
     qh = qc / p.gw; qw = qc - qh * p.gw;
-    const long rrow = ((long)(b * p.heads + h) * p.Nq + qc) * p.rel_ld;
+    const long rrow = (((long)h * p.batch + b) * p.Nq + qc) * p.rel_ld;   // [heads][batch*Nq][rel_ld]
     relh_row = p.rel_h + rrow;
     relw_row = p.rel_w + rrow;
     if (REL == 2) {

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const bf16_t* __restrict
 // one block per output position (n, t)
 __global__ __launch_bounds__(256) void embed_splice_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ embed,
                                                           const bf16_t* __restrict__ feats, bf16_t* __restrict__ out, int N, int L, int P, int Hd,
-                                                          long vocab) {
+                                                          long vocab, long fstride) {
   __shared__ int s_pos;
   const int Tn = L - 1 + P;
   const int n = blockIdx.x / Tn, t = blockIdx.x % Tn;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void embed_splice_kernel(const int64_t* __rest
   const int ip = s_pos;
   const bf16_t* src;
   if (t >= ip && t < ip + P) {
-    src = feats + ((long)n * P + (t - ip)) * Hd;
+    src = feats + (long)n * fstride + (long)(t - ip) * Hd;
   } else {
     long id = ids[(long)n * L + (t < ip ? t : t - P + 1)];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
@@ -254,11 +254,11 @@ extern "C" int llmseg_im2col3x3(const void* x, void* cols, int32_t B, int32_t H,
 }
 
 extern "C" int llmseg_embed_splice(const int64_t* ids, const void* embed, const void* img_feats, void* out, int32_t N, int32_t L, int32_t P,
-                                   int32_t H, int64_t vocab, void* stream) {
-  LL_CHECK(ids && embed && img_feats && out && N > 0 && L > 0 && P > 0 && (H & 7) == 0 && AL16(embed) && AL16(img_feats) && AL16(out),
-           "embed_splice: bad arguments");
+                                   int32_t H, int64_t vocab, int64_t feats_stride_n, void* stream) {
+  LL_CHECK(ids && embed && img_feats && out && N > 0 && L > 0 && P > 0 && (H & 7) == 0 && (feats_stride_n & 7) == 0 && AL16(embed) && AL16(img_feats) &&
+           AL16(out), "embed_splice: bad arguments");
   hipLaunchKernelGGL(embed_splice_kernel, dim3((unsigned)(N * (L - 1 + P))), dim3(256), 0, (hipStream_t)stream, ids, (const bf16_t*)embed,
-                     (const bf16_t*)img_feats, (bf16_t*)out, N, L, P, H, (long)vocab);
+                     (const bf16_t*)img_feats, (bf16_t*)out, N, L, P, H, (long)vocab, (long)feats_stride_n);
   LL_LAUNCH_CHECK("embed_splice");
   return LLMSEG_OK;
 }

@@ -1,0 +1,484 @@
+"""Host-side mirror of the reference's `LISAForCausalLM` interface (reference `model/LISA.py:144-474`) on top of the
+gfx950 kernels.  Same constructor kwargs, same `forward(**collate_dict)` / `model_forward` arguments and return keys,
+same `get_visual_embs` / `get_dinov2_visual_embs` / `mask_pooling` helpers, same state-dict key names.
+
+Everything dense runs in libllmseg_hip.so through `ops`; torch is used for device memory, integer index tables and
+the state dict.  There is no CPU path: tensors must live on a HIP device.
+
+Layout choices (MI355X-first, differ from the reference's eager code on purpose):
+  * activations are token-major [rows, channels] bf16 everywhere (ViT grids are channels-last), so every Linear /
+    1x1 conv / patch-embed is ONE TN GEMM with bias/activation/LayerScale/residual fused in its epilogue;
+  * images of a batch are processed together (the reference loops per image, LISA.py:176-199);
+  * SAM's window partition / un-partition are folded into the LayerNorm store and the attention store (row maps),
+    the zero padding rows of the window buffer are written once and still act as keys (image_encoder.py:278-282);
+  * q.R^T of the decomposed relative position is a strided-batched fp32-out GEMM, the bias add happens inside the
+    fused attention kernel;
+  * bilinear upsample + mask pooling is one pass over the proposals (llmseg_upsample_maskpool);
+  * `text_hidden_fcs` runs on the gathered [SEG] rows only (identical result, ~300x fewer rows -- LISA.py:318-323).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F  # only F.interpolate for the one-time DINOv2 pos-embed resize at weight-prep time
+
+from . import ops
+from .params import LisaConfig, ParamTree, fused_groups, init_random_, lisa_shapes
+
+IMAGE_TOKEN_INDEX = -200
+IGNORE_INDEX = -100
+BF16 = torch.bfloat16
+
+
+def _pad_rows(t, rows):
+    out = torch.zeros((rows,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+    out[: t.shape[0]] = t
+    return out
+
+
+class LISAForCausalLM(nn.Module):
+    def __init__(self, config: LisaConfig, device="cuda", **kwargs):
+        super().__init__()
+        # reference kwargs (model/LISA.py:150-161, training.py:140-150)
+        config.ce_loss_weight = kwargs.pop("ce_loss_weight", config.ce_loss_weight)
+        config.align_loss_weight = kwargs.pop("align_loss_weight", config.align_loss_weight)
+        config.regression_loss_weight = kwargs.pop("regression_loss_weight", config.regression_loss_weight)
+        config.seg_token_idx = kwargs.pop("seg_token_idx", config.seg_token_idx)
+        config.out_dim = kwargs.pop("out_dim", config.out_dim)
+        for k in ("train_mask_decoder", "vision_pretrained", "vision_tower", "use_mm_start_end"):
+            kwargs.pop(k, None)
+        self.config = config
+        self.seg_token_idx = config.seg_token_idx
+        self.device_ = torch.device(device)
+        assert self.device_.type == "cuda", "llmseg_amd has no CPU path (the HIP kernels are the product)"
+        self.shapes = lisa_shapes(config)
+        self.params = ParamTree(self.shapes, self.device_, BF16, fused_groups(config))
+        self._derived = None
+        self._maps = {}
+
+    # the reference's state-dict keys start at the top module ("model.layers...", "lm_head.weight")
+    def state_dict(self, *a, **k):
+        return {n[len("params."):]: v for n, v in super().state_dict(*a, **k).items()}
+
+    def load_state_dict(self, sd, strict=True):
+        own = {n: p for n, p in self.params.named_parameters()}
+        missing = [n for n in own if n not in sd]
+        unexpected = [n for n in sd if n not in own]
+        if strict and (missing or unexpected):
+            raise KeyError(f"missing {missing[:5]} unexpected {unexpected[:5]}")
+        with torch.no_grad():
+            for n, p in own.items():
+                if n in sd:
+                    p.copy_(sd[n].to(device=p.device, dtype=p.dtype))
+        self._derived = None
+        return missing, unexpected
+
+    def init_random(self, seed=0):
+        init_random_(self.params, self.shapes, seed)
+        self._derived = None
+        return self
+
+    def get_model(self):
+        return self
+
+    # ------------------------------------------------------------------------------------------ derived weights
+    @torch.no_grad()
+    def prepare(self):
+        """One-time weight re-layouts (not part of the timed path): patch-embed / 3x3-conv weights as GEMM operands,
+        class/position tables, padded relative-position tables, RoPE tables."""
+        if self._derived is not None:
+            return self._derived
+        c, P, dev = self.config, self.params, self.device_
+        d = {}
+        # CLIP
+        vp = "model.vision_tower.vision_tower.vision_model."
+        kp = 3 * c.clip.patch ** 2
+        kpad = (kp + 7) // 8 * 8
+        d["clip.patch_w"] = F.pad(P[vp + "embeddings.patch_embedding.weight"].reshape(c.clip.dim, kp), (0, kpad - kp)).contiguous()
+        pos = P[vp + "embeddings.position_embedding.weight"].float().clone()
+        pos[0] += P[vp + "embeddings.class_embedding"].float()
+        d["clip.pos"] = pos.to(BF16)
+        d["clip.kpad"] = kpad
+        # DINOv2
+        if "model.visual_model_dinov2.cls_token" in P.flat:
+            dp = "model.visual_model_dinov2."
+            kp = 3 * c.dino.patch ** 2
+            kpad = (kp + 7) // 8 * 8
+            d["dino.patch_w"] = F.pad(P[dp + "patch_embed.proj.weight"].reshape(c.dino.dim, kp), (0, kpad - kp)).contiguous()
+            d["dino.kpad"] = kpad
+            d["dino.pos_cache"] = {}
+            d["dino.conv_w"] = P["model.lisa_dino_conv.weight"].reshape(c.out_dim, c.dino.dim).contiguous()
+        # SAM
+        if "model.visual_model.image_encoder.pos_embed" in P.flat:
+            sp = "model.visual_model.image_encoder."
+            s = c.sam
+            hd = s.dim // s.heads
+            d["sam.patch_w"] = P[sp + "patch_embed.proj.weight"].reshape(s.dim, 3 * s.patch ** 2).contiguous()
+            d["sam.pos"] = P[sp + "pos_embed"].reshape(s.grid * s.grid, s.dim).contiguous()
+            d["sam.neck0_w"] = P[sp + "neck.0.weight"].reshape(s.out_chans, s.dim).contiguous()
+            d["sam.neck2_w"] = P[sp + "neck.2.weight"].permute(0, 2, 3, 1).reshape(s.out_chans, 9 * s.out_chans).contiguous()
+            for i in range(s.depth):
+                sz = s.grid if i in s.global_idx else s.window
+                ld = (2 * sz - 1 + 3) // 4 * 4
+                d[f"sam.relh.{i}"] = _pad_rows(P[f"{sp}blocks.{i}.attn.rel_pos_h"], ld)
+                d[f"sam.relw.{i}"] = _pad_rows(P[f"{sp}blocks.{i}.attn.rel_pos_w"], ld)
+        self._derived = d
+        return d
+
+    def _rope(self, T):
+        key = ("rope", T)
+        if key not in self._maps:
+            c = self.config.llama
+            inv = 1.0 / (c.theta ** (torch.arange(0, c.head_dim, 2, dtype=torch.float32, device=self.device_) / c.head_dim))
+            ang = torch.outer(torch.arange(T, dtype=torch.float32, device=self.device_), inv)
+            self._maps[key] = (ang.cos().contiguous(), ang.sin().contiguous())
+        return self._maps[key]
+
+    def _window_maps(self, B, g, ws):
+        """Row maps of SAM's window_partition / window_unpartition (image_encoder.py:263-318) for B images."""
+        key = ("win", B, g, ws)
+        if key not in self._maps:
+            gp = (g + ws - 1) // ws * ws
+            nw = gp // ws
+            yy, xx = torch.meshgrid(torch.arange(g), torch.arange(g), indexing="ij")
+            win = (yy // ws) * nw + (xx // ws)
+            pos = (yy % ws) * ws + (xx % ws)
+            part1 = (win * ws * ws + pos).reshape(-1)                                   # token -> row within one image
+            per_img = nw * nw * ws * ws
+            part = torch.cat([part1 + b * per_img for b in range(B)]).to(torch.int32)
+            unpart = torch.full((B * per_img,), -1, dtype=torch.int32)
+            unpart[part.long()] = torch.arange(B * g * g, dtype=torch.int32)
+            self._maps[key] = (part.to(self.device_), unpart.to(self.device_), nw * nw, per_img)
+        return self._maps[key]
+
+    # --------------------------------------------------------------------------------------------------- towers
+    def _vit_block(self, x, p, heads, batch, n_tok, eps, act, names, gamma=(None, None)):
+        """One pre-LN ViT block on token-major x [batch*n_tok, D] (CLIP / DINOv2 naming differs, `names` maps it)."""
+        P = self.params
+        D = x.shape[1]
+        h = ops.norm(x, P[p + names["ln1"] + ".weight"], P[p + names["ln1"] + ".bias"], eps=eps)
+        qkv = ops.gemm(h, P[p + names["qkv"] + ".weight"], bias=P[p + names["qkv"] + ".bias"])
+        a = ops.attention_packed(qkv, batch, n_tok, heads, D // heads)
+        x = ops.gemm(a, P[p + names["proj"] + ".weight"], bias=P[p + names["proj"] + ".bias"], residual=x, gamma=gamma[0])
+        h = ops.norm(x, P[p + names["ln2"] + ".weight"], P[p + names["ln2"] + ".bias"], eps=eps)
+        h = ops.gemm(h, P[p + names["fc1"] + ".weight"], bias=P[p + names["fc1"] + ".bias"], act=act)
+        return ops.gemm(h, P[p + names["fc2"] + ".weight"], bias=P[p + names["fc2"] + ".bias"], residual=x, gamma=gamma[1])
+
+    _CLIP_NAMES = dict(ln1="layer_norm1", qkv="self_attn.qkv", proj="self_attn.out_proj", ln2="layer_norm2", fc1="mlp.fc1", fc2="mlp.fc2")
+    _DINO_NAMES = dict(ln1="norm1", qkv="attn.qkv", proj="attn.proj", ln2="norm2", fc1="mlp.fc1", fc2="mlp.fc2")
+
+    def encode_images(self, images_clip):
+        """CLIP ViT-L/14 penultimate-layer patch tokens -> mm_projector (clip_encoder.py:41-60, llava_arch.py:93-96).
+        Returns the projected tokens for ALL 1+P rows per image, [N*(P+1), H]; row 0 of each image (CLS) is unused."""
+        c, P, d = self.config, self.params, self.prepare()
+        N = images_clip.shape[0]
+        n_tok = c.n_img_tokens + 1
+        cols = ops.patchify(images_clip, c.clip.patch, d["clip.kpad"], rows_per_img=n_tok, row_off=1)
+        x = ops.gemm(cols, d["clip.patch_w"])
+        x = ops.add_rows(x, d["clip.pos"])
+        vp = "model.vision_tower.vision_tower.vision_model."
+        x = ops.norm(x, P[vp + "pre_layrnorm.weight"], P[vp + "pre_layrnorm.bias"], eps=c.clip.eps)
+        n_run = c.clip.layers + 1 + c.select_layer if c.select_layer < 0 else c.select_layer
+        for i in range(n_run):
+            x = self._vit_block(x, f"{vp}encoder.layers.{i}.", c.clip.heads, N, n_tok, c.clip.eps, ops.ACT_QUICKGELU, self._CLIP_NAMES)
+        return ops.gemm(x, P["model.mm_projector.weight"], bias=P["model.mm_projector.bias"])
+
+    def _dino_pos(self, gh, gw):
+        d, P, c = self.prepare(), self.params, self.config.dino
+        key = (gh, gw)
+        if key not in d["dino.pos_cache"]:
+            dp = "model.visual_model_dinov2."
+            pe = P[dp + "pos_embed"].float()
+            M = int(math.isqrt(pe.shape[1] - 1))
+            patch = pe[:, 1:]
+            if (gh, gw) != (M, M):   # one-time weight transform: bicubic resize of the learned table (fp32)
+                patch = F.interpolate(patch.reshape(1, M, M, -1).permute(0, 3, 1, 2), size=(gh, gw), mode="bicubic",
+                                      align_corners=False).permute(0, 2, 3, 1).reshape(1, gh * gw, -1)
+            tab = torch.cat([pe[:, :1] + P[dp + "cls_token"].float(), patch + P[dp + "patch_embed.proj.bias"].float()], 1)[0]
+            d["dino.pos_cache"][key] = tab.to(BF16).contiguous()
+        return d["dino.pos_cache"][key]
+
+    def _dinov2_tokens(self, images):
+        """DINOv2 ViT-L/14 x_norm tokens (incl. CLS row) [B*(1+gh*gw), D] (LISA.py:186-199; hub arithmetic restated)."""
+        c, P, d = self.config.dino, self.params, self.prepare()
+        B, _, Hh, Ww = images.shape
+        gh, gw = Hh // c.patch, Ww // c.patch
+        n_tok = gh * gw + 1
+        cols = ops.patchify(images, c.patch, d["dino.kpad"], rows_per_img=n_tok, row_off=1)
+        x = ops.gemm(cols, d["dino.patch_w"])                      # conv bias is folded into the position table
+        x = ops.add_rows(x, self._dino_pos(gh, gw))
+        dp = "model.visual_model_dinov2."
+        for i in range(c.layers):
+            p = f"{dp}blocks.{i}."
+            x = self._vit_block(x, p, c.heads, B, n_tok, c.eps, ops.ACT_GELU, self._DINO_NAMES, gamma=(P[p + "ls1.gamma"], P[p + "ls2.gamma"]))
+        return ops.norm(x, P[dp + "norm.weight"], P[dp + "norm.bias"], eps=c.eps), n_tok, (gh, gw)
+
+    def get_dinov2_visual_embs(self, pixel_values):
+        """Reference API (LISA.py:186-199): [B, D, gh, gw] view of the patch tokens."""
+        x, n_tok, (gh, gw) = self._dinov2_tokens(pixel_values.to(BF16))
+        B = pixel_values.shape[0]
+        return x.view(B, n_tok, -1)[:, 1:].permute(0, 2, 1).reshape(B, -1, gh, gw)
+
+    def _sam_encoder_cl(self, images):
+        """SAM ViT image encoder, channels-last output [B*g*g, out_chans] (image_encoder.py:110-125)."""
+        s, P, d = self.config.sam, self.params, self.prepare()
+        B = images.shape[0]
+        g, D, nh = s.grid, s.dim, s.heads
+        hd = D // nh
+        sp = "model.visual_model.image_encoder."
+        cols = ops.patchify(images, s.patch, 3 * s.patch ** 2)
+        x = ops.gemm(cols, d["sam.patch_w"], bias=P[sp + "patch_embed.proj.bias"])
+        x = ops.add_rows(x, d["sam.pos"])
+        part, unpart, n_win, per_img = self._window_maps(B, g, s.window)
+        winbuf = None
+        for i in range(s.depth):
+            p = f"{sp}blocks.{i}."
+            glob = i in s.global_idx
+            sz = g if glob else s.window
+            ld = d[f"sam.relh.{i}"].shape[0]
+            if glob:
+                h = ops.norm(x, P[p + "norm1.weight"], P[p + "norm1.bias"], eps=s.eps)
+                batch, n_tok = B, g * g
+            else:
+                if winbuf is None:
+                    winbuf = torch.zeros((B * per_img, D), device=x.device, dtype=BF16)   # padding rows stay zero
+                h = ops.norm(x, P[p + "norm1.weight"], P[p + "norm1.bias"], eps=s.eps, out=winbuf, row_map=part)
+                batch, n_tok = B * n_win, s.window * s.window
+            qkv = ops.gemm(h, P[p + "attn.qkv.weight"], bias=P[p + "attn.qkv.bias"])
+            rows = batch * n_tok
+            rel = torch.empty((2, nh, rows, ld), device=x.device, dtype=torch.float32)
+            for j, tab in enumerate((d[f"sam.relh.{i}"], d[f"sam.relw.{i}"])):
+                ops.gemm_batched(qkv, tab, rel[j], M=rows, N=2 * sz - 1, K=hd, lda=3 * D, ldw=hd, ldc=ld, batch=nh, sA=hd, sW=0,
+                                 sC=rows * ld, out_f32=True)
+            a = torch.empty((B * g * g, D), device=x.device, dtype=BF16)
+            ops.attention_packed(qkv, batch, n_tok, nh, hd, out=a, rel_h=rel[0], rel_w=rel[1], rel_ld=ld, grid_hw=(sz, sz),
+                                 o_row_map=None if glob else unpart)
+            x = ops.gemm(a, P[p + "attn.proj.weight"], bias=P[p + "attn.proj.bias"], residual=x)
+            h = ops.norm(x, P[p + "norm2.weight"], P[p + "norm2.bias"], eps=s.eps)
+            h = ops.gemm(h, P[p + "mlp.lin1.weight"], bias=P[p + "mlp.lin1.bias"], act=ops.ACT_GELU)
+            x = ops.gemm(h, P[p + "mlp.lin2.weight"], bias=P[p + "mlp.lin2.bias"], residual=x)
+        y = ops.gemm(x, d["sam.neck0_w"])
+        y = ops.norm(y, P[sp + "neck.1.weight"], P[sp + "neck.1.bias"], eps=s.eps)
+        y = ops.gemm(ops.im2col3x3(y, B, g, g, s.out_chans), d["sam.neck2_w"])
+        return ops.norm(y, P[sp + "neck.3.weight"], P[sp + "neck.3.bias"], eps=s.eps)
+
+    def get_visual_embs(self, pixel_values):
+        """Reference API (LISA.py:173-184): SAM image embeddings [B, out_chans, g, g] (a view of the channels-last result)."""
+        s = self.config.sam
+        y = self._sam_encoder_cl(pixel_values.to(BF16))
+        return y.view(pixel_values.shape[0], s.grid, s.grid, s.out_chans).permute(0, 3, 1, 2)
+
+    def mask_pooling(self, image_embeddings, weight_maps):
+        """Reference API (LISA.py:201-218) on an already-upsampled [D,h,w] map: identity interpolation (g == S)."""
+        Dd, hh, ww = image_embeddings.shape
+        assert hh == ww
+        feat_cl = image_embeddings.permute(1, 2, 0).reshape(hh * ww, Dd).contiguous().to(BF16)
+        return ops.upsample_maskpool(feat_cl, weight_maps.to(BF16).contiguous(), hh, hh)
+
+    # ------------------------------------------------------------------------------------------------ language
+    def _lora(self, x, qkv, p, which, col0):
+        c, P = self.config.llama, self.params
+        a = P.get(p + f"self_attn.{which}_proj.lora_A.default.weight")
+        if a is None or c.lora_r == 0:
+            return
+        # y[:, cols] += (alpha/r) * (x A^T) B^T   (peft 0.4.0 Linear, dropout = identity outside training)
+        r8 = (c.lora_r + 7) // 8 * 8
+        xa = torch.zeros((x.shape[0], r8), device=x.device, dtype=BF16)
+        ops.gemm(x, a, out=xa[:, :c.lora_r]) if c.lora_r % 8 == 0 else xa[:, :c.lora_r].copy_(ops.gemm(x, a))
+        bw = P[p + f"self_attn.{which}_proj.lora_B.default.weight"]
+        if r8 != c.lora_r:
+            bw = F.pad(bw, (0, r8 - c.lora_r)).contiguous()
+        sl = qkv[:, col0:col0 + c.hidden]
+        ops.gemm(xa, bw, residual=sl, out=sl, alpha=c.lora_alpha / c.lora_r)
+
+    def _llama(self, embeds, key_mask_u8):
+        """32 x [RMSNorm -> q|k|v GEMM (+LoRA) -> RoPE -> causal attention -> o_proj(+res) -> RMSNorm -> gate|up GEMM ->
+        SwiGLU -> down(+res)], final RMSNorm (HF LlamaModel, transformers 4.29; call site llava_llama.py:93-102)."""
+        c, P = self.config.llama, self.params
+        N, T, H = embeds.shape
+        x = embeds.reshape(N * T, H)
+        cos, sin = self._rope(T)
+        for i in range(c.layers):
+            p = f"model.layers.{i}."
+            h = ops.norm(x, P[p + "input_layernorm.weight"], eps=c.eps, rms=True)
+            qkv = ops.gemm(h, P[p + "qkv"])
+            self._lora(h, qkv, p, "q", 0)
+            self._lora(h, qkv, p, "v", 2 * H)
+            ops.rope_(qkv, cos, sin, N * T, T, 2 * c.heads, c.head_dim, 3 * H)
+            a = ops.attention_packed(qkv, N, T, c.heads, c.head_dim, causal=True, key_mask=key_mask_u8)
+            x = ops.gemm(a, P[p + "self_attn.o_proj.weight"], residual=x)
+            h = ops.norm(x, P[p + "post_attention_layernorm.weight"], eps=c.eps, rms=True)
+            gu = ops.gemm(h, P[p + "gate_up"])
+            x = ops.gemm(ops.swiglu(gu, c.inter), P[p + "mlp.down_proj.weight"], residual=x)
+        return ops.norm(x, P["model.norm.weight"], eps=c.eps, rms=True).view(N, T, H)
+
+    def llava_forward(self, images_clip, attention_mask, input_ids, labels=None, want_logits=True):
+        """LlavaLlamaForCausalLM.forward (llava_llama.py:55-135): splice, decoder stack, lm_head, shifted CE.
+        -> (ce_loss | None, logits | None, final-norm hidden [N,T,H])."""
+        c, P = self.config, self.params
+        N, L = input_ids.shape
+        n_img = (input_ids == IMAGE_TOKEN_INDEX).sum(1)
+        assert bool((n_img == 1).all()), "exactly one <image> per sequence (the reference's seg_token_mask assumes it too)"
+        Pn = c.n_img_tokens
+        proj = self.encode_images(images_clip)                                            # [N*(P+1), H]
+        H = c.llama.hidden
+        embeds = ops.embed_splice(input_ids.contiguous(), P["model.embed_tokens.weight"], proj[1:], Pn, feats_stride_n=(Pn + 1) * H)
+        T = L - 1 + Pn
+        mask = torch.cat([torch.ones((N, T - L), dtype=torch.bool, device=input_ids.device), attention_mask.bool()], 1)
+        hidden = self._llama(embeds, mask.to(torch.uint8).contiguous())
+        logits, loss = None, None
+        if want_logits or labels is not None:
+            logits = ops.gemm(hidden.view(N * T, H), P["lm_head.weight"]).view(N, T, -1)
+        if labels is not None:
+            pos = (input_ids == IMAGE_TOKEN_INDEX).int().argmax(1)                      # index plumbing for the label splice
+            ar = torch.arange(T, device=labels.device)[None]
+            src = torch.where(ar < pos[:, None], ar, (ar - Pn + 1).clamp(min=0))
+            new_labels = torch.gather(labels, 1, src.clamp(max=L - 1))
+            new_labels = torch.where((ar >= pos[:, None]) & (ar < pos[:, None] + Pn), torch.full_like(new_labels, IGNORE_INDEX), new_labels)
+            acc = ops.ce_loss(logits, new_labels.contiguous())
+            loss = acc[0] / acc[1]
+        return loss, logits, hidden
+
+    # ------------------------------------------------------------------------------------------------------ head
+    def _head_attn_1key(self, p, text):
+        """Attention whose key/value is a single token: softmax over one key == 1, so out = out_proj(v_proj(text))
+        for every query (transformer.py:319-341 with Nk = 1).  text [C, D] -> [C, D]."""
+        P = self.params
+        D = text.shape[1]
+        v = ops.gemm(text, P[p + "qkv.weight"][2 * D:], bias=P[p + "qkv.bias"][2 * D:])
+        return ops.gemm(v, P[p + "out_proj.weight"], bias=P[p + "out_proj.bias"])
+
+    def _bcast_add_norm(self, s, add, Cn, K, wname):
+        """s[c*K + k] = LN(s[c*K + k] + add[c])."""
+        P = self.params
+        for ci in range(Cn):
+            blk = s[ci * K:(ci + 1) * K]
+            ops.add_rows(blk, add[ci:ci + 1].contiguous(), out=blk)
+        return ops.norm(s, P[wname + ".weight"], P[wname + ".bias"], eps=1e-5)
+
+    def _mask_head(self, pooled, text):
+        """LISA.py:363-391 for one image: pooled [K, D] bf16, text [C, D] bf16 -> (pred_iou [C*K] bf16, emb [C*K, D] bf16)."""
+        P = self.params
+        K, D = pooled.shape
+        Cn = text.shape[0]
+        nh, hd = 8, D // 8
+        s = pooled.repeat(Cn, 1) if Cn > 1 else pooled.clone()            # row = c*K + k  (expand, LISA.py:372)
+        t = text.contiguous()
+        for i in range(2):
+            p = f"model.lisa_attention_layers.{i}."
+            qkv = ops.gemm(s, P[p + "self_attn.qkv.weight"], bias=P[p + "self_attn.qkv.bias"])
+            a = ops.attention_packed(qkv, Cn, K, nh, hd)
+            s = ops.gemm(a, P[p + "self_attn.out_proj.weight"], bias=P[p + "self_attn.out_proj.bias"], residual=s)
+            s = ops.norm(s, P[p + "norm1.weight"], P[p + "norm1.bias"], eps=1e-5)
+            s = self._bcast_add_norm(s, self._head_attn_1key(p + "cross_attn_token_to_image.", t), Cn, K, p + "norm2")
+            m = ops.gemm(s, P[p + "mlp.lin1.weight"], bias=P[p + "mlp.lin1.bias"], act=ops.ACT_RELU)
+            s = ops.gemm(m, P[p + "mlp.lin2.weight"], bias=P[p + "mlp.lin2.bias"], residual=s)
+            s = ops.norm(s, P[p + "norm3.weight"], P[p + "norm3.bias"], eps=1e-5)
+            # image -> token: q = text (1 query per conversation), k = v = mask features
+            pc = p + "cross_attn_image_to_token."
+            q = ops.gemm(t, P[pc + "qkv.weight"][:D], bias=P[pc + "qkv.bias"][:D])
+            kv = ops.gemm(s, P[pc + "qkv.weight"][D:], bias=P[pc + "qkv.bias"][D:])       # [C*K, 2D] = k | v
+            o = torch.empty((Cn, D), device=s.device, dtype=BF16)
+            ops.attention(q, kv, kv[:, D:], o, batch=Cn, heads=nh, Nq=1, Nk=K, head_dim=hd, q_strides=(D, hd, D),
+                          k_strides=(K * 2 * D, hd, 2 * D), v_strides=(K * 2 * D, hd, 2 * D), o_strides=(D, hd, D))
+            t = ops.gemm(o, P[pc + "out_proj.weight"], bias=P[pc + "out_proj.bias"], residual=t)
+            t = ops.norm(t, P[p + "norm4.weight"], P[p + "norm4.bias"], eps=1e-5)
+        s = self._bcast_add_norm(s, self._head_attn_1key("model.lisa_final_attn.", t), Cn, K, "model.lisa_norm_final_attn")
+        hi = ops.gemm(s, P["model.lisa_iou_head.0.weight"], bias=P["model.lisa_iou_head.0.bias"], act=ops.ACT_RELU)
+        iou = ops.gemm(hi, P["model.lisa_iou_head.2.weight"], bias=P["model.lisa_iou_head.2.bias"], act=ops.ACT_SIGMOID)
+        he = ops.gemm(s, P["model.lisa_embedding_head.0.weight"], bias=P["model.lisa_embedding_head.0.bias"], act=ops.ACT_RELU)
+        emb = ops.gemm(he, P["model.lisa_embedding_head.2.weight"], bias=P["model.lisa_embedding_head.2.bias"])
+        return iou.view(Cn * K), emb
+
+    # ------------------------------------------------------------------------------------------------ model_forward
+    def visual_features_cl(self, images):
+        """-> (channels-last feature rows bf16, rows per image, row offset of the first patch, grid)."""
+        c = self.config
+        if c.backbone == "sam":
+            return self._sam_encoder_cl(images), c.sam.grid ** 2, 0, c.sam.grid
+        x, n_tok, (gh, gw) = self._dinov2_tokens(images)
+        assert gh == gw
+        d = self.prepare()
+        y = ops.gemm(x, d["dino.conv_w"], bias=self.params["model.lisa_dino_conv.bias"])        # 1x1 conv (LISA.py:245)
+        return y, n_tok, 1, gh
+
+    def forward(self, **kwargs):
+        return self.model_forward(**kwargs)
+
+    @torch.no_grad()
+    def model_forward(self, images, images_clip, input_ids, labels, attention_masks, offset, masks_list=None, label_list=None,
+                      resize_list=None, sam_segs_list=None, sam_ious_list=None, sam_iops_list=None, inference=False,
+                      return_aux=False, **kwargs):
+        c = self.config
+        images, images_clip = images.to(BF16), images_clip.to(BF16)
+        feat, rows_per_img, row0, g = self.visual_features_cl(images.contiguous())
+        B = images.shape[0]
+        assert B == len(offset) - 1
+        Pn = c.n_img_tokens
+        off = offset.tolist()
+        if inference:
+            assert images_clip.shape[0] == 1                                             # LISA.py:271
+            clip_in = images_clip.expand(input_ids.shape[0], -1, -1, -1).contiguous()
+            ce, logits, hidden = self.llava_forward(clip_in, attention_masks, input_ids, None, want_logits=return_aux)
+        else:
+            reps = torch.tensor([off[i + 1] - off[i] for i in range(B)], device=images_clip.device)
+            clip_in = images_clip.repeat_interleave(reps, 0).contiguous()                # LISA.py:293-303
+            ce, logits, hidden = self.llava_forward(clip_in, attention_masks, input_ids, labels)
+
+        # [SEG] rows: mask shifted by one and by the P-1 extra image tokens (LISA.py:254-266), gather first, then the MLP
+        N, T, H = hidden.shape
+        segm = torch.zeros((N, T), dtype=torch.bool, device=input_ids.device)
+        segm[:, Pn - 1:Pn - 1 + input_ids.shape[1] - 1] = input_ids[:, 1:] == self.seg_token_idx
+        idx = segm.view(-1).nonzero().flatten()
+        counts = segm.sum(1).cumsum(0).tolist()
+        seg_off = [0] + counts
+        seg_off = [seg_off[o] for o in off]
+        P = self.params
+        hs = ops.gather_rows(hidden.view(N * T, H), idx)
+        hs = ops.gemm(hs, P["model.text_hidden_fcs.0.0.weight"], bias=P["model.text_hidden_fcs.0.0.bias"], act=ops.ACT_RELU)
+        pred = ops.gemm(hs, P["model.text_hidden_fcs.0.2.weight"], bias=P["model.text_hidden_fcs.0.2.bias"]) if idx.numel() else \
+            torch.empty((0, c.out_dim), device=hidden.device, dtype=BF16)
+        pred_embeddings = [pred[seg_off[b]:seg_off[b + 1]] for b in range(B)]
+
+        ious, embs = [], []
+        for b in range(B):
+            segs = sam_segs_list[b].to(BF16).contiguous()
+            S = segs.shape[-1]
+            fb = feat[b * rows_per_img + row0: b * rows_per_img + row0 + g * g]
+            pooled = ops.upsample_maskpool(fb, segs, g, S)
+            K = segs.shape[0]
+            Cn = pred_embeddings[b].shape[0]
+            if Cn == 0:
+                if not inference:
+                    raise ValueError("number of rounds = 0")                          # LISA.py:435-437
+                ious.append(None); embs.append(None)
+                continue
+            iou, emb = self._mask_head(pooled, pred_embeddings[b])
+            ious.append(iou.view(Cn, K)); embs.append(emb.view(Cn, K, -1))
+
+        if inference:
+            sims = [ops.cosine_scores(pred_embeddings[b][0], embs[b][0])[None] for b in range(B)]
+            out = {"pred_similarity": sims, "gt_masks": masks_list, "pred_iou": [ious[b][:1].float() for b in range(B)]}
+            if return_aux:
+                out.update(logits=logits, hidden=hidden, feats=feat, pred_embeddings=pred_embeddings)
+            return out
+
+        align = torch.zeros((), device=hidden.device, dtype=torch.float32)
+        reg = torch.zeros((), device=hidden.device, dtype=torch.float32)
+        for b in range(B):
+            R = pred_embeddings[b].shape[0]
+            a_r = torch.zeros_like(align); r_r = torch.zeros_like(reg)
+            for r in range(R):
+                o = ops.align_reg_loss(embs[b][r], pred_embeddings[b][r], sam_ious_list[b][r].float().contiguous(),
+                                       ious[b][r], sam_iops_list[b][r].float().contiguous())
+                a_r = a_r + o[0]; r_r = r_r + o[1]
+            align = align + a_r / (R + 1e-8)
+            reg = reg + r_r / (R + 1e-8)
+        align, reg = align / B, reg / B
+        ce = ce * c.ce_loss_weight
+        align = align * c.align_loss_weight
+        reg = reg * c.regression_loss_weight
+        out = {"loss": ce + align + reg, "ce_loss": ce, "align_loss": align, "regression_loss": reg}
+        if return_aux:
+            out.update(logits=logits, hidden=hidden, feats=feat)
+        return out

@@ -141,12 +141,12 @@ def im2col3x3(x, B, H, W, Cc):
     return out
 
 
-def embed_splice(ids, embed, img_feats, P):
+def embed_splice(ids, embed, img_feats, P, feats_stride_n=None):
     N, L = ids.shape
     H = embed.shape[1]
     out = torch.empty((N, L - 1 + P, H), device=embed.device, dtype=BF16)
     _lib.check(_lib.load().llmseg_embed_splice(_ptr(ids), _ptr(embed), _ptr(img_feats), _ptr(out), N, L, P, H, embed.shape[0],
-                                               _stream()), "embed_splice")
+                                               P * H if feats_stride_n is None else feats_stride_n, _stream()), "embed_splice")
     return out
 
 

@@ -105,7 +105,9 @@ def check_attention():
         ld = (R + 3) // 4 * 4
         relh = (torch.randn(B, H, N, ld, generator=torch.Generator().manual_seed(gh + 1)) * 0.5)
         relw = (torch.randn(B, H, N, ld, generator=torch.Generator().manual_seed(gh + 2)) * 0.5)
-        o = ops.attention_packed(qkv.to(DEV), B, N, H, hd, rel_h=relh.to(DEV), rel_w=relw.to(DEV), rel_ld=ld, grid_hw=(gh, gw))
+        # kernel layout is [heads][batch*Nq][ld] (what the strided-batched q.R^T GEMM writes)
+        o = ops.attention_packed(qkv.to(DEV), B, N, H, hd, rel_h=relh.transpose(0, 1).contiguous().to(DEV),
+                                 rel_w=relw.transpose(0, 1).contiguous().to(DEV), rel_ld=ld, grid_hw=(gh, gw))
         x = qkv.view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
         qi = torch.arange(N)
         qh_, qw_ = qi // gw, qi % gw
@@ -184,7 +186,8 @@ def check_pointwise():
         ld = (3 * p * p + 7) // 8 * 8
         got = ops.patchify(img.to(DEV), p, ld)
         ref = F.unfold(img.float(), p, stride=p).transpose(1, 2).reshape(-1, 3 * p * p)
-        out.append((f"patchify p={p}", max(err(got[:, :3 * p * p], ref), got[:, 3 * p * p:].float().abs().max().item()), 0.0))
+        pad = got[:, 3 * p * p:].float().abs().max().item() if ld > 3 * p * p else 0.0
+        out.append((f"patchify p={p}", max(err(got[:, :3 * p * p], ref), pad), 0.0))
     got = ops.patchify(rnd(2, 3, 28, 28, seed=3).to(DEV), 14, 592, rows_per_img=5, row_off=1)
     ref = torch.zeros(10, 588)
     ref.view(2, 5, 588)[:, 1:] = F.unfold(rnd(2, 3, 28, 28, seed=3).float(), 14, stride=14).transpose(1, 2)
@@ -200,9 +203,12 @@ def check_pointwise():
     ids[1, 2], ids[1, 7] = 5, -200
     emb, feats = rnd(V, Hd, seed=14), rnd(N, P, Hd, seed=15)
     got = ops.embed_splice(ids.to(DEV), emb.to(DEV), feats.to(DEV), P)
+    wide = torch.cat([rnd(N, 1, Hd, seed=17), feats], 1).to(DEV)              # a CLS row in front of every image's block
+    got2 = ops.embed_splice(ids.to(DEV), emb.to(DEV), wide.view(-1, Hd)[1:], P, feats_stride_n=(P + 1) * Hd)
     ref = torch.stack([torch.cat([emb[ids[n, :int((ids[n] == -200).nonzero())]], feats[n],
                                   emb[ids[n, int((ids[n] == -200).nonzero()) + 1:]]]) for n in range(N)])
     out.append(("embed_splice", err(got, ref), 0.0))
+    out.append(("embed_splice strided feats", err(got2, ref), 0.0))
     x = rnd(40, 256, seed=16)
     idx = torch.tensor([3, 39, 0, 3], dtype=torch.int64)
     out.append(("gather_rows", err(ops.gather_rows(x.to(DEV), idx.to(DEV)), x[idx]), 0.0))

@@ -1,0 +1,141 @@
+"""Model-level parity checks: the HIP `LISAForCausalLM` vs the CPU oracle on the same seeded weights/inputs.
+
+Weights and inputs are rounded to bf16 once and shared, so what is compared is arithmetic, not weight rounding.
+Three numbers per output: |hip - oracle_fp32|, and for scale |oracle_bf16(CPU) - oracle_fp32| -- the error the
+reference's own bf16 CPU path makes against fp32.  Tolerance = max(floor, 3 x that bf16-CPU error).
+"""
+import dataclasses
+
+import torch
+
+from llmseg_amd import lisa as hip_lisa
+from llmseg_amd import params as hp
+from oracle import cases, lisa as olisa
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def to_hip_cfg(c):
+    return hp.LisaConfig(
+        llama=hp.LlamaConfig(**dataclasses.asdict(c.llama)),
+        clip=hp.VitConfig(**dataclasses.asdict(c.clip)), dino=hp.VitConfig(**dataclasses.asdict(c.dino)),
+        sam=hp.SamConfig(**dataclasses.asdict(c.sam)), out_dim=c.out_dim, seg_token_idx=c.seg_token_idx,
+        select_layer=c.select_layer, backbone=c.backbone, ce_loss_weight=c.ce_loss_weight,
+        align_loss_weight=c.align_loss_weight, regression_loss_weight=c.regression_loss_weight)
+
+
+def build_pair(cfg, seed=3):
+    sd = cases.tiny_lisa_state(cfg, seed)
+    sd_r = {k: v.to(BF).float() for k, v in sd.items()}
+    m = hip_lisa.LISAForCausalLM(to_hip_cfg(cfg), device=DEV)
+    missing, unexpected = m.load_state_dict(sd_r, strict=False)
+    assert not missing, missing[:5]
+    return m, sd_r
+
+
+def _round_batch(batch):
+    out = {}
+    for k, v in batch.items():
+        if torch.is_tensor(v) and v.is_floating_point():
+            out[k] = v.to(BF).float()
+        elif isinstance(v, list) and v and torch.is_tensor(v[0]) and v[0].is_floating_point():
+            out[k] = [t.to(BF).float() if t.dtype != torch.float64 else t for t in v]
+        else:
+            out[k] = v
+    return out
+
+
+def _dev(batch):
+    f = lambda t: t.to(DEV) if torch.is_tensor(t) else t
+    return {k: ([f(t) for t in v] if isinstance(v, list) else f(v)) for k, v in batch.items()}
+
+
+def _bf16_sd(sd):
+    return {k: v.to(BF) for k, v in sd.items()}
+
+
+def _bf16_batch(batch):
+    f = lambda t: t.to(BF) if torch.is_tensor(t) and t.dtype == torch.float32 else t
+    return {k: ([f(t) for t in v] if isinstance(v, list) else f(v)) for k, v in batch.items()}
+
+
+def _e(a, b):
+    return (a.detach().float().cpu() - b.detach().float().cpu()).abs().max().item()
+
+
+def check_tiny_inference(backbone="dinov2", with_bf16_cpu=True):
+    cfg = cases.tiny_lisa_cfg(backbone)
+    m, sd = build_pair(cfg)
+    img = 896 if backbone == "dinov2" else cfg.sam.img
+    batch = _round_batch(cases.first_image_inference(cases.tiny_lisa_batch(img_size=img)))
+    with torch.no_grad():
+        ref = olisa.model_forward(sd, cfg, **batch, inference=True, return_aux=True)
+        got = m.model_forward(**_dev(batch), inference=True, return_aux=True)
+        if with_bf16_cpu:
+            lo = olisa.model_forward(_bf16_sd(sd), cfg, **_bf16_batch(batch), inference=True, return_aux=True)
+    B, C, g, _ = ref["feats"].shape
+    ref_feat = ref["feats"].permute(0, 2, 3, 1).reshape(B * g * g, C)
+    res = []
+
+    def add(name, g_, r_, l_, floor):
+        scale = max(1.0, r_.abs().max().item())
+        lo_e = _e(l_, r_) if with_bf16_cpu else 0.0
+        res.append((f"{backbone} {name} (bf16-CPU err {lo_e:.2e})", _e(g_, r_), max(floor * scale, 3.0 * lo_e)))
+
+    rows_per = got["feats"].shape[0] // B
+    gf = got["feats"].view(B, rows_per, C)[:, rows_per - g * g:].reshape(B * g * g, C)
+    lo_feat = lo["feats"].permute(0, 2, 3, 1).reshape(B * g * g, C) if with_bf16_cpu else None
+    add("feats", gf, ref_feat, lo_feat, 2e-2)
+    add("hidden", got["hidden"], ref["hidden"], lo["hidden"] if with_bf16_cpu else None, 3e-2)
+    add("logits", got["logits"], ref["logits"], lo["logits"] if with_bf16_cpu else None, 3e-2)
+    add("pred_embedding", got["pred_embeddings"][0], ref["pred_embeddings"][0], lo["pred_embeddings"][0] if with_bf16_cpu else None, 2e-2)
+    add("pred_similarity", got["pred_similarity"][0], ref["pred_similarity"][0], lo["pred_similarity"][0] if with_bf16_cpu else None, 1e-3)
+    add("pred_iou", got["pred_iou"][0], ref["pred_iou"][0], lo["pred_iou"][0] if with_bf16_cpu else None, 1e-3)
+    return res
+
+
+def check_tiny_train_losses(backbone="dinov2"):
+    cfg = cases.tiny_lisa_cfg(backbone)
+    m, sd = build_pair(cfg)
+    img = 896 if backbone == "dinov2" else cfg.sam.img
+    batch = _round_batch(cases.tiny_lisa_batch(img_size=img))
+    with torch.no_grad():
+        ref = olisa.model_forward(sd, cfg, **batch, inference=False)
+        lo = olisa.model_forward(_bf16_sd(sd), cfg, **_bf16_batch(batch), inference=False)
+        got = m.model_forward(**_dev(batch), inference=False)
+    res = []
+    for k in ("ce_loss", "align_loss", "regression_loss", "loss"):
+        r = float(ref[k])
+        res.append((f"{backbone} train {k} (ref {r:.4f}, bf16-CPU err {abs(float(lo[k]) - r):.2e})", abs(float(got[k]) - r),
+                    max(2e-3 * max(1.0, abs(r)), 3.0 * abs(float(lo[k]) - r))))
+    return res
+
+
+def check_sam_small_golden(golden_loader):
+    """SAM encoder (2 heads x hd 80, windowed + global block, 30x30 grid -> 14-window padding) against the fixture that
+    was generated from the imported reference `ImageEncoderViT`."""
+    from oracle import seeded
+    g = golden_loader("sam_encoder_small.pt")
+    scfg, sd, img = cases.sam_small_case(batch=1)
+    cfg = cases.tiny_lisa_cfg("sam")
+    cfg.sam = scfg
+    full = seeded.fill_state_dict(seeded.lisa_shapes(cfg), 3)
+    full.update({"model.visual_model.image_encoder." + k: v for k, v in sd.items()})
+    m = hip_lisa.LISAForCausalLM(to_hip_cfg(cfg), device=DEV)
+    m.load_state_dict({k: v for k, v in full.items()}, strict=False)
+    out = m.get_visual_embs(img.to(DEV))
+    ref = g["out"]
+    return [("sam_small vs reference fixture", _e(out, ref), 3e-2 * max(1.0, ref.abs().max().item()))]
+
+
+def check_reference_api():
+    """mask_pooling / get_dinov2_visual_embs keep the reference's shapes."""
+    cfg = cases.tiny_lisa_cfg("dinov2")
+    m, sd = build_pair(cfg)
+    from oracle import mask_head, seeded
+    feat = seeded.uniform((256, 64, 64), 5).to(BF).float()
+    segs = (seeded.uniform((8, 64, 64), 6) > 0.3).float()
+    ref = mask_head.mask_pooling(feat, segs)
+    got = m.mask_pooling(feat.to(DEV), segs.to(DEV))
+    return [("mask_pooling API", _e(got, ref), 1e-2)]

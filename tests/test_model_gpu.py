@@ -1,0 +1,32 @@
+"""GPU: the HIP model (through the C ABI) against the CPU oracle and the reference-generated fixtures."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert(res):
+    bad = [(n, e, t) for n, e, t in res if not (e <= t)]
+    assert not bad, "; ".join(f"{n}: err {e:.3e} > tol {t:.3e}" for n, e, t in bad)
+
+
+def test_sam_encoder_vs_reference_fixture(golden):
+    from tests import model_checks as mc
+    _assert(mc.check_sam_small_golden(golden))
+
+
+@pytest.mark.parametrize("backbone", ["dinov2", "sam"])
+def test_tiny_inference(backbone):
+    from tests import model_checks as mc
+    _assert(mc.check_tiny_inference(backbone))
+
+
+@pytest.mark.parametrize("backbone", ["dinov2", "sam"])
+def test_tiny_train_losses(backbone):
+    from tests import model_checks as mc
+    _assert(mc.check_tiny_train_losses(backbone))
+
+
+def test_reference_api():
+    from tests import model_checks as mc
+    _assert(mc.check_reference_api())
