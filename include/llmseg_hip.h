@@ -51,6 +51,9 @@ typedef struct {
   int out_f32;
 } llmseg_gemm_args;
 int llmseg_gemm_bf16(const llmseg_gemm_args* args, void* stream);
+/* tuning knob: staging variant for K % 64 == 0 shapes (0 = global->VGPR->LDS, 1 = LDS-DMA double buffer [default], 2 = LDS-DMA
+ * single buffer).  Results are identical; only speed differs. */
+int llmseg_gemm_set_variant(int variant);
 
 /* ---- fused attention forward -----------------------------------------------------------------
  * O[b][h][q][:] = softmax_k( scale * Q.K^T + bias + mask ) V, online softmax in fp32, bf16 MFMA.

@@ -42,6 +42,7 @@ SIGNATURES = {
     "llmseg_version": [],
     "llmseg_last_error": [],
     "llmseg_gemm_bf16": [C.POINTER(GemmArgs), _p],
+    "llmseg_gemm_set_variant": [C.c_int],
     "llmseg_attn_fwd": [C.POINTER(AttnArgs), _p],
     "llmseg_norm": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _f32, C.c_int, _p, _p],
     "llmseg_rope": [_p, _p, _p, _i64, _i64, _i32, _i32, _i64, _p],

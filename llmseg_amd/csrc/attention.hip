@@ -36,7 +36,8 @@ struct AttnP {
 __device__ __forceinline__ uint32_t perm_lo(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }
 __device__ __forceinline__ uint32_t perm_hi(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xffff0000u); }
 
-// REL: 0 = no bias, 1 = generic grid, 2 = grid_w == BKV (a K tile is exactly one key row: kh uniform, kw = offset)
+// REL: 0 = no bias, 1 = generic grid (slow, general), 2 = grid_w == BKV (a K tile is exactly one key row: kh uniform,
+// kw = offset), 3 = SAM's 14x14 window (196 keys = 4 unrolled tiles, per-query bias rows live in 28 registers)
 template <int HD, int REL>
 __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(AttnP p) {
   constexpr int KS = HD / 16;                 // k-steps of QK^T
@@ -85,6 +86,21 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(AttnP p) {
           bw_cache[jb * 16 + r] = relw_row[qw - kw + p.gw - 1] * LOG2E;
         }
     }
+  }
+
+  // REL == 3: per-query bias rows in registers, with the lane-half (which selects key or key+4) folded into the LOAD
+  // address so that the tile loop only ever uses compile-time indices: bh_s[kh] = Bh[kh], bh_x[kh] = Bh[kh + half],
+  // bw_y[kw] = Bw[(kw + 4*half) % 14].
+  float bh_s[REL == 3 ? 14 : 1], bh_x[REL == 3 ? 13 : 1], bw_y[REL == 3 ? 14 : 1];
+  if constexpr (REL == 3) {
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+      bh_s[j] = relh_row[qh - j + 13] * LOG2E;
+      const int kw = (j + 4 * half) % 14;
+      bw_y[j] = relw_row[qw - kw + 13] * LOG2E;
+    }
+#pragma unroll
+    for (int j = 0; j < 13; ++j) bh_x[j] = relh_row[qh - (j + half) + 13] * LOG2E;
   }
 
   int kv_len = p.Nk;
@@ -160,86 +176,103 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(AttnP p) {
   LL_STAGE_STORE(0)
   __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles) LL_STAGE_LOAD(t + 1)
-    const int k0 = t * BKV;
+  // One K/V tile.  TT = tile index expression, TC = the same as a LITERAL when the tile loop is unrolled (REL == 3), else 0.
+  // Scores are moved to the log2 domain; masking is compiled out for interior tiles (uniform branch).
+#define LL_SCORE_LOOP(MASKED, TC)                                                                                   \
+  _Pragma("unroll") for (int jb = 0; jb < 2; ++jb)                                                                  \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                  \
+    const int koff = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;                                                   \
+    float v = s[jb][r] * p.scale_log2;                                                                              \
+    if constexpr (REL == 2) v += bh_tile + bw_cache[jb * 16 + r];                                                   \
+    if constexpr (REL == 1) {                                                                                       \
+      const uint32_t kk = lut[koff];                                                                                \
+      const int kh = (int)(kk >> 16), kw = (int)(kk & 0xffffu);                                                     \
+      v += (relh_row[qh - kh + p.gh - 1] + relw_row[qw - kw + p.gw - 1]) * LOG2E;                                   \
+    }                                                                                                               \
+    if constexpr (REL == 3) {   /* 14x14 window, everything below folds to constants after unrolling */             \
+      const int key0 = (TC) * 64 + jb * 32 + (r & 3) + 8 * (r >> 2);   /* this register's key for half 0; half 1: +4 */ \
+      const int kh0 = key0 / 14 > 13 ? 13 : key0 / 14, kw0 = key0 % 14;                                             \
+      const bool cross = kw0 >= 10 && kh0 < 13;                        /* key0 + 4 falls into the next key row */  \
+      v += (cross ? bh_x[kh0 > 12 ? 12 : kh0] : bh_s[kh0]) + bw_y[kw0];                                             \
+    }                                                                                                               \
+    if (MASKED) {                                                                                                   \
+      const int key = k0 + koff;                                                                                    \
+      bool ok = key < p.Nk;                                                                                         \
+      if (p.causal) ok = ok && (key <= q);                                                                          \
+      if (p.key_mask) ok = ok && (p.key_mask[(long)b * p.Nk + min(key, p.Nk - 1)] != 0);                            \
+      v = ok ? v : NEG;                                                                                             \
+    }                                                                                                               \
+    s[jb][r] = v;                                                                                                   \
+    mx = fmaxf(mx, v);                                                                                              \
+  }
 
-    // ---- S^T = K . Q^T : two 32-key blocks ------------------------------------------------------------------------
-    f32x16_t s[2];
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s[jb][e] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (jb * 32 + ql) * PK + (2 * ks + half) * 16);
-        s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[jb], 0, 0, 0);
-      }
+#define LL_TILE_BODY(TT, TC)                                                                                        \
+  {                                                                                                                 \
+    const int k0 = (TT) * BKV;                                                                                      \
+    constexpr bool LAST_WIN = (REL == 3) && ((TC) == 3);      /* keys 192..195 only */                              \
+    f32x16_t s[2];                                                                                                  \
+    _Pragma("unroll") for (int jb = 0; jb < 2; ++jb) {                                                              \
+      _Pragma("unroll") for (int e = 0; e < 16; ++e) s[jb][e] = 0.f;                                                \
+      if (!(LAST_WIN && jb == 1)) {                                                                                 \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                         \
+          const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (jb * 32 + ql) * PK + (2 * ks + half) * 16);  \
+          s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[jb], 0, 0, 0);                              \
+        }                                                                                                           \
+      }                                                                                                             \
+    }                                                                                                               \
+    float bh_tile = 0.f;                                                                                            \
+    if constexpr (REL == 2) {                                                                                       \
+      bh_tile = bh_next;                                                                                            \
+      if ((TT) + 1 < ntiles) bh_next = relh_row[qh - ((TT) + 1) + p.gh - 1] * LOG2E;   /* prefetch next key row */  \
+    }                                                                                                               \
+    float mx = NEG;                                                                                                 \
+    const bool need_mask = p.causal || p.key_mask != nullptr || (k0 + BKV > p.Nk);                                  \
+    if (need_mask) { LL_SCORE_LOOP(true, TC) } else { LL_SCORE_LOOP(false, TC) }                                    \
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                         \
+    const float m_new = fmaxf(m_run, mx);                                                                           \
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                                                      \
+    m_run = m_new;                                                                                                  \
+    float lsum = 0.f;                                                                                               \
+    _Pragma("unroll") for (int jb = 0; jb < 2; ++jb)                                                                \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                \
+      const float pv = __builtin_amdgcn_exp2f(s[jb][r] - m_new);                                                    \
+      s[jb][r] = pv;                                                                                                \
+      lsum += pv;                                                                                                   \
+    }                                                                                                               \
+    l_run = l_run * alpha + lsum;                                                                                   \
+    _Pragma("unroll") for (int d = 0; d < DT; ++d)                                                                  \
+    _Pragma("unroll") for (int e = 0; e < 16; ++e) o[d][e] *= alpha;                                                \
+    /* O^T += V^T . P^T : k-steps of 16 keys; P fragment for step ss = accumulator regs 8*(ss&1)..+7 of block ss>>1 */ \
+    _Pragma("unroll") for (int ss = 0; ss < (LAST_WIN ? 1 : 4); ++ss) {                                             \
+      const int jb = ss >> 1, rb = 8 * (ss & 1);                                                                    \
+      const uint4 pu = make_uint4(pack2bf(s[jb][rb + 0], s[jb][rb + 1]), pack2bf(s[jb][rb + 2], s[jb][rb + 3]),     \
+                                  pack2bf(s[jb][rb + 4], s[jb][rb + 5]), pack2bf(s[jb][rb + 6], s[jb][rb + 7]));    \
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);                                                         \
+      _Pragma("unroll") for (int d = 0; d < DT; ++d) {                                                              \
+        const char* vrow = Vt + (d * 32 + ql) * PV + (16 * ss + 4 * half) * 2;                                      \
+        const uint2 va = *reinterpret_cast<const uint2*>(vrow);                                                     \
+        const uint2 vb = *reinterpret_cast<const uint2*>(vrow + 16);                                                \
+        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(va.x, va.y, vb.x, vb.y));                       \
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);                                      \
+      }                                                                                                             \
+    }                                                                                                               \
+  }
+
+  float bh_next = 0.f;
+  if constexpr (REL == 2) bh_next = relh_row[qh + p.gh - 1] * LOG2E;
+  if constexpr (REL == 3) {          // Nk == 196: exactly 4 tiles, fully unrolled so that every bias index is a constant
+    LL_STAGE_LOAD(1) LL_TILE_BODY(0, 0) __syncthreads(); LL_STAGE_STORE(1) __syncthreads();
+    LL_STAGE_LOAD(2) LL_TILE_BODY(1, 1) __syncthreads(); LL_STAGE_STORE(2) __syncthreads();
+    LL_STAGE_LOAD(3) LL_TILE_BODY(2, 2) __syncthreads(); LL_STAGE_STORE(3) __syncthreads();
+    LL_TILE_BODY(3, 3)
+  } else {
+    for (int t = 0; t < ntiles; ++t) {
+      if (t + 1 < ntiles) LL_STAGE_LOAD(t + 1)
+      LL_TILE_BODY(t, 0)
+      __syncthreads();
+      if (t + 1 < ntiles) LL_STAGE_STORE(t + 1)
+      __syncthreads();
     }
-
-    // ---- scale, bias, masks (log2 domain) ---------------------------------------------------------------------------
-    float bh_tile = 0.f;
-    if (REL == 2) bh_tile = relh_row[qh - t + p.gh - 1] * LOG2E;      // tile t == key row kh
-    float mx = NEG;
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int koff = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int key = k0 + koff;
-        float v = s[jb][r] * p.scale_log2;
-        if (REL == 2) v += bh_tile + bw_cache[jb * 16 + r];
-        if (REL == 1) {
-          const uint32_t kk = lut[koff];
-          const int kh = (int)(kk >> 16), kw = (int)(kk & 0xffffu);
-          v += (relh_row[qh - kh + p.gh - 1] + relw_row[qw - kw + p.gw - 1]) * LOG2E;
-        }
-        bool ok = key < p.Nk;
-        if (p.causal) ok = ok && (key <= q);
-        if (p.key_mask) ok = ok && (p.key_mask[(long)b * p.Nk + min(key, p.Nk - 1)] != 0);
-        v = ok ? v : NEG;
-        s[jb][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float lsum = 0.f;
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(s[jb][r] - m_new);
-        s[jb][r] = pv;
-        lsum += pv;
-      }
-    l_run = l_run * alpha + lsum;
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
-
-    // ---- O^T += V^T . P^T : 4 k-steps of 16 keys; P fragment for step ss = accumulator regs 8*(ss&1)..+7 of block ss>>1
-#pragma unroll
-    for (int ss = 0; ss < 4; ++ss) {
-      const int jb = ss >> 1, rb = 8 * (ss & 1);
-      const uint4 pu = make_uint4(pack2bf(s[jb][rb + 0], s[jb][rb + 1]), pack2bf(s[jb][rb + 2], s[jb][rb + 3]),
-                                  pack2bf(s[jb][rb + 4], s[jb][rb + 5]), pack2bf(s[jb][rb + 6], s[jb][rb + 7]));
-      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
-#pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        const char* vrow = Vt + (d * 32 + ql) * PV + (16 * ss + 4 * half) * 2;
-        const uint2 va = *reinterpret_cast<const uint2*>(vrow);
-        const uint2 vb = *reinterpret_cast<const uint2*>(vrow + 16);
-        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(va.x, va.y, vb.x, vb.y));
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
-      }
-    }
-
-    __syncthreads();
-    if (t + 1 < ntiles) LL_STAGE_STORE(t + 1)
-    __syncthreads();
   }
 
   // ---- normalise and store: lane holds O[q][d..d+3] groups ------------------------------------------------------------
@@ -273,6 +306,7 @@ template <int HD>
 int launch_hd(const AttnP& p, hipStream_t s) {
   dim3 grid((p.Nq + BQ - 1) / BQ, p.heads, p.batch);
   if (p.rel_h == nullptr) hipLaunchKernelGGL((attn_fwd_kernel<HD, 0>), grid, dim3(NT), 0, s, p);
+  else if (HD == 80 && p.gh == 14 && p.gw == 14 && p.Nk == 196 && !p.causal && !p.key_mask) hipLaunchKernelGGL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 3 : 1>), grid, dim3(NT), 0, s, p);
   else if (p.gw == BKV && (p.Nk % BKV) == 0) hipLaunchKernelGGL((attn_fwd_kernel<HD, 2>), grid, dim3(NT), 0, s, p);
   else hipLaunchKernelGGL((attn_fwd_kernel<HD, 1>), grid, dim3(NT), 0, s, p);
   return 0;

@@ -2,24 +2,26 @@
 //
 // Replaces every nn.Linear / 1x1-conv / patch-embed on the LLM-Seg hot path (see include/llmseg_hip.h).
 //
-// Design (CDNA4): 256-thread workgroup = 4 wave64, 128x128 output tile, BK = 64.  Each wave owns a 64x64
-// sub-tile as 2x2 v_mfma_f32_32x32x16_bf16 accumulators (64 fp32 regs/lane).  The MFMA "A" operand is the
-// WEIGHT fragment and the "B" operand the ACTIVATION fragment, so a lane ends up holding 4 consecutive
-// output columns (n) of one output row (m): bias/LayerScale/residual/activation fuse into the epilogue and
-// the bf16 store is 8 bytes per lane.
-// Tiles are staged global -> VGPR -> LDS (16-byte chunks, XOR-swizzled on (row>>1)&7 so that the
-// ds_read_b128 fragment loads are bank-conflict free for the 16-lane service groups of gfx950) and the loop
-// is software pipelined: the global loads of tile t+1 are issued before the MFMAs of tile t and written to the
-// other LDS buffer afterwards -> one barrier per K-tile.  Workgroup ids are remapped so that the 8 XCDs
-// (private L2s) each walk a contiguous, M-grouped range of tiles.
+// Design (CDNA4): 256-thread workgroup = 4 wave64 (2 x 2), output tile (64*MI) x 128, BK = 64.  Each wave owns a
+// (32*MI) x 64 sub-tile as MI x 2 v_mfma_f32_32x32x16_bf16 accumulators.  The MFMA "A" operand is the WEIGHT fragment
+// and the "B" operand the ACTIVATION fragment, so a lane ends up holding 4 consecutive output columns (n) of one output
+// row (m): bias / activation / LayerScale / residual fuse into the epilogue and the bf16 store is 8 bytes per lane
+// (packed with v_cvt_pk_bf16_f32).
+//   MI = 4 (256 x 128 tile): 6 ds_read_b128 feed 8 MFMAs per k-step (0.75 KiB of LDS reads per MFMA) - the default
+//   MI = 2 (128 x 128 tile): used when the bigger tile would leave CUs idle
+// Staging, variant G (K % 64 == 0): direct global -> LDS DMA (global_load_lds_dwordx4).  The DMA writes LDS linearly
+// (wave-uniform base + lane*16), so the XOR swizzle that makes the ds_read_b128 fragment loads conflict-free on gfx950's
+// 16-lane service groups is applied to the per-lane SOURCE address instead (lane -> LDS slot (row, cpos) -> global chunk
+// cpos ^ ((row>>1)&7) of that row; the 8 lanes of a row still read one 128-byte line).  One LDS buffer per workgroup,
+// HBM/L2 latency is hidden by 3-4 co-resident workgroups per CU.  Variant R (any K % 8 == 0): global -> VGPR -> LDS with
+// zero-filled K tail, double-buffered.
+// Workgroup ids are remapped so that each of the 8 XCDs (private L2s) walks a contiguous, M-grouped range of tiles.
 #include "common.h"
 #include "llmseg_hip.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64, NT = 256;
-constexpr int TILE_BYTES = BM * BK * 2;       // 16 KiB per operand tile
-constexpr int BUF_BYTES = 2 * TILE_BYTES;     // A + W
+constexpr int BN = 128, BK = 64, NT = 256;
 constexpr int GROUP_M = 8;
 
 struct GemmP {
@@ -30,7 +32,8 @@ struct GemmP {
   float alpha;
   int act;
   int tiles_m, tiles_n;
-  int c_vec, r_vec;   // host-verified alignment for vector C stores / residual loads
+  int c_vec, r_vec, b_vec;   // host-verified alignment for vector C stores / residual loads / bias+gamma loads
+  int skew;                  // per-XCD rotation of the tile walk (de-phases the 8 XCDs' HBM/MALL channel access)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -46,33 +49,137 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * (BK * 2) + (((chunk ^ (row >> 1)) & 7) << 4); }
 
-template <bool OUT_F32>
-__global__ __launch_bounds__(NT, 2) void gemm_bf16_tn_kernel(GemmP p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
+struct TileXY { int m0, n0; };
 
-  // ---- workgroup -> tile: XCD-contiguous (bid % 8 is the XCD), then GROUP_M-grouped, M fastest ----------------
+// workgroup -> tile: XCD-contiguous (bid % 8 is the XCD), then GROUP_M-grouped, M fastest
+template <int BM>
+__device__ __forceinline__ TileXY tile_of(const GemmP& p, int bid) {
   const int nwg = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
   {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int len = q + (xcd < r ? 1 : 0);                                   // tiles in this XCD's contiguous chunk
+    const int idx = ((bid >> 3) + xcd * p.skew) % len;                       // rotate the walk inside the chunk
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective for any nwg
   }
   const int per_group = GROUP_M * p.tiles_n;
   const int grp = bid / per_group;
   const int first_m = grp * GROUP_M;
   const int gsz = min(p.tiles_m - first_m, GROUP_M);
-  const int tile_m = first_m + (bid % per_group) % gsz;
-  const int tile_n = (bid % per_group) / gsz;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  TileXY t;
+  t.m0 = (first_m + (bid % per_group) % gsz) * BM;
+  t.n0 = ((bid % per_group) / gsz) * BN;
+  return t;
+}
 
+// one BK=64 slab: 4 k-steps x (MI activation + 2 weight fragments, 2*MI MFMAs) for this wave's (32*MI) x 64 sub-tile
+template <int MI>
+__device__ __forceinline__ void mma_slab(const char* abase, const char* wbase, int wm, int wn, int frow, int fhalf, f32x16_t (&acc)[2][MI]) {
+#pragma unroll
+  for (int ks = 0; ks < BK / 16; ++ks) {
+    bf16x8_t af[MI], wf[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(wbase + lds_off(wn * 64 + j * 32 + frow, ks * 2 + fhalf));
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(abase + lds_off(wm * 32 * MI + i * 32 + frow, ks * 2 + fhalf));
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void ld4bf(const bf16_t* p, bool vec, int nv, float* o) {
+  if (vec && nv == 4) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
+    o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = e < nv ? bf2f(p[e]) : 0.f;
+  }
+}
+
+// lane holds C[m][n..n+3] for 4 column groups per accumulator
+template <bool OUT_F32, int MI>
+__device__ __forceinline__ void epilogue(const GemmP& p, const f32x16_t (&acc)[2][MI], int m0, int n0, int wm, int wn, int frow, int fhalf, long bz) {
+  const bool vec_ok = p.c_vec != 0, res_vec = p.r_vec != 0, b_vec = p.b_vec != 0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * fhalf;
+      if (n >= p.N) continue;
+      const int nv = min(4, p.N - n);
+      float bs[4] = {0.f, 0.f, 0.f, 0.f}, gm[4] = {1.f, 1.f, 1.f, 1.f};
+      if (p.bias) ld4bf(p.bias + n, b_vec, nv, bs);
+      if (p.gamma) ld4bf(p.gamma + n, b_vec, nv, gm);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * 32 * MI + i * 32 + frow;
+        if (m >= p.M) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e] * p.alpha + bs[e];
+        if (p.act != LLMSEG_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+        }
+        if (p.gamma) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= gm[e];
+        }
+        if (p.res) {
+          float rr[4];
+          ld4bf(p.res + bz * p.sC + (long)m * p.ldr + n, res_vec, nv, rr);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += rr[e];
+        }
+        if (OUT_F32) {
+          float* cp = reinterpret_cast<float*>(p.C) + bz * p.sC + (long)m * p.ldc + n;
+          if (vec_ok && nv == 4) {
+            *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < nv) cp[e] = v[e];
+          }
+        } else {
+          bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + bz * p.sC + (long)m * p.ldc + n;
+          if (vec_ok && nv == 4) {
+            *reinterpret_cast<uint2*>(cp) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < nv) cp[e] = f2bf(v[e]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int MI>
+__device__ __forceinline__ void zero_acc(f32x16_t (&acc)[2][MI]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+}
+
+// ---- variant R: global -> VGPR -> LDS staging (any K % 8 == 0; zero-fills the K tail), 128 x 128 tile, 2 LDS buffers ----
+template <bool OUT_F32>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16_tn_kernel(GemmP p) {
+  constexpr int MI = 2, BM = 128, TILE = 128 * BK * 2, BUF = 2 * TILE;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  const TileXY tc = tile_of<BM>(p, blockIdx.x);
+  const int m0 = tc.m0, n0 = tc.n0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const long bz = blockIdx.y;
   const bf16_t* __restrict__ Ag = p.A + bz * p.sA;
   const bf16_t* __restrict__ Wg = p.W + bz * p.sW;
 
-  // ---- staging map: thread owns chunk kc of rows (tid>>3)+32*i ------------------------------------------------
-  const int kc = tid & 7, r0 = tid >> 3;
+  const int kc = tid & 7, r0 = tid >> 3;      // thread owns chunk kc of rows r0 + 32*i
   const bf16_t* a_ptr[4];
   const bf16_t* w_ptr[4];
   int st_off[4];
@@ -100,112 +207,102 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_tn_kernel(GemmP p) {
     }
   };
   auto store_tile = [&](int buf) {
-    char* base = smem + buf * BUF_BYTES;
+    char* base = smem + buf * BUF;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       *reinterpret_cast<uint4*>(base + st_off[i]) = ra[i];
-      *reinterpret_cast<uint4*>(base + TILE_BYTES + st_off[i]) = rw[i];
+      *reinterpret_cast<uint4*>(base + TILE + st_off[i]) = rw[i];
     }
   };
 
-  f32x16_t acc[2][2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
-
+  f32x16_t acc[2][MI];
+  zero_acc<MI>(acc);
   const int frow = lane & 31, fhalf = lane >> 5;
 
   load_tile(0);
   store_tile(0);
   __syncthreads();
-
   for (int t = 0; t < nt; ++t) {
     if (t + 1 < nt) load_tile(t + 1);
-    const char* abase = smem + (t & 1) * BUF_BYTES;
-    const char* wbase = abase + TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8_t af[2], wf[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ar = wm * 64 + i * 32 + frow;
-        af[i] = *reinterpret_cast<const bf16x8_t*>(abase + lds_off(ar, ks * 2 + fhalf));
-        const int wr = wn * 64 + i * 32 + frow;
-        wf[i] = *reinterpret_cast<const bf16x8_t*>(wbase + lds_off(wr, ks * 2 + fhalf));
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
-    }
+    const char* abase = smem + (t & 1) * BUF;
+    mma_slab<MI>(abase, abase + TILE, wm, wn, frow, fhalf, acc);
     if (t + 1 < nt) store_tile((t + 1) & 1);
     __syncthreads();
   }
+  epilogue<OUT_F32, MI>(p, acc, m0, n0, wm, wn, frow, fhalf, bz);
+}
 
-  // ---- epilogue: lane holds C[m][n..n+3] for 4 column groups per accumulator -----------------------------------
-  const bool vec_ok = p.c_vec != 0;
-  const bool res_vec = p.r_vec != 0;
+// ---- variant G: direct global -> LDS DMA, K % 64 == 0 ---------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+template <bool OUT_F32, int MI, int NBUF>
+__global__ __launch_bounds__(NT, NBUF == 2 ? (MI == 4 ? 1 : 2) : (MI == 4 ? 2 : 4)) void gemm_bf16_tn_glds_kernel(GemmP p) {
+  constexpr int BM = 64 * MI;
+  constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, BUF = A_BYTES + W_BYTES;
+  constexpr int A_DMA = BM / 32, W_DMA = BN / 32;              // 1-KiB DMA instructions per wave per tile
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF];
+  const TileXY tc = tile_of<BM>(p, blockIdx.x);
+  const int m0 = tc.m0, n0 = tc.n0;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const long bz = blockIdx.y;
+  const bf16_t* __restrict__ Ag = p.A + bz * p.sA;
+  const bf16_t* __restrict__ Wg = p.W + bz * p.sW;
+
+  // DMA instruction i of this wave fills LDS rows (i*4 + wave)*8 .. +7 of the operand tile (1 KiB)
+  const bf16_t* a_src[A_DMA];
+  const bf16_t* w_src[W_DMA];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wm * 64 + i * 32 + frow;
-    if (m >= p.M) continue;
+  for (int i = 0; i < A_DMA; ++i) {
+    const int row = (i * 4 + wave) * 8 + (lane >> 3);
+    a_src[i] = Ag + (long)min(m0 + row, p.M - 1) * p.lda + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+  }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+  for (int i = 0; i < W_DMA; ++i) {
+    const int row = (i * 4 + wave) * 8 + (lane >> 3);
+    w_src[i] = Wg + (long)min(n0 + row, p.N - 1) * p.ldw + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+  }
+  const int nt = p.K / BK;
+
+  auto issue = [&](int t, int buf) {
+    char* base = smem + buf * BUF;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * fhalf;
-        if (n >= p.N) continue;
-        float v[4];
+    for (int i = 0; i < W_DMA; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[i] + (long)t * BK), (lds_ptr_t)(base + A_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e] * p.alpha;
-        const int nv = min(4, p.N - n);
-        if (p.bias) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (e < nv) v[e] += bf2f(p.bias[n + e]);
-        }
-        if (p.act != LLMSEG_ACT_NONE) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
-        }
-        if (p.gamma) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (e < nv) v[e] *= bf2f(p.gamma[n + e]);
-        }
-        if (p.res) {
-          const bf16_t* rp = p.res + bz * p.sC + (long)m * p.ldr + n;
-          if (res_vec && nv == 4) {
-            const uint2 rv = *reinterpret_cast<const uint2*>(rp);
-            v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-            v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (e < nv) v[e] += bf2f(rp[e]);
-          }
-        }
-        if (OUT_F32) {
-          float* cp = reinterpret_cast<float*>(p.C) + bz * p.sC + (long)m * p.ldc + n;
-          if (vec_ok && nv == 4) {
-            *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (e < nv) cp[e] = v[e];
-          }
-        } else {
-          bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + bz * p.sC + (long)m * p.ldc + n;
-          if (vec_ok && nv == 4) {
-            *reinterpret_cast<uint2*>(cp) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (e < nv) cp[e] = f2bf(v[e]);
-          }
-        }
-      }
+    for (int i = 0; i < A_DMA; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + (long)t * BK), (lds_ptr_t)(base + (i * 4 + wave) * 1024), 16, 0, 0);
+  };
+
+  f32x16_t acc[2][MI];
+  zero_acc<MI>(acc);
+  const int frow = lane & 31, fhalf = lane >> 5;
+
+  if (NBUF == 2) {
+    issue(0, 0);
+    __syncthreads();                       // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+      const char* abase = smem + (t & 1) * BUF;
+      mma_slab<MI>(abase, abase + A_BYTES, wm, wn, frow, fhalf, acc);
+      __syncthreads();
+    }
+  } else {
+    for (int t = 0; t < nt; ++t) {
+      issue(t, 0);
+      __syncthreads();
+      mma_slab<MI>(smem, smem + A_BYTES, wm, wn, frow, fhalf, acc);
+      __syncthreads();
     }
   }
+  epilogue<OUT_F32, MI>(p, acc, m0, n0, wm, wn, frow, fhalf, bz);
+}
+
+template <bool OUT_F32, int MI, int NBUF>
+void launch_glds(const GemmP& p, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL((gemm_bf16_tn_glds_kernel<OUT_F32, MI, NBUF>), grid, dim3(NT), 0, s, p);
 }
 
 }  // namespace
@@ -213,6 +310,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_tn_kernel(GemmP p) {
 // profiling hooks (capi.cpp)
 void llmseg_prof_begin(hipStream_t s);
 void llmseg_prof_end(hipStream_t s, double flops);
+
+// tuning knob: 0 = register staging 128x128; 1 = DMA 128x128 x2 buffers; 2 = DMA 128x128 x1; 3 = DMA 256x128 x1; 4 = DMA 256x128 x2;
+// 5 (default) = auto: 256x128 x1 when that still gives every CU >= 2 workgroups, else 128x128 x1
+static int g_gemm_variant = 5, g_gemm_skew = 13;
+extern "C" int llmseg_gemm_set_variant(int v) { g_gemm_variant = v & 15; if (v >= 16) g_gemm_skew = (v >> 4) - 1; return LLMSEG_OK; }
 
 extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   LL_CHECK(a && a->A && a->W && a->C, "gemm: null pointer");
@@ -230,15 +332,31 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   const long batch = a->batch > 0 ? a->batch : 1;
   p.sA = a->strideA; p.sW = a->strideW; p.sC = a->strideC;
   p.alpha = a->alpha; p.act = a->act;
-  p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
   // vector stores/loads need 4-element alignment of every row start; otherwise the kernel goes element-wise
   p.c_vec = ((((uintptr_t)a->C) % (4 * esz)) == 0 && (a->ldc & 3) == 0 && (a->strideC & 3) == 0) ? 1 : 0;
   p.r_vec = (p.res && (((uintptr_t)p.res) & 7) == 0 && (p.ldr & 3) == 0 && (a->strideC & 3) == 0) ? 1 : 0;
+  p.b_vec = ((p.bias == nullptr || (((uintptr_t)p.bias) & 7) == 0) && (p.gamma == nullptr || (((uintptr_t)p.gamma) & 7) == 0)) ? 1 : 0;
+
+  p.skew = g_gemm_skew;
+  int variant = (p.K % BK == 0) ? g_gemm_variant : 0;
+  const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN) * batch;
+  if (variant == 5) variant = 2;   // measured (tools/gemm_bench.py): 128x128 single-buffer DMA wins or ties on the hot-path shapes
+  (void)tiles256;
+  const int bm = (variant == 3 || variant == 4) ? 256 : 128;
+  p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + BN - 1) / BN;
   dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);
   hipStream_t s = (hipStream_t)stream;
   llmseg_prof_begin(s);
-  if (a->out_f32) hipLaunchKernelGGL(gemm_bf16_tn_kernel<true>, grid, dim3(NT), 0, s, p);
-  else hipLaunchKernelGGL(gemm_bf16_tn_kernel<false>, grid, dim3(NT), 0, s, p);
+  const bool f = a->out_f32 != 0;
+  switch (variant) {
+    case 1: f ? launch_glds<true, 2, 2>(p, grid, s) : launch_glds<false, 2, 2>(p, grid, s); break;
+    case 2: f ? launch_glds<true, 2, 1>(p, grid, s) : launch_glds<false, 2, 1>(p, grid, s); break;
+    case 3: f ? launch_glds<true, 4, 1>(p, grid, s) : launch_glds<false, 4, 1>(p, grid, s); break;
+    case 4: f ? launch_glds<true, 4, 2>(p, grid, s) : launch_glds<false, 4, 2>(p, grid, s); break;
+    default:
+      if (f) hipLaunchKernelGGL(gemm_bf16_tn_kernel<true>, grid, dim3(NT), 0, s, p);
+      else hipLaunchKernelGGL(gemm_bf16_tn_kernel<false>, grid, dim3(NT), 0, s, p);
+  }
   llmseg_prof_end(s, 2.0 * (double)a->M * (double)a->N * (double)a->K * (double)batch);
   LL_LAUNCH_CHECK("gemm_bf16_tn");
   return LLMSEG_OK;

@@ -1,0 +1,45 @@
+"""GEMM micro-benchmark on the GPU box: TF/s per staging variant on the hot-path shapes (random data, within-process A/B)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from llmseg_amd import _lib, ops  # noqa: E402
+
+SHAPES = [  # (M, N, K, tag)  B=8 images
+    (32768, 3840, 1280, "sam qkv (global)"), (39200, 3840, 1280, "sam qkv (windows)"), (32768, 1280, 1280, "sam proj"),
+    (32768, 5120, 1280, "sam lin1"), (32768, 1280, 5120, "sam lin2"),
+    (2552, 12288, 4096, "llama qkv"), (2552, 4096, 4096, "llama o"), (2552, 22016, 4096, "llama gate_up"), (2552, 4096, 11008, "llama down"),
+    (2552, 32004, 4096, "lm_head"), (2056, 3072, 1024, "clip qkv"), (4096, 4096, 4096, "4096^3"), (8192, 8192, 8192, "8192^3"),
+]
+variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["2", "18", "226", "482", "3"])]
+lib = _lib.load()
+torch.manual_seed(0)
+print("variants: v & 15 = kernel variant, (v >> 4) - 1 = XCD skew (none = default 13)")
+print(f"{'shape':32s} " + " ".join(f"v{v:>8d}" for v in variants) + "   (TFLOP/s; check = max|v - v0|)")
+for M, N, K, tag in SHAPES:
+    a = (torch.rand(M, K, device="cuda") * 2 - 1).to(torch.bfloat16)
+    w = (torch.rand(N, K, device="cuda") * 2 - 1).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda").to(torch.bfloat16)
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    res, ref, chk = [], None, []
+    for v in variants:
+        lib.llmseg_gemm_set_variant(v)
+        for _ in range(3):
+            ops.gemm(a, w, bias=bias, out=out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 10
+        e0.record()
+        for _ in range(n):
+            ops.gemm(a, w, bias=bias, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        res.append(2.0 * M * N * K / ms / 1e9)
+        if ref is None:
+            ref = out.clone()
+        chk.append((out.float() - ref.float()).abs().max().item())
+    print(f"{tag + f' {M}x{N}x{K}':32s} " + " ".join(f"{r:9.0f}" for r in res) + "   check " + " ".join(f"{c:.1e}" for c in chk), flush=True)
+lib.llmseg_gemm_set_variant(5)
