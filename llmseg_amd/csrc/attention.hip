@@ -26,7 +26,8 @@ struct AttnP {
   const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O;
   long qsb, qsh, qsr, ksb, ksh, ksr, vsb, vsh, vsr, osb, osh, osr;
   int batch, heads, Nq, Nk;
-  float scale_log2;
+  float scale_log2;   // scale * log2(e): scores are exponentiated with exp2(raw * scale_log2 - max * scale_log2)
+  float inv_scale;    // 1 / scale: relative-position bias enters the MFMA accumulator in the raw (unscaled) domain
   int causal;
   const uint8_t* key_mask;
   const float* rel_h; const float* rel_w; int rel_ld, gh, gw;
@@ -39,7 +40,7 @@ __device__ __forceinline__ uint32_t perm_hi(uint32_t a, uint32_t b) { return (a 
 // REL: 0 = no bias, 1 = generic grid (slow, general), 2 = grid_w == BKV (a K tile is exactly one key row: kh uniform,
 // kw = offset), 3 = SAM's 14x14 window (196 keys = 4 unrolled tiles, per-query bias rows live in 28 registers)
 template <int HD, int REL>
-__global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(AttnP p) {
+__global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnP p) {
   constexpr int KS = HD / 16;                 // k-steps of QK^T
   constexpr int DT = (HD + 31) / 32;          // 32-row blocks of O^T
   constexpr int CH = HD / 8;                  // 16-byte chunks per row
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kw = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          bw_cache[jb * 16 + r] = relw_row[qw - kw + p.gw - 1] * LOG2E;
+          bw_cache[jb * 16 + r] = relw_row[qw - kw + p.gw - 1] * p.inv_scale;
         }
     }
   }
@@ -95,12 +96,12 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(AttnP p) {
   if constexpr (REL == 3) {
 #pragma unroll
     for (int j = 0; j < 14; ++j) {
-      bh_s[j] = relh_row[qh - j + 13] * LOG2E;
+      bh_s[j] = relh_row[qh - j + 13] * p.inv_scale;
       const int kw = (j + 4 * half) % 14;
-      bw_y[j] = relw_row[qw - kw + 13] * LOG2E;
+      bw_y[j] = relw_row[qw - kw + 13] * p.inv_scale;
     }
 #pragma unroll
-    for (int j = 0; j < 13; ++j) bh_x[j] = relh_row[qh - (j + half) + 13] * LOG2E;
+    for (int j = 0; j < 13; ++j) bh_x[j] = relh_row[qh - (j + half) + 13] * p.inv_scale;
   }
 
   int kv_len = p.Nk;
@@ -178,31 +179,37 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(AttnP p) {
 
   // One K/V tile.  TT = tile index expression, TC = the same as a LITERAL when the tile loop is unrolled (REL == 3), else 0.
   // Scores are moved to the log2 domain; masking is compiled out for interior tiles (uniform branch).
-#define LL_SCORE_LOOP(MASKED, TC)                                                                                   \
+#define LL_BIAS_INIT(TC)                                                                                            \
   _Pragma("unroll") for (int jb = 0; jb < 2; ++jb)                                                                  \
   _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                  \
-    const int koff = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;                                                   \
-    float v = s[jb][r] * p.scale_log2;                                                                              \
-    if constexpr (REL == 2) v += bh_tile + bw_cache[jb * 16 + r];                                                   \
+    float v = 0.f;                                                                                                  \
+    if constexpr (REL == 2) v = bh_tile + bw_cache[jb * 16 + r];                                                    \
     if constexpr (REL == 1) {                                                                                       \
-      const uint32_t kk = lut[koff];                                                                                \
+      const uint32_t kk = lut[jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];                                         \
       const int kh = (int)(kk >> 16), kw = (int)(kk & 0xffffu);                                                     \
-      v += (relh_row[qh - kh + p.gh - 1] + relw_row[qw - kw + p.gw - 1]) * LOG2E;                                   \
+      v = (relh_row[qh - kh + p.gh - 1] + relw_row[qw - kw + p.gw - 1]) * p.inv_scale;                              \
     }                                                                                                               \
     if constexpr (REL == 3) {   /* 14x14 window, everything below folds to constants after unrolling */             \
       const int key0 = (TC) * 64 + jb * 32 + (r & 3) + 8 * (r >> 2);   /* this register's key for half 0; half 1: +4 */ \
       const int kh0 = key0 / 14 > 13 ? 13 : key0 / 14, kw0 = key0 % 14;                                             \
       const bool cross = kw0 >= 10 && kh0 < 13;                        /* key0 + 4 falls into the next key row */  \
-      v += (cross ? bh_x[kh0 > 12 ? 12 : kh0] : bh_s[kh0]) + bw_y[kw0];                                             \
+      v = (cross ? bh_x[kh0 > 12 ? 12 : kh0] : bh_s[kh0]) + bw_y[kw0];                                              \
     }                                                                                                               \
+    s[jb][r] = v;                                                                                                   \
+  }
+
+#define LL_SCORE_LOOP(MASKED)                                                                                       \
+  _Pragma("unroll") for (int jb = 0; jb < 2; ++jb)                                                                  \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                  \
+    float v = s[jb][r];                                                                                             \
     if (MASKED) {                                                                                                   \
-      const int key = k0 + koff;                                                                                    \
+      const int key = k0 + jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;                                             \
       bool ok = key < p.Nk;                                                                                         \
       if (p.causal) ok = ok && (key <= q);                                                                          \
       if (p.key_mask) ok = ok && (p.key_mask[(long)b * p.Nk + min(key, p.Nk - 1)] != 0);                            \
       v = ok ? v : NEG;                                                                                             \
+      s[jb][r] = v;                                                                                                 \
     }                                                                                                               \
-    s[jb][r] = v;                                                                                                   \
     mx = fmaxf(mx, v);                                                                                              \
   }
 
@@ -210,9 +217,14 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(AttnP p) {
   {                                                                                                                 \
     const int k0 = (TT) * BKV;                                                                                      \
     constexpr bool LAST_WIN = (REL == 3) && ((TC) == 3);      /* keys 192..195 only */                              \
+    float bh_tile = 0.f;                                                                                            \
+    if constexpr (REL == 2) {                                                                                       \
+      bh_tile = bh_next;                                                                                            \
+      if ((TT) + 1 < ntiles) bh_next = relh_row[qh - ((TT) + 1) + p.gh - 1] * p.inv_scale; /* prefetch next row */ \
+    }                                                                                                               \
     f32x16_t s[2];                                                                                                  \
+    LL_BIAS_INIT(TC)          /* raw-domain bias (or 0) is the C input of the QK^T MFMAs */                         \
     _Pragma("unroll") for (int jb = 0; jb < 2; ++jb) {                                                              \
-      _Pragma("unroll") for (int e = 0; e < 16; ++e) s[jb][e] = 0.f;                                                \
       if (!(LAST_WIN && jb == 1)) {                                                                                 \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                         \
           const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (jb * 32 + ql) * PK + (2 * ks + half) * 16);  \
@@ -220,28 +232,27 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(AttnP p) {
         }                                                                                                           \
       }                                                                                                             \
     }                                                                                                               \
-    float bh_tile = 0.f;                                                                                            \
-    if constexpr (REL == 2) {                                                                                       \
-      bh_tile = bh_next;                                                                                            \
-      if ((TT) + 1 < ntiles) bh_next = relh_row[qh - ((TT) + 1) + p.gh - 1] * LOG2E;   /* prefetch next key row */  \
-    }                                                                                                               \
     float mx = NEG;                                                                                                 \
     const bool need_mask = p.causal || p.key_mask != nullptr || (k0 + BKV > p.Nk);                                  \
-    if (need_mask) { LL_SCORE_LOOP(true, TC) } else { LL_SCORE_LOOP(false, TC) }                                    \
+    if (need_mask) { LL_SCORE_LOOP(true) } else { LL_SCORE_LOOP(false) }                                            \
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                         \
     const float m_new = fmaxf(m_run, mx);                                                                           \
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                                                      \
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);                                     \
+    const float nmc = -m_new * p.scale_log2;                                                                        \
+    const bool moved = m_new != m_run;                                                                              \
     m_run = m_new;                                                                                                  \
     float lsum = 0.f;                                                                                               \
     _Pragma("unroll") for (int jb = 0; jb < 2; ++jb)                                                                \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                \
-      const float pv = __builtin_amdgcn_exp2f(s[jb][r] - m_new);                                                    \
+      const float pv = __builtin_amdgcn_exp2f(fmaf(s[jb][r], p.scale_log2, nmc));                                  \
       s[jb][r] = pv;                                                                                                \
       lsum += pv;                                                                                                   \
     }                                                                                                               \
     l_run = l_run * alpha + lsum;                                                                                   \
-    _Pragma("unroll") for (int d = 0; d < DT; ++d)                                                                  \
-    _Pragma("unroll") for (int e = 0; e < 16; ++e) o[d][e] *= alpha;                                                \
+    if (__any(moved)) {        /* wave-uniform: after the first tiles the running max rarely moves */               \
+      _Pragma("unroll") for (int d = 0; d < DT; ++d)                                                                \
+      _Pragma("unroll") for (int e = 0; e < 16; ++e) o[d][e] *= alpha;                                              \
+    }                                                                                                               \
     /* O^T += V^T . P^T : k-steps of 16 keys; P fragment for step ss = accumulator regs 8*(ss&1)..+7 of block ss>>1 */ \
     _Pragma("unroll") for (int ss = 0; ss < (LAST_WIN ? 1 : 4); ++ss) {                                             \
       const int jb = ss >> 1, rb = 8 * (ss & 1);                                                                    \
@@ -259,7 +270,7 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(AttnP p) {
   }
 
   float bh_next = 0.f;
-  if constexpr (REL == 2) bh_next = relh_row[qh + p.gh - 1] * LOG2E;
+  if constexpr (REL == 2) bh_next = relh_row[qh + p.gh - 1] * p.inv_scale;
   if constexpr (REL == 3) {          // Nk == 196: exactly 4 tiles, fully unrolled so that every bias index is a constant
     LL_STAGE_LOAD(1) LL_TILE_BODY(0, 0) __syncthreads(); LL_STAGE_STORE(1) __syncthreads();
     LL_STAGE_LOAD(2) LL_TILE_BODY(1, 1) __syncthreads(); LL_STAGE_STORE(2) __syncthreads();
@@ -335,6 +346,7 @@ extern "C" int llmseg_attn_fwd(const llmseg_attn_args* a, void* stream) {
   p.osb = a->o_stride_b; p.osh = a->o_stride_h; p.osr = a->o_stride_row;
   p.batch = a->batch; p.heads = a->heads; p.Nq = a->Nq; p.Nk = a->Nk;
   p.scale_log2 = a->scale * LOG2E;
+  p.inv_scale = 1.0f / a->scale;
   p.causal = a->causal; p.key_mask = a->key_mask;
   p.rel_h = a->rel_h; p.rel_w = a->rel_w; p.rel_ld = a->rel_ld; p.gh = a->grid_h; p.gw = a->grid_w;
   p.o_row_map = a->o_row_map;

@@ -300,6 +300,94 @@ __global__ __launch_bounds__(NT, NBUF == 2 ? (MI == 4 ? 1 : 2) : (MI == 4 ? 2 : 
   epilogue<OUT_F32, MI>(p, acc, m0, n0, wm, wn, frow, fhalf, bz);
 }
 
+
+// ---- variant B: 256 x 256 tile, 8 waves (2 x 4, each 128 x 64), two 64-KiB LDS stages, software-pipelined DMA -------------
+// One workgroup per CU (128 KiB LDS).  The DMA of tile t+1 is in flight while tile t is multiplied: waits are COUNTED
+// (s_waitcnt vmcnt(8) = "everything but the 8 newest DMA instructions has landed") and the barriers are raw s_barrier, so
+// the compiler does not drain the queue.  Halves L2->CU traffic per flop vs the 128 x 128 tile and needs 6 ds_read_b128 per
+// 8 MFMAs.  K % 64 == 0.
+constexpr int NTB = 512;
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_big_kernel(GemmP p) {
+  constexpr int MI = 4, BMB = 256, BNB = 256;
+  constexpr int A_BYTES = BMB * BK * 2, W_BYTES = BNB * BK * 2, BUF = A_BYTES + W_BYTES;     // 64 KiB per stage
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  // tile mapping (BN = 256 here, so not tile_of<>)
+  int bid = blockIdx.x;
+  const int nwg = p.tiles_m * p.tiles_n;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int len = q + (xcd < r ? 1 : 0);
+    const int idx = ((bid >> 3) + xcd * p.skew) % len;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int per_group = GROUP_M * p.tiles_n;
+  const int first_m = (bid / per_group) * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int m0 = (first_m + (bid % per_group) % gsz) * BMB;
+  const int n0 = ((bid % per_group) / gsz) * BNB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const long bz = blockIdx.y;
+  const bf16_t* __restrict__ Ag = p.A + bz * p.sA;
+  const bf16_t* __restrict__ Wg = p.W + bz * p.sW;
+
+  // DMA instruction i (0..3) of this wave fills LDS rows (i*8 + wave)*8 .. +7 of each operand tile
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 8 + wave) * 8 + (lane >> 3);
+    const int sw = (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+    a_src[i] = Ag + (long)min(m0 + row, p.M - 1) * p.lda + sw;
+    w_src[i] = Wg + (long)min(n0 + row, p.N - 1) * p.ldw + sw;
+  }
+  const int nt = p.K / BK;
+
+  auto issue = [&](int t, int buf) {
+    char* base = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[i] + (long)t * BK), (lds_ptr_t)(base + A_BYTES + (i * 8 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + (long)t * BK), (lds_ptr_t)(base + (i * 8 + wave) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16_t acc[2][MI];
+  zero_acc<MI>(acc);
+  const int frow = lane & 31, fhalf = lane >> 5;
+
+  issue(0, 0);
+  if (nt > 1) issue(1, 1);
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile t landed; tile t+1 may still be in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* abase = smem + (t & 1) * BUF;
+    // this wave's sub-tile: activations rows wm*128.., weights rows wn*64..
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8_t af[MI], wf[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(abase + A_BYTES + lds_off(wn * 64 + j * 32 + frow, ks * 2 + fhalf));
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(abase + lds_off(wm * 128 + i * 32 + frow, ks * 2 + fhalf));
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // own LDS reads retired before the buffer is refilled
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nt) issue(t + 2, t & 1);
+  }
+  // epilogue: same lane->C mapping as the small tile with this wave's origin (wm*128, wn*64)
+  epilogue<OUT_F32, MI>(p, acc, m0 + wm * 128 - wm * 32 * MI, n0 + wn * 64 - (wn & 1) * 64, wm, wn & 1, frow, fhalf, bz);
+}
+
 template <bool OUT_F32, int MI, int NBUF>
 void launch_glds(const GemmP& p, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((gemm_bf16_tn_glds_kernel<OUT_F32, MI, NBUF>), grid, dim3(NT), 0, s, p);
@@ -342,8 +430,9 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN) * batch;
   if (variant == 5) variant = 2;   // measured (tools/gemm_bench.py): 128x128 single-buffer DMA wins or ties on the hot-path shapes
   (void)tiles256;
-  const int bm = (variant == 3 || variant == 4) ? 256 : 128;
-  p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + BN - 1) / BN;
+  const int bm = (variant == 3 || variant == 4 || variant == 6) ? 256 : 128;
+  const int bn = variant == 6 ? 256 : BN;
+  p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
   dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);
   hipStream_t s = (hipStream_t)stream;
   llmseg_prof_begin(s);
@@ -353,6 +442,10 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
     case 2: f ? launch_glds<true, 2, 1>(p, grid, s) : launch_glds<false, 2, 1>(p, grid, s); break;
     case 3: f ? launch_glds<true, 4, 1>(p, grid, s) : launch_glds<false, 4, 1>(p, grid, s); break;
     case 4: f ? launch_glds<true, 4, 2>(p, grid, s) : launch_glds<false, 4, 2>(p, grid, s); break;
+    case 6:
+      if (f) hipLaunchKernelGGL(gemm_bf16_tn_big_kernel<true>, grid, dim3(NTB), 0, s, p);
+      else hipLaunchKernelGGL(gemm_bf16_tn_big_kernel<false>, grid, dim3(NTB), 0, s, p);
+      break;
     default:
       if (f) hipLaunchKernelGGL(gemm_bf16_tn_kernel<true>, grid, dim3(NT), 0, s, p);
       else hipLaunchKernelGGL(gemm_bf16_tn_kernel<false>, grid, dim3(NT), 0, s, p);
