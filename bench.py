@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--prompt-len", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="reduced depth (debug only; result marked invalid)")
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
+                    help="fwd: BASELINE configs[1] (forward only); train: configs[2]/[3] fwd+bwd with LoRA r=8 + DDP, optimizer step every --accum steps")
+    ap.add_argument("--accum", type=int, default=10, help="gradient-accumulation micro-steps per optimizer step (reference: 10)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -128,8 +131,11 @@ def main():
     from llmseg_amd.params import LisaConfig, LlamaConfig, SamConfig, VitConfig
 
     cfg = LisaConfig(backbone=args.backbone, build_unused_towers=False)
+    train = args.mode == "train"
+    if train:
+        cfg.llama = LlamaConfig(lora_r=8)
     if args.small:
-        cfg.llama = LlamaConfig(layers=2)
+        cfg.llama = LlamaConfig(layers=2, lora_r=8 if train else 0)
         cfg.sam = SamConfig(depth=2, global_idx=(1,))
         cfg.clip = VitConfig(layers=3)
     model = LISAForCausalLM(cfg, device=dev).init_random(seed=0)
@@ -137,8 +143,17 @@ def main():
     img = 1024 if args.backbone == "sam" else 896
     batch = synthetic.make_batch(args.batch, img_size=img, L=args.prompt_len, K=args.masks, device=dev, seed=1234 + rank)
 
-    def step():
-        return model.model_forward(**batch, inference=False)
+    if train:
+        from llmseg_amd.train import Trainer
+        model.set_trainable()
+        trainer = Trainer(model, lr=3e-4, grad_accum=args.accum, device_ids=[local])
+
+        def step():
+            return trainer.micro_step(batch)
+    else:
+        def step():
+            with torch.no_grad():
+                return model.model_forward(**batch, inference=False)
 
     for _ in range(args.warmup):
         out = step()
@@ -161,7 +176,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    loss = float(out["loss"])
+    loss = float(out["loss"].detach())
     assert loss == loss, "NaN loss"
 
     if rank == 0:
@@ -171,16 +186,20 @@ def main():
         ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         model_flops = gemm_flops / args.steps + attention_flops(cfg, args.batch, T)
         res = {
-            "metric": "images/sec (1024x1024, 64-tok prompt) model_forward", "value": total_imgs / dt, "unit": "images/s",
+            "metric": "images/sec (1024x1024, 64-tok prompt) model_forward " + ("fwd+bwd" if train else "fwd"), "value": total_imgs / dt,
+            "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[1]: synthetic %dx%d + random-init LLaVA-7B(Llama-7B+CLIP-L/14)/%s, "
-                                    "forward-only model_forward (training-mode forward incl. lm_head+CE+align+IoP losses, no backward), "
-                                    "%d candidate masks, %d-token prompt") % (img, img, "SAM-ViT-H" if args.backbone == "sam" else "DINOv2-L",
-                                                                              args.masks, args.prompt_len),
+                                    "%s, %d candidate masks, %d-token prompt") % (
+                img, img, "SAM-ViT-H" if args.backbone == "sam" else "DINOv2-L",
+                ("fwd+bwd train step (CE + align + IoP losses, LoRA r=8 on q/v + trainable embed/lm_head/text_fcs/lisa_*, frozen towers, "
+                 "torch DDP, AdamW step every %d micro-steps inside the timed region)" % args.accum) if train else
+                "forward-only model_forward (training-mode forward incl. lm_head+CE+align+IoP losses, no backward)",
+                args.masks, args.prompt_len),
                        "images_per_gpu_per_step": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "valid": not args.small},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_tn_kernel", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_tn_glds_kernel (+ gemm_bf16_tn_kernel layouts)", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "launches_per_step": gemm_launches / args.steps,
                          "avg_launch_us": gemm_ms * 1e3 / max(1, gemm_launches),
                          "gemm_time_share_of_step": gemm_ms / (dt * 1e3)},

@@ -49,6 +49,9 @@ typedef struct {
   float alpha;
   int act;
   int out_f32;
+  int trans_a;   /* 1: A is stored [K][M] (M contiguous, lda >= M) -- used by the backward pass (dW = dY^T X) */
+  int trans_w;   /* 1: W is stored [K][N] (N contiguous, ldw >= N) -- used by the backward pass (dX = dY W) */
+  int64_t batch2, strideA2, strideW2, strideC2;   /* optional outer batch dimension (0/1 = none): entry (b1, b2) is at b1*stride + b2*stride2 */
 } llmseg_gemm_args;
 int llmseg_gemm_bf16(const llmseg_gemm_args* args, void* stream);
 /* tuning knob: staging variant for K % 64 == 0 shapes (0 = global->VGPR->LDS, 1 = LDS-DMA double buffer [default], 2 = LDS-DMA
@@ -124,9 +127,10 @@ int llmseg_gather_rows(const void* x, const int64_t* idx, void* out, int64_t n, 
  * pooled[k][c] = sum_p segs[k][p] * Up(feat)[c][p] / (sum_p segs[k][p] + 1e-8), Up = F.interpolate(size=S, bilinear,
  * align_corners=False) of the channels-last bf16 map feat [g*g][C].  Computed as (segs . U) . feat, i.e. the mask is
  * pulled back through the adjoint of the interpolation, so the [C][S][S] upsampled tensor is never materialised and
- * `segs` (K*S*S bf16, the only large operand) is read from HBM exactly once.  feat bf16 [g*g][C]; pooled bf16 [K][C]. */
-int llmseg_upsample_maskpool(const void* feat, const void* segs, void* pooled, int32_t K, int32_t C, int32_t g, int32_t S,
-                             void* stream);
+ * `segs` (K*S*S bf16, the only large operand) is read from HBM exactly once.  feat bf16 [g*g][C]; pooled bf16 [K][C].
+ * Optional outputs for the backward pass (NULL = skip): pulled_back fp32 [K][g*g] = segs . U, wsum fp32 [K] = sum_p segs. */
+int llmseg_upsample_maskpool(const void* feat, const void* segs, void* pooled, float* pulled_back, float* wsum, int32_t K, int32_t C,
+                             int32_t g, int32_t S, void* stream);
 
 /* Cosine scoring (LISA.py:398-403): sim[k] = <t,e_k> / (|t||e_k|); t bf16 [D], e bf16 [K][D]; sim fp32 [K]. */
 int llmseg_cosine_scores(const void* t, const void* e, float* sim, int32_t K, int32_t D, void* stream);
@@ -146,6 +150,38 @@ int llmseg_dice_bce(const float* logits, const float* targets, float* out, int32
  * spliced form; position (n,t) is scored against labels[n][t+1]; ignore_index -100.  acc fp32[2] += {sum nll, count}. */
 int llmseg_ce_loss(const void* logits, const int64_t* labels, float* acc, int32_t N, int32_t T, int64_t V, int64_t ldl,
                    void* stream);
+
+
+/* ---- backward pass + optimizer (trainable part: LoRA'd Llama stack, embed/lm_head, text_hidden_fcs, mask-selection head) -----
+ * GEMM-shaped gradients use llmseg_gemm_bf16 with trans_a / trans_w (dX = dY W, dW = dY^T X); the kernels below are the
+ * streaming pieces.  Gradients of the loss kernels: llmseg_align_reg_loss (d_e, d_t, d_pred). */
+/* out[n] += sum_m x[m][n]  (bias gradients, fp32 accumulation; caller zero-fills out) */
+int llmseg_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ld, void* stream);
+/* LayerNorm / RMSNorm backward (contiguous rows): dx bf16; dw/db fp32 accumulated (NULL = frozen weight) */
+int llmseg_norm_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw, float* db, int64_t rows, int64_t cols,
+                    float eps, int rms, void* stream);
+/* SwiGLU backward: gu [rows][2I] (gate|up), dout [rows][I] -> dgu [rows][2I] */
+int llmseg_swiglu_bwd(const void* gu, const void* dout, void* dgu, int64_t rows, int64_t I, void* stream);
+/* out = dy * f'(y) computed from the OUTPUT y of a fused GEMM epilogue (act = RELU or SIGMOID) */
+int llmseg_act_bwd(const void* dy, const void* y, void* out, int64_t n, int act, void* stream);
+/* Materialised attention probabilities for the backward pass (T <= a few hundred: Llama T=319, head K<=512):
+ * P[b][q][k] = softmax_k(scale * S[b][q][k] + causal/key mask), S fp32 [BH][Tq][ld], P bf16 same shape, columns >= Tk zero.
+ * key_mask uint8 [BH/heads][Tk] or NULL; causal requires Tq == Tk. */
+int llmseg_softmax_rows(const float* S, void* P, int64_t BH, int32_t Tq, int32_t Tk, int32_t ld, float scale, int32_t causal,
+                        const uint8_t* key_mask, int32_t heads, void* stream);
+/* dS[r][k] = scale * P[r][k] * (dP[r][k] - sum_k' P[r][k'] dP[r][k'])  (softmax backward; rows = BH*T) */
+int llmseg_attn_ds(const void* P, const float* dP, void* dS, int64_t rows, int32_t T, int32_t ld, float scale, void* stream);
+/* dlogits = coef[0] * (softmax(logits) - onehot(shifted label)); zero for ignored positions (llava_llama.py:108-118 backward) */
+int llmseg_ce_bwd(const void* logits, const int64_t* labels, const float* coef, void* dlogits, int32_t N, int32_t T, int64_t V,
+                  int64_t ldl, void* stream);
+/* dst[idx[i]][:] += src[i][:] in fp32 (embedding / row-gather gradients; idx < 0 skipped) */
+int llmseg_scatter_add_rows(const void* src, const int64_t* idx, float* dst, int64_t n, int64_t cols, void* stream);
+/* out[0] += sum x^2 (global gradient-norm clipping, training.py:301 "gradient_clipping": 1.0) */
+int llmseg_sumsq(const void* x, int64_t n, int is_f32, float* out, void* stream);
+/* Fused AdamW on fp32 master weights + bf16 model copy (DeepSpeed config training.py:292-332: betas (0.9, 0.95), wd 0).
+ * grad is bf16 (grad_f32 = 0) or fp32; grad_scale (device fp32 scalar or NULL) carries 1/accum and the clip coefficient. */
+int llmseg_adamw(void* p, float* master, const void* grad, int grad_f32, float* m, float* v, int64_t n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, int64_t step, const float* grad_scale, void* stream);
 
 /* ---- per-kernel timing (bench roofline): HIP events recorded around every GEMM launch on its own stream ---------- */
 int llmseg_prof_enable(int on);                 /* 1 = record events around GEMM launches */

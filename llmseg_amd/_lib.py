@@ -19,7 +19,8 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
                 ("lda", C.c_int64), ("ldw", C.c_int64), ("ldc", C.c_int64), ("ldr", C.c_int64),
                 ("batch", C.c_int64), ("strideA", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64),
-                ("alpha", C.c_float), ("act", C.c_int), ("out_f32", C.c_int)]
+                ("alpha", C.c_float), ("act", C.c_int), ("out_f32", C.c_int), ("trans_a", C.c_int), ("trans_w", C.c_int),
+                ("batch2", C.c_int64), ("strideA2", C.c_int64), ("strideW2", C.c_int64), ("strideC2", C.c_int64)]
 
 
 class AttnArgs(C.Structure):
@@ -52,11 +53,21 @@ SIGNATURES = {
     "llmseg_im2col3x3": [_p, _p, _i32, _i32, _i32, _i32, _p],
     "llmseg_embed_splice": [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i64, _i64, _p],
     "llmseg_gather_rows": [_p, _p, _p, _i64, _i64, _i64, _p],
-    "llmseg_upsample_maskpool": [_p, _p, _p, _i32, _i32, _i32, _i32, _p],
+    "llmseg_upsample_maskpool": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p],
     "llmseg_cosine_scores": [_p, _p, _p, _i32, _i32, _p],
     "llmseg_align_reg_loss": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _f32, _p],
     "llmseg_dice_bce": [_p, _p, _p, _i32, _i64, _f32, _p],
     "llmseg_ce_loss": [_p, _p, _p, _i32, _i32, _i64, _i64, _p],
+    "llmseg_colsum": [_p, _p, _i64, _i64, _i64, _p],
+    "llmseg_norm_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _f32, C.c_int, _p],
+    "llmseg_swiglu_bwd": [_p, _p, _p, _i64, _i64, _p],
+    "llmseg_act_bwd": [_p, _p, _p, _i64, C.c_int, _p],
+    "llmseg_softmax_rows": [_p, _p, _i64, _i32, _i32, _i32, _f32, _i32, _p, _i32, _p],
+    "llmseg_attn_ds": [_p, _p, _p, _i64, _i32, _i32, _f32, _p],
+    "llmseg_ce_bwd": [_p, _p, _p, _p, _i32, _i32, _i64, _i64, _p],
+    "llmseg_scatter_add_rows": [_p, _p, _p, _i64, _i64, _p],
+    "llmseg_sumsq": [_p, _i64, C.c_int, _p, _p],
+    "llmseg_adamw": [_p, _p, _p, C.c_int, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _p, _p],
     "llmseg_prof_enable": [C.c_int],
     "llmseg_prof_collect": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)],
 }

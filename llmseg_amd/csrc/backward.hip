@@ -1,0 +1,309 @@
+// Backward-pass and optimizer kernels for the trainable part of the LLM-Seg hot path (LoRA'd Llama stack, embed/lm_head,
+// text_hidden_fcs, mask-selection head).  All HBM-bound streaming kernels; GEMM-shaped gradients go through
+// llmseg_gemm_bf16 with trans_a / trans_w.  See include/llmseg_hip.h for the reference ops each one differentiates.
+#include "common.h"
+#include "llmseg_hip.h"
+
+namespace {
+
+inline unsigned grid_for(long total) {
+  long g = (total + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+// out[n] += sum_m x[m][n]   (bias gradients); block = 64 columns x 4 row-lanes, grid.y splits the rows
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, long M, long N, long ld) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const long col = (long)blockIdx.x * 64 + c;
+  const long rows_per = (M + gridDim.y - 1) / gridDim.y;
+  const long r0 = (long)blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  float s = 0.f;
+  if (col < N)
+    for (long r = r0 + rl; r < r1; r += 4) s += bf2f(x[r * ld + col]);
+  red[rl][c] = s;
+  __syncthreads();
+  if (rl == 0 && col < N) atomicAdd(&out[col], red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+}
+
+// LayerNorm / RMSNorm backward, one wave per row.  dw/db (fp32, may be NULL) are accumulated with atomics.
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                      bf16_t* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, long rows, int cols,
+                                                      float eps, int rms) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * cols;
+  const bf16_t* gr = dy + row * cols;
+  const int nch = cols >> 3;
+  float f[8], g[8], ww[8];
+  float s = 0.f;
+  if (!rms) {
+    for (int c = lane; c < nch; c += 64) {
+      unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += f[e];
+    }
+    s = wave_sum(s);
+  }
+  const float mean = rms ? 0.f : s / (float)cols;
+  float v = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; v += d * d; }
+  }
+  v = wave_sum(v);
+  const float rstd = rsqrtf(v / (float)cols + eps);
+  // c1 = mean(g), c2 = mean(g * xhat) with g = dy * w
+  float c1 = 0.f, c2 = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
+    unpack8(*reinterpret_cast<const uint4*>(gr + c * 8), g);
+    unpack8(*reinterpret_cast<const uint4*>(w + c * 8), ww);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (f[e] - mean) * rstd, gg = g[e] * ww[e];
+      c1 += gg; c2 += gg * xh;
+    }
+  }
+  c1 = wave_sum(c1) / (float)cols; c2 = wave_sum(c2) / (float)cols;
+  if (rms) c1 = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    float o[8];
+    unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
+    unpack8(*reinterpret_cast<const uint4*>(gr + c * 8), g);
+    unpack8(*reinterpret_cast<const uint4*>(w + c * 8), ww);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (f[e] - mean) * rstd;
+      o[e] = rstd * (g[e] * ww[e] - c1 - xh * c2);
+      if (dw) atomicAdd(&dw[c * 8 + e], g[e] * xh);
+      if (db) atomicAdd(&db[c * 8 + e], g[e]);
+    }
+    *reinterpret_cast<uint4*>(dx + row * cols + c * 8) = pack8(o);
+  }
+}
+
+// d_gu[r][c] = d_out * up * silu'(gate), d_gu[r][I+c] = d_out * silu(gate)
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dout, bf16_t* __restrict__ dgu,
+                                                        long rows, long I) {
+  const long ich = I >> 3, total = rows * ich;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / ich, c = i % ich;
+    float g[8], u[8], d[8], og[8], ou[8];
+    unpack8(*reinterpret_cast<const uint4*>(gu + row * 2 * I + c * 8), g);
+    unpack8(*reinterpret_cast<const uint4*>(gu + row * 2 * I + I + c * 8), u);
+    unpack8(*reinterpret_cast<const uint4*>(dout + row * I + c * 8), d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float sg = 1.f / (1.f + __expf(-g[e]));
+      ou[e] = d[e] * g[e] * sg;
+      og[e] = d[e] * u[e] * sg * (1.f + g[e] * (1.f - sg));
+    }
+    *reinterpret_cast<uint4*>(dgu + row * 2 * I + c * 8) = pack8(og);
+    *reinterpret_cast<uint4*>(dgu + row * 2 * I + I + c * 8) = pack8(ou);
+  }
+}
+
+// dpre = dy * f'(y) from the OUTPUT y: relu -> (y > 0), sigmoid -> y (1 - y)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, bf16_t* __restrict__ out, long n, int act) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float g = bf2f(dy[i]), yy = bf2f(y[i]);
+    out[i] = f2bf(act == LLMSEG_ACT_RELU ? (yy > 0.f ? g : 0.f) : g * yy * (1.f - yy));
+  }
+}
+
+// P[b][q][k] = softmax_k(scale * S[b][q][k] + mask), one wave per (b, q) row; columns >= T are written as zero
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, bf16_t* __restrict__ P, long BH, int Tq, int T, int ld,
+                                                          float scale, int causal, const uint8_t* __restrict__ key_mask, int heads) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= BH * Tq) return;
+  const long bh = row / Tq;
+  const int q = (int)(row % Tq);
+  const float* s = S + row * ld;
+  bf16_t* p = P + row * ld;
+  const uint8_t* km = key_mask ? key_mask + (bh / heads) * T : nullptr;
+  float mx = -1e30f;
+  for (int k = lane; k < T; k += 64) {
+    const bool ok = (!causal || k <= q) && (!km || km[k]);
+    if (ok) mx = fmaxf(mx, s[k] * scale);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int k = lane; k < T; k += 64) {
+    const bool ok = (!causal || k <= q) && (!km || km[k]);
+    if (ok) sum += __expf(s[k] * scale - mx);
+  }
+  sum = wave_sum(sum);
+  const float inv = sum > 0.f ? 1.f / sum : 0.f;
+  for (int k = lane; k < ld; k += 64) {
+    const bool ok = k < T && (!causal || k <= q) && (!km || km[k]);
+    p[k] = f2bf(ok ? __expf(s[k] * scale - mx) * inv : 0.f);
+  }
+}
+
+// dS = scale * P * (dP - sum_k P dP), one wave per row; pad columns written as zero
+__global__ __launch_bounds__(256) void attn_ds_kernel(const bf16_t* __restrict__ P, const float* __restrict__ dP, bf16_t* __restrict__ dS, long rows, int T,
+                                                     int ld, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* p = P + row * ld;
+  const float* d = dP + row * ld;
+  float dl = 0.f;
+  for (int k = lane; k < T; k += 64) dl += bf2f(p[k]) * d[k];
+  dl = wave_sum(dl);
+  for (int k = lane; k < ld; k += 64) dS[row * ld + k] = f2bf(k < T ? scale * bf2f(p[k]) * (d[k] - dl) : 0.f);
+}
+
+// dlogits[n][t][:] = coef * (softmax(logits[n][t]) - onehot(labels[n][t+1])), zero rows where the label is ignored / t == T-1
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const bf16_t* __restrict__ logits, const int64_t* __restrict__ labels, const float* __restrict__ coef,
+                                                    bf16_t* __restrict__ dl, int T, long V, long ldl) {
+  __shared__ float red[16];
+  const int n = blockIdx.x / T, t = blockIdx.x % T;
+  const bf16_t* row = logits + ((long)n * T + t) * ldl;
+  bf16_t* out = dl + ((long)n * T + t) * ldl;
+  const long lab = t + 1 < T ? labels[(long)n * T + t + 1] : -100;
+  if (lab < 0 || lab >= V) {
+    for (long i = threadIdx.x; i < V; i += blockDim.x) out[i] = 0;
+    return;
+  }
+  float mx = -1e30f;
+  for (long i = threadIdx.x; i < V; i += blockDim.x) mx = fmaxf(mx, bf2f(row[i]));
+  mx = block_max(mx, red);
+  float s = 0.f;
+  for (long i = threadIdx.x; i < V; i += blockDim.x) s += __expf(bf2f(row[i]) - mx);
+  s = block_sum(s, red);
+  const float c = coef[0], inv = 1.f / s;
+  for (long i = threadIdx.x; i < V; i += blockDim.x) out[i] = f2bf(c * (__expf(bf2f(row[i]) - mx) * inv - (i == lab ? 1.f : 0.f)));
+}
+
+// dst[idx[i]][:] += src[i][:]  (fp32 accumulation; embedding / gather gradients).  idx < 0 rows are skipped.
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const bf16_t* __restrict__ src, const int64_t* __restrict__ idx, float* __restrict__ dst,
+                                                              long n, long cols) {
+  const long total = n * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols, c = i % cols;
+    const long d = idx[r];
+    if (d >= 0) atomicAdd(&dst[d * cols + c], bf2f(src[i]));
+  }
+}
+
+// sum of squares of a bf16 or fp32 buffer -> out[0] += (grad-norm clipping)
+__global__ __launch_bounds__(256) void sumsq_kernel(const void* __restrict__ x, long n, int is_f32, float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = is_f32 ? reinterpret_cast<const float*>(x)[i] : bf2f(reinterpret_cast<const bf16_t*>(x)[i]);
+    s += v * v;
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+// Fused AdamW on fp32 master weights with bf16 model copy (DeepSpeed bf16 + AdamW(beta=(0.9,0.95), wd) semantics restated):
+// g = grad * gscale[0];  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  master -= lr * (mhat / (sqrt(vhat) + eps) + wd * master)
+__global__ __launch_bounds__(256) void adamw_kernel(bf16_t* __restrict__ p, float* __restrict__ master, const void* __restrict__ grad, int grad_f32,
+                                                   float* __restrict__ m, float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                   float wd, float bc1, float bc2, const float* __restrict__ gscale) {
+  const float gs = gscale ? gscale[0] : 1.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float g = gs * (grad_f32 ? reinterpret_cast<const float*>(grad)[i] : bf2f(reinterpret_cast<const bf16_t*>(grad)[i]));
+    const float mi = b1 * m[i] + (1.f - b1) * g;
+    const float vi = b2 * v[i] + (1.f - b2) * g * g;
+    m[i] = mi; v[i] = vi;
+    float w = master[i];
+    w -= lr * ((mi / bc1) / (sqrtf(vi / bc2) + eps) + wd * w);
+    master[i] = w;
+    p[i] = f2bf(w);
+  }
+}
+
+}  // namespace
+
+#define AL16(p) ((((uintptr_t)(p)) & 15) == 0)
+
+extern "C" int llmseg_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ld, void* stream) {
+  LL_CHECK(x && out && M > 0 && N > 0 && ld >= N, "colsum: bad arguments");
+  const unsigned gy = (unsigned)min((long)64, (long)((M + 255) / 256));
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64), gy < 1 ? 1 : gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, (long)M,
+                     (long)N, (long)ld);
+  LL_LAUNCH_CHECK("colsum");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_norm_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw, float* db, int64_t rows, int64_t cols, float eps,
+                               int rms, void* stream) {
+  LL_CHECK(dy && x && w && dx && rows > 0 && cols > 0 && (cols & 7) == 0 && AL16(dy) && AL16(x) && AL16(w) && AL16(dx), "norm_bwd: bad arguments");
+  hipLaunchKernelGGL(norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
+                     (const bf16_t*)w, (bf16_t*)dx, dw, db, (long)rows, (int)cols, eps, rms);
+  LL_LAUNCH_CHECK("norm_bwd");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_swiglu_bwd(const void* gu, const void* dout, void* dgu, int64_t rows, int64_t I, void* stream) {
+  LL_CHECK(gu && dout && dgu && rows > 0 && I > 0 && (I & 7) == 0 && AL16(gu) && AL16(dout) && AL16(dgu), "swiglu_bwd: bad arguments");
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (I >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gu, (const bf16_t*)dout,
+                     (bf16_t*)dgu, (long)rows, (long)I);
+  LL_LAUNCH_CHECK("swiglu_bwd");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_act_bwd(const void* dy, const void* y, void* out, int64_t n, int act, void* stream) {
+  LL_CHECK(dy && y && out && n > 0 && (act == LLMSEG_ACT_RELU || act == LLMSEG_ACT_SIGMOID), "act_bwd: only relu/sigmoid are differentiated");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)out, (long)n, act);
+  LL_LAUNCH_CHECK("act_bwd");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_softmax_rows(const float* S, void* P, int64_t BH, int32_t Tq, int32_t Tk, int32_t ld, float scale, int32_t causal,
+                                   const uint8_t* key_mask, int32_t heads, void* stream) {
+  LL_CHECK(S && P && BH > 0 && Tq > 0 && Tk > 0 && ld >= Tk && heads > 0 && (!causal || Tq == Tk), "softmax_rows: bad arguments");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((BH * Tq + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, (bf16_t*)P, (long)BH, Tq, Tk, ld,
+                     scale, causal, key_mask, heads);
+  LL_LAUNCH_CHECK("softmax_rows");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_attn_ds(const void* P, const float* dP, void* dS, int64_t rows, int32_t T, int32_t ld, float scale, void* stream) {
+  LL_CHECK(P && dP && dS && rows > 0 && T > 0 && ld >= T, "attn_ds: bad arguments");
+  hipLaunchKernelGGL(attn_ds_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)P, dP, (bf16_t*)dS, (long)rows, T,
+                     ld, scale);
+  LL_LAUNCH_CHECK("attn_ds");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_ce_bwd(const void* logits, const int64_t* labels, const float* coef, void* dlogits, int32_t N, int32_t T, int64_t V, int64_t ldl,
+                             void* stream) {
+  LL_CHECK(logits && labels && coef && dlogits && N > 0 && T > 1 && V > 0 && ldl >= V, "ce_bwd: bad arguments");
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)(N * T)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, labels, coef, (bf16_t*)dlogits, T,
+                     (long)V, (long)ldl);
+  LL_LAUNCH_CHECK("ce_bwd");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_scatter_add_rows(const void* src, const int64_t* idx, float* dst, int64_t n, int64_t cols, void* stream) {
+  LL_CHECK(src && idx && dst && n > 0 && cols > 0, "scatter_add_rows: bad arguments");
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for(n * cols)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, idx, dst, (long)n, (long)cols);
+  LL_LAUNCH_CHECK("scatter_add_rows");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_sumsq(const void* x, int64_t n, int is_f32, float* out, void* stream) {
+  LL_CHECK(x && out && n > 0, "sumsq: bad arguments");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (long)n, is_f32, out);
+  LL_LAUNCH_CHECK("sumsq");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_adamw(void* p, float* master, const void* grad, int grad_f32, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int64_t step, const float* grad_scale, void* stream) {
+  LL_CHECK(p && master && grad && m && v && n > 0 && step > 0, "adamw: bad arguments");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p, master, grad, grad_f32, m, v, (long)n, lr, beta1, beta2,
+                     eps, weight_decay, bc1, bc2, grad_scale);
+  LL_LAUNCH_CHECK("adamw");
+  return LLMSEG_OK;
+}

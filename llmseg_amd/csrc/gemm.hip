@@ -28,7 +28,8 @@ struct GemmP {
   const bf16_t* A; const bf16_t* W; void* C;
   const bf16_t* bias; const bf16_t* gamma; const bf16_t* res;
   int M, N, K;
-  long lda, ldw, ldc, ldr, sA, sW, sC;
+  long lda, ldw, ldc, ldr, sA, sW, sC, sA2, sW2, sC2;
+  int batch1;
   float alpha;
   int act;
   int tiles_m, tiles_n;
@@ -130,12 +131,12 @@ __device__ __forceinline__ void epilogue(const GemmP& p, const f32x16_t (&acc)[2
         }
         if (p.res) {
           float rr[4];
-          ld4bf(p.res + bz * p.sC + (long)m * p.ldr + n, res_vec, nv, rr);
+          ld4bf(p.res + bz + (long)m * p.ldr + n, res_vec, nv, rr);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += rr[e];
         }
         if (OUT_F32) {
-          float* cp = reinterpret_cast<float*>(p.C) + bz * p.sC + (long)m * p.ldc + n;
+          float* cp = reinterpret_cast<float*>(p.C) + bz + (long)m * p.ldc + n;
           if (vec_ok && nv == 4) {
             *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
@@ -143,7 +144,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, const f32x16_t (&acc)[2
             for (int e = 0; e < 4; ++e) if (e < nv) cp[e] = v[e];
           }
         } else {
-          bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + bz * p.sC + (long)m * p.ldc + n;
+          bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + bz + (long)m * p.ldc + n;
           if (vec_ok && nv == 4) {
             *reinterpret_cast<uint2*>(cp) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
           } else {
@@ -166,8 +167,86 @@ __device__ __forceinline__ void zero_acc(f32x16_t (&acc)[2][MI]) {
       for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
 }
 
-// ---- variant R: global -> VGPR -> LDS staging (any K % 8 == 0; zero-fills the K tail), 128 x 128 tile, 2 LDS buffers ----
-template <bool OUT_F32>
+// ---- variant R: global -> VGPR -> LDS staging, 128 x 128 tile, 2 LDS buffers -------------------------------------------
+// Handles every layout the backward pass needs without materialising transposes:
+//   TA = false: A stored [M][K] (K contiguous)        TA = true: A stored [K][M] (M contiguous; "A^T given")
+//   TW = false: W stored [N][K] (K contiguous)        TW = true: W stored [K][N] (N contiguous)
+// A K-contiguous operand needs K % 8 == 0; the K tail is zero-filled per 16-byte chunk.  A transposed-stored operand is
+// loaded as 4(k) x 8(rows) blocks, transposed in registers (v_perm) and written as 8-byte LDS rows; any K is fine there.
+__device__ __forceinline__ uint32_t perm_lo16(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }
+__device__ __forceinline__ uint32_t perm_hi16(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xffff0000u); }
+
+template <bool TR>
+struct OperandStage {
+  const bf16_t* ptr[4];
+  int off[4];       // LDS byte offsets (normal: 4 x 16-byte chunks; transposed: base of 8 x 8-byte rows)
+  uint4 r[4];
+  int kq;           // normal: first k of this thread's chunk inside the tile; transposed: first stored row inside the tile
+  long ld;
+
+  __device__ __forceinline__ void init(const bf16_t* g, long ld_, int x0, int R, int tid) {
+    ld = ld_;
+    if (!TR) {
+      const int kc = tid & 7, r0 = tid >> 3;
+      kq = kc * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ptr[i] = g + (long)min(x0 + r0 + 32 * i, R - 1) * ld + kc * 8;     // rows past R: clamp (results discarded)
+        off[i] = lds_off(r0 + 32 * i, kc);
+      }
+    } else {
+      const int kb = tid & 15, mb = tid >> 4;                               // 4 stored rows kb*4.., 8 columns mb*8..
+      kq = kb * 4;
+      const int col = min(x0 + mb * 8, ((R - 1) >> 3) << 3);                 // stay inside the row allocation (ld % 8 == 0)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ptr[j] = g + (long)(kb * 4 + j) * ld + col;
+      off[0] = mb * 8; off[1] = kb;                                          // row base, k-quad
+    }
+  }
+  __device__ __forceinline__ void load(int t, int K) {
+    if (!TR) {
+      if (t * BK + kq < K) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const uint4*>(ptr[i] + (long)t * BK);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = make_uint4(0, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        r[j] = (t * BK + kq + j < K) ? *reinterpret_cast<const uint4*>(ptr[j] + (long)t * BK * ld) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  __device__ __forceinline__ void store(char* base) const {
+    if (!TR) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(base + off[i]) = r[i];
+    } else {
+      const int row0 = off[0], kb = off[1];
+      const int ch = kb >> 1, sub = (kb & 1) * 8;
+      // r[j] = 8 consecutive rows' values for stored row j; out row e gets (r0[e], r1[e], r2[e], r3[e]) = 8 bytes
+      const uint2 o0 = make_uint2(perm_lo16(r[0].x, r[1].x), perm_lo16(r[2].x, r[3].x));
+      const uint2 o1 = make_uint2(perm_hi16(r[0].x, r[1].x), perm_hi16(r[2].x, r[3].x));
+      const uint2 o2 = make_uint2(perm_lo16(r[0].y, r[1].y), perm_lo16(r[2].y, r[3].y));
+      const uint2 o3 = make_uint2(perm_hi16(r[0].y, r[1].y), perm_hi16(r[2].y, r[3].y));
+      const uint2 o4 = make_uint2(perm_lo16(r[0].z, r[1].z), perm_lo16(r[2].z, r[3].z));
+      const uint2 o5 = make_uint2(perm_hi16(r[0].z, r[1].z), perm_hi16(r[2].z, r[3].z));
+      const uint2 o6 = make_uint2(perm_lo16(r[0].w, r[1].w), perm_lo16(r[2].w, r[3].w));
+      const uint2 o7 = make_uint2(perm_hi16(r[0].w, r[1].w), perm_hi16(r[2].w, r[3].w));
+      *reinterpret_cast<uint2*>(base + lds_off(row0 + 0, ch) + sub) = o0;
+      *reinterpret_cast<uint2*>(base + lds_off(row0 + 1, ch) + sub) = o1;
+      *reinterpret_cast<uint2*>(base + lds_off(row0 + 2, ch) + sub) = o2;
+      *reinterpret_cast<uint2*>(base + lds_off(row0 + 3, ch) + sub) = o3;
+      *reinterpret_cast<uint2*>(base + lds_off(row0 + 4, ch) + sub) = o4;
+      *reinterpret_cast<uint2*>(base + lds_off(row0 + 5, ch) + sub) = o5;
+      *reinterpret_cast<uint2*>(base + lds_off(row0 + 6, ch) + sub) = o6;
+      *reinterpret_cast<uint2*>(base + lds_off(row0 + 7, ch) + sub) = o7;
+    }
+  }
+};
+
+template <bool OUT_F32, bool TA, bool TW>
 __global__ __launch_bounds__(NT, 2) void gemm_bf16_tn_kernel(GemmP p) {
   constexpr int MI = 2, BM = 128, TILE = 128 * BK * 2, BUF = 2 * TILE;
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
@@ -175,58 +254,27 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_tn_kernel(GemmP p) {
   const int m0 = tc.m0, n0 = tc.n0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const long bz = blockIdx.y;
-  const bf16_t* __restrict__ Ag = p.A + bz * p.sA;
-  const bf16_t* __restrict__ Wg = p.W + bz * p.sW;
+  const long b1 = blockIdx.y % p.batch1, b2 = blockIdx.y / p.batch1;
+  const long bz = b1 * p.sC + b2 * p.sC2;          // element offset of this batch entry in C / residual
 
-  const int kc = tid & 7, r0 = tid >> 3;      // thread owns chunk kc of rows r0 + 32*i
-  const bf16_t* a_ptr[4];
-  const bf16_t* w_ptr[4];
-  int st_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = r0 + 32 * i;
-    a_ptr[i] = Ag + (long)min(m0 + r, p.M - 1) * p.lda + kc * 8;   // rows past M/N: clamp (results discarded)
-    w_ptr[i] = Wg + (long)min(n0 + r, p.N - 1) * p.ldw + kc * 8;
-    st_off[i] = lds_off(r, kc);
-  }
+  OperandStage<TA> sa;
+  OperandStage<TW> sw;
+  sa.init(p.A + b1 * p.sA + b2 * p.sA2, p.lda, m0, p.M, tid);
+  sw.init(p.W + b1 * p.sW + b2 * p.sW2, p.ldw, n0, p.N, tid);
   const int nt = (p.K + BK - 1) / BK;
-  uint4 ra[4], rw[4];
-
-  auto load_tile = [&](int t) {
-    const int k = t * BK + kc * 8;
-    if (k < p.K) {      // K % 8 == 0: a 16-byte chunk is entirely inside or entirely outside
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ra[i] = *reinterpret_cast<const uint4*>(a_ptr[i] + (long)t * BK);
-        rw[i] = *reinterpret_cast<const uint4*>(w_ptr[i] + (long)t * BK);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { ra[i] = make_uint4(0, 0, 0, 0); rw[i] = make_uint4(0, 0, 0, 0); }
-    }
-  };
-  auto store_tile = [&](int buf) {
-    char* base = smem + buf * BUF;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<uint4*>(base + st_off[i]) = ra[i];
-      *reinterpret_cast<uint4*>(base + TILE + st_off[i]) = rw[i];
-    }
-  };
 
   f32x16_t acc[2][MI];
   zero_acc<MI>(acc);
   const int frow = lane & 31, fhalf = lane >> 5;
 
-  load_tile(0);
-  store_tile(0);
+  sa.load(0, p.K); sw.load(0, p.K);
+  sa.store(smem); sw.store(smem + TILE);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) load_tile(t + 1);
+    if (t + 1 < nt) { sa.load(t + 1, p.K); sw.load(t + 1, p.K); }
     const char* abase = smem + (t & 1) * BUF;
     mma_slab<MI>(abase, abase + TILE, wm, wn, frow, fhalf, acc);
-    if (t + 1 < nt) store_tile((t + 1) & 1);
+    if (t + 1 < nt) { char* nb = smem + ((t + 1) & 1) * BUF; sa.store(nb); sw.store(nb + TILE); }
     __syncthreads();
   }
   epilogue<OUT_F32, MI>(p, acc, m0, n0, wm, wn, frow, fhalf, bz);
@@ -247,9 +295,10 @@ __global__ __launch_bounds__(NT, NBUF == 2 ? (MI == 4 ? 1 : 2) : (MI == 4 ? 2 : 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const long bz = blockIdx.y;
-  const bf16_t* __restrict__ Ag = p.A + bz * p.sA;
-  const bf16_t* __restrict__ Wg = p.W + bz * p.sW;
+  const long b1 = blockIdx.y % p.batch1, b2 = blockIdx.y / p.batch1;
+  const long bz = b1 * p.sC + b2 * p.sC2;          // element offset of this batch entry in C / residual
+  const bf16_t* __restrict__ Ag = p.A + b1 * p.sA + b2 * p.sA2;
+  const bf16_t* __restrict__ Wg = p.W + b1 * p.sW + b2 * p.sW2;
 
   // DMA instruction i of this wave fills LDS rows (i*4 + wave)*8 .. +7 of the operand tile (1 KiB)
   const bf16_t* a_src[A_DMA];
@@ -331,9 +380,10 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_big_kernel(GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const long bz = blockIdx.y;
-  const bf16_t* __restrict__ Ag = p.A + bz * p.sA;
-  const bf16_t* __restrict__ Wg = p.W + bz * p.sW;
+  const long b1 = blockIdx.y % p.batch1, b2 = blockIdx.y / p.batch1;
+  const long bz = b1 * p.sC + b2 * p.sC2;          // element offset of this batch entry in C / residual
+  const bf16_t* __restrict__ Ag = p.A + b1 * p.sA + b2 * p.sA2;
+  const bf16_t* __restrict__ Wg = p.W + b1 * p.sW + b2 * p.sW2;
 
   // DMA instruction i (0..3) of this wave fills LDS rows (i*8 + wave)*8 .. +7 of each operand tile
   const bf16_t* a_src[4];
@@ -407,26 +457,34 @@ extern "C" int llmseg_gemm_set_variant(int v) { g_gemm_variant = v & 15; if (v >
 extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   LL_CHECK(a && a->A && a->W && a->C, "gemm: null pointer");
   LL_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "gemm: bad shape M=%ld N=%ld K=%ld", (long)a->M, (long)a->N, (long)a->K);
-  LL_CHECK((a->K & 7) == 0 && (a->lda & 7) == 0 && (a->ldw & 7) == 0, "gemm: K/lda/ldw must be multiples of 8 (K=%ld lda=%ld ldw=%ld)",
-           (long)a->K, (long)a->lda, (long)a->ldw);
+  const bool ta = a->trans_a != 0, tw = a->trans_w != 0;
+  LL_CHECK((a->lda & 7) == 0 && (a->ldw & 7) == 0, "gemm: lda/ldw must be multiples of 8 (lda=%ld ldw=%ld)", (long)a->lda, (long)a->ldw);
+  // a K-contiguous operand is read in 16-byte chunks: K % 8 == 0, or its rows are padded (ld >= roundup8(K)) with ZEROS
+  const long k8 = (a->K + 7) & ~7L;
+  LL_CHECK((ta || (a->K & 7) == 0 || a->lda >= k8) && (tw || (a->K & 7) == 0 || a->ldw >= k8),
+           "gemm: K=%ld is not a multiple of 8 and the K-contiguous operand is not padded", (long)a->K);
+  LL_CHECK((!ta || a->lda >= a->M) && (!tw || a->ldw >= a->N), "gemm: transposed operand needs ld >= rows");
   LL_CHECK((((uintptr_t)a->A) & 15) == 0 && (((uintptr_t)a->W) & 15) == 0, "gemm: A/W must be 16-byte aligned");
-  LL_CHECK((a->strideA & 7) == 0 && (a->strideW & 7) == 0, "gemm: batch strides of A/W must be multiples of 8");
+  LL_CHECK(((a->strideA | a->strideW | a->strideA2 | a->strideW2) & 7) == 0, "gemm: batch strides of A/W must be multiples of 8");
   const int esz = a->out_f32 ? 4 : 2;
   GemmP p;
   p.A = (const bf16_t*)a->A; p.W = (const bf16_t*)a->W; p.C = a->C;
   p.bias = (const bf16_t*)a->bias; p.gamma = (const bf16_t*)a->gamma; p.res = (const bf16_t*)a->residual;
   p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
   p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc; p.ldr = a->residual ? a->ldr : 0;
-  const long batch = a->batch > 0 ? a->batch : 1;
+  const long batch1 = a->batch > 0 ? a->batch : 1, batch2 = a->batch2 > 0 ? a->batch2 : 1;
+  const long batch = batch1 * batch2;
+  p.batch1 = (int)batch1;
   p.sA = a->strideA; p.sW = a->strideW; p.sC = a->strideC;
+  p.sA2 = a->strideA2; p.sW2 = a->strideW2; p.sC2 = a->strideC2;
   p.alpha = a->alpha; p.act = a->act;
   // vector stores/loads need 4-element alignment of every row start; otherwise the kernel goes element-wise
-  p.c_vec = ((((uintptr_t)a->C) % (4 * esz)) == 0 && (a->ldc & 3) == 0 && (a->strideC & 3) == 0) ? 1 : 0;
-  p.r_vec = (p.res && (((uintptr_t)p.res) & 7) == 0 && (p.ldr & 3) == 0 && (a->strideC & 3) == 0) ? 1 : 0;
+  p.c_vec = ((((uintptr_t)a->C) % (4 * esz)) == 0 && (a->ldc & 3) == 0 && ((a->strideC | a->strideC2) & 3) == 0) ? 1 : 0;
+  p.r_vec = (p.res && (((uintptr_t)p.res) & 7) == 0 && (p.ldr & 3) == 0 && ((a->strideC | a->strideC2) & 3) == 0) ? 1 : 0;
   p.b_vec = ((p.bias == nullptr || (((uintptr_t)p.bias) & 7) == 0) && (p.gamma == nullptr || (((uintptr_t)p.gamma) & 7) == 0)) ? 1 : 0;
 
   p.skew = g_gemm_skew;
-  int variant = (p.K % BK == 0) ? g_gemm_variant : 0;
+  int variant = (p.K % BK == 0 && !ta && !tw) ? g_gemm_variant : 0;
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN) * batch;
   if (variant == 5) variant = 2;   // measured (tools/gemm_bench.py): 128x128 single-buffer DMA wins or ties on the hot-path shapes
   (void)tiles256;
@@ -446,9 +504,19 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
       if (f) hipLaunchKernelGGL(gemm_bf16_tn_big_kernel<true>, grid, dim3(NTB), 0, s, p);
       else hipLaunchKernelGGL(gemm_bf16_tn_big_kernel<false>, grid, dim3(NTB), 0, s, p);
       break;
-    default:
-      if (f) hipLaunchKernelGGL(gemm_bf16_tn_kernel<true>, grid, dim3(NT), 0, s, p);
-      else hipLaunchKernelGGL(gemm_bf16_tn_kernel<false>, grid, dim3(NT), 0, s, p);
+    default: {
+      const int key = (f ? 4 : 0) | (ta ? 2 : 0) | (tw ? 1 : 0);
+      switch (key) {
+        case 0: hipLaunchKernelGGL((gemm_bf16_tn_kernel<false, false, false>), grid, dim3(NT), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((gemm_bf16_tn_kernel<false, false, true>), grid, dim3(NT), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((gemm_bf16_tn_kernel<false, true, false>), grid, dim3(NT), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((gemm_bf16_tn_kernel<false, true, true>), grid, dim3(NT), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, false, false>), grid, dim3(NT), 0, s, p); break;
+        case 5: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, false, true>), grid, dim3(NT), 0, s, p); break;
+        case 6: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, true, false>), grid, dim3(NT), 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, true, true>), grid, dim3(NT), 0, s, p); break;
+      }
+    }
   }
   llmseg_prof_end(s, 2.0 * (double)a->M * (double)a->N * (double)a->K * (double)batch);
   LL_LAUNCH_CHECK("gemm_bf16_tn");

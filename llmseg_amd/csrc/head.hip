@@ -12,7 +12,8 @@ namespace {
 // accumulator in LDS (ds_add_f32; 4 taps per pixel).  Phase 2 is the small dense product with the L2-resident
 // channels-last feature map.  The [C][S][S] upsampled tensor of the reference is never formed.
 __global__ __launch_bounds__(256) void upsample_maskpool_kernel(const bf16_t* __restrict__ feat, const bf16_t* __restrict__ segs,
-                                                               bf16_t* __restrict__ pooled, int C, int g, int S) {
+                                                               bf16_t* __restrict__ pooled, float* __restrict__ pb_out, float* __restrict__ wsum_out, int C, int g,
+                                                               int S) {
   extern __shared__ float acc[];                 // g*g (+16 for reductions)
   float* red = acc + g * g;
   const int k = blockIdx.x;
@@ -42,6 +43,9 @@ __global__ __launch_bounds__(256) void upsample_maskpool_kernel(const bf16_t* __
   }
   wsum = block_sum(wsum, red);      // includes the barriers that publish acc[]
   const float inv = 1.f / (wsum + 1e-8f);
+  if (pb_out)
+    for (int i = threadIdx.x; i < g * g; i += blockDim.x) pb_out[(long)k * g * g + i] = acc[i];
+  if (wsum_out && threadIdx.x == 0) wsum_out[k] = wsum;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float a = 0.f;
     for (int s = 0; s < g * g; ++s) a += acc[s] * bf2f(feat[(long)s * C + c]);
@@ -163,13 +167,13 @@ __global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logi
 
 }  // namespace
 
-extern "C" int llmseg_upsample_maskpool(const void* feat, const void* segs, void* pooled, int32_t K, int32_t C, int32_t g, int32_t S,
-                                        void* stream) {
+extern "C" int llmseg_upsample_maskpool(const void* feat, const void* segs, void* pooled, float* pulled_back, float* wsum, int32_t K, int32_t C,
+                                        int32_t g, int32_t S, void* stream) {
   LL_CHECK(feat && segs && pooled && K > 0 && C > 0 && g > 0 && S >= g, "upsample_maskpool: bad arguments");
   const size_t lds = ((size_t)g * g + 16) * sizeof(float);
   LL_CHECK(lds <= 64 * 1024, "upsample_maskpool: feature grid %d too large for LDS", g);
   hipLaunchKernelGGL(upsample_maskpool_kernel, dim3(K), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)feat, (const bf16_t*)segs,
-                     (bf16_t*)pooled, C, g, S);
+                     (bf16_t*)pooled, pulled_back, wsum, C, g, S);
   LL_LAUNCH_CHECK("upsample_maskpool");
   return LLMSEG_OK;
 }

@@ -24,6 +24,7 @@ import torch.nn.functional as F  # only F.interpolate for the one-time DINOv2 po
 
 from . import ops
 from .params import LisaConfig, ParamTree, fused_groups, init_random_, lisa_shapes
+from .trainable import TrainableMixin
 
 IMAGE_TOKEN_INDEX = -200
 IGNORE_INDEX = -100
@@ -36,7 +37,7 @@ def _pad_rows(t, rows):
     return out
 
 
-class LISAForCausalLM(nn.Module):
+class LISAForCausalLM(TrainableMixin, nn.Module):
     def __init__(self, config: LisaConfig, device="cuda", **kwargs):
         super().__init__()
         # reference kwargs (model/LISA.py:150-161, training.py:140-150)
@@ -274,211 +275,3 @@ class LISAForCausalLM(nn.Module):
         assert hh == ww
         feat_cl = image_embeddings.permute(1, 2, 0).reshape(hh * ww, Dd).contiguous().to(BF16)
         return ops.upsample_maskpool(feat_cl, weight_maps.to(BF16).contiguous(), hh, hh)
-
-    # ------------------------------------------------------------------------------------------------ language
-    def _lora(self, x, qkv, p, which, col0):
-        c, P = self.config.llama, self.params
-        a = P.get(p + f"self_attn.{which}_proj.lora_A.default.weight")
-        if a is None or c.lora_r == 0:
-            return
-        # y[:, cols] += (alpha/r) * (x A^T) B^T   (peft 0.4.0 Linear, dropout = identity outside training)
-        r8 = (c.lora_r + 7) // 8 * 8
-        xa = torch.zeros((x.shape[0], r8), device=x.device, dtype=BF16)
-        ops.gemm(x, a, out=xa[:, :c.lora_r]) if c.lora_r % 8 == 0 else xa[:, :c.lora_r].copy_(ops.gemm(x, a))
-        bw = P[p + f"self_attn.{which}_proj.lora_B.default.weight"]
-        if r8 != c.lora_r:
-            bw = F.pad(bw, (0, r8 - c.lora_r)).contiguous()
-        sl = qkv[:, col0:col0 + c.hidden]
-        ops.gemm(xa, bw, residual=sl, out=sl, alpha=c.lora_alpha / c.lora_r)
-
-    def _llama(self, embeds, key_mask_u8):
-        """32 x [RMSNorm -> q|k|v GEMM (+LoRA) -> RoPE -> causal attention -> o_proj(+res) -> RMSNorm -> gate|up GEMM ->
-        SwiGLU -> down(+res)], final RMSNorm (HF LlamaModel, transformers 4.29; call site llava_llama.py:93-102)."""
-        c, P = self.config.llama, self.params
-        N, T, H = embeds.shape
-        x = embeds.reshape(N * T, H)
-        cos, sin = self._rope(T)
-        for i in range(c.layers):
-            p = f"model.layers.{i}."
-            h = ops.norm(x, P[p + "input_layernorm.weight"], eps=c.eps, rms=True)
-            qkv = ops.gemm(h, P[p + "qkv"])
-            self._lora(h, qkv, p, "q", 0)
-            self._lora(h, qkv, p, "v", 2 * H)
-            ops.rope_(qkv, cos, sin, N * T, T, 2 * c.heads, c.head_dim, 3 * H)
-            a = ops.attention_packed(qkv, N, T, c.heads, c.head_dim, causal=True, key_mask=key_mask_u8)
-            x = ops.gemm(a, P[p + "self_attn.o_proj.weight"], residual=x)
-            h = ops.norm(x, P[p + "post_attention_layernorm.weight"], eps=c.eps, rms=True)
-            gu = ops.gemm(h, P[p + "gate_up"])
-            x = ops.gemm(ops.swiglu(gu, c.inter), P[p + "mlp.down_proj.weight"], residual=x)
-        return ops.norm(x, P["model.norm.weight"], eps=c.eps, rms=True).view(N, T, H)
-
-    def llava_forward(self, images_clip, attention_mask, input_ids, labels=None, want_logits=True):
-        """LlavaLlamaForCausalLM.forward (llava_llama.py:55-135): splice, decoder stack, lm_head, shifted CE.
-        -> (ce_loss | None, logits | None, final-norm hidden [N,T,H])."""
-        c, P = self.config, self.params
-        N, L = input_ids.shape
-        n_img = (input_ids == IMAGE_TOKEN_INDEX).sum(1)
-        assert bool((n_img == 1).all()), "exactly one <image> per sequence (the reference's seg_token_mask assumes it too)"
-        Pn = c.n_img_tokens
-        proj = self.encode_images(images_clip)                                            # [N*(P+1), H]
-        H = c.llama.hidden
-        embeds = ops.embed_splice(input_ids.contiguous(), P["model.embed_tokens.weight"], proj[1:], Pn, feats_stride_n=(Pn + 1) * H)
-        T = L - 1 + Pn
-        mask = torch.cat([torch.ones((N, T - L), dtype=torch.bool, device=input_ids.device), attention_mask.bool()], 1)
-        hidden = self._llama(embeds, mask.to(torch.uint8).contiguous())
-        logits, loss = None, None
-        if want_logits or labels is not None:
-            logits = ops.gemm(hidden.view(N * T, H), P["lm_head.weight"]).view(N, T, -1)
-        if labels is not None:
-            pos = (input_ids == IMAGE_TOKEN_INDEX).int().argmax(1)                      # index plumbing for the label splice
-            ar = torch.arange(T, device=labels.device)[None]
-            src = torch.where(ar < pos[:, None], ar, (ar - Pn + 1).clamp(min=0))
-            new_labels = torch.gather(labels, 1, src.clamp(max=L - 1))
-            new_labels = torch.where((ar >= pos[:, None]) & (ar < pos[:, None] + Pn), torch.full_like(new_labels, IGNORE_INDEX), new_labels)
-            acc = ops.ce_loss(logits, new_labels.contiguous())
-            loss = acc[0] / acc[1]
-        return loss, logits, hidden
-
-    # ------------------------------------------------------------------------------------------------------ head
-    def _head_attn_1key(self, p, text):
-        """Attention whose key/value is a single token: softmax over one key == 1, so out = out_proj(v_proj(text))
-        for every query (transformer.py:319-341 with Nk = 1).  text [C, D] -> [C, D]."""
-        P = self.params
-        D = text.shape[1]
-        v = ops.gemm(text, P[p + "qkv.weight"][2 * D:], bias=P[p + "qkv.bias"][2 * D:])
-        return ops.gemm(v, P[p + "out_proj.weight"], bias=P[p + "out_proj.bias"])
-
-    def _bcast_add_norm(self, s, add, Cn, K, wname):
-        """s[c*K + k] = LN(s[c*K + k] + add[c])."""
-        P = self.params
-        for ci in range(Cn):
-            blk = s[ci * K:(ci + 1) * K]
-            ops.add_rows(blk, add[ci:ci + 1].contiguous(), out=blk)
-        return ops.norm(s, P[wname + ".weight"], P[wname + ".bias"], eps=1e-5)
-
-    def _mask_head(self, pooled, text):
-        """LISA.py:363-391 for one image: pooled [K, D] bf16, text [C, D] bf16 -> (pred_iou [C*K] bf16, emb [C*K, D] bf16)."""
-        P = self.params
-        K, D = pooled.shape
-        Cn = text.shape[0]
-        nh, hd = 8, D // 8
-        s = pooled.repeat(Cn, 1) if Cn > 1 else pooled.clone()            # row = c*K + k  (expand, LISA.py:372)
-        t = text.contiguous()
-        for i in range(2):
-            p = f"model.lisa_attention_layers.{i}."
-            qkv = ops.gemm(s, P[p + "self_attn.qkv.weight"], bias=P[p + "self_attn.qkv.bias"])
-            a = ops.attention_packed(qkv, Cn, K, nh, hd)
-            s = ops.gemm(a, P[p + "self_attn.out_proj.weight"], bias=P[p + "self_attn.out_proj.bias"], residual=s)
-            s = ops.norm(s, P[p + "norm1.weight"], P[p + "norm1.bias"], eps=1e-5)
-            s = self._bcast_add_norm(s, self._head_attn_1key(p + "cross_attn_token_to_image.", t), Cn, K, p + "norm2")
-            m = ops.gemm(s, P[p + "mlp.lin1.weight"], bias=P[p + "mlp.lin1.bias"], act=ops.ACT_RELU)
-            s = ops.gemm(m, P[p + "mlp.lin2.weight"], bias=P[p + "mlp.lin2.bias"], residual=s)
-            s = ops.norm(s, P[p + "norm3.weight"], P[p + "norm3.bias"], eps=1e-5)
-            # image -> token: q = text (1 query per conversation), k = v = mask features
-            pc = p + "cross_attn_image_to_token."
-            q = ops.gemm(t, P[pc + "qkv.weight"][:D], bias=P[pc + "qkv.bias"][:D])
-            kv = ops.gemm(s, P[pc + "qkv.weight"][D:], bias=P[pc + "qkv.bias"][D:])       # [C*K, 2D] = k | v
-            o = torch.empty((Cn, D), device=s.device, dtype=BF16)
-            ops.attention(q, kv, kv[:, D:], o, batch=Cn, heads=nh, Nq=1, Nk=K, head_dim=hd, q_strides=(D, hd, D),
-                          k_strides=(K * 2 * D, hd, 2 * D), v_strides=(K * 2 * D, hd, 2 * D), o_strides=(D, hd, D))
-            t = ops.gemm(o, P[pc + "out_proj.weight"], bias=P[pc + "out_proj.bias"], residual=t)
-            t = ops.norm(t, P[p + "norm4.weight"], P[p + "norm4.bias"], eps=1e-5)
-        s = self._bcast_add_norm(s, self._head_attn_1key("model.lisa_final_attn.", t), Cn, K, "model.lisa_norm_final_attn")
-        hi = ops.gemm(s, P["model.lisa_iou_head.0.weight"], bias=P["model.lisa_iou_head.0.bias"], act=ops.ACT_RELU)
-        iou = ops.gemm(hi, P["model.lisa_iou_head.2.weight"], bias=P["model.lisa_iou_head.2.bias"], act=ops.ACT_SIGMOID)
-        he = ops.gemm(s, P["model.lisa_embedding_head.0.weight"], bias=P["model.lisa_embedding_head.0.bias"], act=ops.ACT_RELU)
-        emb = ops.gemm(he, P["model.lisa_embedding_head.2.weight"], bias=P["model.lisa_embedding_head.2.bias"])
-        return iou.view(Cn * K), emb
-
-    # ------------------------------------------------------------------------------------------------ model_forward
-    def visual_features_cl(self, images):
-        """-> (channels-last feature rows bf16, rows per image, row offset of the first patch, grid)."""
-        c = self.config
-        if c.backbone == "sam":
-            return self._sam_encoder_cl(images), c.sam.grid ** 2, 0, c.sam.grid
-        x, n_tok, (gh, gw) = self._dinov2_tokens(images)
-        assert gh == gw
-        d = self.prepare()
-        y = ops.gemm(x, d["dino.conv_w"], bias=self.params["model.lisa_dino_conv.bias"])        # 1x1 conv (LISA.py:245)
-        return y, n_tok, 1, gh
-
-    def forward(self, **kwargs):
-        return self.model_forward(**kwargs)
-
-    @torch.no_grad()
-    def model_forward(self, images, images_clip, input_ids, labels, attention_masks, offset, masks_list=None, label_list=None,
-                      resize_list=None, sam_segs_list=None, sam_ious_list=None, sam_iops_list=None, inference=False,
-                      return_aux=False, **kwargs):
-        c = self.config
-        images, images_clip = images.to(BF16), images_clip.to(BF16)
-        feat, rows_per_img, row0, g = self.visual_features_cl(images.contiguous())
-        B = images.shape[0]
-        assert B == len(offset) - 1
-        Pn = c.n_img_tokens
-        off = offset.tolist()
-        if inference:
-            assert images_clip.shape[0] == 1                                             # LISA.py:271
-            clip_in = images_clip.expand(input_ids.shape[0], -1, -1, -1).contiguous()
-            ce, logits, hidden = self.llava_forward(clip_in, attention_masks, input_ids, None, want_logits=return_aux)
-        else:
-            reps = torch.tensor([off[i + 1] - off[i] for i in range(B)], device=images_clip.device)
-            clip_in = images_clip.repeat_interleave(reps, 0).contiguous()                # LISA.py:293-303
-            ce, logits, hidden = self.llava_forward(clip_in, attention_masks, input_ids, labels)
-
-        # [SEG] rows: mask shifted by one and by the P-1 extra image tokens (LISA.py:254-266), gather first, then the MLP
-        N, T, H = hidden.shape
-        segm = torch.zeros((N, T), dtype=torch.bool, device=input_ids.device)
-        segm[:, Pn - 1:Pn - 1 + input_ids.shape[1] - 1] = input_ids[:, 1:] == self.seg_token_idx
-        idx = segm.view(-1).nonzero().flatten()
-        counts = segm.sum(1).cumsum(0).tolist()
-        seg_off = [0] + counts
-        seg_off = [seg_off[o] for o in off]
-        P = self.params
-        hs = ops.gather_rows(hidden.view(N * T, H), idx)
-        hs = ops.gemm(hs, P["model.text_hidden_fcs.0.0.weight"], bias=P["model.text_hidden_fcs.0.0.bias"], act=ops.ACT_RELU)
-        pred = ops.gemm(hs, P["model.text_hidden_fcs.0.2.weight"], bias=P["model.text_hidden_fcs.0.2.bias"]) if idx.numel() else \
-            torch.empty((0, c.out_dim), device=hidden.device, dtype=BF16)
-        pred_embeddings = [pred[seg_off[b]:seg_off[b + 1]] for b in range(B)]
-
-        ious, embs = [], []
-        for b in range(B):
-            segs = sam_segs_list[b].to(BF16).contiguous()
-            S = segs.shape[-1]
-            fb = feat[b * rows_per_img + row0: b * rows_per_img + row0 + g * g]
-            pooled = ops.upsample_maskpool(fb, segs, g, S)
-            K = segs.shape[0]
-            Cn = pred_embeddings[b].shape[0]
-            if Cn == 0:
-                if not inference:
-                    raise ValueError("number of rounds = 0")                          # LISA.py:435-437
-                ious.append(None); embs.append(None)
-                continue
-            iou, emb = self._mask_head(pooled, pred_embeddings[b])
-            ious.append(iou.view(Cn, K)); embs.append(emb.view(Cn, K, -1))
-
-        if inference:
-            sims = [ops.cosine_scores(pred_embeddings[b][0], embs[b][0])[None] for b in range(B)]
-            out = {"pred_similarity": sims, "gt_masks": masks_list, "pred_iou": [ious[b][:1].float() for b in range(B)]}
-            if return_aux:
-                out.update(logits=logits, hidden=hidden, feats=feat, pred_embeddings=pred_embeddings)
-            return out
-
-        align = torch.zeros((), device=hidden.device, dtype=torch.float32)
-        reg = torch.zeros((), device=hidden.device, dtype=torch.float32)
-        for b in range(B):
-            R = pred_embeddings[b].shape[0]
-            a_r = torch.zeros_like(align); r_r = torch.zeros_like(reg)
-            for r in range(R):
-                o = ops.align_reg_loss(embs[b][r], pred_embeddings[b][r], sam_ious_list[b][r].float().contiguous(),
-                                       ious[b][r], sam_iops_list[b][r].float().contiguous())
-                a_r = a_r + o[0]; r_r = r_r + o[1]
-            align = align + a_r / (R + 1e-8)
-            reg = reg + r_r / (R + 1e-8)
-        align, reg = align / B, reg / B
-        ce = ce * c.ce_loss_weight
-        align = align * c.align_loss_weight
-        reg = reg * c.regression_loss_weight
-        out = {"loss": ce + align + reg, "ce_loss": ce, "align_loss": align, "regression_loss": reg}
-        if return_aux:
-            out.update(logits=logits, hidden=hidden, feats=feat)
-        return out

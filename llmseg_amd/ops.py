@@ -28,12 +28,14 @@ def _req(t, dtype=BF16):
     return t
 
 
-def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alpha=1.0, out_f32=False):
-    """out[M,N] = residual + gamma * act(alpha * a[M,K] @ w[N,K]^T + bias).  a/w: 2-D bf16, last dim contiguous."""
+def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alpha=1.0, out_f32=False, trans_a=False, trans_w=False):
+    """out[M,N] = residual + gamma * act(alpha * A @ W^T + bias) with A = a [M,K] (or a^T when trans_a: a stored [K,M]) and
+    W = w [N,K] (or w^T when trans_w: w stored [K,N]).  2-D bf16 operands, last dim contiguous."""
     _req(a); _req(w)
-    assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1] and a.stride(1) == 1 and w.stride(1) == 1
-    M, K = a.shape
-    N = w.shape[0]
+    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    N, Kw = (w.shape[1], w.shape[0]) if trans_w else w.shape
+    assert K == Kw, (a.shape, w.shape, trans_a, trans_w)
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else BF16)
     assert out.shape == (M, N) and out.stride(1) == 1
@@ -43,18 +45,21 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alp
                  residual=None if residual is None else _req(residual).data_ptr(),
                  M=M, N=N, K=K, lda=a.stride(0), ldw=w.stride(0), ldc=out.stride(0),
                  ldr=0 if residual is None else residual.stride(0),
-                 batch=1, strideA=0, strideW=0, strideC=0, alpha=alpha, act=act, out_f32=1 if out_f32 else 0)
+                 batch=1, strideA=0, strideW=0, strideC=0, alpha=alpha, act=act, out_f32=1 if out_f32 else 0,
+                 trans_a=1 if trans_a else 0, trans_w=1 if trans_w else 0)
     if residual is not None:
         assert residual.shape == (M, N) and residual.stride(1) == 1
     _lib.check(_lib.load().llmseg_gemm_bf16(C.byref(g), _stream()), "gemm")
     return out
 
 
-def gemm_batched(a, w, out, M, N, K, lda, ldw, ldc, batch, sA, sW, sC, out_f32=True, alpha=1.0):
+def gemm_batched(a, w, out, M, N, K, lda, ldw, ldc, batch, sA, sW, sC, out_f32=True, alpha=1.0, trans_a=False, trans_w=False,
+                 batch2=1, sA2=0, sW2=0, sC2=0):
     """Strided-batched GEMM on raw strides (elements); used for the per-head q.R^T relative-position products."""
     g = GemmArgs(A=a.data_ptr(), W=w.data_ptr(), C=out.data_ptr(), bias=None, gamma=None, residual=None,
                  M=M, N=N, K=K, lda=lda, ldw=ldw, ldc=ldc, ldr=0, batch=batch, strideA=sA, strideW=sW, strideC=sC,
-                 alpha=alpha, act=ACT_NONE, out_f32=1 if out_f32 else 0)
+                 alpha=alpha, act=ACT_NONE, out_f32=1 if out_f32 else 0, trans_a=1 if trans_a else 0, trans_w=1 if trans_w else 0,
+                 batch2=batch2, strideA2=sA2, strideW2=sW2, strideC2=sC2)
     _lib.check(_lib.load().llmseg_gemm_bf16(C.byref(g), _stream()), "gemm_batched")
     return out
 
@@ -159,14 +164,17 @@ def gather_rows(x, idx):
     return out
 
 
-def upsample_maskpool(feat_cl, segs, g, S):
-    """feat_cl bf16 [g*g, C] channels-last, segs bf16 [K, S, S] -> pooled bf16 [K, C]."""
+def upsample_maskpool(feat_cl, segs, g, S, want_aux=False):
+    """feat_cl bf16 [g*g, C] channels-last, segs bf16 [K, S, S] -> pooled bf16 [K, C] (+ (pulled_back fp32 [K,g*g], wsum fp32 [K]))."""
     _req(feat_cl); _req(segs)
     assert feat_cl.is_contiguous() and segs.is_contiguous()
     K, Cc = segs.shape[0], feat_cl.shape[1]
     out = torch.empty((K, Cc), device=segs.device, dtype=BF16)
-    _lib.check(_lib.load().llmseg_upsample_maskpool(_ptr(feat_cl), _ptr(segs), _ptr(out), K, Cc, g, S, _stream()), "upsample_maskpool")
-    return out
+    pb = torch.empty((K, g * g), device=segs.device, dtype=torch.float32) if want_aux else None
+    ws = torch.empty((K,), device=segs.device, dtype=torch.float32) if want_aux else None
+    _lib.check(_lib.load().llmseg_upsample_maskpool(_ptr(feat_cl), _ptr(segs), _ptr(out), _ptr(pb), _ptr(ws), K, Cc, g, S, _stream()),
+               "upsample_maskpool")
+    return (out, pb, ws) if want_aux else out
 
 
 def cosine_scores(t, e):
@@ -202,6 +210,73 @@ def ce_loss(logits, labels):
     acc = torch.zeros((2,), device=logits.device, dtype=torch.float32)
     _lib.check(_lib.load().llmseg_ce_loss(_ptr(logits), _ptr(labels), _ptr(acc), N, T, V, logits.stride(1), _stream()), "ce_loss")
     return acc
+
+
+# ---- backward / optimizer -------------------------------------------------------------------------------------------
+def colsum(x, out=None):
+    M, N = x.shape
+    if out is None:
+        out = torch.zeros((N,), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().llmseg_colsum(_ptr(x), _ptr(out), M, N, x.stride(0), _stream()), "colsum")
+    return out
+
+
+def norm_bwd(dy, x, w, eps, rms, dw=None, db=None):
+    rows, cols = x.shape
+    assert dy.is_contiguous() and x.is_contiguous()
+    dx = torch.empty_like(x)
+    _lib.check(_lib.load().llmseg_norm_bwd(_ptr(dy), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), rows, cols, eps, 1 if rms else 0,
+                                           _stream()), "norm_bwd")
+    return dx
+
+
+def swiglu_bwd(gu, dout, inter):
+    assert gu.is_contiguous() and dout.is_contiguous()
+    dgu = torch.empty_like(gu)
+    _lib.check(_lib.load().llmseg_swiglu_bwd(_ptr(gu), _ptr(dout), _ptr(dgu), gu.shape[0], inter, _stream()), "swiglu_bwd")
+    return dgu
+
+
+def act_bwd(dy, y, act):
+    assert dy.is_contiguous() and y.is_contiguous()
+    out = torch.empty_like(dy)
+    _lib.check(_lib.load().llmseg_act_bwd(_ptr(dy), _ptr(y), _ptr(out), dy.numel(), act, _stream()), "act_bwd")
+    return out
+
+
+def softmax_rows(S, BH, Tq, Tk, ld, scale, causal=False, key_mask=None, heads=1):
+    P = torch.empty((BH, Tq, ld), device=S.device, dtype=BF16)
+    _lib.check(_lib.load().llmseg_softmax_rows(_ptr(S), _ptr(P), BH, Tq, Tk, ld, scale, 1 if causal else 0, _ptr(key_mask), heads, _stream()),
+               "softmax_rows")
+    return P
+
+
+def attn_ds(P, dP, T, ld, scale):
+    dS = torch.empty_like(P)
+    _lib.check(_lib.load().llmseg_attn_ds(_ptr(P), _ptr(dP), _ptr(dS), P.shape[0] * P.shape[1], T, ld, scale, _stream()), "attn_ds")
+    return dS
+
+
+def ce_bwd(logits, labels, coef):
+    N, T, V = logits.shape
+    dl = torch.empty_like(logits)
+    _lib.check(_lib.load().llmseg_ce_bwd(_ptr(logits), _ptr(labels), _ptr(coef), _ptr(dl), N, T, V, logits.stride(1), _stream()), "ce_bwd")
+    return dl
+
+
+def scatter_add_rows(src, idx, dst):
+    _lib.check(_lib.load().llmseg_scatter_add_rows(_ptr(src), _ptr(idx), _ptr(dst), src.shape[0], src.shape[1], _stream()), "scatter_add_rows")
+    return dst
+
+
+def sumsq(x, out):
+    _lib.check(_lib.load().llmseg_sumsq(_ptr(x), x.numel(), 1 if x.dtype == torch.float32 else 0, _ptr(out), _stream()), "sumsq")
+    return out
+
+
+def adamw_(p, master, grad, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=None):
+    _lib.check(_lib.load().llmseg_adamw(_ptr(p), _ptr(master), _ptr(grad), 1 if grad.dtype == torch.float32 else 0, _ptr(m), _ptr(v), p.numel(),
+                                        lr, beta1, beta2, eps, wd, step, _ptr(grad_scale), _stream()), "adamw")
 
 
 def prof_enable(on):

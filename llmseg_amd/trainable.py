@@ -1,0 +1,323 @@
+"""The trainable half of the path (mixed into `LISAForCausalLM`): LLaVA splice + Llama-7B stack (+LoRA) + lm_head/CE,
+`text_hidden_fcs`, mask pooling, the mask-selection transformer and the losses -- reference `model/LISA.py:254-474`,
+`model/llava/model/language_model/llava_llama.py:55-135`, `model/transformer.py:215-341`, `model/loss.py:50-94`.
+
+Every op goes through a small namespace `F`: `_Direct` calls the kernels straight (inference / no-grad), `_Auto` routes the
+same calls through the autograd Functions of `autograd.py` so that `loss.backward()` runs the HIP backward kernels.
+What is trainable follows the reference (`training.py:183-241`): LoRA A/B on every q_proj/v_proj, `embed_tokens`,
+`lm_head`, `text_hidden_fcs`, every `lisa_*` module; CLIP, mm_projector, SAM, DINOv2 and the Llama base weights are frozen.
+"""
+import torch
+
+from . import autograd as ag
+from . import ops
+
+IMAGE_TOKEN_INDEX = -200
+IGNORE_INDEX = -100
+BF16 = torch.bfloat16
+
+
+class _Direct:
+    grad = False
+    linear = staticmethod(lambda x, w, b=None, act=ops.ACT_NONE, residual=None: ops.gemm(x, w, bias=b, act=act, residual=residual))
+    norm = staticmethod(lambda x, w, b=None, eps=1e-5, rms=False: ops.norm(x, w, b, eps=eps, rms=rms))
+    rope = staticmethod(lambda qkv, cos, sin, rows, T, heads, hd, ld: ops.rope_(qkv, cos, sin, rows, T, heads, hd, ld))
+    attn_packed = staticmethod(lambda qkv, batch, n, heads, hd, causal=False, key_mask=None:
+                               ops.attention_packed(qkv, batch, n, heads, hd, causal=causal, key_mask=key_mask))
+    swiglu = staticmethod(lambda gu, inter: ops.swiglu(gu, inter))
+    embed_splice = staticmethod(lambda ids, emb, feats, P, fs: ops.embed_splice(ids, emb, feats, P, feats_stride_n=fs))
+    gather_rows = staticmethod(lambda x, idx: ops.gather_rows(x, idx))
+    maskpool = staticmethod(lambda feat, segs, g, S: ops.upsample_maskpool(feat, segs, g, S))
+
+    @staticmethod
+    def lora_qkv(x, wqkv, aq, bq, av, bv, s):
+        H = wqkv.shape[1]
+        qkv = ops.gemm(x, wqkv)
+        ops.gemm(ops.gemm(x, aq), bq, residual=qkv[:, :H], out=qkv[:, :H], alpha=s)
+        ops.gemm(ops.gemm(x, av), bv, residual=qkv[:, 2 * H:], out=qkv[:, 2 * H:], alpha=s)
+        return qkv
+
+    @staticmethod
+    def ce(logits, labels):
+        acc = ops.ce_loss(logits, labels)
+        return acc[0] / acc[1]
+
+    @staticmethod
+    def align_reg(e, t, pred, gt_iou, gt_iop):
+        return ops.align_reg_loss(e, t, gt_iou, pred, gt_iop)
+
+    @staticmethod
+    def bcast_add(s, add, Cn, K):
+        for ci in range(Cn):
+            blk = s[ci * K:(ci + 1) * K]
+            ops.add_rows(blk, add[ci:ci + 1].contiguous(), out=blk)
+        return s
+
+    @staticmethod
+    def cross_attn_1q(q, kv, Cn, K, heads, hd):
+        D = heads * hd
+        o = torch.empty((Cn, D), device=q.device, dtype=BF16)
+        ops.attention(q, kv, kv[:, D:], o, batch=Cn, heads=heads, Nq=1, Nk=K, head_dim=hd, q_strides=(D, hd, D),
+                      k_strides=(K * 2 * D, hd, 2 * D), v_strides=(K * 2 * D, hd, 2 * D), o_strides=(D, hd, D))
+        return o
+
+
+class _Auto:
+    grad = True
+    linear = staticmethod(ag.linear)
+    norm = staticmethod(ag.norm)
+    rope = staticmethod(lambda qkv, cos, sin, rows, T, heads, hd, ld: ag.RopeFn.apply(qkv, cos, sin, rows, T, heads, hd, ld))
+    attn_packed = staticmethod(lambda qkv, batch, n, heads, hd, causal=False, key_mask=None:
+                               ag.PackedAttnFn.apply(qkv, batch, n, heads, hd, causal, key_mask))
+    swiglu = staticmethod(lambda gu, inter: ag.SwigluFn.apply(gu, inter))
+    embed_splice = staticmethod(lambda ids, emb, feats, P, fs: ag.EmbedSpliceFn.apply(ids, emb, feats, P, fs))
+    gather_rows = staticmethod(lambda x, idx: ag.GatherRowsFn.apply(x, idx))
+    maskpool = staticmethod(lambda feat, segs, g, S: ag.MaskPoolFn.apply(feat, segs, g, S))
+    lora_qkv = staticmethod(lambda x, wqkv, aq, bq, av, bv, s: ag.LoraQKVFn.apply(x, wqkv, aq, bq, av, bv, s))
+    ce = staticmethod(lambda logits, labels: ag.CELossFn.apply(logits, labels))
+    align_reg = staticmethod(lambda e, t, pred, gt_iou, gt_iop: ag.AlignRegFn.apply(e, t, pred, gt_iou, gt_iop))
+    bcast_add = staticmethod(lambda s, add, Cn, K: ag.BcastAddFn.apply(s, add, Cn, K))
+    cross_attn_1q = staticmethod(lambda q, kv, Cn, K, heads, hd: ag.CrossAttn1QFn.apply(q, kv, Cn, K, heads, hd))
+
+
+class TrainableMixin:
+    # ------------------------------------------------------------------------------------------------ plumbing
+    def set_trainable(self):
+        """requires_grad as `training.py:183-241` leaves it, minus the parameters whose gradient is identically zero or
+        absent on this path -- freezing them is equivalent under AdamW(wd=0) and keeps DDP's reducer free of unused
+        parameters: the q/k projections of attentions over a single key (softmax over one key is constant:
+        `cross_attn_token_to_image`, `lisa_final_attn`), and `lisa_dino_conv` when the SAM backbone feeds the head."""
+        dead = ("cross_attn_token_to_image.q_proj", "cross_attn_token_to_image.k_proj", "lisa_final_attn.q_proj", "lisa_final_attn.k_proj")
+        for name, prm in self.params.named_parameters():
+            on = any(k in name for k in ("lm_head", "embed_tokens", "text_hidden_fcs", "lisa_", "lora_"))
+            if any(d in name for d in dead) or (self.config.backbone == "sam" and "lisa_dino_conv" in name):
+                on = False
+            prm.requires_grad_(on)
+        return self
+
+    def trainable_parameters(self):
+        return [p for p in self.params.parameters() if p.requires_grad]
+
+    def _F(self):
+        return _Auto if torch.is_grad_enabled() else _Direct
+
+    def _w(self, name, F):
+        """Weight tensor for `name`: the Parameter itself under autograd, its storage otherwise."""
+        t = self.params.flat[name]
+        if F.grad and isinstance(t, torch.nn.Parameter):
+            return t
+        return t.data if isinstance(t, torch.nn.Parameter) else t
+
+    def _wcat(self, fused, members, F):
+        """Fused [q|k|v]-style operand: the single backing tensor, or a cat of the member Parameters when they train."""
+        if F.grad and any(self.params.flat[m].requires_grad for m in members):
+            return torch.cat([self.params.flat[m] for m in members], 0)
+        return self.params.flat[fused]
+
+    def _qkv_wb(self, p, F):
+        names_w = [p + f"{n}_proj.weight" for n in "qkv"]
+        names_b = [p + f"{n}_proj.bias" for n in "qkv"]
+        return self._wcat(p + "qkv.weight", names_w, F), self._wcat(p + "qkv.bias", names_b, F)
+
+    # ------------------------------------------------------------------------------------------------ language
+    def _llama(self, embeds, key_mask_u8, F):
+        """32 x [RMSNorm -> q|k|v GEMM (+LoRA) -> RoPE -> causal attention -> o_proj(+res) -> RMSNorm -> gate|up GEMM ->
+        SwiGLU -> down(+res)], final RMSNorm (HF LlamaModel, transformers 4.29; call site llava_llama.py:93-102).
+        Activations of every layer are kept for the backward pass (288 GB HBM: no recompute, unlike the reference's
+        gradient checkpointing, training.py:165-166)."""
+        c = self.config.llama
+        N, T, H = embeds.shape
+        x = embeds.reshape(N * T, H)
+        cos, sin = self._rope(T)
+        s = c.lora_alpha / c.lora_r if c.lora_r > 0 else 0.0
+        for i in range(c.layers):
+            p = f"model.layers.{i}."
+            h = F.norm(x, self._w(p + "input_layernorm.weight", F), None, c.eps, True)
+            if c.lora_r > 0:
+                lp = p + "self_attn."
+                qkv = F.lora_qkv(h, self._w(p + "qkv", F), self._w(lp + "q_proj.lora_A.default.weight", F),
+                                 self._w(lp + "q_proj.lora_B.default.weight", F), self._w(lp + "v_proj.lora_A.default.weight", F),
+                                 self._w(lp + "v_proj.lora_B.default.weight", F), s)
+            else:
+                qkv = F.linear(h, self._wcat(p + "qkv", [p + f"self_attn.{n}_proj.weight" for n in "qkv"], F))
+            qkv = F.rope(qkv, cos, sin, N * T, T, 2 * c.heads, c.head_dim, 3 * H)
+            a = F.attn_packed(qkv, N, T, c.heads, c.head_dim, causal=True, key_mask=key_mask_u8)
+            x = F.linear(a, self._w(p + "self_attn.o_proj.weight", F), None, ops.ACT_NONE, x)
+            h = F.norm(x, self._w(p + "post_attention_layernorm.weight", F), None, c.eps, True)
+            gu = F.linear(h, self._wcat(p + "gate_up", [p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"], F))
+            x = F.linear(F.swiglu(gu, c.inter), self._w(p + "mlp.down_proj.weight", F), None, ops.ACT_NONE, x)
+        return F.norm(x, self._w("model.norm.weight", F), None, c.eps, True).view(N, T, H)
+
+    def llava_forward(self, images_clip, attention_mask, input_ids, labels=None, want_logits=True):
+        """LlavaLlamaForCausalLM.forward (llava_llama.py:55-135): splice, decoder stack, lm_head, shifted CE.
+        -> (ce_loss | None, logits | None, final-norm hidden [N,T,H])."""
+        c = self.config
+        F = self._F()
+        N, L = input_ids.shape
+        n_img = (input_ids == IMAGE_TOKEN_INDEX).sum(1)
+        assert bool((n_img == 1).all()), "exactly one <image> per sequence (the reference's seg_token_mask assumes it too)"
+        Pn = c.n_img_tokens
+        with torch.no_grad():                                              # CLIP + mm_projector are frozen
+            proj = self.encode_images(images_clip)                         # [N*(P+1), H]
+        H = c.llama.hidden
+        embeds = F.embed_splice(input_ids.contiguous(), self._w("model.embed_tokens.weight", F), proj[1:], Pn, (Pn + 1) * H)
+        T = L - 1 + Pn
+        mask = torch.cat([torch.ones((N, T - L), dtype=torch.bool, device=input_ids.device), attention_mask.bool()], 1)
+        hidden = self._llama(embeds, mask.to(torch.uint8).contiguous(), F)
+        logits, loss = None, None
+        if want_logits or labels is not None:
+            logits = F.linear(hidden.view(N * T, H), self._w("lm_head.weight", F)).view(N, T, -1)
+        if labels is not None:
+            pos = (input_ids == IMAGE_TOKEN_INDEX).int().argmax(1)          # index plumbing for the label splice
+            ar = torch.arange(T, device=labels.device)[None]
+            src = torch.where(ar < pos[:, None], ar, (ar - Pn + 1).clamp(min=0))
+            new_labels = torch.gather(labels, 1, src.clamp(max=L - 1))
+            new_labels = torch.where((ar >= pos[:, None]) & (ar < pos[:, None] + Pn), torch.full_like(new_labels, IGNORE_INDEX), new_labels)
+            loss = F.ce(logits, new_labels.contiguous())
+        return loss, logits, hidden
+
+    # ------------------------------------------------------------------------------------------------------ head
+    def _head_attn_1key(self, p, text, F):
+        """Attention whose key/value is a single token: softmax over one key == 1, so out = out_proj(v_proj(text)) for every
+        query (transformer.py:319-341 with Nk = 1); q_proj/k_proj get exactly-zero gradients, as in the reference."""
+        v = F.linear(text, self._w(p + "v_proj.weight", F), self._w(p + "v_proj.bias", F))
+        return F.linear(v, self._w(p + "out_proj.weight", F), self._w(p + "out_proj.bias", F))
+
+    def _ln(self, x, name, F):
+        return F.norm(x, self._w(name + ".weight", F), self._w(name + ".bias", F), 1e-5, False)
+
+    def _mask_head(self, pooled, text, F):
+        """LISA.py:363-391 for one image: pooled [K, D] bf16, text [C, D] bf16 -> (pred_iou [C*K] bf16, emb [C*K, D] bf16)."""
+        K, D = pooled.shape
+        Cn = text.shape[0]
+        nh, hd = 8, D // 8
+        s = pooled.repeat(Cn, 1) if Cn > 1 else (pooled.clone() if not F.grad else pooled)     # row = c*K + k (LISA.py:372)
+        t = text.contiguous()
+        lin = lambda x, p, act=ops.ACT_NONE, res=None: F.linear(x, self._w(p + ".weight", F), self._w(p + ".bias", F), act, res)
+        for i in range(2):
+            p = f"model.lisa_attention_layers.{i}."
+            w, b = self._qkv_wb(p + "self_attn.", F)
+            a = F.attn_packed(F.linear(s, w, b), Cn, K, nh, hd)
+            s = self._ln(lin(a, p + "self_attn.out_proj", res=s), p + "norm1", F)
+            s = self._ln(F.bcast_add(s, self._head_attn_1key(p + "cross_attn_token_to_image.", t, F), Cn, K), p + "norm2", F)
+            s = self._ln(lin(lin(s, p + "mlp.lin1", ops.ACT_RELU), p + "mlp.lin2", res=s), p + "norm3", F)
+            # image -> token: q = text (1 query per conversation), k = v = mask features
+            pc = p + "cross_attn_image_to_token."
+            q = lin(t, pc + "q_proj")
+            if F.grad and self.params.flat[pc + "k_proj.weight"].requires_grad:
+                kvw = torch.cat([self.params.flat[pc + "k_proj.weight"], self.params.flat[pc + "v_proj.weight"]], 0)
+                kvb = torch.cat([self.params.flat[pc + "k_proj.bias"], self.params.flat[pc + "v_proj.bias"]], 0)
+            else:
+                kvw, kvb = self.params[pc + "qkv.weight"][D:], self.params[pc + "qkv.bias"][D:]
+            kv = F.linear(s, kvw, kvb)                                                      # [C*K, 2D] = k | v
+            o = F.cross_attn_1q(q, kv, Cn, K, nh, hd)
+            t = self._ln(lin(o, pc + "out_proj", res=t), p + "norm4", F)
+        s = self._ln(F.bcast_add(s, self._head_attn_1key("model.lisa_final_attn.", t, F), Cn, K), "model.lisa_norm_final_attn", F)
+        iou = lin(lin(s, "model.lisa_iou_head.0", ops.ACT_RELU), "model.lisa_iou_head.2", ops.ACT_SIGMOID)
+        emb = lin(lin(s, "model.lisa_embedding_head.0", ops.ACT_RELU), "model.lisa_embedding_head.2")
+        return iou.view(Cn * K), emb
+
+    # ------------------------------------------------------------------------------------------------ model_forward
+    def visual_features_cl(self, images, F):
+        """-> (channels-last feature rows bf16, rows per image, row offset of the first patch, grid)."""
+        c = self.config
+        with torch.no_grad():                                              # both backbones are frozen
+            if c.backbone == "sam":
+                return self._sam_encoder_cl(images), c.sam.grid ** 2, 0, c.sam.grid
+            x, n_tok, (gh, gw) = self._dinov2_tokens(images)
+        assert gh == gw
+        d = self.prepare()
+        w = self._w("model.lisa_dino_conv.weight", F)
+        w = w.reshape(c.out_dim, c.dino.dim) if F.grad else d["dino.conv_w"]
+        y = F.linear(x, w, self._w("model.lisa_dino_conv.bias", F))                          # 1x1 conv (LISA.py:245)
+        return y, n_tok, 1, gh
+
+    def forward(self, **kwargs):
+        return self.model_forward(**kwargs)
+
+    def model_forward(self, images, images_clip, input_ids, labels, attention_masks, offset, masks_list=None, label_list=None,
+                      resize_list=None, sam_segs_list=None, sam_ious_list=None, sam_iops_list=None, inference=False,
+                      return_aux=False, **kwargs):
+        if inference:
+            with torch.no_grad():
+                return self._model_forward(images, images_clip, input_ids, labels, attention_masks, offset, masks_list, sam_segs_list,
+                                           sam_ious_list, sam_iops_list, True, return_aux)
+        return self._model_forward(images, images_clip, input_ids, labels, attention_masks, offset, masks_list, sam_segs_list, sam_ious_list,
+                                   sam_iops_list, False, return_aux)
+
+    def _model_forward(self, images, images_clip, input_ids, labels, attention_masks, offset, masks_list, sam_segs_list, sam_ious_list,
+                       sam_iops_list, inference, return_aux):
+        c = self.config
+        F = self._F()
+        images, images_clip = images.to(BF16), images_clip.to(BF16)
+        feat, rows_per_img, row0, g = self.visual_features_cl(images.contiguous(), F)
+        B = images.shape[0]
+        assert B == len(offset) - 1
+        Pn = c.n_img_tokens
+        off = offset.tolist()
+        if inference:
+            assert images_clip.shape[0] == 1                                             # LISA.py:271
+            clip_in = images_clip.expand(input_ids.shape[0], -1, -1, -1).contiguous()
+            ce, logits, hidden = self.llava_forward(clip_in, attention_masks, input_ids, None, want_logits=return_aux)
+        else:
+            reps = torch.tensor([off[i + 1] - off[i] for i in range(B)], device=images_clip.device)
+            clip_in = images_clip.repeat_interleave(reps, 0).contiguous()                # LISA.py:293-303
+            ce, logits, hidden = self.llava_forward(clip_in, attention_masks, input_ids, labels)
+
+        # [SEG] rows: mask shifted by one and by the P-1 extra image tokens (LISA.py:254-266); gather first, then the MLP
+        N, T, H = hidden.shape
+        segm = torch.zeros((N, T), dtype=torch.bool, device=input_ids.device)
+        segm[:, Pn - 1:Pn - 1 + input_ids.shape[1] - 1] = input_ids[:, 1:] == self.seg_token_idx
+        idx = segm.view(-1).nonzero().flatten()
+        seg_off = [0] + segm.sum(1).cumsum(0).tolist()
+        seg_off = [seg_off[o] for o in off]
+        if idx.numel():
+            hs = F.gather_rows(hidden.view(N * T, H), idx)
+            hs = F.linear(hs, self._w("model.text_hidden_fcs.0.0.weight", F), self._w("model.text_hidden_fcs.0.0.bias", F), ops.ACT_RELU)
+            pred = F.linear(hs, self._w("model.text_hidden_fcs.0.2.weight", F), self._w("model.text_hidden_fcs.0.2.bias", F))
+        else:
+            pred = torch.empty((0, c.out_dim), device=hidden.device, dtype=BF16)
+        pred_embeddings = [pred[seg_off[b]:seg_off[b + 1]] for b in range(B)]
+
+        ious, embs = [], []
+        for b in range(B):
+            segs = sam_segs_list[b].to(BF16).contiguous()
+            S = segs.shape[-1]
+            fb = feat[b * rows_per_img + row0: b * rows_per_img + row0 + g * g]
+            pooled = F.maskpool(fb, segs, g, S)
+            K = segs.shape[0]
+            Cn = pred_embeddings[b].shape[0]
+            if Cn == 0:
+                if not inference:
+                    raise ValueError("number of rounds = 0")                          # LISA.py:435-437
+                ious.append(None); embs.append(None)
+                continue
+            iou, emb = self._mask_head(pooled, pred_embeddings[b], F)
+            ious.append(iou.view(Cn, K)); embs.append(emb.view(Cn, K, -1))
+
+        if inference:
+            sims = [ops.cosine_scores(pred_embeddings[b][0], embs[b][0])[None] for b in range(B)]
+            out = {"pred_similarity": sims, "gt_masks": masks_list, "pred_iou": [ious[b][:1].float() for b in range(B)]}
+            if return_aux:
+                out.update(logits=logits, hidden=hidden, feats=feat, pred_embeddings=pred_embeddings)
+            return out
+
+        align = torch.zeros((), device=hidden.device, dtype=torch.float32)
+        reg = torch.zeros((), device=hidden.device, dtype=torch.float32)
+        for b in range(B):
+            R = pred_embeddings[b].shape[0]
+            a_r = torch.zeros_like(align); r_r = torch.zeros_like(reg)
+            for r in range(R):
+                o = F.align_reg(embs[b][r].contiguous(), pred_embeddings[b][r].contiguous(), ious[b][r].contiguous(),
+                                sam_ious_list[b][r].float().contiguous(), sam_iops_list[b][r].float().contiguous())
+                a_r = a_r + o[0]; r_r = r_r + o[1]
+            align = align + a_r / (R + 1e-8)
+            reg = reg + r_r / (R + 1e-8)
+        align, reg = align / B, reg / B
+        ce = ce * c.ce_loss_weight
+        align = align * c.align_loss_weight
+        reg = reg * c.regression_loss_weight
+        out = {"loss": ce + align + reg, "ce_loss": ce, "align_loss": align, "regression_loss": reg}
+        if return_aux:
+            out.update(logits=logits, hidden=hidden, feats=feat)
+        return out

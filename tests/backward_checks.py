@@ -1,0 +1,244 @@
+"""Backward-pass parity: HIP backward kernels / autograd Functions vs torch autograd on fp32 CPU copies, and the whole
+model's parameter gradients vs the oracle (and the reference-generated gradient fixture)."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from llmseg_amd import autograd as ag
+from llmseg_amd import ops
+from tests.kernel_checks import BF, DEV, err, rnd
+
+
+def rel_tol(ref, k=2.0 ** -6):
+    return k * max(1e-6, ref.float().abs().max().item())
+
+
+def check_gemm_layouts():
+    out = []
+    M, N, K = 304, 264, 200
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / 14)
+    ref = a.float() @ w.float().t()
+    ad, wd = a.to(DEV), w.to(DEV)
+    at, wt = a.t().contiguous().to(DEV), w.t().contiguous().to(DEV)      # stored [K, M] / [K, N]
+    out.append(("gemm trans_w", err(ops.gemm(ad, wt, trans_w=True), ref), rel_tol(ref)))
+    out.append(("gemm trans_a", err(ops.gemm(at, wd, trans_a=True), ref), rel_tol(ref)))
+    out.append(("gemm trans_a+trans_w", err(ops.gemm(at, wt, trans_a=True, trans_w=True), ref), rel_tol(ref)))
+    # odd contraction length with both operands transposed (attention backward: K' = 319)
+    M, N, K = 319, 128, 319
+    a, w = rnd(K, 320, seed=3), rnd(K, N, seed=4, scale=1 / 16)
+    ref = a[:, :M].float().t() @ w.float()
+    got = torch.empty(M, N, device=DEV, dtype=BF)
+    ops.gemm_batched(a.to(DEV), w.to(DEV), got, M=M, N=N, K=K, lda=320, ldw=N, ldc=N, batch=1, sA=0, sW=0, sC=0, out_f32=False,
+                     trans_a=True, trans_w=True)
+    out.append(("gemm trans both K=319", err(got, ref), rel_tol(ref)))
+    # K = 319 with a zero-padded K-contiguous A (dQ = dS K)
+    a = rnd(64, 320, seed=5)
+    a[:, 319] = 0
+    w = rnd(319, 128, seed=6, scale=1 / 16)
+    ref = a[:, :319].float() @ w.float()
+    got = torch.empty(64, 128, device=DEV, dtype=BF)
+    ops.gemm_batched(a.to(DEV), w.to(DEV), got, M=64, N=128, K=319, lda=320, ldw=128, ldc=128, batch=1, sA=0, sW=0, sC=0, out_f32=False,
+                     trans_w=True)
+    out.append(("gemm K=319 padded A, trans_w", err(got, ref), rel_tol(ref)))
+    # 2-D batch
+    b1, b2, M, N, K = 3, 2, 70, 40, 64
+    a, w = rnd(b2, b1, M, K, seed=7), rnd(b2, b1, N, K, seed=8, scale=1 / 8)
+    ref = a.float() @ w.float().transpose(-1, -2)
+    got = torch.empty(b2, b1, M, N, device=DEV, dtype=torch.float32)
+    ops.gemm_batched(a.to(DEV), w.to(DEV), got, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, batch=b1, sA=M * K, sW=N * K, sC=M * N, batch2=b2,
+                     sA2=b1 * M * K, sW2=b1 * N * K, sC2=b1 * M * N, out_f32=True)
+    out.append(("gemm 2-D batch", err(got, ref), 1e-3))
+    return out
+
+
+def _grads(fn_ref, fn_hip, inputs, names):
+    """inputs: list of bf16 CPU tensors.  Returns [(name, err, tol)] for the output and every input gradient."""
+    res = []
+    xs = [t.float().clone().requires_grad_(True) for t in inputs]
+    y = fn_ref(*xs)
+    gen = torch.Generator().manual_seed(99)
+    gy = torch.randn(y.shape, generator=gen).to(BF)
+    y.backward(gy.float())
+    xd = [t.to(DEV).clone().requires_grad_(True) for t in inputs]
+    yd = fn_hip(*xd)
+    yd.backward(gy.to(DEV))
+    res.append((names[0] + " fwd", err(yd, y), rel_tol(y)))
+    for n, a, b in zip(names[1:], xd, xs):
+        if b.grad is not None:
+            res.append((f"{names[0]} d{n}", err(a.grad, b.grad), rel_tol(b.grad, 2.0 ** -5)))
+    return res
+
+
+def check_autograd_ops():
+    out = []
+    x, w, b, r = rnd(200, 256, seed=1), rnd(264, 256, seed=2, scale=1 / 16), rnd(264, seed=3), rnd(200, 264, seed=4)
+    out += _grads(lambda x, w, b, r: F.linear(x, w, b) + r, lambda x, w, b, r: ag.linear(x, w, b, ops.ACT_NONE, r), [x, w, b, r],
+                  ["linear+res", "x", "w", "b", "res"])
+    out += _grads(lambda x, w, b: F.relu(F.linear(x, w, b)), lambda x, w, b: ag.linear(x, w, b, ops.ACT_RELU), [x, w, b], ["linear relu", "x", "w", "b"])
+    w1, b1 = rnd(1, 256, seed=5, scale=1 / 16), rnd(1, seed=6)
+    out += _grads(lambda x, w, b: torch.sigmoid(F.linear(x, w, b)), lambda x, w, b: ag.linear(x, w, b, ops.ACT_SIGMOID), [x, w1, b1],
+                  ["linear N=1 sigmoid", "x", "w", "b"])
+    g, bb = rnd(256, seed=7), rnd(256, seed=8)
+    out += _grads(lambda x, g, b: F.layer_norm(x, (256,), g, b, 1e-5), lambda x, g, b: ag.norm(x, g, b, 1e-5, False), [x, g, bb], ["layernorm", "x", "w", "b"])
+    out += _grads(lambda x, g: g * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6)), lambda x, g: ag.norm(x, g, None, 1e-6, True), [x, g],
+                  ["rmsnorm", "x", "w"])
+    gu = rnd(100, 2 * 128, seed=9)
+    out += _grads(lambda t: F.silu(t[:, :128]) * t[:, 128:], lambda t: ag.SwigluFn.apply(t, 128), [gu], ["swiglu", "gu"])
+    # packed causal attention with a key mask (Llama form), hd = 128, T = 37 (odd: exercises the padded P buffers)
+    Nn, T, nh, hd = 2, 37, 2, 128
+    qkv = rnd(Nn * T, 3 * nh * hd, seed=10, scale=0.5)
+    km = torch.ones(Nn, T, dtype=torch.uint8)
+    km[1, 30:] = 0
+
+    def attn_ref(t):
+        x = t.view(Nn, T, 3, nh, hd).permute(2, 0, 3, 1, 4)
+        s = (x[0] @ x[1].transpose(-1, -2)) / math.sqrt(hd)
+        m = torch.ones(T, T, dtype=torch.bool).tril()[None, None] & (km != 0)[:, None, None, :]
+        p = torch.softmax(s.masked_fill(~m, -1e30), -1)
+        return (p @ x[2]).transpose(1, 2).reshape(Nn * T, nh * hd)
+    out += _grads(attn_ref, lambda t: ag.PackedAttnFn.apply(t, Nn, T, nh, hd, True, km.to(DEV)), [qkv], ["attn causal", "qkv"])
+    # head shapes: self attention hd 32 and the 1-query cross attention
+    Cn, K, nh, hd = 2, 48, 8, 32
+    D = nh * hd
+    qkv = rnd(Cn * K, 3 * D, seed=11, scale=0.5)
+
+    def sa_ref(t):
+        x = t.view(Cn, K, 3, nh, hd).permute(2, 0, 3, 1, 4)
+        p = torch.softmax((x[0] @ x[1].transpose(-1, -2)) / math.sqrt(hd), -1)
+        return (p @ x[2]).transpose(1, 2).reshape(Cn * K, D)
+    out += _grads(sa_ref, lambda t: ag.PackedAttnFn.apply(t, Cn, K, nh, hd, False, None), [qkv], ["attn head self", "qkv"])
+    q, kv = rnd(Cn, D, seed=12), rnd(Cn * K, 2 * D, seed=13, scale=0.5)
+
+    def ca_ref(q, kv):
+        qq = q.view(Cn, 1, nh, hd).transpose(1, 2)
+        kk = kv[:, :D].view(Cn, K, nh, hd).transpose(1, 2)
+        vv = kv[:, D:].view(Cn, K, nh, hd).transpose(1, 2)
+        p = torch.softmax((qq @ kk.transpose(-1, -2)) / math.sqrt(hd), -1)
+        return (p @ vv).transpose(1, 2).reshape(Cn, D)
+    out += _grads(ca_ref, lambda q, kv: ag.CrossAttn1QFn.apply(q, kv, Cn, K, nh, hd), [q, kv], ["attn head 1q", "q", "kv"])
+    # rope
+    T, nh, hd, N = 19, 2, 128, 2
+    qkv = rnd(N * T, 3 * nh * hd, seed=14)
+    inv = 1.0 / (10000 ** (torch.arange(0, hd, 2).float() / hd))
+    ang = torch.outer(torch.arange(T).float(), inv)
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+
+    def rope_ref(t):
+        x = t.view(N, T, 3, nh, hd)
+        c2, s2 = torch.cat([cos, cos], -1)[None, :, None], torch.cat([sin, sin], -1)[None, :, None]
+        rot = lambda u: torch.cat([-u[..., hd // 2:], u[..., :hd // 2]], -1)
+        return torch.stack([x[:, :, 0] * c2 + rot(x[:, :, 0]) * s2, x[:, :, 1] * c2 + rot(x[:, :, 1]) * s2, x[:, :, 2]], 2).reshape(N * T, -1)
+    out += _grads(rope_ref, lambda t: ag.RopeFn.apply(t.clone(), cos.to(DEV), sin.to(DEV), N * T, T, 2 * nh, hd, 3 * nh * hd), [qkv], ["rope", "qkv"])
+    # CE
+    Nn, T, V = 2, 7, 1000
+    logits = rnd(Nn, T, V, seed=15, scale=2.0)
+    labels = torch.randint(0, V, (Nn, T), generator=torch.Generator().manual_seed(1))
+    labels[:, :2] = -100
+    out += _grads(lambda l: F.cross_entropy(l[:, :-1].reshape(-1, V), labels[:, 1:].reshape(-1), ignore_index=-100),
+                  lambda l: ag.CELossFn.apply(l, labels.to(DEV)), [logits], ["shifted CE", "logits"])
+    # LoRA-fused qkv
+    H, r, M = 256, 8, 50
+    x, wq = rnd(M, H, seed=16), rnd(3 * H, H, seed=17, scale=1 / 16)
+    aq, bq, av, bv = rnd(r, H, seed=18, scale=1 / 16), rnd(H, r, seed=19, scale=0.3), rnd(r, H, seed=20, scale=1 / 16), rnd(H, r, seed=21, scale=0.3)
+
+    def lora_ref(x, aq, bq, av, bv):
+        y = F.linear(x, wq.float())
+        dq, dv = 2.0 * F.linear(F.linear(x, aq), bq), 2.0 * F.linear(F.linear(x, av), bv)
+        return torch.cat([y[:, :H] + dq, y[:, H:2 * H], y[:, 2 * H:] + dv], 1)
+    out += _grads(lora_ref, lambda x, aq, bq, av, bv: ag.LoraQKVFn.apply(x, wq.to(DEV), aq, bq, av, bv, 2.0), [x, aq, bq, av, bv],
+                  ["lora qkv", "x", "Aq", "Bq", "Av", "Bv"])
+    # embedding splice + gather
+    Nn, L, P, Hd, V = 2, 9, 4, 64, 50
+    ids = torch.randint(0, V, (Nn, L), generator=torch.Generator().manual_seed(2))
+    ids[:, 2] = -200
+    ids[0, 5] = ids[0, 6]                                                   # a repeated token: gradient accumulation
+    emb, feats = rnd(V, Hd, seed=22), rnd(Nn, P, Hd, seed=23)
+
+    def splice_ref(e):
+        return torch.stack([torch.cat([e[ids[n, :2]], feats[n].float(), e[ids[n, 3:]]]) for n in range(Nn)])
+    out += _grads(splice_ref, lambda e: ag.EmbedSpliceFn.apply(ids.to(DEV), e, feats.to(DEV), P, P * Hd), [emb], ["embed_splice", "embed"])
+    idx = torch.tensor([3, 17, 0], dtype=torch.int64)
+    xx = rnd(20, 64, seed=24)
+    out += _grads(lambda t: t[idx], lambda t: ag.GatherRowsFn.apply(t, idx.to(DEV)), [xx], ["gather_rows", "x"])
+    # mask pooling backward
+    K, Cc, g, S = 8, 64, 16, 64
+    feat = rnd(g * g, Cc, seed=25)
+    segs = (torch.rand(K, S, S, generator=torch.Generator().manual_seed(3)) > 0.6).to(BF)
+
+    def pool_ref(f):
+        up = F.interpolate(f.t().reshape(1, Cc, g, g), size=(S, S), mode="bilinear", align_corners=False)[0]
+        wv = segs.float().flatten(1)
+        return (wv @ up.flatten(1).t()) / (wv.sum(-1, keepdim=True) + 1e-8)
+    out += _grads(pool_ref, lambda f: ag.MaskPoolFn.apply(f, segs.to(DEV), g, S), [feat], ["maskpool", "feat"])
+    s, add = rnd(2 * 10, 64, seed=26), rnd(2, 64, seed=27)
+    out += _grads(lambda s, a: s + a.repeat_interleave(10, 0), lambda s, a: ag.BcastAddFn.apply(s, a, 2, 10), [s, add], ["bcast_add", "s", "add"])
+    return out
+
+
+def check_adamw():
+    n = 1000
+    gen = torch.Generator().manual_seed(0)
+    w0 = torch.randn(n, generator=gen)
+    p = w0.to(BF).to(DEV)
+    master = p.float().clone()
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    ref_w = p.float().cpu().clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref_w], lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.01)
+    for step in range(1, 4):
+        g = torch.randn(n, generator=gen).to(BF)
+        ref_w.grad = g.float()
+        opt.step()
+        ops.adamw_(p, master, g.to(DEV), m, v, 1e-2, 0.9, 0.95, 1e-8, 0.01, step)
+    acc = torch.zeros(1, device=DEV)
+    ops.sumsq(p, acc)
+    return [("adamw master", err(master, ref_w.detach()), 1e-5), ("adamw bf16 copy", err(p, ref_w.detach()), 2.0 ** -7 * 4),
+            ("sumsq", abs(acc.item() - p.float().pow(2).sum().item()), 1e-2)]
+
+
+def check_model_grads(golden_loader=None):
+    """Parameter gradients of the tiny end-to-end model: HIP backward vs autograd through the fp32 oracle (same bf16-rounded
+    weights), plus the fixture recorded from the imported reference."""
+    from oracle import cases, lisa as olisa
+    from tests import model_checks as mc
+    cfg = cases.tiny_lisa_cfg("dinov2")
+    m, sd = mc.build_pair(cfg)
+    names = ["model.text_hidden_fcs.0.2.weight", "model.text_hidden_fcs.0.0.bias", "lm_head.weight", "model.lisa_iou_head.0.weight",
+             "model.lisa_embedding_head.2.weight", "model.layers.1.self_attn.q_proj.weight", "model.layers.0.mlp.down_proj.weight",
+             "model.embed_tokens.weight", "model.lisa_attention_layers.0.self_attn.q_proj.weight",
+             "model.lisa_attention_layers.1.cross_attn_image_to_token.k_proj.weight", "model.lisa_attention_layers.0.norm1.weight",
+             "model.lisa_dino_conv.weight", "model.lisa_final_attn.v_proj.weight", "model.layers.1.input_layernorm.weight"]
+    for n in names:
+        sd[n].requires_grad_(True)
+    batch = mc._round_batch(cases.tiny_lisa_batch(img_size=896))
+    olisa.model_forward(sd, cfg, **batch, inference=False)["loss"].backward()
+    # the same gradients from the bf16 CPU oracle: the error scale of bf16 arithmetic itself on this (ill-conditioned) tiny case
+    sd_lo = {k: v.detach().to(BF) for k, v in sd.items()}
+    for n in names:
+        sd_lo[n].requires_grad_(True)
+    olisa.model_forward(sd_lo, cfg, **mc._bf16_batch(batch), inference=False)["loss"].backward()
+    for n, p in m.params.named_parameters():
+        p.requires_grad_(n in names)
+    out = m.model_forward(**mc._dev(batch), inference=False)
+    out["loss"].backward()
+    res = []
+    prm = dict(m.params.named_parameters())
+    for n in names:
+        ref = sd[n].grad
+        got = prm[n].grad
+        assert got is not None, n
+        lo_e = (sd_lo[n].grad.float() - ref).abs().max().item()
+        res.append((f"grad {n} (bf16-CPU err {lo_e:.2e}, |ref| {ref.abs().max().item():.2e})", err(got.reshape(ref.shape), ref),
+                    max(0.06 * ref.abs().max().item(), 3.0 * lo_e)))
+    if golden_loader is not None:
+        # gradients recorded from the imported reference (fp32, un-rounded weights): same policy, the bf16-CPU error as the scale
+        g = golden_loader("lisa_tiny.pt")["grads"]
+        for key, n in (("text_fc2_w", "model.text_hidden_fcs.0.2.weight"), ("iou_head0_w", "model.lisa_iou_head.0.weight")):
+            ref = g[key]
+            lo_e = (sd_lo[n].grad.float() - ref).abs().max().item()
+            res.append((f"grad {key} vs reference fixture (bf16-CPU err {lo_e:.2e})", err(prm[n].grad, ref),
+                        max(0.06 * ref.abs().max().item(), 3.0 * lo_e)))
+    return res
+
+
+ALL = [check_gemm_layouts, check_autograd_ops, check_adamw]

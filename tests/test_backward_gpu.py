@@ -1,0 +1,29 @@
+"""GPU: backward kernels, autograd Functions and whole-model gradients against torch autograd / the oracle / the fixture."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert(res):
+    bad = [(n, e, t) for n, e, t in res if not (e <= t)]
+    assert not bad, "; ".join(f"{n}: err {e:.3e} > tol {t:.3e}" for n, e, t in bad)
+
+
+def test_gemm_layouts():
+    from tests import backward_checks as bc
+    _assert(bc.check_gemm_layouts())
+
+
+def test_autograd_ops():
+    from tests import backward_checks as bc
+    _assert(bc.check_autograd_ops())
+
+
+def test_adamw():
+    from tests import backward_checks as bc
+    _assert(bc.check_adamw())
+
+
+def test_model_grads(golden):
+    from tests import backward_checks as bc
+    _assert(bc.check_model_grads(golden))

@@ -1,0 +1,93 @@
+"""CPU: the data-parallel trainer (DDP over gloo, world_size 2): gradient accumulation with no_sync, one all-reduce per optimizer
+step, clipping, WarmupDecayLR.  The optimizer arithmetic is injected (CPU restatement of llmseg_adamw) because the product's
+optimizer kernels are HIP-only; what is under test here is the distributed / accumulation logic of llmseg_amd.train."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from llmseg_amd.train import Trainer, warmup_decay_lr
+
+
+class CpuAdamW:
+    """Same update rule as llmseg_adamw (fp32 master, bias correction, decoupled weight decay, external grad scale)."""
+
+    def __init__(self, params, betas=(0.9, 0.95), eps=1e-8, wd=0.0):
+        self.params = list(params)
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        self.b, self.eps, self.wd, self.t = betas, eps, wd, 0
+
+    def grad_sumsq(self):
+        return sum((p.grad.float() ** 2).sum() for p in self.params if p.grad is not None).reshape(1)
+
+    def step(self, lr, grad_scale):
+        self.t += 1
+        for p, m, v in zip(self.params, self.m, self.v):
+            g = p.grad * grad_scale
+            m.mul_(self.b[0]).add_(g, alpha=1 - self.b[0])
+            v.mul_(self.b[1]).addcmul_(g, g, value=1 - self.b[1])
+            mh, vh = m / (1 - self.b[0] ** self.t), v / (1 - self.b[1] ** self.t)
+            p.data.add_(-(lr * (mh / (vh.sqrt() + self.eps) + self.wd * p.data)))
+
+
+class Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.a = nn.Linear(6, 5)
+        self.b = nn.Linear(5, 1)
+
+    def forward(self, x, y):
+        return {"loss": ((self.b(torch.tanh(self.a(x))) - y) ** 2).mean()}
+
+
+def _data(rank, step):
+    g = torch.Generator().manual_seed(100 * step + rank)
+    return torch.randn(4, 6, generator=g), torch.randn(4, 1, generator=g)
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = Toy()
+    tr = Trainer(m, lr=1e-2, clip=1.0, grad_accum=3, warmup=2, total_steps=10, optimizer=CpuAdamW([p for p in m.parameters()]))
+    for s in range(6):
+        x, y = _data(rank, s)
+        tr.micro_step(dict(x=x, y=y))
+    ret[rank] = (tr.opt_steps, torch.cat([p.detach().flatten() for p in m.parameters()]))
+    dist.destroy_process_group()
+
+
+def test_ddp_gloo_matches_single_process():
+    world, port = 2, 29611
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret[0][0] == 2 and ret[1][0] == 2                       # 6 micro-steps / accum 3
+    assert torch.allclose(ret[0][1], ret[1][1], atol=0, rtol=0)    # replicas stay bit-identical
+    # single process over the union of both ranks' micro-batches (DDP averages over ranks)
+    m = Toy()
+    opt = CpuAdamW(list(m.parameters()))
+    for o in range(2):
+        for p in m.parameters():
+            p.grad = None
+        for s in range(3 * o, 3 * o + 3):
+            for r in range(world):
+                x, y = _data(r, s)
+                (m(x, y)["loss"] / world).backward()
+        ss = opt.grad_sumsq()
+        norm = ss.sqrt() / 3
+        coef = torch.clamp(1.0 / (norm + 1e-6), max=1.0) / 3
+        opt.step(warmup_decay_lr(o, 1e-2, 2, 10), coef)
+    ref = torch.cat([p.detach().flatten() for p in m.parameters()])
+    assert torch.allclose(ret[0][1], ref, atol=1e-6), (ret[0][1] - ref).abs().max()
+
+
+def test_warmup_decay_lr():
+    assert warmup_decay_lr(0, 1.0, 100, 5000) == 0.0
+    assert abs(warmup_decay_lr(50, 1.0, 100, 5000) - 0.5) < 1e-12
+    assert warmup_decay_lr(100, 1.0, 100, 5000) == 1.0
+    assert abs(warmup_decay_lr(2550, 1.0, 100, 5000) - 0.5) < 1e-12
+    assert warmup_decay_lr(5000, 1.0, 100, 5000) == 0.0
