@@ -111,8 +111,10 @@ def main():
     ap.add_argument("--prompt-len", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="reduced depth (debug only; result marked invalid)")
-    ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
-                    help="fwd: BASELINE configs[1] (forward only); train: configs[2]/[3] fwd+bwd with LoRA r=8 + DDP, optimizer step every --accum steps")
+    ap.add_argument("--mode", default="train", choices=["fwd", "train"],
+                    help="train (default; BASELINE metric 'fwd+bwd'): fwd+bwd with LoRA r=8 + DDP, optimizer step every --accum steps, and a "
+                         "forward-only pass (BASELINE configs[1]) reported under 'fwd_only'; fwd: forward only")
+    ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP even at world size 1 (exercises the reducer on one GPU)")
     ap.add_argument("--accum", type=int, default=10, help="gradient-accumulation micro-steps per optimizer step (reference: 10)")
     args = ap.parse_args()
 
@@ -122,8 +124,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_ddp:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from llmseg_amd import ops, synthetic
@@ -146,7 +153,7 @@ def main():
     if train:
         from llmseg_amd.train import Trainer
         model.set_trainable()
-        trainer = Trainer(model, lr=3e-4, grad_accum=args.accum, device_ids=[local])
+        trainer = Trainer(model, lr=3e-4, grad_accum=args.accum, device_ids=[local], force_ddp=args.force_ddp)
 
         def step():
             return trainer.micro_step(batch)
@@ -179,6 +186,31 @@ def main():
     loss = float(out["loss"].detach())
     assert loss == loss, "NaN loss"
 
+    fwd_only = None
+    if train:                                   # BASELINE configs[1]: the same batch, forward only (no grad)
+        def fstep():
+            with torch.no_grad():
+                return model.model_forward(**batch, inference=False)
+        for _ in range(max(1, args.warmup)):
+            fstep()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        f0 = time.perf_counter()
+        for _ in range(args.steps):
+            fstep()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        fdt = time.perf_counter() - f0
+        if dist:
+            t = torch.tensor([fdt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            fdt = float(t.item())
+        fwd_only = {"value": args.batch * world * args.steps / fdt, "unit": "images/s", "ms_per_step": fdt / args.steps * 1e3,
+                    "workload": "BASELINE.json configs[1]: forward-only model_forward, same batch"}
+
     if rank == 0:
         T = args.prompt_len - 1 + cfg.n_img_tokens
         ms = dt / args.steps * 1e3
@@ -207,6 +239,8 @@ def main():
             "model_mfma_frac": model_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
             "loss": loss,
         }
+        if fwd_only is not None:
+            res["fwd_only"] = fwd_only
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -26,8 +26,10 @@ class LinearFn(Function):
     """y = act(x @ w^T + b) + residual  (act in {none, relu, sigmoid}; act and residual are not combined on this path)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, residual):
+    def forward(ctx, x, w, b, act, residual, wt=None):
+        """wt: optional pre-transposed copy of a FROZEN w ([K, N]) so that dX runs on the fast K-contiguous DMA kernel."""
         y = ops.gemm(x, w, bias=b, act=act, residual=residual)
+        ctx.wt = wt
         ctx.act = act
         ctx.has_b = b is not None
         ctx.has_res = residual is not None
@@ -50,7 +52,7 @@ class LinearFn(Function):
         else:
             dpre_p, w_p = dpre, w
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm(dpre_p, w_p, trans_w=True)                      # [M,N] @ [N,K]
+            dx = ops.gemm(dpre, ctx.wt) if (ctx.wt is not None and N % 8 == 0) else ops.gemm(dpre_p, w_p, trans_w=True)   # [M,N] @ [N,K]
         if ctx.needs_input_grad[1]:
             dw = ops.gemm(dpre_p, x, trans_a=True, trans_w=True)[:N]      # [N,M] @ [M,K]
             if dw.shape[0] != N or not dw.is_contiguous():
@@ -58,11 +60,11 @@ class LinearFn(Function):
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = ops.colsum(dpre).to(BF16)
         dres = dy if (ctx.has_res and ctx.needs_input_grad[4]) else None
-        return dx, dw, db, None, dres
+        return dx, dw, db, None, dres, None
 
 
-def linear(x, w, b=None, act=ops.ACT_NONE, residual=None):
-    return LinearFn.apply(x, w, b, act, residual)
+def linear(x, w, b=None, act=ops.ACT_NONE, residual=None, wt=None):
+    return LinearFn.apply(x, w, b, act, residual, wt)
 
 
 class LoraQKVFn(Function):
@@ -70,7 +72,8 @@ class LoraQKVFn(Function):
     q += s (x Aq^T) Bq^T, v += s (x Av^T) Bv^T, s = alpha / r (peft 0.4.0 Linear; base weight frozen).  PARITY UNPINNED."""
 
     @staticmethod
-    def forward(ctx, x, wqkv, aq, bq, av, bv, s):
+    def forward(ctx, x, wqkv, aq, bq, av, bv, s, wqkv_t=None):
+        ctx.wqkv_t = wqkv_t
         H = wqkv.shape[1]
         qkv = ops.gemm(x, wqkv)
         xaq, xav = ops.gemm(x, aq), ops.gemm(x, av)                       # [M, r]
@@ -88,14 +91,14 @@ class LoraQKVFn(Function):
         dq, dv = d[:, :H], d[:, 2 * H:]
         tq = ops.gemm(dq, bq, trans_w=True, alpha=s)                      # [M, r] = s dq Bq
         tv = ops.gemm(dv, bv, trans_w=True, alpha=s)
-        dx = ops.gemm(d, wqkv, trans_w=True)
+        dx = ops.gemm(d, ctx.wqkv_t) if ctx.wqkv_t is not None else ops.gemm(d, wqkv, trans_w=True)
         ops.gemm(tq, aq, trans_w=True, residual=dx, out=dx)
         ops.gemm(tv, av, trans_w=True, residual=dx, out=dx)
         dbq = ops.gemm(dq, xaq, trans_a=True, trans_w=True, alpha=s)      # [H, r]
         dbv = ops.gemm(dv, xav, trans_a=True, trans_w=True, alpha=s)
         daq = ops.gemm(tq, x, trans_a=True, trans_w=True)                 # [r, H]
         dav = ops.gemm(tv, x, trans_a=True, trans_w=True)
-        return dx, None, daq, dbq, dav, dbv, None
+        return dx, None, daq, dbq, dav, dbv, None, None
 
 
 class NormFn(Function):

@@ -72,11 +72,13 @@ class LISAForCausalLM(TrainableMixin, nn.Module):
                 if n in sd:
                     p.copy_(sd[n].to(device=p.device, dtype=p.dtype))
         self._derived = None
+        self.__dict__.pop("_wt_cache", None)
         return missing, unexpected
 
     def init_random(self, seed=0):
         init_random_(self.params, self.shapes, seed)
         self._derived = None
+        self.__dict__.pop("_wt_cache", None)
         return self
 
     def get_model(self):

@@ -64,11 +64,11 @@ class Trainer:
     """One process per GPU.  `module(**batch)` must return a dict with a scalar "loss"."""
 
     def __init__(self, module, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.0, clip=1.0, grad_accum=10, warmup=100, total_steps=5000,
-                 optimizer=None, device_ids=None):
+                 optimizer=None, device_ids=None, force_ddp=False):
         self.module = module
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.ddp = None
-        if self.world > 1:
+        if self.world > 1 or (force_ddp and dist.is_initialized()):
             self.ddp = torch.nn.parallel.DistributedDataParallel(module, device_ids=device_ids, broadcast_buffers=False,
                                                                gradient_as_bucket_view=False)
         self.params = [p for p in module.parameters() if p.requires_grad]

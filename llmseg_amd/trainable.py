@@ -19,7 +19,7 @@ BF16 = torch.bfloat16
 
 class _Direct:
     grad = False
-    linear = staticmethod(lambda x, w, b=None, act=ops.ACT_NONE, residual=None: ops.gemm(x, w, bias=b, act=act, residual=residual))
+    linear = staticmethod(lambda x, w, b=None, act=ops.ACT_NONE, residual=None, wt=None: ops.gemm(x, w, bias=b, act=act, residual=residual))
     norm = staticmethod(lambda x, w, b=None, eps=1e-5, rms=False: ops.norm(x, w, b, eps=eps, rms=rms))
     rope = staticmethod(lambda qkv, cos, sin, rows, T, heads, hd, ld: ops.rope_(qkv, cos, sin, rows, T, heads, hd, ld))
     attn_packed = staticmethod(lambda qkv, batch, n, heads, hd, causal=False, key_mask=None:
@@ -30,7 +30,7 @@ class _Direct:
     maskpool = staticmethod(lambda feat, segs, g, S: ops.upsample_maskpool(feat, segs, g, S))
 
     @staticmethod
-    def lora_qkv(x, wqkv, aq, bq, av, bv, s):
+    def lora_qkv(x, wqkv, aq, bq, av, bv, s, wqkv_t=None):
         H = wqkv.shape[1]
         qkv = ops.gemm(x, wqkv)
         ops.gemm(ops.gemm(x, aq), bq, residual=qkv[:, :H], out=qkv[:, :H], alpha=s)
@@ -73,7 +73,7 @@ class _Auto:
     embed_splice = staticmethod(lambda ids, emb, feats, P, fs: ag.EmbedSpliceFn.apply(ids, emb, feats, P, fs))
     gather_rows = staticmethod(lambda x, idx: ag.GatherRowsFn.apply(x, idx))
     maskpool = staticmethod(lambda feat, segs, g, S: ag.MaskPoolFn.apply(feat, segs, g, S))
-    lora_qkv = staticmethod(lambda x, wqkv, aq, bq, av, bv, s: ag.LoraQKVFn.apply(x, wqkv, aq, bq, av, bv, s))
+    lora_qkv = staticmethod(lambda x, wqkv, aq, bq, av, bv, s, wqkv_t=None: ag.LoraQKVFn.apply(x, wqkv, aq, bq, av, bv, s, wqkv_t))
     ce = staticmethod(lambda logits, labels: ag.CELossFn.apply(logits, labels))
     align_reg = staticmethod(lambda e, t, pred, gt_iou, gt_iop: ag.AlignRegFn.apply(e, t, pred, gt_iou, gt_iop))
     bcast_add = staticmethod(lambda s, add, Cn, K: ag.BcastAddFn.apply(s, add, Cn, K))
@@ -114,6 +114,22 @@ class TrainableMixin:
             return torch.cat([self.params.flat[m] for m in members], 0)
         return self.params.flat[fused]
 
+    def _wT(self, name, F):
+        """Cached [K, N] transposed copy of a FROZEN [N, K] weight (one-time re-layout): lets dX = dY W use the fast TN kernel."""
+        if not F.grad:
+            return None
+        t = self.params.flat[name]
+        if isinstance(t, torch.nn.Parameter) and t.requires_grad:
+            return None
+        cache = self.__dict__.setdefault("_wt_cache", {})
+        if name not in cache:
+            with torch.no_grad():
+                cache[name] = (t.data if isinstance(t, torch.nn.Parameter) else t).t().contiguous()
+        return cache[name]
+
+    def _frozen(self, members):
+        return not any(self.params.flat[m].requires_grad for m in members)
+
     def _qkv_wb(self, p, F):
         names_w = [p + f"{n}_proj.weight" for n in "qkv"]
         names_b = [p + f"{n}_proj.bias" for n in "qkv"]
@@ -137,15 +153,17 @@ class TrainableMixin:
                 lp = p + "self_attn."
                 qkv = F.lora_qkv(h, self._w(p + "qkv", F), self._w(lp + "q_proj.lora_A.default.weight", F),
                                  self._w(lp + "q_proj.lora_B.default.weight", F), self._w(lp + "v_proj.lora_A.default.weight", F),
-                                 self._w(lp + "v_proj.lora_B.default.weight", F), s)
+                                 self._w(lp + "v_proj.lora_B.default.weight", F), s, self._wT(p + "qkv", F))
             else:
-                qkv = F.linear(h, self._wcat(p + "qkv", [p + f"self_attn.{n}_proj.weight" for n in "qkv"], F))
+                mem = [p + f"self_attn.{n}_proj.weight" for n in "qkv"]
+                qkv = F.linear(h, self._wcat(p + "qkv", mem, F), None, ops.ACT_NONE, None, self._wT(p + "qkv", F) if self._frozen(mem) else None)
             qkv = F.rope(qkv, cos, sin, N * T, T, 2 * c.heads, c.head_dim, 3 * H)
             a = F.attn_packed(qkv, N, T, c.heads, c.head_dim, causal=True, key_mask=key_mask_u8)
-            x = F.linear(a, self._w(p + "self_attn.o_proj.weight", F), None, ops.ACT_NONE, x)
+            x = F.linear(a, self._w(p + "self_attn.o_proj.weight", F), None, ops.ACT_NONE, x, self._wT(p + "self_attn.o_proj.weight", F))
             h = F.norm(x, self._w(p + "post_attention_layernorm.weight", F), None, c.eps, True)
-            gu = F.linear(h, self._wcat(p + "gate_up", [p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"], F))
-            x = F.linear(F.swiglu(gu, c.inter), self._w(p + "mlp.down_proj.weight", F), None, ops.ACT_NONE, x)
+            mem = [p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"]
+            gu = F.linear(h, self._wcat(p + "gate_up", mem, F), None, ops.ACT_NONE, None, self._wT(p + "gate_up", F) if self._frozen(mem) else None)
+            x = F.linear(F.swiglu(gu, c.inter), self._w(p + "mlp.down_proj.weight", F), None, ops.ACT_NONE, x, self._wT(p + "mlp.down_proj.weight", F))
         return F.norm(x, self._w("model.norm.weight", F), None, c.eps, True).view(N, T, H)
 
     def llava_forward(self, images_clip, attention_mask, input_ids, labels=None, want_logits=True):
