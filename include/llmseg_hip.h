@@ -152,6 +152,10 @@ int llmseg_ce_loss(const void* logits, const int64_t* labels, float* acc, int32_
                    void* stream);
 
 
+/* gIoU / cIoU bookkeeping (reference utils/utils.py:119-132 `intersectionAndUnionGPU`, K = 2 classes): pred/target uint8 [n],
+ * pixels with target == ignore_index are dropped; out int64[6] += {I0, I1, U0, U1, T0, T1} (exact integer counts). */
+int llmseg_intersection_union(const uint8_t* pred, const uint8_t* target, int64_t n, int32_t ignore_index, int64_t* out, void* stream);
+
 /* ---- backward pass + optimizer (trainable part: LoRA'd Llama stack, embed/lm_head, text_hidden_fcs, mask-selection head) -----
  * GEMM-shaped gradients use llmseg_gemm_bf16 with trans_a / trans_w (dX = dY W, dW = dY^T X); the kernels below are the
  * streaming pieces.  Gradients of the loss kernels: llmseg_align_reg_loss (d_e, d_t, d_pred). */

@@ -210,3 +210,44 @@ extern "C" int llmseg_ce_loss(const void* logits, const int64_t* labels, float* 
   LL_LAUNCH_CHECK("ce_loss");
   return LLMSEG_OK;
 }
+
+// ---- gIoU / cIoU metric: 2-class intersection / union histograms (reference utils/utils.py:119-132) -------------------------
+// pred/target uint8 [n]; target == ignore_index is excluded.  out int64[6] += {I0, I1, U0, U1, T0, T1}.
+namespace {
+__global__ __launch_bounds__(256) void inter_union_kernel(const uint8_t* __restrict__ pred, const uint8_t* __restrict__ tgt, long n, int ignore,
+                                                         unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long sh[6];
+  if (threadIdx.x < 6) sh[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned int c[6] = {0, 0, 0, 0, 0, 0};    // I0 I1 P0 P1 T0 T1
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int t = tgt[i];
+    if (t == ignore) continue;
+    const int p = pred[i];
+    if (p < 2) { c[2 + p]++; if (p == t) c[p]++; }
+    if (t < 2) c[4 + t]++;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    unsigned int v = c[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&sh[k], (unsigned long long)v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    atomicAdd(&out[threadIdx.x], sh[threadIdx.x]);                                                     // intersection
+    atomicAdd(&out[2 + threadIdx.x], sh[2 + threadIdx.x] + sh[4 + threadIdx.x] - sh[threadIdx.x]);     // union = P + T - I
+    atomicAdd(&out[4 + threadIdx.x], sh[4 + threadIdx.x]);                                             // target area
+  }
+}
+}  // namespace
+
+extern "C" int llmseg_intersection_union(const uint8_t* pred, const uint8_t* target, int64_t n, int32_t ignore_index, int64_t* out, void* stream) {
+  LL_CHECK(pred && target && out && n > 0, "intersection_union: bad arguments");
+  long g = (n + 256 * 16 - 1) / (256 * 16);
+  hipLaunchKernelGGL(inter_union_kernel, dim3((unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g))), dim3(256), 0, (hipStream_t)stream, pred, target, (long)n,
+                     ignore_index, (unsigned long long*)out);
+  LL_LAUNCH_CHECK("intersection_union");
+  return LLMSEG_OK;
+}

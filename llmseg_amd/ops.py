@@ -212,6 +212,16 @@ def ce_loss(logits, labels):
     return acc
 
 
+def intersection_union(pred_u8, target_u8, ignore_index=255, out=None):
+    """-> int64[6] = {I0, I1, U0, U1, T0, T1} accumulated into `out` (validate_threshold's per-image I/U, training.py:764)."""
+    assert pred_u8.dtype == torch.uint8 and target_u8.dtype == torch.uint8 and pred_u8.numel() == target_u8.numel()
+    if out is None:
+        out = torch.zeros((6,), device=pred_u8.device, dtype=torch.int64)
+    _lib.check(_lib.load().llmseg_intersection_union(_ptr(pred_u8.contiguous()), _ptr(target_u8.contiguous()), pred_u8.numel(), ignore_index,
+                                                     _ptr(out), _stream()), "intersection_union")
+    return out
+
+
 # ---- backward / optimizer -------------------------------------------------------------------------------------------
 def colsum(x, out=None):
     M, N = x.shape

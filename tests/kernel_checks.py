@@ -260,4 +260,19 @@ def check_head():
     return out
 
 
-ALL = [check_gemm, check_attention, check_pointwise, check_head]
+def check_metric(golden_loader=None):
+    """gIoU bookkeeping kernel vs the oracle restatement (and the fixture recorded from the reference's intersectionAndUnionGPU)."""
+    from oracle import cases
+    out = []
+    g = golden_loader("iou_metric.pt")["IUT"] if golden_loader else None
+    for n, (pred, tgt) in enumerate(cases.iou_metric_cases()):
+        got = ops.intersection_union(pred.to(torch.uint8).to(DEV), tgt.to(torch.uint8).to(DEV)).cpu()
+        i, u, t = olosses.intersection_and_union(pred, tgt, 2, 255)
+        ref = torch.cat([i, u, t]).long()
+        out.append((f"intersection/union case {n}", float((got - ref).abs().max()), 0.0))
+        if g is not None:
+            out.append((f"intersection/union case {n} vs reference fixture", float((got.float() - g[n].reshape(-1)).abs().max()), 0.0))
+    return out
+
+
+ALL = [check_gemm, check_attention, check_pointwise, check_head, check_metric]

@@ -34,3 +34,8 @@ def test_pointwise():
 def test_head():
     from tests import kernel_checks as kc
     _run(kc.check_head)
+
+
+def test_metric(golden):
+    from tests import kernel_checks as kc
+    _run(lambda: kc.check_metric(golden))
