@@ -40,7 +40,13 @@ struct GemmP {
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case LLMSEG_ACT_RELU: return fmaxf(v, 0.f);
-    case LLMSEG_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    case LLMSEG_ACT_GELU: {   // exact (erf) GELU; erf via Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7 (far below bf16 resolution)
+      const float z = fabsf(v) * 0.70710678118654752f;
+      const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+      const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+      const float erfa = 1.f - poly * __expf(-z * z);
+      return 0.5f * v * (1.f + copysignf(erfa, v));
+    }
     case LLMSEG_ACT_QUICKGELU: return v / (1.f + __expf(-1.702f * v));
     case LLMSEG_ACT_SILU: return v / (1.f + __expf(-v));
     case LLMSEG_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
@@ -151,6 +157,91 @@ __device__ __forceinline__ void epilogue(const GemmP& p, const f32x16_t (&acc)[2
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (e < nv) cp[e] = f2bf(v[e]);
           }
+        }
+      }
+    }
+  }
+}
+
+
+// Coalesced epilogue: the accumulator fragment (lane = one output row, 4 x 4 consecutive columns) is bounced through a
+// per-wave 32 x 64 fp32 LDS slab (XOR-swizzled 16-byte chunks: conflict-free both ways) so that afterwards 16 adjacent lanes
+// hold one output row's 64 consecutive columns: residual loads and C stores become full 128-byte lines instead of 8-byte
+// pieces scattered over 32 rows (measured on 32768x1280x1280 + bias + residual: 480 -> see profiles).  LDS ops of one wave
+// execute in order, so no barrier is needed; the slab aliases the (finished) operand tiles.
+template <bool OUT_F32, int MI>
+__device__ __forceinline__ void epilogue_lds(const GemmP& p, const f32x16_t (&acc)[2][MI], char* smem, int wave, int m0, int n0, int wm, int wn,
+                                             int lane, long bz) {
+  float* slab = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int c = lane & 15, rsub = lane >> 4;
+  const int n = n0 + wn * 64 + c * 4;
+  const int nv = min(4, p.N - n);
+  const bool vec_ok = p.c_vec != 0, res_vec = p.r_vec != 0, b_vec = p.b_vec != 0;
+  float bs[4] = {0.f, 0.f, 0.f, 0.f}, gm[4] = {1.f, 1.f, 1.f, 1.f};
+  if (nv > 0) {
+    if (p.bias) ld4bf(p.bias + n, b_vec, nv, bs);
+    if (p.gamma) ld4bf(p.gamma + n, b_vec, nv, gm);
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    uint2 rpre[8];
+    if (p.res && res_vec && nv == 4) {          // issue the 8 residual loads of this pass first: they fly during the LDS bounce
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int m = min(m0 + wm * 32 * MI + i * 32 + it * 4 + rsub, p.M - 1);
+        rpre[it] = *reinterpret_cast<const uint2*>(p.res + bz + (long)m * p.ldr + n);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int chunk = (j * 32 + 8 * g + 4 * fhalf) >> 2;
+        *reinterpret_cast<float4*>(slab + frow * 64 + ((chunk ^ (frow & 15)) << 2)) =
+            make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+      }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 4 + rsub;
+      const float4 a4 = *reinterpret_cast<const float4*>(slab + row * 64 + ((c ^ (row & 15)) << 2));
+      const int m = m0 + wm * 32 * MI + i * 32 + row;
+      if (m >= p.M || nv <= 0) continue;
+      float v[4] = {a4.x * p.alpha + bs[0], a4.y * p.alpha + bs[1], a4.z * p.alpha + bs[2], a4.w * p.alpha + bs[3]};
+      if (p.act != LLMSEG_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+      }
+      if (p.gamma) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gm[e];
+      }
+      if (p.res) {
+        if (res_vec && nv == 4) {
+          v[0] += __uint_as_float(rpre[it].x << 16); v[1] += __uint_as_float(rpre[it].x & 0xffff0000u);
+          v[2] += __uint_as_float(rpre[it].y << 16); v[3] += __uint_as_float(rpre[it].y & 0xffff0000u);
+        } else {
+          float rr[4];
+          ld4bf(p.res + bz + (long)m * p.ldr + n, false, nv, rr);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += rr[e];
+        }
+      }
+      if (OUT_F32) {
+        float* cp = reinterpret_cast<float*>(p.C) + bz + (long)m * p.ldc + n;
+        if (vec_ok && nv == 4) {
+          *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (e < nv) cp[e] = v[e];
+        }
+      } else {
+        bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + bz + (long)m * p.ldc + n;
+        if (vec_ok && nv == 4) {
+          *reinterpret_cast<uint2*>(cp) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (e < nv) cp[e] = f2bf(v[e]);
         }
       }
     }
@@ -277,7 +368,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_tn_kernel(GemmP p) {
     if (t + 1 < nt) { char* nb = smem + ((t + 1) & 1) * BUF; sa.store(nb); sw.store(nb + TILE); }
     __syncthreads();
   }
-  epilogue<OUT_F32, MI>(p, acc, m0, n0, wm, wn, frow, fhalf, bz);
+  epilogue_lds<OUT_F32, MI>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
 }
 
 // ---- variant G: direct global -> LDS DMA, K % 64 == 0 ---------------------------------------------------------------------
@@ -346,7 +437,7 @@ __global__ __launch_bounds__(NT, NBUF == 2 ? (MI == 4 ? 1 : 2) : (MI == 4 ? 2 : 
       __syncthreads();
     }
   }
-  epilogue<OUT_F32, MI>(p, acc, m0, n0, wm, wn, frow, fhalf, bz);
+  epilogue_lds<OUT_F32, MI>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
 }
 
 
@@ -435,7 +526,7 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_big_kernel(GemmP p) {
     if (t + 2 < nt) issue(t + 2, t & 1);
   }
   // epilogue: same lane->C mapping as the small tile with this wave's origin (wm*128, wn*64)
-  epilogue<OUT_F32, MI>(p, acc, m0 + wm * 128 - wm * 32 * MI, n0 + wn * 64 - (wn & 1) * 64, wm, wn & 1, frow, fhalf, bz);
+  epilogue_lds<OUT_F32, MI>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
 }
 
 template <bool OUT_F32, int MI, int NBUF>
