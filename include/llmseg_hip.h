@@ -81,6 +81,9 @@ typedef struct {
   const uint8_t* key_mask;   /* [batch][Nk] 1 = attend, or NULL */
   const float* rel_h; const float* rel_w; int32_t rel_ld, grid_h, grid_w;
   const int32_t* o_row_map;
+  /* Fused variant for SAM's 14x14 windows (head_dim 80): instead of rel_h/rel_w pass the bf16 tables themselves,
+   * [32][head_dim] with rows >= 27 zero; q . R^T is then computed inside the kernel (grid_h = grid_w = 14 still required). */
+  const void* rel_tab_h; const void* rel_tab_w;
 } llmseg_attn_args;
 int llmseg_attn_fwd(const llmseg_attn_args* args, void* stream);
 
@@ -180,6 +183,13 @@ int llmseg_ce_bwd(const void* logits, const int64_t* labels, const float* coef, 
                   int64_t ldl, void* stream);
 /* dst[idx[i]][:] += src[i][:] in fp32 (embedding / row-gather gradients; idx < 0 skipped) */
 int llmseg_scatter_add_rows(const void* src, const int64_t* idx, float* dst, int64_t n, int64_t cols, void* stream);
+/* Rank-8 LoRA products (peft==0.4.0 Linear with r = 8, training.py:218-226) -- skinny shapes a tiled GEMM cannot fill:
+ *   lora_down:  y[M][8]  = alpha * x[M][K] . W^T      (W stored [8][K], or [K][8] when w_kr)          fwd x.A^T, bwd dq.B
+ *   lora_outer: out(n,r) += alpha * sum_m a[m][n] b[m][r]  (fp32 [N][8], or [8][N] when out_rn; caller zero-fills)   dB, dA
+ *   lora_apply: y[M][N] += alpha * xa[M][8] . W^T     (W stored [N][8], or [8][N] when w_rn)           fwd +s.xa.B^T, bwd +tq.A */
+int llmseg_lora_down(const void* x, int64_t ldx, const void* w, void* y, int64_t M, int64_t K, int32_t w_kr, float alpha, void* stream);
+int llmseg_lora_outer(const void* a, int64_t lda, const void* b, float* out, int64_t M, int64_t N, int32_t out_rn, float alpha, void* stream);
+int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, const void* w, int64_t M, int64_t N, int32_t w_rn, float alpha, void* stream);
 /* out[0] += sum x^2 (global gradient-norm clipping, training.py:301 "gradient_clipping": 1.0) */
 int llmseg_sumsq(const void* x, int64_t n, int is_f32, float* out, void* stream);
 /* Fused AdamW on fp32 master weights + bf16 model copy (DeepSpeed config training.py:292-332: betas (0.9, 0.95), wd 0).

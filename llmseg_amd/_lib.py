@@ -33,7 +33,7 @@ class AttnArgs(C.Structure):
                 ("scale", C.c_float), ("causal", C.c_int32),
                 ("key_mask", C.c_void_p), ("rel_h", C.c_void_p), ("rel_w", C.c_void_p),
                 ("rel_ld", C.c_int32), ("grid_h", C.c_int32), ("grid_w", C.c_int32),
-                ("o_row_map", C.c_void_p)]
+                ("o_row_map", C.c_void_p), ("rel_tab_h", C.c_void_p), ("rel_tab_w", C.c_void_p)]
 
 
 _i64, _i32, _f32, _p = C.c_int64, C.c_int32, C.c_float, C.c_void_p
@@ -67,6 +67,9 @@ SIGNATURES = {
     "llmseg_attn_ds": [_p, _p, _p, _i64, _i32, _i32, _f32, _p],
     "llmseg_ce_bwd": [_p, _p, _p, _p, _i32, _i32, _i64, _i64, _p],
     "llmseg_scatter_add_rows": [_p, _p, _p, _i64, _i64, _p],
+    "llmseg_lora_down": [_p, _i64, _p, _p, _i64, _i64, _i32, _f32, _p],
+    "llmseg_lora_outer": [_p, _i64, _p, _p, _i64, _i64, _i32, _f32, _p],
+    "llmseg_lora_apply": [_p, _i64, _p, _p, _i64, _i64, _i32, _f32, _p],
     "llmseg_sumsq": [_p, _i64, C.c_int, _p, _p],
     "llmseg_adamw": [_p, _p, _p, C.c_int, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _p, _p],
     "llmseg_prof_enable": [C.c_int],

@@ -76,9 +76,15 @@ class LoraQKVFn(Function):
         ctx.wqkv_t = wqkv_t
         H = wqkv.shape[1]
         qkv = ops.gemm(x, wqkv)
-        xaq, xav = ops.gemm(x, aq), ops.gemm(x, av)                       # [M, r]
-        ops.gemm(xaq, bq, residual=qkv[:, :H], out=qkv[:, :H], alpha=s)
-        ops.gemm(xav, bv, residual=qkv[:, 2 * H:], out=qkv[:, 2 * H:], alpha=s)
+        ctx.fast = aq.shape[0] == 8                                      # rank-8 skinny kernels
+        if ctx.fast:
+            xaq, xav = ops.lora_down(x, aq), ops.lora_down(x, av)           # [M, 8]
+            ops.lora_apply_(qkv[:, :H], xaq, bq, alpha=s)
+            ops.lora_apply_(qkv[:, 2 * H:], xav, bv, alpha=s)
+        else:
+            xaq, xav = ops.gemm(x, aq), ops.gemm(x, av)                   # [M, r]
+            ops.gemm(xaq, bq, residual=qkv[:, :H], out=qkv[:, :H], alpha=s)
+            ops.gemm(xav, bv, residual=qkv[:, 2 * H:], out=qkv[:, 2 * H:], alpha=s)
         ctx.s = s
         ctx.save_for_backward(x, wqkv, aq, bq, av, bv, xaq, xav)
         return qkv
@@ -89,6 +95,14 @@ class LoraQKVFn(Function):
         s, H = ctx.s, wqkv.shape[1]
         d = d.contiguous()
         dq, dv = d[:, :H], d[:, 2 * H:]
+        if ctx.fast:
+            tq, tv = ops.lora_down(dq, bq, w_kr=True, alpha=s), ops.lora_down(dv, bv, w_kr=True, alpha=s)   # [M, 8] = s dq Bq
+            dx = ops.gemm(d, ctx.wqkv_t) if ctx.wqkv_t is not None else ops.gemm(d, wqkv, trans_w=True)
+            ops.lora_apply_(dx, tq, aq, w_rn=True)
+            ops.lora_apply_(dx, tv, av, w_rn=True)
+            dbq, dbv = ops.lora_outer(dq, xaq, alpha=s).to(BF16), ops.lora_outer(dv, xav, alpha=s).to(BF16)        # [H, 8]
+            daq, dav = ops.lora_outer(x, tq, out_rn=True).to(BF16), ops.lora_outer(x, tv, out_rn=True).to(BF16)    # [8, H]
+            return dx, None, daq, dbq, dav, dbv, None, None
         tq = ops.gemm(dq, bq, trans_w=True, alpha=s)                      # [M, r] = s dq Bq
         tv = ops.gemm(dv, bv, trans_w=True, alpha=s)
         dx = ops.gemm(d, ctx.wqkv_t) if ctx.wqkv_t is not None else ops.gemm(d, wqkv, trans_w=True)
@@ -138,7 +152,9 @@ class RopeFn(Function):
     def backward(ctx, d):
         cos, sin = ctx.saved_tensors
         rows, T, heads, hd, ld = ctx.args
-        d = d.contiguous().clone()
+        # The incoming gradient is the freshly allocated dqkv of PackedAttnFn.backward (qkv has exactly one consumer), so the
+        # inverse rotation is applied in place instead of on a 60 MB clone per layer.
+        d = d if d.is_contiguous() else d.contiguous()
         ops.rope_(d, cos, (-sin).contiguous(), rows, T, heads, hd, ld)
         return d, None, None, None, None, None, None, None
 

@@ -32,6 +32,7 @@ struct AttnP {
   const uint8_t* key_mask;
   const float* rel_h; const float* rel_w; int rel_ld, gh, gw;
   const int32_t* o_row_map;
+  const bf16_t* rtab_h; const bf16_t* rtab_w;   // REL == 4: bf16 [32][head_dim] relative-position tables (rows >= 2*14-1 are zero)
 };
 
 __device__ __forceinline__ uint32_t perm_lo(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }
@@ -46,7 +47,9 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnP p) {
   constexpr int CH = HD / 8;                  // 16-byte chunks per row
   constexpr int PK = (HD + 8) * 2;            // K_lds row pitch (bytes): CH+1 chunks -> odd
   constexpr int PV = (BKV + 4) * 2;           // Vt row pitch (bytes) = 136 = 8 * 17
-  __shared__ __attribute__((aligned(16))) char smem[BKV * PK + DT * 32 * PV + BKV * 4];
+  constexpr bool WIN = (REL == 3 || REL == 4);            // SAM 14x14 window; 4 = q.R^T computed here (no rel_h/rel_w arrays)
+  constexpr int G_SLAB = 32 * 33;                          // per-wave fp32 [32 queries][33] slab per table (REL == 4)
+  __shared__ __attribute__((aligned(16))) char smem[BKV * PK + DT * 32 * PV + BKV * 4 + (REL == 4 ? 4 * 2 * G_SLAB * 4 : 0)];
   char* Ks = smem;
   char* Vt = smem + BKV * PK;
   uint32_t* lut = reinterpret_cast<uint32_t*>(smem + BKV * PK + DT * 32 * PV);
@@ -76,8 +79,10 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnP p) {
   if (REL != 0) {
     qh = qc / p.gw; qw = qc - qh * p.gw;
     const long rrow = (((long)h * p.batch + b) * p.Nq + qc) * p.rel_ld;   // [heads][batch*Nq][rel_ld]
-    relh_row = p.rel_h + rrow;
-    relw_row = p.rel_w + rrow;
+    if (REL != 4) {
+      relh_row = p.rel_h + rrow;
+      relw_row = p.rel_w + rrow;
+    }
     if (REL == 2) {
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb)
@@ -92,7 +97,36 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnP p) {
   // REL == 3: per-query bias rows in registers, with the lane-half (which selects key or key+4) folded into the LOAD
   // address so that the tile loop only ever uses compile-time indices: bh_s[kh] = Bh[kh], bh_x[kh] = Bh[kh + half],
   // bw_y[kw] = Bw[(kw + 4*half) % 14].
-  float bh_s[REL == 3 ? 14 : 1], bh_x[REL == 3 ? 13 : 1], bw_y[REL == 3 ? 14 : 1];
+  float bh_s[WIN ? 14 : 1], bh_x[WIN ? 13 : 1], bw_y[WIN ? 14 : 1];
+  if constexpr (REL == 4) {
+    // Fused decomposed rel-pos (image_encoder.py:354-392): G^T = R . Q^T on the matrix cores (R = the 27-row table, zero
+    // padded to 32 rows; Q fragments are already in registers), bounced through a per-wave LDS slab because each lane needs the
+    // entries at its own (qh - kh + 13) / (qw - kw + 13): replaces two skinny fp32 GEMM launches + 41 scattered loads per lane.
+    float* gs = reinterpret_cast<float*>(smem + BKV * PK + DT * 32 * PV + BKV * 4) + wave * (2 * G_SLAB);
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+      const bf16_t* tab = tb == 0 ? p.rtab_h : p.rtab_w;
+      f32x16_t g;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) g[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t rf = *reinterpret_cast<const bf16x8_t*>(tab + ql * HD + ks * 16 + half * 8);
+        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rf, qf[ks], g, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) gs[tb * G_SLAB + ql * 33 + (e & 3) + 8 * (e >> 2) + 4 * half] = g[e];
+    }
+    const float* gh = gs + ql * 33;
+    const float* gw = gs + G_SLAB + ql * 33;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+      bh_s[j] = gh[qh - j + 13] * p.inv_scale;
+      bw_y[j] = gw[qw - ((j + 4 * half) % 14) + 13] * p.inv_scale;
+    }
+#pragma unroll
+    for (int j = 0; j < 13; ++j) bh_x[j] = gh[qh - (j + half) + 13] * p.inv_scale;
+  }
   if constexpr (REL == 3) {
 #pragma unroll
     for (int j = 0; j < 14; ++j) {
@@ -189,7 +223,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnP p) {
       const int kh = (int)(kk >> 16), kw = (int)(kk & 0xffffu);                                                     \
       v = (relh_row[qh - kh + p.gh - 1] + relw_row[qw - kw + p.gw - 1]) * p.inv_scale;                              \
     }                                                                                                               \
-    if constexpr (REL == 3) {   /* 14x14 window, everything below folds to constants after unrolling */             \
+    if constexpr (WIN) {        /* 14x14 window, everything below folds to constants after unrolling */             \
       const int key0 = (TC) * 64 + jb * 32 + (r & 3) + 8 * (r >> 2);   /* this register's key for half 0; half 1: +4 */ \
       const int kh0 = key0 / 14 > 13 ? 13 : key0 / 14, kw0 = key0 % 14;                                             \
       const bool cross = kw0 >= 10 && kh0 < 13;                        /* key0 + 4 falls into the next key row */  \
@@ -216,7 +250,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnP p) {
 #define LL_TILE_BODY(TT, TC)                                                                                        \
   {                                                                                                                 \
     const int k0 = (TT) * BKV;                                                                                      \
-    constexpr bool LAST_WIN = (REL == 3) && ((TC) == 3);      /* keys 192..195 only */                              \
+    constexpr bool LAST_WIN = WIN && ((TC) == 3);             /* keys 192..195 only */                              \
     float bh_tile = 0.f;                                                                                            \
     if constexpr (REL == 2) {                                                                                       \
       bh_tile = bh_next;                                                                                            \
@@ -271,7 +305,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnP p) {
 
   float bh_next = 0.f;
   if constexpr (REL == 2) bh_next = relh_row[qh + p.gh - 1] * p.inv_scale;
-  if constexpr (REL == 3) {          // Nk == 196: exactly 4 tiles, fully unrolled so that every bias index is a constant
+  if constexpr (WIN) {               // Nk == 196: exactly 4 tiles, fully unrolled so that every bias index is a constant
     LL_STAGE_LOAD(1) LL_TILE_BODY(0, 0) __syncthreads(); LL_STAGE_STORE(1) __syncthreads();
     LL_STAGE_LOAD(2) LL_TILE_BODY(1, 1) __syncthreads(); LL_STAGE_STORE(2) __syncthreads();
     LL_STAGE_LOAD(3) LL_TILE_BODY(2, 2) __syncthreads(); LL_STAGE_STORE(3) __syncthreads();
@@ -316,7 +350,8 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnP p) {
 template <int HD>
 int launch_hd(const AttnP& p, hipStream_t s) {
   dim3 grid((p.Nq + BQ - 1) / BQ, p.heads, p.batch);
-  if (p.rel_h == nullptr) hipLaunchKernelGGL((attn_fwd_kernel<HD, 0>), grid, dim3(NT), 0, s, p);
+  if (p.rtab_h != nullptr) hipLaunchKernelGGL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 4 : 0>), grid, dim3(NT), 0, s, p);
+  else if (p.rel_h == nullptr) hipLaunchKernelGGL((attn_fwd_kernel<HD, 0>), grid, dim3(NT), 0, s, p);
   else if (HD == 80 && p.gh == 14 && p.gw == 14 && p.Nk == 196 && !p.causal && !p.key_mask) hipLaunchKernelGGL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 3 : 1>), grid, dim3(NT), 0, s, p);
   else if (p.gw == BKV && (p.Nk % BKV) == 0) hipLaunchKernelGGL((attn_fwd_kernel<HD, 2>), grid, dim3(NT), 0, s, p);
   else hipLaunchKernelGGL((attn_fwd_kernel<HD, 1>), grid, dim3(NT), 0, s, p);
@@ -333,6 +368,11 @@ extern "C" int llmseg_attn_fwd(const llmseg_attn_args* a, void* stream) {
              a->q_stride_b | a->k_stride_b | a->v_stride_b) & 7) == 0, "attn: Q/K/V strides must be multiples of 8 elements");
   LL_CHECK(((a->o_stride_row | a->o_stride_h | a->o_stride_b) & 3) == 0, "attn: O strides must be multiples of 4 elements");
   LL_CHECK((((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V) & 15) == 0 && (((uintptr_t)a->O) & 7) == 0, "attn: misaligned pointer");
+  if (a->rel_tab_h || a->rel_tab_w) {
+    LL_CHECK(a->rel_tab_h && a->rel_tab_w && !a->rel_h && !a->rel_w && a->head_dim == 80 && a->grid_h == 14 && a->grid_w == 14 && a->Nk == 196 &&
+             a->Nq == 196 && !a->causal && !a->key_mask, "attn: fused rel-pos tables are supported for SAM's 14x14 windows (head_dim 80) only");
+    LL_CHECK((((uintptr_t)a->rel_tab_h | (uintptr_t)a->rel_tab_w) & 15) == 0, "attn: rel tables must be 16-byte aligned");
+  }
   if (a->rel_h || a->rel_w) {
     LL_CHECK(a->rel_h && a->rel_w && a->grid_h > 0 && a->grid_w > 0 && a->grid_h * a->grid_w == a->Nk && a->Nq == a->Nk &&
              a->rel_ld >= 2 * (a->grid_h > a->grid_w ? a->grid_h : a->grid_w) - 1, "attn: bad relative-position arguments");
@@ -350,6 +390,7 @@ extern "C" int llmseg_attn_fwd(const llmseg_attn_args* a, void* stream) {
   p.causal = a->causal; p.key_mask = a->key_mask;
   p.rel_h = a->rel_h; p.rel_w = a->rel_w; p.rel_ld = a->rel_ld; p.gh = a->grid_h; p.gw = a->grid_w;
   p.o_row_map = a->o_row_map;
+  p.rtab_h = (const bf16_t*)a->rel_tab_h; p.rtab_w = (const bf16_t*)a->rel_tab_w;
   hipStream_t s = (hipStream_t)stream;
   switch (a->head_dim) {
     case 32: launch_hd<32>(p, s); break;

@@ -307,3 +307,122 @@ extern "C" int llmseg_adamw(void* p, float* master, const void* grad, int grad_f
   LL_LAUNCH_CHECK("adamw");
   return LLMSEG_OK;
 }
+
+// ---- rank-8 LoRA kernels (peft Linear, r = 8): the skinny products a 128x128-tile GEMM wastes >90 % of its tile on ------------
+namespace {
+constexpr int LR = 8;
+
+// y[m][r] = alpha * sum_k x[m][k] * W(r,k).  One wave per row.  w_kr = 0: W stored [8][K]; 1: W stored [K][8].
+__global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+                                                       long M, int K, int w_kr, float alpha) {
+  const int lane = threadIdx.x & 63;
+  const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  float acc[LR];
+#pragma unroll
+  for (int r = 0; r < LR; ++r) acc[r] = 0.f;
+  const bf16_t* xr = x + m * ldx;
+  for (int k = lane * 8; k < K; k += 64 * 8) {
+    float xv[8], wv[8];
+    unpack8(*reinterpret_cast<const uint4*>(xr + k), xv);
+    if (w_kr) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        unpack8(*reinterpret_cast<const uint4*>(w + (long)(k + j) * LR), wv);
+#pragma unroll
+        for (int r = 0; r < LR; ++r) acc[r] += xv[j] * wv[r];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < LR; ++r) {
+        unpack8(*reinterpret_cast<const uint4*>(w + (long)r * K + k), wv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[r] += xv[j] * wv[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < LR; ++r) acc[r] = wave_sum(acc[r]) * alpha;
+  if (lane == 0) *reinterpret_cast<uint4*>(y + m * LR) = pack8(acc);
+}
+
+// out(n,r) += alpha * sum_m a[m][n] * b[m][r]  (fp32 atomics; caller zero-fills).  out_rn = 0: out [N][8]; 1: out [8][N].
+__global__ __launch_bounds__(256) void lora_outer_kernel(const bf16_t* __restrict__ a, long lda, const bf16_t* __restrict__ b, float* __restrict__ out,
+                                                        long M, long N, int out_rn, float alpha) {
+  const long n = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
+  const long per = (M + gridDim.y - 1) / gridDim.y;
+  const long m0 = (long)blockIdx.y * per, m1 = min(M, m0 + per);
+  if (n >= N) return;
+  float a0[LR], a1[LR];
+#pragma unroll
+  for (int r = 0; r < LR; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+  for (long m = m0; m < m1; ++m) {
+    const uint32_t av = *reinterpret_cast<const uint32_t*>(a + m * lda + n);
+    const float x0 = __uint_as_float(av << 16), x1 = __uint_as_float(av & 0xffff0000u);
+    float bv[8];
+    unpack8(*reinterpret_cast<const uint4*>(b + m * LR), bv);
+#pragma unroll
+    for (int r = 0; r < LR; ++r) { a0[r] += x0 * bv[r]; a1[r] += x1 * bv[r]; }
+  }
+#pragma unroll
+  for (int r = 0; r < LR; ++r) {
+    if (out_rn) { atomicAdd(&out[(long)r * N + n], a0[r] * alpha); atomicAdd(&out[(long)r * N + n + 1], a1[r] * alpha); }
+    else { atomicAdd(&out[n * LR + r], a0[r] * alpha); atomicAdd(&out[(n + 1) * LR + r], a1[r] * alpha); }
+  }
+}
+
+// y[m][n..n+7] += alpha * sum_r xa[m][r] * W(n,r).  w_rn = 0: W stored [N][8]; 1: W stored [8][N].
+__global__ __launch_bounds__(256) void lora_apply_kernel(bf16_t* __restrict__ y, long ldy, const bf16_t* __restrict__ xa, const bf16_t* __restrict__ w,
+                                                        long M, long N, int w_rn, float alpha) {
+  const long nch = N >> 3, total = M * nch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / nch, c = i % nch;
+    float yv[8], xv[8], wv[8];
+    unpack8(*reinterpret_cast<const uint4*>(y + m * ldy + c * 8), yv);
+    unpack8(*reinterpret_cast<const uint4*>(xa + m * LR), xv);
+    if (w_rn) {
+#pragma unroll
+      for (int r = 0; r < LR; ++r) {
+        unpack8(*reinterpret_cast<const uint4*>(w + (long)r * N + c * 8), wv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) yv[j] += alpha * xv[r] * wv[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        unpack8(*reinterpret_cast<const uint4*>(w + (c * 8 + j) * LR), wv);
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < LR; ++r) s += xv[r] * wv[r];
+        yv[j] += alpha * s;
+      }
+    }
+    *reinterpret_cast<uint4*>(y + m * ldy + c * 8) = pack8(yv);
+  }
+}
+}  // namespace
+
+extern "C" int llmseg_lora_down(const void* x, int64_t ldx, const void* w, void* y, int64_t M, int64_t K, int32_t w_kr, float alpha, void* stream) {
+  LL_CHECK(x && w && y && M > 0 && K > 0 && (K & 7) == 0 && (ldx & 7) == 0 && AL16(x) && AL16(w) && AL16(y), "lora_down: bad arguments");
+  hipLaunchKernelGGL(lora_down_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ldx, (const bf16_t*)w,
+                     (bf16_t*)y, (long)M, (int)K, w_kr, alpha);
+  LL_LAUNCH_CHECK("lora_down");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_lora_outer(const void* a, int64_t lda, const void* b, float* out, int64_t M, int64_t N, int32_t out_rn, float alpha, void* stream) {
+  LL_CHECK(a && b && out && M > 0 && N > 0 && (N & 1) == 0 && (lda & 1) == 0 && AL16(b), "lora_outer: bad arguments");
+  const unsigned gy = (unsigned)max((long)1, min((long)32, M / 64));
+  hipLaunchKernelGGL(lora_outer_kernel, dim3((unsigned)((N / 2 + 255) / 256), gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (long)lda,
+                     (const bf16_t*)b, out, (long)M, (long)N, out_rn, alpha);
+  LL_LAUNCH_CHECK("lora_outer");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, const void* w, int64_t M, int64_t N, int32_t w_rn, float alpha, void* stream) {
+  LL_CHECK(y && xa && w && M > 0 && N > 0 && (N & 7) == 0 && (ldy & 7) == 0 && AL16(y) && AL16(xa) && AL16(w), "lora_apply: bad arguments");
+  hipLaunchKernelGGL(lora_apply_kernel, dim3(grid_for(M * (N >> 3))), dim3(256), 0, (hipStream_t)stream, (bf16_t*)y, (long)ldy, (const bf16_t*)xa,
+                     (const bf16_t*)w, (long)M, (long)N, w_rn, alpha);
+  LL_LAUNCH_CHECK("lora_apply");
+  return LLMSEG_OK;
+}

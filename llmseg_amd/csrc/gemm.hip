@@ -539,6 +539,7 @@ void launch_glds(const GemmP& p, dim3 grid, hipStream_t s) {
 // profiling hooks (capi.cpp)
 void llmseg_prof_begin(hipStream_t s);
 void llmseg_prof_end(hipStream_t s, double flops);
+void llmseg_prof_tag(long a, long b, long c, long d);
 
 // tuning knob: 0 = register staging 128x128; 1 = DMA 128x128 x2 buffers; 2 = DMA 128x128 x1; 3 = DMA 256x128 x1; 4 = DMA 256x128 x2;
 // 5 (default) = auto: 256x128 x1 when that still gives every CU >= 2 workgroups, else 128x128 x1
@@ -585,6 +586,7 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);
   hipStream_t s = (hipStream_t)stream;
   llmseg_prof_begin(s);
+  llmseg_prof_tag(p.M, p.N, p.K, variant * 1000 + (ta ? 200 : 0) + (tw ? 100 : 0) + (p.res ? 20 : 0) + p.act * 2 + (a->out_f32 ? 1 : 0) + 40 * (batch > 1));
   const bool f = a->out_f32 != 0;
   switch (variant) {
     case 1: f ? launch_glds<true, 2, 2>(p, grid, s) : launch_glds<false, 2, 2>(p, grid, s); break;

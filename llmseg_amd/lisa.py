@@ -122,7 +122,7 @@ class LISAForCausalLM(TrainableMixin, nn.Module):
             d["sam.neck2_w"] = P[sp + "neck.2.weight"].permute(0, 2, 3, 1).reshape(s.out_chans, 9 * s.out_chans).contiguous()
             for i in range(s.depth):
                 sz = s.grid if i in s.global_idx else s.window
-                ld = (2 * sz - 1 + 3) // 4 * 4
+                ld = (2 * sz - 1 + 3) // 4 * 4 if i in s.global_idx else 32     # window tables feed the fused kernel: 32 MFMA rows
                 d[f"sam.relh.{i}"] = _pad_rows(P[f"{sp}blocks.{i}.attn.rel_pos_h"], ld)
                 d[f"sam.relw.{i}"] = _pad_rows(P[f"{sp}blocks.{i}.attn.rel_pos_w"], ld)
         self._derived = d
@@ -249,13 +249,18 @@ class LISAForCausalLM(TrainableMixin, nn.Module):
                 batch, n_tok = B * n_win, s.window * s.window
             qkv = ops.gemm(h, P[p + "attn.qkv.weight"], bias=P[p + "attn.qkv.bias"])
             rows = batch * n_tok
-            rel = torch.empty((2, nh, rows, ld), device=x.device, dtype=torch.float32)
-            for j, tab in enumerate((d[f"sam.relh.{i}"], d[f"sam.relw.{i}"])):
-                ops.gemm_batched(qkv, tab, rel[j], M=rows, N=2 * sz - 1, K=hd, lda=3 * D, ldw=hd, ldc=ld, batch=nh, sA=hd, sW=0,
-                                 sC=rows * ld, out_f32=True)
             a = torch.empty((B * g * g, D), device=x.device, dtype=BF16)
-            ops.attention_packed(qkv, batch, n_tok, nh, hd, out=a, rel_h=rel[0], rel_w=rel[1], rel_ld=ld, grid_hw=(sz, sz),
-                                 o_row_map=None if glob else unpart)
+            if (not glob) and hd == 80 and sz == 14:
+                # fused: q.R^T is computed inside the attention kernel from the (32-row padded) tables
+                ops.attention_packed(qkv, batch, n_tok, nh, hd, out=a, rel_tab_h=d[f"sam.relh.{i}"], rel_tab_w=d[f"sam.relw.{i}"],
+                                     grid_hw=(sz, sz), o_row_map=unpart)
+            else:
+                rel = torch.empty((2, nh, rows, ld), device=x.device, dtype=torch.float32)
+                for j, tab in enumerate((d[f"sam.relh.{i}"], d[f"sam.relw.{i}"])):
+                    ops.gemm_batched(qkv, tab, rel[j], M=rows, N=2 * sz - 1, K=hd, lda=3 * D, ldw=hd, ldc=ld, batch=nh, sA=hd, sW=0,
+                                     sC=rows * ld, out_f32=True)
+                ops.attention_packed(qkv, batch, n_tok, nh, hd, out=a, rel_h=rel[0], rel_w=rel[1], rel_ld=ld, grid_hw=(sz, sz),
+                                     o_row_map=None if glob else unpart)
             x = ops.gemm(a, P[p + "attn.proj.weight"], bias=P[p + "attn.proj.bias"], residual=x)
             h = ops.norm(x, P[p + "norm2.weight"], P[p + "norm2.bias"], eps=s.eps)
             h = ops.gemm(h, P[p + "mlp.lin1.weight"], bias=P[p + "mlp.lin1.bias"], act=ops.ACT_GELU)

@@ -65,7 +65,7 @@ def gemm_batched(a, w, out, M, N, K, lda, ldw, ldc, batch, sA, sW, sC, out_f32=T
 
 
 def attention(q, k, v, out, *, batch, heads, Nq, Nk, head_dim, q_strides, k_strides, v_strides, o_strides, scale=None,
-              causal=False, key_mask=None, rel_h=None, rel_w=None, rel_ld=0, grid_hw=(0, 0), o_row_map=None):
+              causal=False, key_mask=None, rel_h=None, rel_w=None, rel_ld=0, grid_hw=(0, 0), o_row_map=None, rel_tab_h=None, rel_tab_w=None):
     """Strided fused attention.  *_strides = (batch, head, row) in elements relative to the given tensors' data_ptr."""
     a = AttnArgs(Q=q.data_ptr(), K=k.data_ptr(), V=v.data_ptr(), O=out.data_ptr(),
                  q_stride_b=q_strides[0], q_stride_h=q_strides[1], q_stride_row=q_strides[2],
@@ -77,7 +77,8 @@ def attention(q, k, v, out, *, batch, heads, Nq, Nk, head_dim, q_strides, k_stri
                  key_mask=None if key_mask is None else key_mask.data_ptr(),
                  rel_h=None if rel_h is None else rel_h.data_ptr(), rel_w=None if rel_w is None else rel_w.data_ptr(),
                  rel_ld=rel_ld, grid_h=grid_hw[0], grid_w=grid_hw[1],
-                 o_row_map=None if o_row_map is None else o_row_map.data_ptr())
+                 o_row_map=None if o_row_map is None else o_row_map.data_ptr(),
+                 rel_tab_h=None if rel_tab_h is None else rel_tab_h.data_ptr(), rel_tab_w=None if rel_tab_w is None else rel_tab_w.data_ptr())
     _lib.check(_lib.load().llmseg_attn_fwd(C.byref(a), _stream()), "attn_fwd")
     return out
 
@@ -277,6 +278,29 @@ def ce_bwd(logits, labels, coef):
 def scatter_add_rows(src, idx, dst):
     _lib.check(_lib.load().llmseg_scatter_add_rows(_ptr(src), _ptr(idx), _ptr(dst), src.shape[0], src.shape[1], _stream()), "scatter_add_rows")
     return dst
+
+
+def lora_down(x, w, w_kr=False, alpha=1.0):
+    """y [M, 8] = alpha * x [M, K] @ W^T; W stored [8, K] (or [K, 8] when w_kr).  x may be a column view (row stride = ld)."""
+    M, K = x.shape
+    y = torch.empty((M, 8), device=x.device, dtype=BF16)
+    _lib.check(_lib.load().llmseg_lora_down(_ptr(x), x.stride(0), _ptr(w), _ptr(y), M, K, 1 if w_kr else 0, alpha, _stream()), "lora_down")
+    return y
+
+
+def lora_outer(a, b, out_rn=False, alpha=1.0):
+    """out [N, 8] (or [8, N] when out_rn) = alpha * a[M, N]^T @ b[M, 8], fp32."""
+    M, N = a.shape
+    out = torch.zeros((8, N) if out_rn else (N, 8), device=a.device, dtype=torch.float32)
+    _lib.check(_lib.load().llmseg_lora_outer(_ptr(a), a.stride(0), _ptr(b), _ptr(out), M, N, 1 if out_rn else 0, alpha, _stream()), "lora_outer")
+    return out
+
+
+def lora_apply_(y, xa, w, w_rn=False, alpha=1.0):
+    """y [M, N] += alpha * xa [M, 8] @ W^T in place; W stored [N, 8] (or [8, N] when w_rn).  y may be a column view."""
+    M, N = y.shape
+    _lib.check(_lib.load().llmseg_lora_apply(_ptr(y), y.stride(0), _ptr(xa), _ptr(w), M, N, 1 if w_rn else 0, alpha, _stream()), "lora_apply")
+    return y
 
 
 def sumsq(x, out):

@@ -116,6 +116,23 @@ def check_attention():
         bias = torch.gather(relh, 3, ih[None, None].expand(B, H, N, N)) + torch.gather(relw, 3, iw[None, None].expand(B, H, N, N))
         ref = _attn_ref(x[0], x[1], x[2], hd ** -0.5, bias).transpose(1, 2).reshape(B * N, D)
         out.append((f"attn rel-pos grid {gh}x{gw}", err(o, ref), tol_bf16(ref, 2.0)))
+    # fused window rel-pos: pass the tables, q.R^T is computed inside the kernel (SAM 14x14, hd 80)
+    gh = gw = 14
+    hd, N, B, H = 80, 196, 3, 2
+    D = H * hd
+    qkv = rnd(B * N, 3 * D, seed=41, scale=0.7)
+    th, tw = torch.zeros(32, hd, dtype=BF), torch.zeros(32, hd, dtype=BF)
+    th[:27], tw[:27] = rnd(27, hd, seed=42, scale=0.3), rnd(27, hd, seed=43, scale=0.3)
+    o = ops.attention_packed(qkv.to(DEV), B, N, H, hd, rel_tab_h=th.to(DEV), rel_tab_w=tw.to(DEV), grid_hw=(gh, gw))
+    x = qkv.view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    qi = torch.arange(N)
+    qh_, qw_ = qi // gw, qi % gw
+    Gh, Gw = x[0].float() @ th[:27].float().t(), x[0].float() @ tw[:27].float().t()          # [B,H,N,27]
+    ih = (qh_[:, None] - qh_[None, :] + gh - 1)[None, None].expand(B, H, N, N)
+    iw = (qw_[:, None] - qw_[None, :] + gw - 1)[None, None].expand(B, H, N, N)
+    bias = torch.gather(Gh, 3, ih) + torch.gather(Gw, 3, iw)
+    ref = _attn_ref(x[0], x[1], x[2], hd ** -0.5, bias).transpose(1, 2).reshape(B * N, D)
+    out.append(("attn fused window rel-pos (tables)", err(o, ref), tol_bf16(ref, 2.0)))
     # o_row_map: scatter rows (window un-partition): reverse order, skip every 5th query
     hd, B, H, N = 80, 2, 2, 196
     D = H * hd
