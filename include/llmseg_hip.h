@@ -131,9 +131,10 @@ int llmseg_gather_rows(const void* x, const int64_t* idx, void* out, int64_t n, 
  * align_corners=False) of the channels-last bf16 map feat [g*g][C].  Computed as (segs . U) . feat, i.e. the mask is
  * pulled back through the adjoint of the interpolation, so the [C][S][S] upsampled tensor is never materialised and
  * `segs` (K*S*S bf16, the only large operand) is read from HBM exactly once.  feat bf16 [g*g][C]; pooled bf16 [K][C].
+ * ws: caller-provided bf16 [K][g*g] workspace (the normalised pulled-back masks; stage 2 is an MFMA GEMM over it).
  * Optional outputs for the backward pass (NULL = skip): pulled_back fp32 [K][g*g] = segs . U, wsum fp32 [K] = sum_p segs. */
-int llmseg_upsample_maskpool(const void* feat, const void* segs, void* pooled, float* pulled_back, float* wsum, int32_t K, int32_t C,
-                             int32_t g, int32_t S, void* stream);
+int llmseg_upsample_maskpool(const void* feat, const void* segs, void* pooled, void* ws, float* pulled_back, float* wsum, int32_t K,
+                             int32_t C, int32_t g, int32_t S, void* stream);
 
 /* Cosine scoring (LISA.py:398-403): sim[k] = <t,e_k> / (|t||e_k|); t bf16 [D], e bf16 [K][D]; sim fp32 [K]. */
 int llmseg_cosine_scores(const void* t, const void* e, float* sim, int32_t K, int32_t D, void* stream);

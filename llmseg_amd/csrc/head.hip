@@ -7,50 +7,77 @@
 namespace {
 
 // ---- pooled[k][:] = (segs[k] . U) . feat / (sum segs[k] + 1e-8) -------------------------------------------------------
-// One workgroup per proposal k.  Phase 1 streams the S x S mask once (the only large HBM operand: K*S*S*2 bytes in
-// total) and scatters every non-zero pixel through the ADJOINT of the bilinear interpolation into a g x g fp32
-// accumulator in LDS (ds_add_f32; 4 taps per pixel).  Phase 2 is the small dense product with the L2-resident
-// channels-last feature map.  The [C][S][S] upsampled tensor of the reference is never formed.
-__global__ __launch_bounds__(256) void upsample_maskpool_kernel(const bf16_t* __restrict__ feat, const bf16_t* __restrict__ segs,
-                                                               bf16_t* __restrict__ pooled, float* __restrict__ pb_out, float* __restrict__ wsum_out, int C, int g,
-                                                               int S) {
-  extern __shared__ float acc[];                 // g*g (+16 for reductions)
+// Stage 1 (this kernel, one workgroup per proposal): pull the S x S mask back through the ADJOINT of the bilinear
+// interpolation, separably and without atomics: rows first (tmp[py][sx] = sum_px m[py][px] Ux[px][sx], half of the rows at a
+// time in LDS), then columns (acc[sy][sx] += sum_py Uy[py][sy] tmp[py][sx]).  `segs` (K*S*S bf16, the only large operand) is
+// read from HBM once.  Because every bilinear weight row sums to 1, sum_s acc[s] == sum_p m[p], so the normaliser comes for
+// free.  Output: wn[k][s] = acc[s] / (sum + 1e-8) as bf16 (+ optional raw fp32 acc / sum for the backward pass).
+// Stage 2 is a plain GEMM pooled = wn . feat on the matrix cores (feat is channels-last [g*g][C] = "W stored [K][N]").
+// The [C][S][S] upsampled tensor of the reference is never formed.
+__device__ __forceinline__ float bilin_w(int p, int cell, float scale, int g) {
+  // weight of destination pixel p on source cell `cell` (F.interpolate bilinear, align_corners=False, clamped at the borders)
+  const float s = fmaxf(0.f, ((float)p + 0.5f) * scale - 0.5f);
+  const int c0 = (int)s, c1 = min(c0 + 1, g - 1);
+  const float l1 = s - (float)c0;
+  return (c0 == cell ? 1.f - l1 : 0.f) + (c1 == cell ? l1 : 0.f);
+}
+
+__global__ __launch_bounds__(256) void mask_pullback_kernel(const bf16_t* __restrict__ segs, bf16_t* __restrict__ wn, float* __restrict__ pb_out,
+                                                           float* __restrict__ wsum_out, int g, int S) {
+  extern __shared__ float lds[];                 // tmp[HALF][g] | acc[g][g] | red[16]
+  const int HALF = (S + 1) / 2;
+  float* tmp = lds;
+  float* acc = lds + HALF * g;
   float* red = acc + g * g;
-  const int k = blockIdx.x;
-  for (int i = threadIdx.x; i < g * g; i += blockDim.x) acc[i] = 0.f;
-  __syncthreads();
+  const int k = blockIdx.x, tid = threadIdx.x;
   const float scale = (float)g / (float)S;
   const bf16_t* m = segs + (long)k * S * S;
-  float wsum = 0.f;
-  for (int px = threadIdx.x; px < S; px += blockDim.x) {
-    // F.interpolate(bilinear, align_corners=False): src = max(0, (dst + .5) * scale - .5)
-    const float sx = fmaxf(0.f, ((float)px + 0.5f) * scale - 0.5f);
-    const int x0 = (int)sx, x1 = min(x0 + 1, g - 1);
-    const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
-    for (int py = 0; py < S; ++py) {
-      const float v = bf2f(m[(long)py * S + px]);
-      if (v != 0.f) {
-        wsum += v;
-        const float sy = fmaxf(0.f, ((float)py + 0.5f) * scale - 0.5f);
-        const int y0 = (int)sy, y1 = min(y0 + 1, g - 1);
-        const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
-        atomicAdd(&acc[y0 * g + x0], v * ly0 * lx0);
-        atomicAdd(&acc[y0 * g + x1], v * ly0 * lx1);
-        atomicAdd(&acc[y1 * g + x0], v * ly1 * lx0);
-        atomicAdd(&acc[y1 * g + x1], v * ly1 * lx1);
+  for (int i = tid; i < g * g; i += blockDim.x) acc[i] = 0.f;
+  const int rows_par = blockDim.x / g;          // rows handled per sweep (blockDim.x is a multiple of g; host checks)
+  const int sx = tid % g, ro = tid / g;
+  // taps of this thread's source column sx (a superset range; bilin_w() zeroes the rest)
+  const int plo = max(0, (int)floorf(((float)sx - 0.5f) / scale - 0.5f) - 1);
+  const int phi = min(S - 1, (int)ceilf(((float)sx + 1.5f) / scale - 0.5f) + 1);
+  for (int h0 = 0; h0 < S; h0 += HALF) {
+    const int h1 = min(S, h0 + HALF);
+    __syncthreads();                             // acc zero-fill / previous half's column pass done
+    if (phi - plo < 16) {                        // common case (S/g <= 6): tap weights of this column live in registers
+      float wx[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) wx[j] = (plo + j <= phi) ? bilin_w(plo + j, sx, scale, g) : 0.f;
+      for (int py = h0 + ro; py < h1; py += rows_par) {
+        const bf16_t* row = m + (long)py * S;
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += bf2f(row[min(plo + j, S - 1)]) * wx[j];
+        tmp[(py - h0) * g + sx] = t;
+      }
+    } else {
+      for (int py = h0 + ro; py < h1; py += rows_par) {
+        float t = 0.f;
+        for (int px = plo; px <= phi; ++px) t += bf2f(m[(long)py * S + px]) * bilin_w(px, sx, scale, g);
+        tmp[(py - h0) * g + sx] = t;
       }
     }
+    __syncthreads();
+    for (int sy = ro; sy < g; sy += rows_par) {
+      const int qlo = max(h0, (int)floorf(((float)sy - 0.5f) / scale - 0.5f) - 1);
+      const int qhi = min(h1 - 1, (int)ceilf(((float)sy + 1.5f) / scale - 0.5f) + 1);
+      float a = 0.f;
+      for (int py = qlo; py <= qhi; ++py) a += tmp[(py - h0) * g + sx] * bilin_w(py, sy, scale, g);
+      acc[sy * g + sx] += a;
+    }
   }
-  wsum = block_sum(wsum, red);      // includes the barriers that publish acc[]
+  __syncthreads();
+  float part = 0.f;
+  for (int i = tid; i < g * g; i += blockDim.x) part += acc[i];
+  const float wsum = block_sum(part, red);
   const float inv = 1.f / (wsum + 1e-8f);
-  if (pb_out)
-    for (int i = threadIdx.x; i < g * g; i += blockDim.x) pb_out[(long)k * g * g + i] = acc[i];
-  if (wsum_out && threadIdx.x == 0) wsum_out[k] = wsum;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float a = 0.f;
-    for (int s = 0; s < g * g; ++s) a += acc[s] * bf2f(feat[(long)s * C + c]);
-    pooled[(long)k * C + c] = f2bf(a * inv);
+  for (int i = tid; i < g * g; i += blockDim.x) {
+    wn[(long)k * g * g + i] = f2bf(acc[i] * inv);
+    if (pb_out) pb_out[(long)k * g * g + i] = acc[i];
   }
+  if (wsum_out && tid == 0) wsum_out[k] = wsum;
 }
 
 // ---- cosine scores: one wave per proposal ------------------------------------------------------------------------------
@@ -167,15 +194,21 @@ __global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logi
 
 }  // namespace
 
-extern "C" int llmseg_upsample_maskpool(const void* feat, const void* segs, void* pooled, float* pulled_back, float* wsum, int32_t K, int32_t C,
-                                        int32_t g, int32_t S, void* stream) {
-  LL_CHECK(feat && segs && pooled && K > 0 && C > 0 && g > 0 && S >= g, "upsample_maskpool: bad arguments");
-  const size_t lds = ((size_t)g * g + 16) * sizeof(float);
-  LL_CHECK(lds <= 64 * 1024, "upsample_maskpool: feature grid %d too large for LDS", g);
-  hipLaunchKernelGGL(upsample_maskpool_kernel, dim3(K), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)feat, (const bf16_t*)segs,
-                     (bf16_t*)pooled, pulled_back, wsum, C, g, S);
-  LL_LAUNCH_CHECK("upsample_maskpool");
-  return LLMSEG_OK;
+extern "C" int llmseg_upsample_maskpool(const void* feat, const void* segs, void* pooled, void* ws, float* pulled_back, float* wsum, int32_t K,
+                                        int32_t C, int32_t g, int32_t S, void* stream) {
+  LL_CHECK(feat && segs && pooled && ws && K > 0 && C > 0 && g > 0 && S >= g, "upsample_maskpool: bad arguments");
+  LL_CHECK(256 % g == 0 && ((g * g) & 7) == 0 && (C & 7) == 0, "upsample_maskpool: feature grid %d must divide 256 (and C %% 8 == 0)", g);
+  const size_t lds = ((size_t)((S + 1) / 2) * g + (size_t)g * g + 16) * sizeof(float);
+  LL_CHECK(lds <= 64 * 1024, "upsample_maskpool: S=%d g=%d need %zu bytes of LDS", S, g, lds);
+  hipLaunchKernelGGL(mask_pullback_kernel, dim3(K), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)segs, (bf16_t*)ws, pulled_back, wsum, g, S);
+  LL_LAUNCH_CHECK("mask_pullback");
+  // pooled[K][C] = wn[K][g*g] . feat[g*g][C]
+  llmseg_gemm_args ga = {};
+  ga.A = ws; ga.W = feat; ga.C = pooled;
+  ga.M = K; ga.N = C; ga.K = (int64_t)g * g;
+  ga.lda = (int64_t)g * g; ga.ldw = C; ga.ldc = C;
+  ga.batch = 1; ga.alpha = 1.f; ga.act = LLMSEG_ACT_NONE; ga.trans_w = 1;
+  return llmseg_gemm_bf16(&ga, stream);
 }
 
 extern "C" int llmseg_cosine_scores(const void* t, const void* e, float* sim, int32_t K, int32_t D, void* stream) {

@@ -173,7 +173,8 @@ def upsample_maskpool(feat_cl, segs, g, S, want_aux=False):
     out = torch.empty((K, Cc), device=segs.device, dtype=BF16)
     pb = torch.empty((K, g * g), device=segs.device, dtype=torch.float32) if want_aux else None
     ws = torch.empty((K,), device=segs.device, dtype=torch.float32) if want_aux else None
-    _lib.check(_lib.load().llmseg_upsample_maskpool(_ptr(feat_cl), _ptr(segs), _ptr(out), _ptr(pb), _ptr(ws), K, Cc, g, S, _stream()),
+    wn = torch.empty((K, g * g), device=segs.device, dtype=BF16)
+    _lib.check(_lib.load().llmseg_upsample_maskpool(_ptr(feat_cl), _ptr(segs), _ptr(out), _ptr(wn), _ptr(pb), _ptr(ws), K, Cc, g, S, _stream()),
                "upsample_maskpool")
     return (out, pb, ws) if want_aux else out
 
