@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="images per rank per step")
+    ap.add_argument("--batch", type=int, default=16, help="images per rank per step")
     ap.add_argument("--backbone", default="sam", choices=["sam", "dinov2"])
     ap.add_argument("--masks", type=int, default=256)
     ap.add_argument("--prompt-len", type=int, default=64)
@@ -178,7 +178,9 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ops.prof_enable(False)
-    gemm_ms, gemm_flops, gemm_launches = ops.prof_collect()
+    prof = ops.prof_collect()
+    gemm_ms, gemm_flops, gemm_launches = prof["all"]
+    dom_ms, dom_flops, dom_launches = prof["dominant"]
     if dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -215,7 +217,8 @@ def main():
         T = args.prompt_len - 1 + cfg.n_img_tokens
         ms = dt / args.steps * 1e3
         total_imgs = args.batch * world * args.steps
-        ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        ach = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        ach_all = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         model_flops = gemm_flops / args.steps + attention_flops(cfg, args.batch, T)
         res = {
             "metric": "images/sec (1024x1024, 64-tok prompt) model_forward " + ("fwd+bwd" if train else "fwd"), "value": total_imgs / dt,
@@ -231,10 +234,12 @@ def main():
                 args.masks, args.prompt_len),
                        "images_per_gpu_per_step": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "valid": not args.small},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_tn_glds_kernel (+ gemm_bf16_tn_kernel layouts)", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "launches_per_step": gemm_launches / args.steps,
-                         "avg_launch_us": gemm_ms * 1e3 / max(1, gemm_launches),
-                         "gemm_time_share_of_step": gemm_ms / (dt * 1e3)},
+            # dominant kernel = the bf16 128x128 LDS-DMA GEMM; achieved = its algorithmic 2MNK per launch / its HIP-event duration
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_tn_glds_kernel<false, 2, 1>", "achieved": ach, "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "launches_per_step": dom_launches / args.steps,
+                         "avg_launch_us": dom_ms * 1e3 / max(1, dom_launches), "time_share_of_step": dom_ms / (dt * 1e3),
+                         "all_gemm_kernels": {"achieved": ach_all, "launches_per_step": gemm_launches / args.steps,
+                                              "avg_launch_us": gemm_ms * 1e3 / max(1, gemm_launches), "time_share_of_step": gemm_ms / (dt * 1e3)}},
             "model_tflop_per_image": model_flops / args.batch / 1e12,
             "model_mfma_frac": model_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
             "loss": loss,

@@ -73,7 +73,8 @@ SIGNATURES = {
     "llmseg_sumsq": [_p, _i64, C.c_int, _p, _p],
     "llmseg_adamw": [_p, _p, _p, C.c_int, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _p, _p],
     "llmseg_prof_enable": [C.c_int],
-    "llmseg_prof_collect": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)],
+    "llmseg_prof_collect": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                            C.POINTER(C.c_int64)],
 }
 
 _lib = None

@@ -64,9 +64,10 @@ extern "C" int llmseg_prof_enable(int on) {
   return LLMSEG_OK;
 }
 
-extern "C" int llmseg_prof_collect(double* total_ms, double* total_flops, int64_t* launches) {
+extern "C" int llmseg_prof_collect(double* total_ms, double* total_flops, int64_t* launches, double* dom_ms, double* dom_flops, int64_t* dom_launches) {
   std::lock_guard<std::mutex> lk(g_mu);
-  double ms = 0, fl = 0;
+  double ms = 0, fl = 0, dms = 0, dfl = 0;
+  int64_t dn = 0;
   std::map<std::array<long, 4>, std::array<double, 3>> by_shape;      // (M,N,K,variant) -> {ms, flops, count}
   for (auto& r : g_recs) {
     hipEventSynchronize(r.b);
@@ -74,6 +75,7 @@ extern "C" int llmseg_prof_collect(double* total_ms, double* total_flops, int64_
     hipEventElapsedTime(&t, r.a, r.b);
     ms += t;
     fl += r.flops;
+    if (r.tag[3] / 1000 == 2 && (r.tag[3] & 1) == 0) { dms += t; dfl += r.flops; ++dn; }   // gemm_bf16_tn_glds_kernel<false, 2, 1>
     auto& e = by_shape[{r.tag[0], r.tag[1], r.tag[2], r.tag[3]}];
     e[0] += t; e[1] += r.flops; e[2] += 1;
     g_pool.push_back(r);
@@ -92,6 +94,9 @@ extern "C" int llmseg_prof_collect(double* total_ms, double* total_flops, int64_
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;
   if (launches) *launches = (int64_t)g_recs.size();
+  if (dom_ms) *dom_ms = dms;
+  if (dom_flops) *dom_flops = dfl;
+  if (dom_launches) *dom_launches = dn;
   g_recs.clear();
   return LLMSEG_OK;
 }

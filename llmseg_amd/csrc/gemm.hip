@@ -529,6 +529,108 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_big_kernel(GemmP p) {
   epilogue_lds<OUT_F32, MI>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
 }
 
+// ---- variant P: 256 x 256 tile, BK = 32, 4-stage LDS ring (128 KiB), three stages (96 KiB) of DMA in flight ------------------
+// Measurements (profiles/) show the single-buffer and double-buffer kernels are bound by bytes-in-flight / DMA
+// latency (~2 us under load): 128 KiB in flight per CU at 64 flop/B (128x128 tiles) caps them at ~900 TFLOP/s.  This variant
+// doubles the arithmetic intensity (256x256: 128 flop/B) AND keeps three stages in flight.  One barrier per stage: at
+// iteration t every wave waits for its own DMA of stage t (counted vmcnt), the barrier then proves (a) everybody's part of
+// stage t has landed and (b) everybody finished the MFMAs of stage t-1, so slot (t-1)%4 is immediately refilled with stage
+// t+3.  8 waves (2 x 4), each a 128 x 64 sub-tile = 4 x 2 MFMA 32x32x16 accumulators; 64-byte LDS rows, chunk XOR (row>>2)&3.
+__device__ __forceinline__ int lds_off32(int row, int chunk) { return row * 64 + (((chunk ^ (row >> 2)) & 3) << 4); }
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_ring_kernel(GemmP p) {
+  constexpr int MI = 4, BMB = 256, BNB = 256, BKR = 32, NST = 4;
+  constexpr int A_BYTES = BMB * BKR * 2, STAGE = 2 * A_BYTES;        // 16 KiB + 16 KiB
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+  int bid = blockIdx.x;
+  const int nwg = p.tiles_m * p.tiles_n;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int len = q + (xcd < r ? 1 : 0);
+    const int idx = ((bid >> 3) + xcd * p.skew) % len;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int per_group = GROUP_M * p.tiles_n;
+  const int first_m = (bid / per_group) * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int m0 = (first_m + (bid % per_group) % gsz) * BMB;
+  const int n0 = ((bid % per_group) / gsz) * BNB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const long b1 = blockIdx.y % p.batch1, b2 = blockIdx.y / p.batch1;
+  const long bz = b1 * p.sC + b2 * p.sC2;
+  const bf16_t* __restrict__ Ag = p.A + b1 * p.sA + b2 * p.sA2;
+  const bf16_t* __restrict__ Wg = p.W + b1 * p.sW + b2 * p.sW2;
+
+  // DMA instruction i (0..1) of this wave fills LDS rows (i*8 + wave)*16 .. +15 (64 B each) of each operand tile
+  const bf16_t* a_src[2];
+  const bf16_t* w_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (i * 8 + wave) * 16 + (lane >> 2);
+    const int sw = (((lane & 3) ^ ((row >> 2) & 3)) << 3);
+    a_src[i] = Ag + (long)min(m0 + row, p.M - 1) * p.lda + sw;
+    w_src[i] = Wg + (long)min(n0 + row, p.N - 1) * p.ldw + sw;
+  }
+  const int nt = p.K / BKR;
+
+  auto issue = [&](int t) {
+    char* base = smem + (t & (NST - 1)) * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[i] + (long)t * BKR), (lds_ptr_t)(base + A_BYTES + (i * 8 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + (long)t * BKR), (lds_ptr_t)(base + (i * 8 + wave) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16_t acc[2][MI];
+  zero_acc<MI>(acc);
+  const int frow = lane & 31, fhalf = lane >> 5;
+
+  issue(0);
+  if (nt > 1) issue(1);
+  if (nt > 2) issue(2);
+  for (int t = 0; t < nt; ++t) {
+    // outstanding DMA instructions of this wave: stages t .. min(t+2, nt-1), 4 each; stage t is the oldest
+    const int newer = min(2, nt - 1 - t);
+    if (newer == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // slot (t+3)%4 == (t-1)%4 is free since every wave passed this barrier.  The refill DMA is issued in the SHADOW of the
+    // MFMAs (an LDS-DMA instruction costs ~100 issue cycles; right after the barrier it would stall both lock-stepped waves
+    // of a SIMD with the matrix pipe idle): all fragment reads first, then {8 MFMAs, 2 DMA} x 2.
+    const bool refill = t + 3 < nt;
+    char* rbase = smem + ((t + 3) & (NST - 1)) * STAGE;
+    const char* abase = smem + (t & (NST - 1)) * STAGE;
+    bf16x8_t af[2][MI], wf[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8_t*>(abase + A_BYTES + lds_off32(wn * 64 + j * 32 + frow, ks * 2 + fhalf));
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[ks][i] = *reinterpret_cast<const bf16x8_t*>(abase + lds_off32(wm * 128 + i * 32 + frow, ks * 2 + fhalf));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][j], af[ks][i], acc[j][i], 0, 0, 0);
+      if (refill) {
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[ks] + (long)(t + 3) * BKR), (lds_ptr_t)(rbase + A_BYTES + (ks * 8 + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[ks] + (long)(t + 3) * BKR), (lds_ptr_t)(rbase + (ks * 8 + wave) * 1024), 16, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                          // all MFMAs' LDS reads retired: the ring becomes the epilogue slab
+  epilogue_lds<OUT_F32, MI>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
+}
+
 template <bool OUT_F32, int MI, int NBUF>
 void launch_glds(const GemmP& p, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((gemm_bf16_tn_glds_kernel<OUT_F32, MI, NBUF>), grid, dim3(NT), 0, s, p);
@@ -580,8 +682,8 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN) * batch;
   if (variant == 5) variant = 2;   // measured (tools/gemm_bench.py): 128x128 single-buffer DMA wins or ties on the hot-path shapes
   (void)tiles256;
-  const int bm = (variant == 3 || variant == 4 || variant == 6) ? 256 : 128;
-  const int bn = variant == 6 ? 256 : BN;
+  const int bm = (variant == 3 || variant == 4 || variant == 6 || variant == 7) ? 256 : 128;
+  const int bn = (variant == 6 || variant == 7) ? 256 : BN;
   p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
   dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);
   hipStream_t s = (hipStream_t)stream;
@@ -593,6 +695,10 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
     case 2: f ? launch_glds<true, 2, 1>(p, grid, s) : launch_glds<false, 2, 1>(p, grid, s); break;
     case 3: f ? launch_glds<true, 4, 1>(p, grid, s) : launch_glds<false, 4, 1>(p, grid, s); break;
     case 4: f ? launch_glds<true, 4, 2>(p, grid, s) : launch_glds<false, 4, 2>(p, grid, s); break;
+    case 7:
+      if (f) hipLaunchKernelGGL(gemm_bf16_tn_ring_kernel<true>, grid, dim3(NTB), 0, s, p);
+      else hipLaunchKernelGGL(gemm_bf16_tn_ring_kernel<false>, grid, dim3(NTB), 0, s, p);
+      break;
     case 6:
       if (f) hipLaunchKernelGGL(gemm_bf16_tn_big_kernel<true>, grid, dim3(NTB), 0, s, p);
       else hipLaunchKernelGGL(gemm_bf16_tn_big_kernel<false>, grid, dim3(NTB), 0, s, p);

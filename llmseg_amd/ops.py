@@ -319,6 +319,7 @@ def prof_enable(on):
 
 
 def prof_collect():
-    ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
-    _lib.load().llmseg_prof_collect(C.byref(ms), C.byref(fl), C.byref(n))
-    return ms.value, fl.value, n.value
+    """-> dict(all=(ms, flops, launches), dominant=(ms, flops, launches)) of the GEMM launches since prof_enable(True)."""
+    ms, fl, n, dms, dfl, dn = C.c_double(), C.c_double(), C.c_int64(), C.c_double(), C.c_double(), C.c_int64()
+    _lib.load().llmseg_prof_collect(C.byref(ms), C.byref(fl), C.byref(n), C.byref(dms), C.byref(dfl), C.byref(dn))
+    return {"all": (ms.value, fl.value, n.value), "dominant": (dms.value, dfl.value, dn.value)}

@@ -13,7 +13,7 @@ SHAPES = [  # (M, N, K, tag)  B=8 images
     (2552, 12288, 4096, "llama qkv"), (2552, 4096, 4096, "llama o"), (2552, 22016, 4096, "llama gate_up"), (2552, 4096, 11008, "llama down"),
     (2552, 32004, 4096, "lm_head"), (2056, 3072, 1024, "clip qkv"), (4096, 4096, 4096, "4096^3"), (8192, 8192, 8192, "8192^3"),
 ]
-variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["2", "6"])]
+variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["2", "6", "7"])]
 lib = _lib.load()
 torch.manual_seed(0)
 print("variants: v & 15 = kernel variant, (v >> 4) - 1 = XCD skew (none = default 13)")
