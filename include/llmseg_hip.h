@@ -160,6 +160,12 @@ int llmseg_ce_loss(const void* logits, const int64_t* labels, float* acc, int32_
  * pixels with target == ignore_index are dropped; out int64[6] += {I0, I1, U0, U1, T0, T1} (exact integer counts). */
 int llmseg_intersection_union(const uint8_t* pred, const uint8_t* target, int64_t n, int32_t ignore_index, int64_t* out, void* stream);
 
+/* validate_threshold's per-image body (training.py:712-766) in one pass: union of the proposals with select[k] != 0 (segs uint8
+ * [H][W][K], the reader's layout), nearest-resize of that union and of gt (uint8 [Hg][Wg], 255 = ignore) to out_size^2, 2-class I/U.
+ * out int64[6] += {I0, I1, U0, U1, T0, T1}. */
+int llmseg_union_resize_iou(const uint8_t* segs, const uint8_t* select, const uint8_t* gt, int32_t H, int32_t W, int32_t K, int32_t Hg, int32_t Wg,
+                            int32_t out_size, int32_t ignore_index, int64_t* out, void* stream);
+
 /* ---- backward pass + optimizer (trainable part: LoRA'd Llama stack, embed/lm_head, text_hidden_fcs, mask-selection head) -----
  * GEMM-shaped gradients use llmseg_gemm_bf16 with trans_a / trans_w (dX = dY W, dW = dY^T X); the kernels below are the
  * streaming pieces.  Gradients of the loss kernels: llmseg_align_reg_loss (d_e, d_t, d_pred). */

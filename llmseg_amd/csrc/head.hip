@@ -284,3 +284,55 @@ extern "C" int llmseg_intersection_union(const uint8_t* pred, const uint8_t* tar
   LL_LAUNCH_CHECK("intersection_union");
   return LLMSEG_OK;
 }
+
+// ---- validate_threshold inner loop (reference training.py:712-766) fused: union of the selected proposals at original
+// resolution -> nearest resize of prediction and ground truth to out x out -> 2-class I/U with ignore 255.
+// segs uint8 [H][W][K] (the reader's (H, W, K) layout), select uint8 [K] (pred_iou > threshold), gt uint8 [Hg][Wg].
+namespace {
+__global__ __launch_bounds__(256) void union_resize_iou_kernel(const uint8_t* __restrict__ segs, const uint8_t* __restrict__ select, const uint8_t* __restrict__ gt,
+                                                              int H, int W, int K, int Hg, int Wg, int out, int ignore, unsigned long long* __restrict__ res) {
+  __shared__ unsigned long long sh[6];
+  extern __shared__ uint8_t sel[];
+  if (threadIdx.x < 6) sh[threadIdx.x] = 0;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) sel[k] = select[k];
+  __syncthreads();
+  unsigned int c[6] = {0, 0, 0, 0, 0, 0};
+  const long n = (long)out * out;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int y = (int)(i / out), x = (int)(i % out);
+    // F.interpolate(mode="nearest"): src = min(floor(dst * in / out), in - 1)
+    const int sy = min((int)floorf((float)y * ((float)H / (float)out)), H - 1), sx = min((int)floorf((float)x * ((float)W / (float)out)), W - 1);
+    const int gy = min((int)floorf((float)y * ((float)Hg / (float)out)), Hg - 1), gx = min((int)floorf((float)x * ((float)Wg / (float)out)), Wg - 1);
+    const int t = gt[(long)gy * Wg + gx];
+    if (t == ignore) continue;
+    const uint8_t* px = segs + ((long)sy * W + sx) * K;
+    int p = 0;
+    for (int k = 0; k < K; ++k) p |= (sel[k] & (px[k] != 0));
+    c[2 + p]++;
+    if (p == t) c[p]++;
+    if (t < 2) c[4 + t]++;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    unsigned int v = c[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&sh[k], (unsigned long long)v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    atomicAdd(&res[threadIdx.x], sh[threadIdx.x]);
+    atomicAdd(&res[2 + threadIdx.x], sh[2 + threadIdx.x] + sh[4 + threadIdx.x] - sh[threadIdx.x]);
+    atomicAdd(&res[4 + threadIdx.x], sh[4 + threadIdx.x]);
+  }
+}
+}  // namespace
+
+extern "C" int llmseg_union_resize_iou(const uint8_t* segs, const uint8_t* select, const uint8_t* gt, int32_t H, int32_t W, int32_t K, int32_t Hg,
+                                       int32_t Wg, int32_t out_size, int32_t ignore_index, int64_t* out, void* stream) {
+  LL_CHECK(segs && select && gt && out && H > 0 && W > 0 && K > 0 && Hg > 0 && Wg > 0 && out_size > 0, "union_resize_iou: bad arguments");
+  hipLaunchKernelGGL(union_resize_iou_kernel, dim3(1024), dim3(256), (size_t)K, (hipStream_t)stream, segs, select, gt, H, W, K, Hg, Wg, out_size,
+                     ignore_index, (unsigned long long*)out);
+  LL_LAUNCH_CHECK("union_resize_iou");
+  return LLMSEG_OK;
+}

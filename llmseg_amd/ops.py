@@ -224,6 +224,17 @@ def intersection_union(pred_u8, target_u8, ignore_index=255, out=None):
     return out
 
 
+def union_resize_iou(segs_hwk_u8, select_u8, gt_u8, out_size=1024, ignore_index=255, out=None):
+    """Union of selected proposals (segs [H,W,K] uint8) + nearest resize of it and of gt [Hg,Wg] to out_size^2 + I/U -> int64[6]."""
+    H, W, K = segs_hwk_u8.shape
+    Hg, Wg = gt_u8.shape
+    if out is None:
+        out = torch.zeros((6,), device=segs_hwk_u8.device, dtype=torch.int64)
+    _lib.check(_lib.load().llmseg_union_resize_iou(_ptr(segs_hwk_u8.contiguous()), _ptr(select_u8.contiguous()), _ptr(gt_u8.contiguous()), H, W, K,
+                                                   Hg, Wg, out_size, ignore_index, _ptr(out), _stream()), "union_resize_iou")
+    return out
+
+
 # ---- backward / optimizer -------------------------------------------------------------------------------------------
 def colsum(x, out=None):
     M, N = x.shape

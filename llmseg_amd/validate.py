@@ -1,0 +1,35 @@
+"""gIoU / cIoU validation loop (reference `training.py:690-870` `validate_threshold`): per validation image run
+`model_forward(inference=True)`, keep the proposals whose predicted IoP exceeds the threshold, score their union against the
+ground truth at 1024 x 1024.  The per-image body after the model call is ONE kernel (`llmseg_union_resize_iou`); the meters are
+integer sums, reduced across ranks with three `all_reduce`s like the reference's `AverageMeter.all_reduce` (utils/utils.py:76-97).
+
+Each sample dict carries the `model_forward` kwargs plus `origin_segs` (uint8 [H, W, K], the reader's layout,
+`utils/sam_mask_reader.py`) and `gt_mask` (uint8 [H', W'], 255 = ignore)."""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+@torch.no_grad()
+def validate_threshold(model, samples, threshold=0.5, out_size=1024):
+    dev = next(model.parameters()).device
+    inter = torch.zeros(2, device=dev, dtype=torch.float64)
+    union = torch.zeros(2, device=dev, dtype=torch.float64)
+    acc = torch.zeros(2, device=dev, dtype=torch.float64)
+    count = torch.zeros(1, device=dev, dtype=torch.float64)
+    for s in samples:
+        kw = {k: v for k, v in s.items() if k not in ("origin_segs", "gt_mask")}
+        out = model.model_forward(**kw, inference=True)
+        select = (out["pred_iou"][0][0] > threshold).to(torch.uint8)                    # training.py:712-718
+        iu = ops.union_resize_iou(s["origin_segs"], select, s["gt_mask"], out_size=out_size).double()
+        i, u = iu[0:2], iu[2:4]
+        a = i / (u + 1e-8)
+        a = torch.where(u == 0, a + 1.0, a)                                             # no-object target (training.py:768)
+        inter += i; union += u; acc += a; count += 1
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        for t in (inter, union, acc, count):
+            dist.all_reduce(t)
+    giou = (acc / count.clamp(min=1))[1].item()
+    ciou = (inter / (union + 1e-10))[1].item()
+    return {"giou": giou, "ciou": ciou, "images": int(count.item())}

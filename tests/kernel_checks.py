@@ -292,4 +292,23 @@ def check_metric(golden_loader=None):
     return out
 
 
-ALL = [check_gemm, check_attention, check_pointwise, check_head, check_metric]
+def check_validate_body():
+    """Fused union + nearest-resize + I/U kernel vs the oracle restatement of validate_threshold's loop body."""
+    from oracle import metric
+    out = []
+    gen = torch.Generator().manual_seed(5)
+    for n, (H, W, K, Hg, Wg) in enumerate([(300, 427, 20, 300, 427), (1024, 768, 50, 512, 384), (64, 64, 3, 1024, 1024)]):
+        segs = (torch.rand(H, W, K, generator=gen) > 0.9).to(torch.uint8)
+        gt = (torch.rand(Hg, Wg, generator=gen) > 0.6).to(torch.uint8)
+        if n == 1:
+            gt[torch.rand(Hg, Wg, generator=gen) > 0.9] = 255
+        piou = torch.rand(K, generator=gen)
+        if n == 2:
+            piou[:] = 0.1                                                              # nothing selected: empty prediction
+        i, u, t, _ = metric.union_resize_iou(segs, piou, gt)
+        got = ops.union_resize_iou(segs.to(DEV), (piou > 0.5).to(torch.uint8).to(DEV), gt.to(DEV)).cpu()
+        out.append((f"union+resize+I/U case {n}", float((got - torch.cat([i, u, t]).long()).abs().max()), 0.0))
+    return out
+
+
+ALL = [check_gemm, check_attention, check_pointwise, check_head, check_metric, check_validate_body]

@@ -139,3 +139,39 @@ def check_reference_api():
     ref = mask_head.mask_pooling(feat, segs)
     got = m.mask_pooling(feat.to(DEV), segs.to(DEV))
     return [("mask_pooling API", _e(got, ref), 1e-2)]
+
+
+def check_validate_loop(backbone="dinov2"):
+    """validate.validate_threshold over 3 images vs the oracle loop body fed with the same pred_iou rows (a threshold flip
+    between bf16 and fp32 would change WHICH proposals are selected; the model's numbers are covered by check_tiny_inference)."""
+    from llmseg_amd import validate
+    from oracle import metric
+    cfg = cases.tiny_lisa_cfg(backbone)
+    m, _ = build_pair(cfg)
+    img = 896 if backbone == "dinov2" else cfg.sam.img
+    gen = torch.Generator().manual_seed(17)
+    samples, segs_cpu, gts_cpu = [], [], []
+    for n, (H, W) in enumerate([(300, 420), (512, 512), (97, 130)]):
+        b = _round_batch(cases.first_image_inference(cases.tiny_lisa_batch(img_size=img)))
+        b["images"] = b["images"] + 0.1 * n
+        K = b["sam_segs_list"][0].shape[0]
+        segs = (torch.rand(H, W, K, generator=gen) > 0.8).to(torch.uint8)
+        gt = (torch.rand(H, W, generator=gen) > 0.5).to(torch.uint8) if n < 2 else torch.zeros(H, W, dtype=torch.uint8)
+        segs_cpu.append(segs); gts_cpu.append(gt)
+        s = _dev(b)
+        s["origin_segs"], s["gt_mask"] = segs.to("cuda"), gt.to("cuda")
+        samples.append(s)
+    thr = 0.45
+    got = validate.validate_threshold(m, samples, threshold=thr)
+    I = torch.zeros(2, dtype=torch.float64); U = torch.zeros(2, dtype=torch.float64); A = torch.zeros(2, dtype=torch.float64)
+    nsel = 0
+    for s, segs, gt in zip(samples, segs_cpu, gts_cpu):
+        kw = {k: v for k, v in s.items() if k not in ("origin_segs", "gt_mask")}
+        with torch.no_grad():
+            row = m.model_forward(**kw, inference=True)["pred_iou"][0][0].float().cpu()
+        nsel += int((row > thr).sum())
+        i, u, _, a = metric.union_resize_iou(segs, row, gt, threshold=thr)
+        I += i.double(); U += u.double(); A += a.double()
+    ref_g, ref_c = (A / 3)[1].item(), (I / (U + 1e-10))[1].item()
+    return [(f"{backbone} validate gIoU ({nsel} proposals selected)", abs(got["giou"] - ref_g), 1e-9),
+            (f"{backbone} validate cIoU", abs(got["ciou"] - ref_c), 1e-9)]

@@ -39,3 +39,8 @@ def test_head():
 def test_metric(golden):
     from tests import kernel_checks as kc
     _run(lambda: kc.check_metric(golden))
+
+
+def test_validate_body():
+    from tests import kernel_checks as kc
+    _run(kc.check_validate_body)

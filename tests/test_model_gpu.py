@@ -30,3 +30,8 @@ def test_tiny_train_losses(backbone):
 def test_reference_api():
     from tests import model_checks as mc
     _assert(mc.check_reference_api())
+
+
+def test_validate_loop():
+    from tests import model_checks as mc
+    _assert(mc.check_validate_loop("dinov2"))
