@@ -631,6 +631,140 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_ring_kernel(GemmP p) {
   epilogue_lds<OUT_F32, MI>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
 }
 
+// ---- variant Q: 256 x 256 tile, 8 waves in two groups that run ONE BARRIER APART ("ping-pong") ----------------------------
+// Each K-tile (BK = 64) is four phases; a phase is {LDS fragment reads + one half-tile of DMA issue} | barrier | {8 MFMAs} |
+// barrier.  Waves wm = 1 execute one extra barrier up front, so on every SIMD the wm = 0 wave's MFMA section overlaps the
+// wm = 1 wave's read/DMA section and vice versa: the matrix pipe sees back-to-back MFMAs while the partner hides LDS latency.
+//   operands per buffer (2 buffers x 64 KiB): A[256][64], W[256][64] bf16, 128-byte rows, chunk XOR (row>>1)&7
+//   half-tiles (16 KiB, one 2-instruction DMA issue by all 8 waves):  A0/A1 = rows {0..63, 128..191} / {64..127, 192..255}
+//   (sub-tile 0/1 of BOTH wave rows), W0/W1 = the first / second 32 rows of every 64-row wave column block.
+//   phase:        p0                p1               p2               p3
+//   reads         W0, A0 (12)       W1 (4)           A1 (8)           -
+//   MFMAs         acc[0][0..1]      acc[1][0..1]     acc[1][2..3]     acc[0][2..3]
+//   DMA issue     W1(t+1)           A1(t+1)          A0(t+2)          W0(t+2)          (issue sequence S[g+6] at phase g)
+//   s_waitcnt     vmcnt(8)          vmcnt(8)         -                vmcnt(8)         (retires what phase g+1 reads)
+// Ordering rules (MI355X_MICROARCH.md "LDS-DMA"): a half-tile is read one phase AFTER the phase whose pre-barrier vmcnt retired
+// it (both groups' waits precede a barrier the reader has passed); a slot is re-issued >= 2 phases after its last read (the
+// lagging group's reads retire one barrier later).  Four half-tiles (64 KiB) stay in flight per workgroup.  K % 64 == 0, K >= 128.
+#define PP_DMA(src, i, tt, dst) \
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)((src)[i] + (long)(tt) * BK), (lds_ptr_t)(dst), 16, 0, 0)
+#define PP_ISSUE_A(h, tt, base)                                                  \
+  do {                                                                           \
+    PP_DMA(a_src[h], 0, tt, (base) + ((h) * 64 + wave * 8) * 128);               \
+    PP_DMA(a_src[h], 1, tt, (base) + (128 + (h) * 64 + wave * 8) * 128);         \
+  } while (0)
+#define PP_ISSUE_W(h, tt, base)                                                                              \
+  do {                                                                                                       \
+    PP_DMA(w_src[h], 0, tt, (base) + OP_BYTES + (((wave >> 2)) * 64 + (h) * 32 + (wave & 3) * 8) * 128);     \
+    PP_DMA(w_src[h], 1, tt, (base) + OP_BYTES + ((2 + (wave >> 2)) * 64 + (h) * 32 + (wave & 3) * 8) * 128); \
+  } while (0)
+#define PP_READ_W(dst, j, base)                                                                                            \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                       \
+      dst[ks] = *reinterpret_cast<const bf16x8_t*>((base) + OP_BYTES + lds_off(wn * 64 + (j) * 32 + frow, ks * 2 + fhalf))
+#define PP_READ_A(i0, base)                                                                                       \
+  _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)             \
+      af[ii][ks] = *reinterpret_cast<const bf16x8_t*>((base) + lds_off(wm * 128 + ((i0) + ii) * 32 + frow, ks * 2 + fhalf))
+#define PP_MMA(wfx, j, i0)                                                                \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) \
+      acc[j][(i0) + ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfx[ks], af[ii][ks], acc[j][(i0) + ii], 0, 0, 0)
+#define PP_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define PP_NOP ((void)0)
+#define PP_PHASE(READS, ISSUE, WAIT, MMA)               \
+  do {                                                  \
+    READS; ISSUE; WAIT;                                 \
+    __builtin_amdgcn_sched_barrier(0);                  \
+    __builtin_amdgcn_s_barrier();                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                  \
+    __builtin_amdgcn_s_setprio(1);                      \
+    MMA;                                                \
+    __builtin_amdgcn_s_setprio(0);                      \
+    __builtin_amdgcn_sched_barrier(0);                  \
+    __builtin_amdgcn_s_barrier();                       \
+    __builtin_amdgcn_sched_barrier(0);                  \
+  } while (0)
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
+  constexpr int MI = 4, BMB = 256, BNB = 256;
+  constexpr int OP_BYTES = 256 * BK * 2, BUF = 2 * OP_BYTES;     // 32 KiB per operand, 64 KiB per buffer
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  int bid = blockIdx.x;
+  const int nwg = p.tiles_m * p.tiles_n;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int len = q + (xcd < r ? 1 : 0);
+    const int idx = ((bid >> 3) + xcd * p.skew) % len;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int per_group = GROUP_M * p.tiles_n;
+  const int first_m = (bid / per_group) * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int m0 = (first_m + (bid % per_group) % gsz) * BMB;
+  const int n0 = ((bid % per_group) / gsz) * BNB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const long b1 = blockIdx.y % p.batch1, b2 = blockIdx.y / p.batch1;
+  const long bz = b1 * p.sC + b2 * p.sC2;
+  const bf16_t* __restrict__ Ag = p.A + b1 * p.sA + b2 * p.sA2;
+  const bf16_t* __restrict__ Wg = p.W + b1 * p.sW + b2 * p.sW2;
+
+  // per-lane DMA sources: [half][instruction]; the lane's LDS slot is (row0 + lane/8, chunk lane%8), it fetches global chunk
+  // (lane%8) ^ swizzle(row) of that row
+  const bf16_t* a_src[2][2];
+  const bf16_t* w_src[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ra = i * 128 + h * 64 + wave * 8 + (lane >> 3);
+      const int rw = (i * 2 + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + (lane >> 3);
+      a_src[h][i] = Ag + (long)min(m0 + ra, p.M - 1) * p.lda + (((lane & 7) ^ ((ra >> 1) & 7)) << 3);
+      w_src[h][i] = Wg + (long)min(n0 + rw, p.N - 1) * p.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) << 3);
+    }
+  const int nt = p.K / BK;
+
+  f32x16_t acc[2][MI];
+  zero_acc<MI>(acc);
+  bf16x8_t af[2][4], wf0[4], wf1[4];
+  const int frow = lane & 31, fhalf = lane >> 5;
+
+  // prologue: S[0..5] = A0(0) W0(0) W1(0) A1(0) A0(1) W0(1)
+  PP_ISSUE_A(0, 0, smem); PP_ISSUE_W(0, 0, smem); PP_ISSUE_W(1, 0, smem); PP_ISSUE_A(1, 0, smem);
+  PP_ISSUE_A(0, 1, smem + BUF); PP_ISSUE_W(0, 1, smem + BUF);
+  PP_VM(8);
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();            // the stagger
+  __builtin_amdgcn_sched_barrier(0);
+
+  int t = 0;
+  for (; t < nt - 2; ++t) {
+    char* cur = smem + (t & 1) * BUF;
+    char* oth = smem + ((t + 1) & 1) * BUF;
+    PP_PHASE(PP_READ_W(wf0, 0, cur); PP_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM(8), PP_MMA(wf0, 0, 0));
+    PP_PHASE(PP_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM(8), PP_MMA(wf1, 1, 0));
+    PP_PHASE(PP_READ_A(2, cur), PP_ISSUE_A(0, t + 2, cur), PP_NOP, PP_MMA(wf1, 1, 2));
+    PP_PHASE(PP_NOP, PP_ISSUE_W(0, t + 2, cur), PP_VM(8), PP_MMA(wf0, 0, 2));
+  }
+  {   // K-tile nt-2: the last two half-tiles are issued, then the queue drains
+    char* cur = smem + (t & 1) * BUF;
+    char* oth = smem + ((t + 1) & 1) * BUF;
+    PP_PHASE(PP_READ_W(wf0, 0, cur); PP_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM(8), PP_MMA(wf0, 0, 0));
+    PP_PHASE(PP_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM(8), PP_MMA(wf1, 1, 0));
+    PP_PHASE(PP_READ_A(2, cur), PP_NOP, PP_NOP, PP_MMA(wf1, 1, 2));
+    PP_PHASE(PP_NOP, PP_NOP, PP_VM(4), PP_MMA(wf0, 0, 2));
+    cur = oth;   // K-tile nt-1
+    PP_PHASE(PP_READ_W(wf0, 0, cur); PP_READ_A(0, cur), PP_NOP, PP_VM(2), PP_MMA(wf0, 0, 0));
+    PP_PHASE(PP_READ_W(wf1, 1, cur), PP_NOP, PP_VM(0), PP_MMA(wf1, 1, 0));
+    PP_PHASE(PP_READ_A(2, cur), PP_NOP, PP_NOP, PP_MMA(wf1, 1, 2));
+    PP_PHASE(PP_NOP, PP_NOP, PP_NOP, PP_MMA(wf0, 0, 2));
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();            // re-join: every wave's reads and DMA are retired past this point
+  epilogue_lds<OUT_F32, MI>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
+}
+
 template <bool OUT_F32, int MI, int NBUF>
 void launch_glds(const GemmP& p, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((gemm_bf16_tn_glds_kernel<OUT_F32, MI, NBUF>), grid, dim3(NT), 0, s, p);
@@ -680,10 +814,11 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   p.skew = g_gemm_skew;
   int variant = (p.K % BK == 0 && !ta && !tw) ? g_gemm_variant : 0;
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN) * batch;
+  if (variant == 8 && p.K < 2 * BK) variant = 2;
   if (variant == 5) variant = 2;   // measured (tools/gemm_bench.py): 128x128 single-buffer DMA wins or ties on the hot-path shapes
   (void)tiles256;
-  const int bm = (variant == 3 || variant == 4 || variant == 6 || variant == 7) ? 256 : 128;
-  const int bn = (variant == 6 || variant == 7) ? 256 : BN;
+  const int bm = (variant == 3 || variant == 4 || variant >= 6) ? 256 : 128;
+  const int bn = variant >= 6 ? 256 : BN;
   p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
   dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);
   hipStream_t s = (hipStream_t)stream;
@@ -698,6 +833,10 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
     case 7:
       if (f) hipLaunchKernelGGL(gemm_bf16_tn_ring_kernel<true>, grid, dim3(NTB), 0, s, p);
       else hipLaunchKernelGGL(gemm_bf16_tn_ring_kernel<false>, grid, dim3(NTB), 0, s, p);
+      break;
+    case 8:
+      if (f) hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<true>, grid, dim3(NTB), 0, s, p);
+      else hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<false>, grid, dim3(NTB), 0, s, p);
       break;
     case 6:
       if (f) hipLaunchKernelGGL(gemm_bf16_tn_big_kernel<true>, grid, dim3(NTB), 0, s, p);

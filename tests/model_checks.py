@@ -173,5 +173,5 @@ def check_validate_loop(backbone="dinov2"):
         i, u, _, a = metric.union_resize_iou(segs, row, gt, threshold=thr)
         I += i.double(); U += u.double(); A += a.double()
     ref_g, ref_c = (A / 3)[1].item(), (I / (U + 1e-10))[1].item()
-    return [(f"{backbone} validate gIoU ({nsel} proposals selected)", abs(got["giou"] - ref_g), 1e-9),
-            (f"{backbone} validate cIoU", abs(got["ciou"] - ref_c), 1e-9)]
+    return [(f"{backbone} validate gIoU ({nsel} proposals selected)", abs(got["giou"] - ref_g), 1e-6),
+            (f"{backbone} validate cIoU", abs(got["ciou"] - ref_c), 1e-6)]

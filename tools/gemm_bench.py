@@ -7,12 +7,13 @@ import torch  # noqa: E402
 
 from llmseg_amd import _lib, ops  # noqa: E402
 
-SHAPES = [  # (M, N, K, tag)  B=8 images
-    (32768, 3840, 1280, "sam qkv (global)"), (39200, 3840, 1280, "sam qkv (windows)"), (32768, 1280, 1280, "sam proj"),
-    (32768, 5120, 1280, "sam lin1"), (32768, 1280, 5120, "sam lin2"),
-    (2552, 12288, 4096, "llama qkv"), (2552, 4096, 4096, "llama o"), (2552, 22016, 4096, "llama gate_up"), (2552, 4096, 11008, "llama down"),
-    (2552, 32004, 4096, "lm_head"), (2056, 3072, 1024, "clip qkv"), (4096, 4096, 4096, "4096^3"), (8192, 8192, 8192, "8192^3"),
+SHAPES = [  # (M, N, K, tag)  B=16 images
+    (65536, 3840, 1280, "sam qkv (global)"), (78400, 3840, 1280, "sam qkv (windows)"), (65536, 1280, 1280, "sam proj"),
+    (65536, 5120, 1280, "sam lin1"), (65536, 1280, 5120, "sam lin2"),
+    (5104, 12288, 4096, "llama qkv"), (5104, 4096, 4096, "llama o"), (5104, 22016, 4096, "llama gate_up"), (5104, 4096, 11008, "llama down"),
+    (5104, 32004, 4096, "lm_head"), (4112, 3072, 1024, "clip qkv"), (1000, 520, 128, "edge"), (4096, 4096, 4096, "4096^3"), (8192, 8192, 8192, "8192^3"),
 ]
+RACE_REPEATS = int(os.environ.get("RACE_REPEATS", "0"))
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["2", "6", "7"])]
 lib = _lib.load()
 torch.manual_seed(0)
@@ -41,5 +42,11 @@ for M, N, K, tag in SHAPES:
         if ref is None:
             ref = out.clone()
         chk.append((out.float() - ref.float()).abs().max().item())
+        if RACE_REPEATS and v == variants[-1]:   # determinism screen: any run-to-run difference is a synchronisation bug
+            first, bad = out.clone(), 0
+            for _ in range(RACE_REPEATS):
+                ops.gemm(a, w, bias=bias, out=out)
+                bad += int(not torch.equal(out, first))
+            chk.append(float(bad))
     print(f"{tag + f' {M}x{N}x{K}':32s} " + " ".join(f"{r:9.0f}" for r in res) + "   check " + " ".join(f"{c:.1e}" for c in chk), flush=True)
 lib.llmseg_gemm_set_variant(5)
