@@ -16,6 +16,8 @@
 // HBM/L2 latency is hidden by 3-4 co-resident workgroups per CU.  Variant R (any K % 8 == 0): global -> VGPR -> LDS with
 // zero-filled K tail, double-buffered.
 // Workgroup ids are remapped so that each of the 8 XCDs (private L2s) walks a contiguous, M-grouped range of tiles.
+#include <algorithm>
+#include <cstdlib>
 #include "common.h"
 #include "llmseg_hip.h"
 
@@ -34,6 +36,7 @@ struct GemmP {
   int act;
   int tiles_m, tiles_n;
   int c_vec, r_vec, b_vec;   // host-verified alignment for vector C stores / residual loads / bias+gamma loads
+  int dbg, batch_total;      // experiment switches (LLMSEG_GEMM_DBG); batch1 * batch2
   int skew;                  // per-XCD rotation of the tile walk (de-phases the 8 XCDs' HBM/MALL channel access)
 };
 
@@ -47,9 +50,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
       const float erfa = 1.f - poly * __expf(-z * z);
       return 0.5f * v * (1.f + copysignf(erfa, v));
     }
-    case LLMSEG_ACT_QUICKGELU: return v / (1.f + __expf(-1.702f * v));
-    case LLMSEG_ACT_SILU: return v / (1.f + __expf(-v));
-    case LLMSEG_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+    case LLMSEG_ACT_QUICKGELU: return v * __frcp_rn(1.f + __expf(-1.702f * v));
+    case LLMSEG_ACT_SILU: return v * __frcp_rn(1.f + __expf(-v));
+    case LLMSEG_ACT_SIGMOID: return __frcp_rn(1.f + __expf(-v));
     default: return v;
   }
 }
@@ -170,8 +173,8 @@ __device__ __forceinline__ void epilogue(const GemmP& p, const f32x16_t (&acc)[2
 // pieces scattered over 32 rows (measured on 32768x1280x1280 + bias + residual: 480 -> see profiles).  LDS ops of one wave
 // execute in order, so no barrier is needed; the slab aliases the (finished) operand tiles.
 template <bool OUT_F32, int MI>
-__device__ __forceinline__ void epilogue_lds(const GemmP& p, const f32x16_t (&acc)[2][MI], char* smem, int wave, int m0, int n0, int wm, int wn,
-                                             int lane, long bz) {
+__device__ __forceinline__ void epilogue_lds_edge(const GemmP& p, const f32x16_t (&acc)[2][MI], char* smem, int wave, int m0, int n0, int wm, int wn,
+                                               int lane, long bz) {
   float* slab = reinterpret_cast<float*>(smem) + wave * (32 * 64);
   const int frow = lane & 31, fhalf = lane >> 5;
   const int c = lane & 15, rsub = lane >> 4;
@@ -245,6 +248,85 @@ __device__ __forceinline__ void epilogue_lds(const GemmP& p, const f32x16_t (&ac
         }
       }
     }
+  }
+}
+
+// Interior tiles (the wave's whole (32*MI) x 64 block inside C, every row start 4-element aligned): the same LDS bounce as
+// straight-line code - no per-lane bounds or alignment branches, the activation resolved once per tile (ACT is a template
+// argument of the body), LDS offsets hoisted out of the pass loop, running 64-bit row pointers instead of a 64-bit multiply per
+// row.  The branchy edge version above costs ~10-18 us per 256 x 256 tile (instruction-bound with 2 waves/SIMD).
+template <bool OUT_F32, int MI, int ACT>
+__device__ __forceinline__ void epilogue_lds_body(const GemmP& p, const f32x16_t (&acc)[2][MI], float* slab, int mw, int nw, int lane, long bz) {
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int c = lane & 15, rsub = lane >> 4;
+  const int n = nw + c * 4;
+  float bs[4] = {0.f, 0.f, 0.f, 0.f}, gm[4] = {1.f, 1.f, 1.f, 1.f};
+  if (p.bias) ld4bf(p.bias + n, true, 4, bs);
+  if (p.gamma) ld4bf(p.gamma + n, true, 4, gm);
+  int woff[8], roff[4];
+#pragma unroll
+  for (int jg = 0; jg < 8; ++jg) woff[jg] = frow * 64 + (((((jg >> 2) * 8 + (jg & 3) * 2 + fhalf)) ^ (frow & 15)) << 2);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) roff[it] = (it * 4 + rsub) * 64 + ((c ^ ((it * 4 + rsub) & 15)) << 2);
+  const long row0 = (long)(mw + rsub);
+  char* cp = reinterpret_cast<char*>(p.C) + (bz + row0 * p.ldc + n) * (OUT_F32 ? 4 : 2);
+  const long cstep = 4 * p.ldc * (OUT_F32 ? 4 : 2);
+  const bf16_t* rp = p.res ? p.res + bz + row0 * p.ldr + n : nullptr;
+  const long rstep = 4 * p.ldr;
+  const float alpha = p.alpha;
+  const bool has_gamma = p.gamma != nullptr;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    uint2 rpre[8];
+    if (rp) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) { rpre[it] = *reinterpret_cast<const uint2*>(rp); rp += rstep; }
+    }
+#pragma unroll
+    for (int jg = 0; jg < 8; ++jg) {
+      const int j = jg >> 2, g = jg & 3;
+      *reinterpret_cast<float4*>(slab + woff[jg]) = make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const float4 a4 = *reinterpret_cast<const float4*>(slab + roff[it & 3] + (it >> 2) * (16 * 64));
+      float v[4] = {fmaf(a4.x, alpha, bs[0]), fmaf(a4.y, alpha, bs[1]), fmaf(a4.z, alpha, bs[2]), fmaf(a4.w, alpha, bs[3])};
+      if (ACT != LLMSEG_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], ACT);
+      }
+      if (has_gamma) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gm[e];
+      }
+      if (rp) {
+        v[0] += __uint_as_float(rpre[it].x << 16); v[1] += __uint_as_float(rpre[it].x & 0xffff0000u);
+        v[2] += __uint_as_float(rpre[it].y << 16); v[3] += __uint_as_float(rpre[it].y & 0xffff0000u);
+      }
+      if (OUT_F32) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+      else *reinterpret_cast<uint2*>(cp) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      cp += cstep;
+    }
+  }
+}
+
+template <bool OUT_F32, int MI>
+__device__ __forceinline__ void epilogue_lds(const GemmP& p, const f32x16_t (&acc)[2][MI], char* smem, int wave, int m0, int n0, int wm, int wn,
+                                             int lane, long bz) {
+  const int mw = m0 + wm * 32 * MI, nw = n0 + wn * 64;
+  const bool interior = mw + 32 * MI <= p.M && nw + 64 <= p.N && p.c_vec && p.b_vec && (!p.res || p.r_vec);
+  if (!interior) {
+    epilogue_lds_edge<OUT_F32, MI>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
+    return;
+  }
+  float* slab = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+  switch (p.act) {
+    case LLMSEG_ACT_NONE: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_NONE>(p, acc, slab, mw, nw, lane, bz); break;
+    case LLMSEG_ACT_GELU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_GELU>(p, acc, slab, mw, nw, lane, bz); break;
+    case LLMSEG_ACT_QUICKGELU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_QUICKGELU>(p, acc, slab, mw, nw, lane, bz); break;
+    case LLMSEG_ACT_SILU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_SILU>(p, acc, slab, mw, nw, lane, bz); break;
+    case LLMSEG_ACT_RELU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_RELU>(p, acc, slab, mw, nw, lane, bz); break;
+    default: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_SIGMOID>(p, acc, slab, mw, nw, lane, bz); break;
   }
 }
 
@@ -665,11 +747,184 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_ring_kernel(GemmP p) {
   _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)             \
       af[ii][ks] = *reinterpret_cast<const bf16x8_t*>((base) + lds_off(wm * 128 + ((i0) + ii) * 32 + frow, ks * 2 + fhalf))
 #define PP_MMA(wfx, j, i0)                                                                \
-  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) \
-      acc[j][(i0) + ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfx[ks], af[ii][ks], acc[j][(i0) + ii], 0, 0, 0)
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) { \
+      acc[j][(i0) + ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfx[ks], af[ii][ks], acc[j][(i0) + ii], 0, 0, 0); \
+      if (DBG && tim && ks == 0 && ii == 0) { __builtin_amdgcn_sched_barrier(0); T1n = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } }
 #define PP_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define PP_NOP ((void)0)
 #define PP_PHASE(READS, ISSUE, WAIT, MMA)               \
+  do {                                                  \
+    if (!DBG || !(p.dbg & 8)) { READS; }                \
+    if (!DBG || !(p.dbg & 4)) { ISSUE; }                \
+    WAIT;                                               \
+    __builtin_amdgcn_sched_barrier(0);                  \
+    __builtin_amdgcn_s_barrier();                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                  \
+    __builtin_amdgcn_s_setprio(1);                      \
+    if (!DBG || !(p.dbg & 16)) { MMA; }                 \
+    __builtin_amdgcn_s_setprio(0);                      \
+    if (DBG && tim) {                                   \
+      sM += (uint32_t)(T2p - T1p); sB += (uint32_t)(T3p - T2p); sL += (uint32_t)(T1n - T3p); T1p = T1n; \
+    }                                                   \
+    __builtin_amdgcn_sched_barrier(0);                  \
+    if (DBG && tim) T2p = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_s_barrier();                       \
+    if (DBG && tim) T3p = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0);                  \
+  } while (0)
+
+// PERSIST: one workgroup per CU walks tiles blockIdx.x, +gridDim.x, ...; the next tile's first four half-tiles are issued
+// BEFORE this tile's epilogue (which bounces through buffer 1), so the DMA latency, the workgroup launch and part of the store
+// drain overlap.
+template <bool OUT_F32, bool PERSIST, bool DBG>
+__global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
+  constexpr int MI = 4, BMB = 256, BNB = 256;
+  constexpr int OP_BYTES = 256 * BK * 2, BUF = 2 * OP_BYTES;     // 32 KiB per operand, 64 KiB per buffer
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int total = PERSIST ? nwg * p.batch_total : 0;
+
+  int m0, n0;
+  long bz;
+  // per-lane DMA sources: [half][instruction]; the lane's LDS slot is (row0 + lane/8, chunk lane%8), it fetches global chunk
+  // (lane%8) ^ swizzle(row) of that row
+  const bf16_t* a_src[2][2];
+  const bf16_t* w_src[2][2];
+  auto setup = [&](int tile, int by) {
+    int bid = tile;
+    if (PERSIST) { by = tile / nwg; bid = tile - by * nwg; }
+    {
+      const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+      const int len = q + (xcd < r ? 1 : 0);
+      const int idx = ((bid >> 3) + xcd * p.skew) % len;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int per_group = GROUP_M * p.tiles_n;
+    const int first_m = (bid / per_group) * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    m0 = (first_m + (bid % per_group) % gsz) * BMB;
+    n0 = ((bid % per_group) / gsz) * BNB;
+    const long b1 = by % p.batch1, b2 = by / p.batch1;
+    bz = b1 * p.sC + b2 * p.sC2;
+    const bf16_t* __restrict__ Ag = p.A + b1 * p.sA + b2 * p.sA2;
+    const bf16_t* __restrict__ Wg = p.W + b1 * p.sW + b2 * p.sW2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ra = i * 128 + h * 64 + wave * 8 + (lane >> 3);
+        const int rw = (i * 2 + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + (lane >> 3);
+        a_src[h][i] = Ag + (long)min(m0 + ra, p.M - 1) * p.lda + (((lane & 7) ^ ((ra >> 1) & 7)) << 3);
+        w_src[h][i] = Wg + (long)min(n0 + rw, p.N - 1) * p.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) << 3);
+      }
+  };
+  const int nt = (p.dbg & 2) ? 2 : p.K / BK;
+  const int gsel = DBG ? (p.dbg >> 5) & 3 : 0;           // experiment: which waves form the lagging group
+  const bool nostag = gsel == 3;
+  const bool tim = DBG && (p.dbg & 128);
+  uint64_t T1n = 0, T1p = 0, T2p = 0, T3p = 0;
+  uint32_t sM = 0, sB = 0, sL = 0;
+  uint64_t T0 = 0;
+  if (tim) { T0 = T1p = T2p = T3p = __builtin_amdgcn_s_memtime(); }
+  const bool lag = gsel == 0 ? wm == 1 : gsel == 1 ? (wave & 1) : gsel == 2 ? ((wave >> 1) & 1) : false;
+
+  f32x16_t acc[2][MI];
+  bf16x8_t af[2][4] = {}, wf0[4] = {}, wf1[4] = {};
+
+  int tile = blockIdx.x;
+  setup(tile, blockIdx.y);
+  // prologue: S[0..5] = A0(0) W0(0) W1(0) A1(0) A0(1) W0(1)
+  PP_ISSUE_A(0, 0, smem); PP_ISSUE_W(0, 0, smem); PP_ISSUE_W(1, 0, smem); PP_ISSUE_A(1, 0, smem);
+  PP_ISSUE_A(0, 1, smem + BUF); PP_ISSUE_W(0, 1, smem + BUF);
+  while (true) {
+    zero_acc<MI>(acc);
+    PP_VM(8);
+    __builtin_amdgcn_s_barrier();
+    if (lag) __builtin_amdgcn_s_barrier();                // the stagger
+    __builtin_amdgcn_sched_barrier(0);
+
+    int t = 0;
+    for (; t < nt - 2; ++t) {
+      char* cur = smem + (t & 1) * BUF;
+      char* oth = smem + ((t + 1) & 1) * BUF;
+      PP_PHASE(PP_READ_W(wf0, 0, cur); PP_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM(8), PP_MMA(wf0, 0, 0));
+      PP_PHASE(PP_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM(8), PP_MMA(wf1, 1, 0));
+      PP_PHASE(PP_READ_A(2, cur), PP_ISSUE_A(0, t + 2, cur), PP_NOP, PP_MMA(wf1, 1, 2));
+      PP_PHASE(PP_NOP, PP_ISSUE_W(0, t + 2, cur), PP_VM(8), PP_MMA(wf0, 0, 2));
+    }
+    {   // K-tile nt-2: the last two half-tiles are issued, then the queue drains
+      char* cur = smem + (t & 1) * BUF;
+      char* oth = smem + ((t + 1) & 1) * BUF;
+      PP_PHASE(PP_READ_W(wf0, 0, cur); PP_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM(8), PP_MMA(wf0, 0, 0));
+      PP_PHASE(PP_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM(8), PP_MMA(wf1, 1, 0));
+      PP_PHASE(PP_READ_A(2, cur), PP_NOP, PP_NOP, PP_MMA(wf1, 1, 2));
+      PP_PHASE(PP_NOP, PP_NOP, PP_VM(4), PP_MMA(wf0, 0, 2));
+      cur = oth;   // K-tile nt-1
+      PP_PHASE(PP_READ_W(wf0, 0, cur); PP_READ_A(0, cur), PP_NOP, PP_VM(2), PP_MMA(wf0, 0, 0));
+      PP_PHASE(PP_READ_W(wf1, 1, cur), PP_NOP, PP_VM(0), PP_MMA(wf1, 1, 0));
+      PP_PHASE(PP_READ_A(2, cur), PP_NOP, PP_NOP, PP_MMA(wf1, 1, 2));
+      PP_PHASE(PP_NOP, PP_NOP, PP_NOP, PP_MMA(wf0, 0, 2));
+    }
+    if (!lag && !nostag) __builtin_amdgcn_s_barrier();    // re-join: every wave's reads and DMA are retired past this point
+    if (DBG && tim && blockIdx.x < 4 && blockIdx.y == 0 && lane == 0) {
+      uint32_t* o = reinterpret_cast<uint32_t*>(p.C) + (blockIdx.x * 8 + wave) * 4;
+      o[0] = sM; o[1] = sB; o[2] = sL; o[3] = (uint32_t)(__builtin_amdgcn_s_memtime() - T0);
+    }
+    if (!PERSIST) {
+      if (!(p.dbg & 1)) epilogue_lds<OUT_F32, MI>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
+      break;
+    }
+    const int em0 = m0, en0 = n0;
+    const long ebz = bz;
+    const int next = tile + gridDim.x;
+    if (next < total) {
+      setup(next, 0);
+      PP_ISSUE_A(0, 0, smem); PP_ISSUE_W(0, 0, smem); PP_ISSUE_W(1, 0, smem); PP_ISSUE_A(1, 0, smem);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(p.dbg & 1)) epilogue_lds<OUT_F32, MI>(p, acc, smem + BUF, wave, em0, en0, wm, wn, lane, ebz);
+    if (next >= total) break;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // every wave is done with its slab in buffer 1
+    PP_ISSUE_A(0, 1, smem + BUF); PP_ISSUE_W(0, 1, smem + BUF);
+    tile = next;
+  }
+}
+
+// ---- variant Q4: the ping-pong kernel with K-HALF phases: every MFMA section runs 8 MFMAs over FOUR independent accumulators ----
+// Measured on variant Q (tools/gemm_timing.py): one wave alternating two accumulators issues a 32x32x16 MFMA every ~42-46
+// cycles (dependent-issue latency ~85 cycles), not every 32.  Here a phase is (k-half kh, weight sub-block j): acc[j][0..3] +=
+// W[j][kh] x A[0..3][kh], dependent distance 4 MFMAs.
+//   LDS per buffer (64 KiB): A[kh][256][32], W[kh][256][32] bf16 = four 16 KiB half-tiles with 64-byte rows, chunk XOR (row>>2)&3
+//   phase:        p0 (kh0, j0)      p1 (kh0, j1)     p2 (kh1, j0)      p3 (kh1, j1)
+//   reads         A_kh0 (8) W (2)   W (2)            A_kh1 (8) W (2)   W (2)
+//   DMA issue     S[g+6] with S = A_kh0, W_kh0, A_kh1, W_kh1 per K-tile (re-issue exactly 2 phases after the slot's last read)
+//   s_waitcnt     -                 vmcnt(8)         -                 vmcnt(8)          (retires the k-half phase g+1 starts reading)
+#define PQ_DMA(src, i, koff, dst) __builtin_amdgcn_global_load_lds((gbl_ptr_t)((src)[i] + (koff)), (lds_ptr_t)(dst), 16, 0, 0)
+// n = issue sequence index: K-tile n>>2, half-tile n&3 (0 A_kh0, 1 W_kh0, 2 A_kh1, 3 W_kh1) -> LDS slot of buffer (n>>2)&1
+#define PQ_ISSUE(n)                                                                             \
+  do {                                                                                          \
+    const int n_ = (n);                                                                         \
+    char* d_ = smem + ((n_ >> 2) & 1) * BUF + ((n_ & 1) * 2 + ((n_ >> 1) & 1)) * HT + wave * 1024; \
+    const long k_ = (long)(n_ >> 2) * BK + ((n_ >> 1) & 1) * 32;                                \
+    if (n_ & 1) { PQ_DMA(w_src, 0, k_, d_); PQ_DMA(w_src, 1, k_, d_ + 8192); }                  \
+    else        { PQ_DMA(a_src, 0, k_, d_); PQ_DMA(a_src, 1, k_, d_ + 8192); }                  \
+  } while (0)
+#define PQ_READ_A(kh, base)                                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)               \
+      af[i][ks] = *reinterpret_cast<const bf16x8_t*>((base) + (kh) * HT + lds_off32(wm * 128 + i * 32 + frow, ks * 2 + fhalf))
+#define PQ_READ_W(dst, kh, j, base)                                                                             \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
+      dst[ks] = *reinterpret_cast<const bf16x8_t*>((base) + (2 + (kh)) * HT + lds_off32(wn * 64 + (j) * 32 + frow, ks * 2 + fhalf))
+#define PQ_MMA(wfx, j)                                                                      \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) \
+      acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfx[ks], af[i][ks], acc[j][i], 0, 0, 0)
+#define PQ_PHASE(READS, ISSUE, WAIT, MMA)               \
   do {                                                  \
     READS; ISSUE; WAIT;                                 \
     __builtin_amdgcn_sched_barrier(0);                  \
@@ -685,9 +940,9 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_ring_kernel(GemmP p) {
   } while (0)
 
 template <bool OUT_F32>
-__global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
+__global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pq_kernel(GemmP p) {
   constexpr int MI = 4, BMB = 256, BNB = 256;
-  constexpr int OP_BYTES = 256 * BK * 2, BUF = 2 * OP_BYTES;     // 32 KiB per operand, 64 KiB per buffer
+  constexpr int HT = 256 * 32 * 2, BUF = 4 * HT;                  // 16 KiB half-tiles, 64 KiB per buffer
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   int bid = blockIdx.x;
   const int nwg = p.tiles_m * p.tiles_n;
@@ -711,29 +966,25 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
   const bf16_t* __restrict__ Ag = p.A + b1 * p.sA + b2 * p.sA2;
   const bf16_t* __restrict__ Wg = p.W + b1 * p.sW + b2 * p.sW2;
 
-  // per-lane DMA sources: [half][instruction]; the lane's LDS slot is (row0 + lane/8, chunk lane%8), it fetches global chunk
-  // (lane%8) ^ swizzle(row) of that row
-  const bf16_t* a_src[2][2];
-  const bf16_t* w_src[2][2];
+  // DMA instruction i of this wave fills LDS rows (i*8 + wave)*16 .. +15 (64 B each) of a half-tile: lane -> (row, slot lane%4),
+  // fetching global chunk (lane%4) ^ swizzle(row) of the k-half
+  const bf16_t* a_src[2];
+  const bf16_t* w_src[2];
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ra = i * 128 + h * 64 + wave * 8 + (lane >> 3);
-      const int rw = (i * 2 + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + (lane >> 3);
-      a_src[h][i] = Ag + (long)min(m0 + ra, p.M - 1) * p.lda + (((lane & 7) ^ ((ra >> 1) & 7)) << 3);
-      w_src[h][i] = Wg + (long)min(n0 + rw, p.N - 1) * p.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) << 3);
-    }
+  for (int i = 0; i < 2; ++i) {
+    const int row = (i * 8 + wave) * 16 + (lane >> 2);
+    const int sw = (((lane & 3) ^ ((row >> 2) & 3)) << 3);
+    a_src[i] = Ag + (long)min(m0 + row, p.M - 1) * p.lda + sw;
+    w_src[i] = Wg + (long)min(n0 + row, p.N - 1) * p.ldw + sw;
+  }
   const int nt = p.K / BK;
 
   f32x16_t acc[2][MI];
   zero_acc<MI>(acc);
-  bf16x8_t af[2][4], wf0[4], wf1[4];
+  bf16x8_t af[4][2], wf0[2], wf1[2];
   const int frow = lane & 31, fhalf = lane >> 5;
 
-  // prologue: S[0..5] = A0(0) W0(0) W1(0) A1(0) A0(1) W0(1)
-  PP_ISSUE_A(0, 0, smem); PP_ISSUE_W(0, 0, smem); PP_ISSUE_W(1, 0, smem); PP_ISSUE_A(1, 0, smem);
-  PP_ISSUE_A(0, 1, smem + BUF); PP_ISSUE_W(0, 1, smem + BUF);
+  PQ_ISSUE(0); PQ_ISSUE(1); PQ_ISSUE(2); PQ_ISSUE(3); PQ_ISSUE(4); PQ_ISSUE(5);
   PP_VM(8);
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();            // the stagger
@@ -741,25 +992,25 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
 
   int t = 0;
   for (; t < nt - 2; ++t) {
-    char* cur = smem + (t & 1) * BUF;
-    char* oth = smem + ((t + 1) & 1) * BUF;
-    PP_PHASE(PP_READ_W(wf0, 0, cur); PP_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM(8), PP_MMA(wf0, 0, 0));
-    PP_PHASE(PP_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM(8), PP_MMA(wf1, 1, 0));
-    PP_PHASE(PP_READ_A(2, cur), PP_ISSUE_A(0, t + 2, cur), PP_NOP, PP_MMA(wf1, 1, 2));
-    PP_PHASE(PP_NOP, PP_ISSUE_W(0, t + 2, cur), PP_VM(8), PP_MMA(wf0, 0, 2));
+    const char* cur = smem + (t & 1) * BUF;
+    const int g = 4 * t;
+    PQ_PHASE(PQ_READ_A(0, cur); PQ_READ_W(wf0, 0, 0, cur), PQ_ISSUE(g + 6), PP_NOP, PQ_MMA(wf0, 0));
+    PQ_PHASE(PQ_READ_W(wf1, 0, 1, cur), PQ_ISSUE(g + 7), PP_VM(8), PQ_MMA(wf1, 1));
+    PQ_PHASE(PQ_READ_A(1, cur); PQ_READ_W(wf0, 1, 0, cur), PQ_ISSUE(g + 8), PP_NOP, PQ_MMA(wf0, 0));
+    PQ_PHASE(PQ_READ_W(wf1, 1, 1, cur), PQ_ISSUE(g + 9), PP_VM(8), PQ_MMA(wf1, 1));
   }
-  {   // K-tile nt-2: the last two half-tiles are issued, then the queue drains
-    char* cur = smem + (t & 1) * BUF;
-    char* oth = smem + ((t + 1) & 1) * BUF;
-    PP_PHASE(PP_READ_W(wf0, 0, cur); PP_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM(8), PP_MMA(wf0, 0, 0));
-    PP_PHASE(PP_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM(8), PP_MMA(wf1, 1, 0));
-    PP_PHASE(PP_READ_A(2, cur), PP_NOP, PP_NOP, PP_MMA(wf1, 1, 2));
-    PP_PHASE(PP_NOP, PP_NOP, PP_VM(4), PP_MMA(wf0, 0, 2));
-    cur = oth;   // K-tile nt-1
-    PP_PHASE(PP_READ_W(wf0, 0, cur); PP_READ_A(0, cur), PP_NOP, PP_VM(2), PP_MMA(wf0, 0, 0));
-    PP_PHASE(PP_READ_W(wf1, 1, cur), PP_NOP, PP_VM(0), PP_MMA(wf1, 1, 0));
-    PP_PHASE(PP_READ_A(2, cur), PP_NOP, PP_NOP, PP_MMA(wf1, 1, 2));
-    PP_PHASE(PP_NOP, PP_NOP, PP_NOP, PP_MMA(wf0, 0, 2));
+  {   // K-tile nt-2: S[4nt-2], S[4nt-1] are the last issues, then the queue drains
+    const char* cur = smem + (t & 1) * BUF;
+    const int g = 4 * t;
+    PQ_PHASE(PQ_READ_A(0, cur); PQ_READ_W(wf0, 0, 0, cur), PQ_ISSUE(g + 6), PP_NOP, PQ_MMA(wf0, 0));
+    PQ_PHASE(PQ_READ_W(wf1, 0, 1, cur), PQ_ISSUE(g + 7), PP_VM(8), PQ_MMA(wf1, 1));
+    PQ_PHASE(PQ_READ_A(1, cur); PQ_READ_W(wf0, 1, 0, cur), PP_NOP, PP_NOP, PQ_MMA(wf0, 0));
+    PQ_PHASE(PQ_READ_W(wf1, 1, 1, cur), PP_NOP, PP_VM(4), PQ_MMA(wf1, 1));     // A_kh0, W_kh0 of the last K-tile landed
+    cur = smem + ((t + 1) & 1) * BUF;
+    PQ_PHASE(PQ_READ_A(0, cur); PQ_READ_W(wf0, 0, 0, cur), PP_NOP, PP_NOP, PQ_MMA(wf0, 0));
+    PQ_PHASE(PQ_READ_W(wf1, 0, 1, cur), PP_NOP, PP_VM(0), PQ_MMA(wf1, 1));     // A_kh1, W_kh1 landed
+    PQ_PHASE(PQ_READ_A(1, cur); PQ_READ_W(wf0, 1, 0, cur), PP_NOP, PP_NOP, PQ_MMA(wf0, 0));
+    PQ_PHASE(PQ_READ_W(wf1, 1, 1, cur), PP_NOP, PP_NOP, PQ_MMA(wf1, 1));
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();            // re-join: every wave's reads and DMA are retired past this point
   epilogue_lds<OUT_F32, MI>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
@@ -780,6 +1031,10 @@ void llmseg_prof_tag(long a, long b, long c, long d);
 // tuning knob: 0 = register staging 128x128; 1 = DMA 128x128 x2 buffers; 2 = DMA 128x128 x1; 3 = DMA 256x128 x1; 4 = DMA 256x128 x2;
 // 5 (default) = auto: 256x128 x1 when that still gives every CU >= 2 workgroups, else 128x128 x1
 static int g_gemm_variant = 5, g_gemm_skew = 13;
+static int num_cus() {
+  static int n = [] { int dev = 0, v = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
+  return n;
+}
 extern "C" int llmseg_gemm_set_variant(int v) { g_gemm_variant = v & 15; if (v >= 16) g_gemm_skew = (v >> 4) - 1; return LLMSEG_OK; }
 
 extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
@@ -812,11 +1067,18 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   p.b_vec = ((p.bias == nullptr || (((uintptr_t)p.bias) & 7) == 0) && (p.gamma == nullptr || (((uintptr_t)p.gamma) & 7) == 0)) ? 1 : 0;
 
   p.skew = g_gemm_skew;
+  static const int dbg = getenv("LLMSEG_GEMM_DBG") ? atoi(getenv("LLMSEG_GEMM_DBG")) : 0;
+  p.dbg = dbg; p.batch_total = (int)batch;
   int variant = (p.K % BK == 0 && !ta && !tw) ? g_gemm_variant : 0;
-  const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN) * batch;
-  if (variant == 8 && p.K < 2 * BK) variant = 2;
-  if (variant == 5) variant = 2;   // measured (tools/gemm_bench.py): 128x128 single-buffer DMA wins or ties on the hot-path shapes
-  (void)tiles256;
+  if (variant >= 8 && p.K < 2 * BK) variant = 2;
+  if (variant == 5) {
+    // auto: the 256 x 256 ping-pong kernel (one workgroup per CU) when its tiles fill >= 70 % of whole rounds of the CUs (edge
+    // tiles counted by their useful area); the 128 x 128 single-buffer DMA kernel (4 workgroups/CU) otherwise.  Measured with
+    // tools/gemm_bench.py: +15..35 % on every hot-path shape that passes the test, -10 % on the 320-tile Llama N = 4096 shapes.
+    const long tm = (p.M + 255) / 256, tn = (p.N + 255) / 256, tiles = tm * tn * batch, ncu = num_cus();
+    const double fill = (double)tiles / (double)(((tiles + ncu - 1) / ncu) * ncu) * ((double)p.M * p.N / ((double)tm * 256 * tn * 256));
+    variant = fill >= 0.7 ? 8 : 2;
+  }
   const int bm = (variant == 3 || variant == 4 || variant >= 6) ? 256 : 128;
   const int bn = variant >= 6 ? 256 : BN;
   p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
@@ -835,9 +1097,21 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
       else hipLaunchKernelGGL(gemm_bf16_tn_ring_kernel<false>, grid, dim3(NTB), 0, s, p);
       break;
     case 8:
-      if (f) hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<true>, grid, dim3(NTB), 0, s, p);
-      else hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<false>, grid, dim3(NTB), 0, s, p);
+      if (f) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<true, false, false>), grid, dim3(NTB), 0, s, p);
+      else hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, false, false>), grid, dim3(NTB), 0, s, p);
       break;
+    case 11:
+      if (f) hipLaunchKernelGGL(gemm_bf16_tn_pq_kernel<true>, grid, dim3(NTB), 0, s, p);
+      else hipLaunchKernelGGL(gemm_bf16_tn_pq_kernel<false>, grid, dim3(NTB), 0, s, p);
+      break;
+    case 10: hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, false, true>), grid, dim3(NTB), 0, s, p); break;
+    case 9: {
+      const long total = (long)p.tiles_m * p.tiles_n * batch;
+      dim3 pgrid((unsigned)std::min<long>(total, num_cus()));
+      if (f) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<true, true, false>), pgrid, dim3(NTB), 0, s, p);
+      else hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, true, false>), pgrid, dim3(NTB), 0, s, p);
+      break;
+    }
     case 6:
       if (f) hipLaunchKernelGGL(gemm_bf16_tn_big_kernel<true>, grid, dim3(NTB), 0, s, p);
       else hipLaunchKernelGGL(gemm_bf16_tn_big_kernel<false>, grid, dim3(NTB), 0, s, p);

@@ -63,6 +63,35 @@ def check_gemm():
     ops.gemm_batched(qd, tabd, o, M=rows, N=R, K=hd, lda=3 * heads * hd, ldw=hd, ldc=32, batch=heads, sA=hd, sW=0, sC=rows * 32)
     ref = torch.stack([q[:, h * hd:(h + 1) * hd].float() @ tab[:R].float().t() for h in range(heads)])
     out.append(("gemm batched rel-pos", err(o[:, :, :R], ref), 1e-3))
+    # the 256 x 256 ping-pong kernel: picked automatically for long-K / many-tile shapes, and forced (variant 8) on ragged
+    # edge tiles, the K = 128 minimum, the fused epilogue, fp32 output and a strided batch
+    from llmseg_amd import _lib
+    M, N, K = 4096, 4096, 2048
+    a, w = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=1 / math.sqrt(K))
+    ref = a.float() @ w.float().t()
+    out.append((f"gemm auto->ping-pong {M}x{N}x{K}", err(ops.gemm(a.to(DEV), w.to(DEV)), ref), tol_bf16(ref)))
+    lib = _lib.load()
+    lib.llmseg_gemm_set_variant(8)
+    try:
+        for i, (M, N, K) in enumerate([(1000, 520, 128), (257, 300, 192), (513, 256, 1280)]):
+            a, w = rnd(M, K, seed=40 + i), rnd(N, K, seed=50 + i, scale=1 / math.sqrt(K))
+            ref = a.float() @ w.float().t()
+            out.append((f"gemm ping-pong {M}x{N}x{K}", err(ops.gemm(a.to(DEV), w.to(DEV)), ref), tol_bf16(ref)))
+        M, N, K = 300, 520, 256
+        a, w, b, g, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / 16), rnd(N, seed=3), rnd(N, seed=4), rnd(M, N, seed=5)
+        ref = r.float() + g.float() * F.gelu(a.float() @ w.float().t() + b.float())
+        got = ops.gemm(a.to(DEV), w.to(DEV), bias=b.to(DEV), act=ops.ACT_GELU, residual=r.to(DEV), gamma=g.to(DEV))
+        out.append(("gemm ping-pong epilogue gelu", err(got, ref), tol_bf16(ref, 1.5)))
+        ref = 0.5 * (a.float() @ w.float().t())
+        out.append(("gemm ping-pong f32-out", err(ops.gemm(a.to(DEV), w.to(DEV), alpha=0.5, out_f32=True), ref), 1e-3))
+        nb, M, N, K = 3, 260, 300, 128
+        ab, wb = rnd(nb * M, K, seed=61), rnd(nb * N, K, seed=62, scale=1 / 8)
+        ob = torch.zeros(nb, M, N, device=DEV, dtype=torch.float32)
+        ops.gemm_batched(ab.to(DEV), wb.to(DEV), ob, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, batch=nb, sA=M * K, sW=N * K, sC=M * N)
+        ref = torch.stack([ab[i * M:(i + 1) * M].float() @ wb[i * N:(i + 1) * N].float().t() for i in range(nb)])
+        out.append(("gemm ping-pong batched", err(ob, ref), 1e-3))
+    finally:
+        lib.llmseg_gemm_set_variant(5)
     return out
 
 

@@ -108,7 +108,9 @@ def check_tiny_train_losses(backbone="dinov2"):
     for k in ("ce_loss", "align_loss", "regression_loss", "loss"):
         r = float(ref[k])
         res.append((f"{backbone} train {k} (ref {r:.4f}, bf16-CPU err {abs(float(lo[k]) - r):.2e})", abs(float(got[k]) - r),
-                    max(2e-3 * max(1.0, abs(r)), 3.0 * abs(float(lo[k]) - r))))
+                    # scalar losses carry the bf16 rounding of the whole network (eps = 3.9e-3): 0.5 % of the value, or three
+                    # times what the SAME fp32 oracle run in bf16 on the CPU deviates, whichever is larger
+                    max(5e-3 * max(1.0, abs(r)), 3.0 * abs(float(lo[k]) - r))))
     return res
 
 

@@ -14,6 +14,8 @@ SHAPES = [  # (M, N, K, tag)  B=16 images
     (5104, 32004, 4096, "lm_head"), (4112, 3072, 1024, "clip qkv"), (1000, 520, 128, "edge"), (4096, 4096, 4096, "4096^3"), (8192, 8192, 8192, "8192^3"),
 ]
 RACE_REPEATS = int(os.environ.get("RACE_REPEATS", "0"))
+if os.environ.get("GEMM_SHAPES"):
+    SHAPES = [SHAPES[int(i)] for i in os.environ["GEMM_SHAPES"].split(",")]
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["2", "6", "7"])]
 lib = _lib.load()
 torch.manual_seed(0)
