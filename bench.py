@@ -105,7 +105,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="images per rank per step")
+    ap.add_argument("--batch", type=int, default=24,
+                    help="images per rank per step (24: every Llama GEMM, M = 24 x 319 rows, fills whole rounds of 256 x 256 tiles)")
     ap.add_argument("--backbone", default="sam", choices=["sam", "dinov2"])
     ap.add_argument("--masks", type=int, default=256)
     ap.add_argument("--prompt-len", type=int, default=64)
@@ -234,8 +235,9 @@ def main():
                 args.masks, args.prompt_len),
                        "images_per_gpu_per_step": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "valid": not args.small},
-            # dominant kernel = the bf16 128x128 LDS-DMA GEMM; achieved = its algorithmic 2MNK per launch / its HIP-event duration
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_tn_glds_kernel<false, 2, 1>", "achieved": ach, "peak": PEAK_BF16_TFLOPS,
+            # dominant kernel = the GEMM kernel class with the largest total time (the 256x256 ping-pong LDS-DMA GEMM on this
+            # workload); achieved = its algorithmic 2MNK per launch / its HIP-event duration
+            "roofline": {"bound": "mfma", "kernel": prof["dominant_kernel"], "achieved": ach, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "launches_per_step": dom_launches / args.steps,
                          "avg_launch_us": dom_ms * 1e3 / max(1, dom_launches), "time_share_of_step": dom_ms / (dt * 1e3),
                          "all_gemm_kernels": {"achieved": ach_all, "launches_per_step": gemm_launches / args.steps,

@@ -7,6 +7,7 @@
 #include <array>
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 #include "llmseg_hip.h"
 
@@ -30,6 +31,7 @@ bool g_prof_on = false;
 std::vector<ProfRec> g_recs;
 std::vector<ProfRec> g_pool;
 hipEvent_t g_cur = nullptr;
+char g_dom_name[128] = "";
 }  // namespace
 
 void llmseg_prof_begin(hipStream_t s) {
@@ -64,10 +66,12 @@ extern "C" int llmseg_prof_enable(int on) {
   return LLMSEG_OK;
 }
 
+extern "C" const char* llmseg_prof_dominant_kernel(void) { return g_dom_name; }
+
 extern "C" int llmseg_prof_collect(double* total_ms, double* total_flops, int64_t* launches, double* dom_ms, double* dom_flops, int64_t* dom_launches) {
   std::lock_guard<std::mutex> lk(g_mu);
-  double ms = 0, fl = 0, dms = 0, dfl = 0;
-  int64_t dn = 0;
+  double ms = 0, fl = 0;
+  std::map<long, std::array<double, 3>> by_class;                      // kernel class (staging variant, fp32-out) -> {ms, flops, count}
   std::map<std::array<long, 4>, std::array<double, 3>> by_shape;      // (M,N,K,variant) -> {ms, flops, count}
   for (auto& r : g_recs) {
     hipEventSynchronize(r.b);
@@ -75,7 +79,8 @@ extern "C" int llmseg_prof_collect(double* total_ms, double* total_flops, int64_
     hipEventElapsedTime(&t, r.a, r.b);
     ms += t;
     fl += r.flops;
-    if (r.tag[3] / 1000 == 2 && (r.tag[3] & 1) == 0) { dms += t; dfl += r.flops; ++dn; }   // gemm_bf16_tn_glds_kernel<false, 2, 1>
+    auto& c = by_class[(r.tag[3] / 1000) * 2 + (r.tag[3] & 1)];
+    c[0] += t; c[1] += r.flops; c[2] += 1;
     auto& e = by_shape[{r.tag[0], r.tag[1], r.tag[2], r.tag[3]}];
     e[0] += t; e[1] += r.flops; e[2] += 1;
     g_pool.push_back(r);
@@ -94,9 +99,23 @@ extern "C" int llmseg_prof_collect(double* total_ms, double* total_flops, int64_
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;
   if (launches) *launches = (int64_t)g_recs.size();
-  if (dom_ms) *dom_ms = dms;
-  if (dom_flops) *dom_flops = dfl;
-  if (dom_launches) *dom_launches = dn;
+  // dominant kernel = the GEMM kernel class with the largest total time in this window
+  long dom = -1;
+  for (auto& kv : by_class) if (dom < 0 || kv.second[0] > by_class[dom][0]) dom = kv.first;
+  static const char* names[] = {"gemm_bf16_tn_kernel (register staging, 128x128)", "gemm_bf16_tn_glds_kernel<*, 2, 2>", "gemm_bf16_tn_glds_kernel<*, 2, 1>",
+                                "gemm_bf16_tn_glds_kernel<*, 4, 1>", "gemm_bf16_tn_glds_kernel<*, 4, 2>", "?", "gemm_bf16_tn_big_kernel",
+                                "gemm_bf16_tn_ring_kernel", "gemm_bf16_tn_pp_kernel<*, false, false>", "gemm_bf16_tn_pp_kernel<*, true, false>",
+                                "gemm_bf16_tn_pp_kernel<*, false, true>", "gemm_bf16_tn_pq_kernel"};
+  if (dom >= 0) {
+    const long v = dom / 2;
+    std::string nm = (v >= 0 && v < 12) ? names[v] : "?";
+    const size_t star = nm.find('*');
+    if (star != std::string::npos) nm.replace(star, 1, (dom & 1) ? "true" : "false");
+    snprintf(g_dom_name, sizeof(g_dom_name), "%s", nm.c_str());
+  } else g_dom_name[0] = 0;
+  if (dom_ms) *dom_ms = dom >= 0 ? by_class[dom][0] : 0;
+  if (dom_flops) *dom_flops = dom >= 0 ? by_class[dom][1] : 0;
+  if (dom_launches) *dom_launches = dom >= 0 ? (int64_t)by_class[dom][2] : 0;
   g_recs.clear();
   return LLMSEG_OK;
 }

@@ -2,20 +2,21 @@
 //
 // Replaces every nn.Linear / 1x1-conv / patch-embed on the LLM-Seg hot path (see include/llmseg_hip.h).
 //
-// Design (CDNA4): 256-thread workgroup = 4 wave64 (2 x 2), output tile (64*MI) x 128, BK = 64.  Each wave owns a
-// (32*MI) x 64 sub-tile as MI x 2 v_mfma_f32_32x32x16_bf16 accumulators.  The MFMA "A" operand is the WEIGHT fragment
-// and the "B" operand the ACTIVATION fragment, so a lane ends up holding 4 consecutive output columns (n) of one output
-// row (m): bias / activation / LayerScale / residual fuse into the epilogue and the bf16 store is 8 bytes per lane
-// (packed with v_cvt_pk_bf16_f32).
-//   MI = 4 (256 x 128 tile): 6 ds_read_b128 feed 8 MFMAs per k-step (0.75 KiB of LDS reads per MFMA) - the default
-//   MI = 2 (128 x 128 tile): used when the bigger tile would leave CUs idle
-// Staging, variant G (K % 64 == 0): direct global -> LDS DMA (global_load_lds_dwordx4).  The DMA writes LDS linearly
-// (wave-uniform base + lane*16), so the XOR swizzle that makes the ds_read_b128 fragment loads conflict-free on gfx950's
-// 16-lane service groups is applied to the per-lane SOURCE address instead (lane -> LDS slot (row, cpos) -> global chunk
-// cpos ^ ((row>>1)&7) of that row; the 8 lanes of a row still read one 128-byte line).  One LDS buffer per workgroup,
-// HBM/L2 latency is hidden by 3-4 co-resident workgroups per CU.  Variant R (any K % 8 == 0): global -> VGPR -> LDS with
-// zero-filled K tail, double-buffered.
-// Workgroup ids are remapped so that each of the 8 XCDs (private L2s) walks a contiguous, M-grouped range of tiles.
+// Three kernels, one epilogue (the MFMA "A" operand is the WEIGHT fragment and the "B" operand the ACTIVATION fragment, so a
+// lane ends up holding 4 consecutive output columns of one output row: bias / activation / LayerScale / residual fuse into the
+// epilogue, which bounces through LDS so that stores and residual loads are whole 128-byte lines):
+//   Q  gemm_bf16_tn_pp_kernel    256 x 256 tile, 8 waves in two groups one barrier apart ("ping-pong"), half-tile LDS-DMA ring with
+//                                counted vmcnt, one workgroup per CU.  Used when the tile count fills whole rounds of the CUs.
+//   G  gemm_bf16_tn_glds_kernel  128 x 128 tile, 4 waves, one LDS buffer filled by LDS-DMA, 4 workgroups per CU hide each other's
+//                                latency.  Used for everything else with K % 64 == 0.
+//   R  gemm_bf16_tn_kernel       128 x 128 tile, global -> VGPR -> LDS staging (double-buffered); any K % 8 == 0, zero-filled K
+//                                tail, and the transposed-operand layouts of the backward pass.
+// LDS-DMA (global_load_lds_dwordx4) writes LDS linearly (wave-uniform base + lane*16), so the XOR swizzle that makes the
+// ds_read_b128 fragment loads conflict-free on gfx950's 16-lane service groups is applied to the per-lane SOURCE address
+// (lane -> LDS slot (row, cpos) -> global chunk cpos ^ ((row>>1)&7) of that row; the 8 lanes of a row still read one 128-byte
+// line).  Workgroup ids are remapped so that each of the 8 XCDs (private L2s) walks a contiguous, M-grouped range of tiles.
+// Kernels tried and dropped (numbers in DESIGN.md): 256 x 128 LDS-DMA tiles, a lock-step 256 x 256 two-stage kernel, a 4-stage
+// BK = 32 ring, a persistent ping-pong with the next tile's DMA issued before the epilogue, K-half ping-pong phases.
 #include <algorithm>
 #include <cstdlib>
 #include "common.h"
@@ -36,7 +37,6 @@ struct GemmP {
   int act;
   int tiles_m, tiles_n;
   int c_vec, r_vec, b_vec;   // host-verified alignment for vector C stores / residual loads / bias+gamma loads
-  int dbg, batch_total;      // experiment switches (LLMSEG_GEMM_DBG); batch1 * batch2
   int skew;                  // per-XCD rotation of the tile walk (de-phases the 8 XCDs' HBM/MALL channel access)
 };
 
@@ -523,196 +523,6 @@ __global__ __launch_bounds__(NT, NBUF == 2 ? (MI == 4 ? 1 : 2) : (MI == 4 ? 2 : 
 }
 
 
-// ---- variant B: 256 x 256 tile, 8 waves (2 x 4, each 128 x 64), two 64-KiB LDS stages, software-pipelined DMA -------------
-// One workgroup per CU (128 KiB LDS).  The DMA of tile t+1 is in flight while tile t is multiplied: waits are COUNTED
-// (s_waitcnt vmcnt(8) = "everything but the 8 newest DMA instructions has landed") and the barriers are raw s_barrier, so
-// the compiler does not drain the queue.  Halves L2->CU traffic per flop vs the 128 x 128 tile and needs 6 ds_read_b128 per
-// 8 MFMAs.  K % 64 == 0.
-constexpr int NTB = 512;
-
-template <bool OUT_F32>
-__global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_big_kernel(GemmP p) {
-  constexpr int MI = 4, BMB = 256, BNB = 256;
-  constexpr int A_BYTES = BMB * BK * 2, W_BYTES = BNB * BK * 2, BUF = A_BYTES + W_BYTES;     // 64 KiB per stage
-  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
-  // tile mapping (BN = 256 here, so not tile_of<>)
-  int bid = blockIdx.x;
-  const int nwg = p.tiles_m * p.tiles_n;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int len = q + (xcd < r ? 1 : 0);
-    const int idx = ((bid >> 3) + xcd * p.skew) % len;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int per_group = GROUP_M * p.tiles_n;
-  const int first_m = (bid / per_group) * GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, GROUP_M);
-  const int m0 = (first_m + (bid % per_group) % gsz) * BMB;
-  const int n0 = ((bid % per_group) / gsz) * BNB;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const long b1 = blockIdx.y % p.batch1, b2 = blockIdx.y / p.batch1;
-  const long bz = b1 * p.sC + b2 * p.sC2;          // element offset of this batch entry in C / residual
-  const bf16_t* __restrict__ Ag = p.A + b1 * p.sA + b2 * p.sA2;
-  const bf16_t* __restrict__ Wg = p.W + b1 * p.sW + b2 * p.sW2;
-
-  // DMA instruction i (0..3) of this wave fills LDS rows (i*8 + wave)*8 .. +7 of each operand tile
-  const bf16_t* a_src[4];
-  const bf16_t* w_src[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (i * 8 + wave) * 8 + (lane >> 3);
-    const int sw = (((lane & 7) ^ ((row >> 1) & 7)) << 3);
-    a_src[i] = Ag + (long)min(m0 + row, p.M - 1) * p.lda + sw;
-    w_src[i] = Wg + (long)min(n0 + row, p.N - 1) * p.ldw + sw;
-  }
-  const int nt = p.K / BK;
-
-  auto issue = [&](int t, int buf) {
-    char* base = smem + buf * BUF;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[i] + (long)t * BK), (lds_ptr_t)(base + A_BYTES + (i * 8 + wave) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + (long)t * BK), (lds_ptr_t)(base + (i * 8 + wave) * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x16_t acc[2][MI];
-  zero_acc<MI>(acc);
-  const int frow = lane & 31, fhalf = lane >> 5;
-
-  issue(0, 0);
-  if (nt > 1) issue(1, 1);
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile t landed; tile t+1 may still be in flight
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const char* abase = smem + (t & 1) * BUF;
-    // this wave's sub-tile: activations rows wm*128.., weights rows wn*64..
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8_t af[MI], wf[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(abase + A_BYTES + lds_off(wn * 64 + j * 32 + frow, ks * 2 + fhalf));
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(abase + lds_off(wm * 128 + i * 32 + frow, ks * 2 + fhalf));
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // own LDS reads retired before the buffer is refilled
-    __builtin_amdgcn_s_barrier();
-    if (t + 2 < nt) issue(t + 2, t & 1);
-  }
-  // epilogue: same lane->C mapping as the small tile with this wave's origin (wm*128, wn*64)
-  epilogue_lds<OUT_F32, MI>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
-}
-
-// ---- variant P: 256 x 256 tile, BK = 32, 4-stage LDS ring (128 KiB), three stages (96 KiB) of DMA in flight ------------------
-// Measurements (profiles/) show the single-buffer and double-buffer kernels are bound by bytes-in-flight / DMA
-// latency (~2 us under load): 128 KiB in flight per CU at 64 flop/B (128x128 tiles) caps them at ~900 TFLOP/s.  This variant
-// doubles the arithmetic intensity (256x256: 128 flop/B) AND keeps three stages in flight.  One barrier per stage: at
-// iteration t every wave waits for its own DMA of stage t (counted vmcnt), the barrier then proves (a) everybody's part of
-// stage t has landed and (b) everybody finished the MFMAs of stage t-1, so slot (t-1)%4 is immediately refilled with stage
-// t+3.  8 waves (2 x 4), each a 128 x 64 sub-tile = 4 x 2 MFMA 32x32x16 accumulators; 64-byte LDS rows, chunk XOR (row>>2)&3.
-__device__ __forceinline__ int lds_off32(int row, int chunk) { return row * 64 + (((chunk ^ (row >> 2)) & 3) << 4); }
-
-template <bool OUT_F32>
-__global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_ring_kernel(GemmP p) {
-  constexpr int MI = 4, BMB = 256, BNB = 256, BKR = 32, NST = 4;
-  constexpr int A_BYTES = BMB * BKR * 2, STAGE = 2 * A_BYTES;        // 16 KiB + 16 KiB
-  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
-  int bid = blockIdx.x;
-  const int nwg = p.tiles_m * p.tiles_n;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int len = q + (xcd < r ? 1 : 0);
-    const int idx = ((bid >> 3) + xcd * p.skew) % len;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int per_group = GROUP_M * p.tiles_n;
-  const int first_m = (bid / per_group) * GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, GROUP_M);
-  const int m0 = (first_m + (bid % per_group) % gsz) * BMB;
-  const int n0 = ((bid % per_group) / gsz) * BNB;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const long b1 = blockIdx.y % p.batch1, b2 = blockIdx.y / p.batch1;
-  const long bz = b1 * p.sC + b2 * p.sC2;
-  const bf16_t* __restrict__ Ag = p.A + b1 * p.sA + b2 * p.sA2;
-  const bf16_t* __restrict__ Wg = p.W + b1 * p.sW + b2 * p.sW2;
-
-  // DMA instruction i (0..1) of this wave fills LDS rows (i*8 + wave)*16 .. +15 (64 B each) of each operand tile
-  const bf16_t* a_src[2];
-  const bf16_t* w_src[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (i * 8 + wave) * 16 + (lane >> 2);
-    const int sw = (((lane & 3) ^ ((row >> 2) & 3)) << 3);
-    a_src[i] = Ag + (long)min(m0 + row, p.M - 1) * p.lda + sw;
-    w_src[i] = Wg + (long)min(n0 + row, p.N - 1) * p.ldw + sw;
-  }
-  const int nt = p.K / BKR;
-
-  auto issue = [&](int t) {
-    char* base = smem + (t & (NST - 1)) * STAGE;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[i] + (long)t * BKR), (lds_ptr_t)(base + A_BYTES + (i * 8 + wave) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + (long)t * BKR), (lds_ptr_t)(base + (i * 8 + wave) * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x16_t acc[2][MI];
-  zero_acc<MI>(acc);
-  const int frow = lane & 31, fhalf = lane >> 5;
-
-  issue(0);
-  if (nt > 1) issue(1);
-  if (nt > 2) issue(2);
-  for (int t = 0; t < nt; ++t) {
-    // outstanding DMA instructions of this wave: stages t .. min(t+2, nt-1), 4 each; stage t is the oldest
-    const int newer = min(2, nt - 1 - t);
-    if (newer == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // slot (t+3)%4 == (t-1)%4 is free since every wave passed this barrier.  The refill DMA is issued in the SHADOW of the
-    // MFMAs (an LDS-DMA instruction costs ~100 issue cycles; right after the barrier it would stall both lock-stepped waves
-    // of a SIMD with the matrix pipe idle): all fragment reads first, then {8 MFMAs, 2 DMA} x 2.
-    const bool refill = t + 3 < nt;
-    char* rbase = smem + ((t + 3) & (NST - 1)) * STAGE;
-    const char* abase = smem + (t & (NST - 1)) * STAGE;
-    bf16x8_t af[2][MI], wf[2][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8_t*>(abase + A_BYTES + lds_off32(wn * 64 + j * 32 + frow, ks * 2 + fhalf));
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af[ks][i] = *reinterpret_cast<const bf16x8_t*>(abase + lds_off32(wm * 128 + i * 32 + frow, ks * 2 + fhalf));
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][j], af[ks][i], acc[j][i], 0, 0, 0);
-      if (refill) {
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[ks] + (long)(t + 3) * BKR), (lds_ptr_t)(rbase + A_BYTES + (ks * 8 + wave) * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[ks] + (long)(t + 3) * BKR), (lds_ptr_t)(rbase + (ks * 8 + wave) * 1024), 16, 0, 0);
-      }
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                          // all MFMAs' LDS reads retired: the ring becomes the epilogue slab
-  epilogue_lds<OUT_F32, MI>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
-}
-
 // ---- variant Q: 256 x 256 tile, 8 waves in two groups that run ONE BARRIER APART ("ping-pong") ----------------------------
 // Each K-tile (BK = 64) is four phases; a phase is {LDS fragment reads + one half-tile of DMA issue} | barrier | {8 MFMAs} |
 // barrier.  Waves wm = 1 execute one extra barrier up front, so on every SIMD the wm = 0 wave's MFMA section overlaps the
@@ -747,184 +557,11 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_ring_kernel(GemmP p) {
   _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)             \
       af[ii][ks] = *reinterpret_cast<const bf16x8_t*>((base) + lds_off(wm * 128 + ((i0) + ii) * 32 + frow, ks * 2 + fhalf))
 #define PP_MMA(wfx, j, i0)                                                                \
-  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) { \
-      acc[j][(i0) + ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfx[ks], af[ii][ks], acc[j][(i0) + ii], 0, 0, 0); \
-      if (DBG && tim && ks == 0 && ii == 0) { __builtin_amdgcn_sched_barrier(0); T1n = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } }
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) \
+      acc[j][(i0) + ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfx[ks], af[ii][ks], acc[j][(i0) + ii], 0, 0, 0)
 #define PP_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define PP_NOP ((void)0)
 #define PP_PHASE(READS, ISSUE, WAIT, MMA)               \
-  do {                                                  \
-    if (!DBG || !(p.dbg & 8)) { READS; }                \
-    if (!DBG || !(p.dbg & 4)) { ISSUE; }                \
-    WAIT;                                               \
-    __builtin_amdgcn_sched_barrier(0);                  \
-    __builtin_amdgcn_s_barrier();                       \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-    __builtin_amdgcn_sched_barrier(0);                  \
-    __builtin_amdgcn_s_setprio(1);                      \
-    if (!DBG || !(p.dbg & 16)) { MMA; }                 \
-    __builtin_amdgcn_s_setprio(0);                      \
-    if (DBG && tim) {                                   \
-      sM += (uint32_t)(T2p - T1p); sB += (uint32_t)(T3p - T2p); sL += (uint32_t)(T1n - T3p); T1p = T1n; \
-    }                                                   \
-    __builtin_amdgcn_sched_barrier(0);                  \
-    if (DBG && tim) T2p = __builtin_amdgcn_s_memtime(); \
-    __builtin_amdgcn_s_barrier();                       \
-    if (DBG && tim) T3p = __builtin_amdgcn_s_memtime(); \
-    __builtin_amdgcn_sched_barrier(0);                  \
-  } while (0)
-
-// PERSIST: one workgroup per CU walks tiles blockIdx.x, +gridDim.x, ...; the next tile's first four half-tiles are issued
-// BEFORE this tile's epilogue (which bounces through buffer 1), so the DMA latency, the workgroup launch and part of the store
-// drain overlap.
-template <bool OUT_F32, bool PERSIST, bool DBG>
-__global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
-  constexpr int MI = 4, BMB = 256, BNB = 256;
-  constexpr int OP_BYTES = 256 * BK * 2, BUF = 2 * OP_BYTES;     // 32 KiB per operand, 64 KiB per buffer
-  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int frow = lane & 31, fhalf = lane >> 5;
-  const int total = PERSIST ? nwg * p.batch_total : 0;
-
-  int m0, n0;
-  long bz;
-  // per-lane DMA sources: [half][instruction]; the lane's LDS slot is (row0 + lane/8, chunk lane%8), it fetches global chunk
-  // (lane%8) ^ swizzle(row) of that row
-  const bf16_t* a_src[2][2];
-  const bf16_t* w_src[2][2];
-  auto setup = [&](int tile, int by) {
-    int bid = tile;
-    if (PERSIST) { by = tile / nwg; bid = tile - by * nwg; }
-    {
-      const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-      const int len = q + (xcd < r ? 1 : 0);
-      const int idx = ((bid >> 3) + xcd * p.skew) % len;
-      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int per_group = GROUP_M * p.tiles_n;
-    const int first_m = (bid / per_group) * GROUP_M;
-    const int gsz = min(p.tiles_m - first_m, GROUP_M);
-    m0 = (first_m + (bid % per_group) % gsz) * BMB;
-    n0 = ((bid % per_group) / gsz) * BNB;
-    const long b1 = by % p.batch1, b2 = by / p.batch1;
-    bz = b1 * p.sC + b2 * p.sC2;
-    const bf16_t* __restrict__ Ag = p.A + b1 * p.sA + b2 * p.sA2;
-    const bf16_t* __restrict__ Wg = p.W + b1 * p.sW + b2 * p.sW2;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ra = i * 128 + h * 64 + wave * 8 + (lane >> 3);
-        const int rw = (i * 2 + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + (lane >> 3);
-        a_src[h][i] = Ag + (long)min(m0 + ra, p.M - 1) * p.lda + (((lane & 7) ^ ((ra >> 1) & 7)) << 3);
-        w_src[h][i] = Wg + (long)min(n0 + rw, p.N - 1) * p.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) << 3);
-      }
-  };
-  const int nt = (p.dbg & 2) ? 2 : p.K / BK;
-  const int gsel = DBG ? (p.dbg >> 5) & 3 : 0;           // experiment: which waves form the lagging group
-  const bool nostag = gsel == 3;
-  const bool tim = DBG && (p.dbg & 128);
-  uint64_t T1n = 0, T1p = 0, T2p = 0, T3p = 0;
-  uint32_t sM = 0, sB = 0, sL = 0;
-  uint64_t T0 = 0;
-  if (tim) { T0 = T1p = T2p = T3p = __builtin_amdgcn_s_memtime(); }
-  const bool lag = gsel == 0 ? wm == 1 : gsel == 1 ? (wave & 1) : gsel == 2 ? ((wave >> 1) & 1) : false;
-
-  f32x16_t acc[2][MI];
-  bf16x8_t af[2][4] = {}, wf0[4] = {}, wf1[4] = {};
-
-  int tile = blockIdx.x;
-  setup(tile, blockIdx.y);
-  // prologue: S[0..5] = A0(0) W0(0) W1(0) A1(0) A0(1) W0(1)
-  PP_ISSUE_A(0, 0, smem); PP_ISSUE_W(0, 0, smem); PP_ISSUE_W(1, 0, smem); PP_ISSUE_A(1, 0, smem);
-  PP_ISSUE_A(0, 1, smem + BUF); PP_ISSUE_W(0, 1, smem + BUF);
-  while (true) {
-    zero_acc<MI>(acc);
-    PP_VM(8);
-    __builtin_amdgcn_s_barrier();
-    if (lag) __builtin_amdgcn_s_barrier();                // the stagger
-    __builtin_amdgcn_sched_barrier(0);
-
-    int t = 0;
-    for (; t < nt - 2; ++t) {
-      char* cur = smem + (t & 1) * BUF;
-      char* oth = smem + ((t + 1) & 1) * BUF;
-      PP_PHASE(PP_READ_W(wf0, 0, cur); PP_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM(8), PP_MMA(wf0, 0, 0));
-      PP_PHASE(PP_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM(8), PP_MMA(wf1, 1, 0));
-      PP_PHASE(PP_READ_A(2, cur), PP_ISSUE_A(0, t + 2, cur), PP_NOP, PP_MMA(wf1, 1, 2));
-      PP_PHASE(PP_NOP, PP_ISSUE_W(0, t + 2, cur), PP_VM(8), PP_MMA(wf0, 0, 2));
-    }
-    {   // K-tile nt-2: the last two half-tiles are issued, then the queue drains
-      char* cur = smem + (t & 1) * BUF;
-      char* oth = smem + ((t + 1) & 1) * BUF;
-      PP_PHASE(PP_READ_W(wf0, 0, cur); PP_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM(8), PP_MMA(wf0, 0, 0));
-      PP_PHASE(PP_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM(8), PP_MMA(wf1, 1, 0));
-      PP_PHASE(PP_READ_A(2, cur), PP_NOP, PP_NOP, PP_MMA(wf1, 1, 2));
-      PP_PHASE(PP_NOP, PP_NOP, PP_VM(4), PP_MMA(wf0, 0, 2));
-      cur = oth;   // K-tile nt-1
-      PP_PHASE(PP_READ_W(wf0, 0, cur); PP_READ_A(0, cur), PP_NOP, PP_VM(2), PP_MMA(wf0, 0, 0));
-      PP_PHASE(PP_READ_W(wf1, 1, cur), PP_NOP, PP_VM(0), PP_MMA(wf1, 1, 0));
-      PP_PHASE(PP_READ_A(2, cur), PP_NOP, PP_NOP, PP_MMA(wf1, 1, 2));
-      PP_PHASE(PP_NOP, PP_NOP, PP_NOP, PP_MMA(wf0, 0, 2));
-    }
-    if (!lag && !nostag) __builtin_amdgcn_s_barrier();    // re-join: every wave's reads and DMA are retired past this point
-    if (DBG && tim && blockIdx.x < 4 && blockIdx.y == 0 && lane == 0) {
-      uint32_t* o = reinterpret_cast<uint32_t*>(p.C) + (blockIdx.x * 8 + wave) * 4;
-      o[0] = sM; o[1] = sB; o[2] = sL; o[3] = (uint32_t)(__builtin_amdgcn_s_memtime() - T0);
-    }
-    if (!PERSIST) {
-      if (!(p.dbg & 1)) epilogue_lds<OUT_F32, MI>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
-      break;
-    }
-    const int em0 = m0, en0 = n0;
-    const long ebz = bz;
-    const int next = tile + gridDim.x;
-    if (next < total) {
-      setup(next, 0);
-      PP_ISSUE_A(0, 0, smem); PP_ISSUE_W(0, 0, smem); PP_ISSUE_W(1, 0, smem); PP_ISSUE_A(1, 0, smem);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(p.dbg & 1)) epilogue_lds<OUT_F32, MI>(p, acc, smem + BUF, wave, em0, en0, wm, wn, lane, ebz);
-    if (next >= total) break;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                         // every wave is done with its slab in buffer 1
-    PP_ISSUE_A(0, 1, smem + BUF); PP_ISSUE_W(0, 1, smem + BUF);
-    tile = next;
-  }
-}
-
-// ---- variant Q4: the ping-pong kernel with K-HALF phases: every MFMA section runs 8 MFMAs over FOUR independent accumulators ----
-// Measured on variant Q (tools/gemm_timing.py): one wave alternating two accumulators issues a 32x32x16 MFMA every ~42-46
-// cycles (dependent-issue latency ~85 cycles), not every 32.  Here a phase is (k-half kh, weight sub-block j): acc[j][0..3] +=
-// W[j][kh] x A[0..3][kh], dependent distance 4 MFMAs.
-//   LDS per buffer (64 KiB): A[kh][256][32], W[kh][256][32] bf16 = four 16 KiB half-tiles with 64-byte rows, chunk XOR (row>>2)&3
-//   phase:        p0 (kh0, j0)      p1 (kh0, j1)     p2 (kh1, j0)      p3 (kh1, j1)
-//   reads         A_kh0 (8) W (2)   W (2)            A_kh1 (8) W (2)   W (2)
-//   DMA issue     S[g+6] with S = A_kh0, W_kh0, A_kh1, W_kh1 per K-tile (re-issue exactly 2 phases after the slot's last read)
-//   s_waitcnt     -                 vmcnt(8)         -                 vmcnt(8)          (retires the k-half phase g+1 starts reading)
-#define PQ_DMA(src, i, koff, dst) __builtin_amdgcn_global_load_lds((gbl_ptr_t)((src)[i] + (koff)), (lds_ptr_t)(dst), 16, 0, 0)
-// n = issue sequence index: K-tile n>>2, half-tile n&3 (0 A_kh0, 1 W_kh0, 2 A_kh1, 3 W_kh1) -> LDS slot of buffer (n>>2)&1
-#define PQ_ISSUE(n)                                                                             \
-  do {                                                                                          \
-    const int n_ = (n);                                                                         \
-    char* d_ = smem + ((n_ >> 2) & 1) * BUF + ((n_ & 1) * 2 + ((n_ >> 1) & 1)) * HT + wave * 1024; \
-    const long k_ = (long)(n_ >> 2) * BK + ((n_ >> 1) & 1) * 32;                                \
-    if (n_ & 1) { PQ_DMA(w_src, 0, k_, d_); PQ_DMA(w_src, 1, k_, d_ + 8192); }                  \
-    else        { PQ_DMA(a_src, 0, k_, d_); PQ_DMA(a_src, 1, k_, d_ + 8192); }                  \
-  } while (0)
-#define PQ_READ_A(kh, base)                                                                                     \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)               \
-      af[i][ks] = *reinterpret_cast<const bf16x8_t*>((base) + (kh) * HT + lds_off32(wm * 128 + i * 32 + frow, ks * 2 + fhalf))
-#define PQ_READ_W(dst, kh, j, base)                                                                             \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
-      dst[ks] = *reinterpret_cast<const bf16x8_t*>((base) + (2 + (kh)) * HT + lds_off32(wn * 64 + (j) * 32 + frow, ks * 2 + fhalf))
-#define PQ_MMA(wfx, j)                                                                      \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) \
-      acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfx[ks], af[i][ks], acc[j][i], 0, 0, 0)
-#define PQ_PHASE(READS, ISSUE, WAIT, MMA)               \
   do {                                                  \
     READS; ISSUE; WAIT;                                 \
     __builtin_amdgcn_sched_barrier(0);                  \
@@ -939,10 +576,12 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
     __builtin_amdgcn_sched_barrier(0);                  \
   } while (0)
 
+constexpr int NTB = 512;
+
 template <bool OUT_F32>
-__global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pq_kernel(GemmP p) {
+__global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
   constexpr int MI = 4, BMB = 256, BNB = 256;
-  constexpr int HT = 256 * 32 * 2, BUF = 4 * HT;                  // 16 KiB half-tiles, 64 KiB per buffer
+  constexpr int OP_BYTES = 256 * BK * 2, BUF = 2 * OP_BYTES;     // 32 KiB per operand, 64 KiB per buffer
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   int bid = blockIdx.x;
   const int nwg = p.tiles_m * p.tiles_n;
@@ -966,25 +605,29 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pq_kernel(GemmP p) {
   const bf16_t* __restrict__ Ag = p.A + b1 * p.sA + b2 * p.sA2;
   const bf16_t* __restrict__ Wg = p.W + b1 * p.sW + b2 * p.sW2;
 
-  // DMA instruction i of this wave fills LDS rows (i*8 + wave)*16 .. +15 (64 B each) of a half-tile: lane -> (row, slot lane%4),
-  // fetching global chunk (lane%4) ^ swizzle(row) of the k-half
-  const bf16_t* a_src[2];
-  const bf16_t* w_src[2];
+  // per-lane DMA sources: [half][instruction]; the lane's LDS slot is (row0 + lane/8, chunk lane%8), it fetches global chunk
+  // (lane%8) ^ swizzle(row) of that row
+  const bf16_t* a_src[2][2];
+  const bf16_t* w_src[2][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (i * 8 + wave) * 16 + (lane >> 2);
-    const int sw = (((lane & 3) ^ ((row >> 2) & 3)) << 3);
-    a_src[i] = Ag + (long)min(m0 + row, p.M - 1) * p.lda + sw;
-    w_src[i] = Wg + (long)min(n0 + row, p.N - 1) * p.ldw + sw;
-  }
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ra = i * 128 + h * 64 + wave * 8 + (lane >> 3);
+      const int rw = (i * 2 + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + (lane >> 3);
+      a_src[h][i] = Ag + (long)min(m0 + ra, p.M - 1) * p.lda + (((lane & 7) ^ ((ra >> 1) & 7)) << 3);
+      w_src[h][i] = Wg + (long)min(n0 + rw, p.N - 1) * p.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) << 3);
+    }
   const int nt = p.K / BK;
 
   f32x16_t acc[2][MI];
   zero_acc<MI>(acc);
-  bf16x8_t af[4][2], wf0[2], wf1[2];
+  bf16x8_t af[2][4], wf0[4], wf1[4];
   const int frow = lane & 31, fhalf = lane >> 5;
 
-  PQ_ISSUE(0); PQ_ISSUE(1); PQ_ISSUE(2); PQ_ISSUE(3); PQ_ISSUE(4); PQ_ISSUE(5);
+  // prologue: S[0..5] = A0(0) W0(0) W1(0) A1(0) A0(1) W0(1)
+  PP_ISSUE_A(0, 0, smem); PP_ISSUE_W(0, 0, smem); PP_ISSUE_W(1, 0, smem); PP_ISSUE_A(1, 0, smem);
+  PP_ISSUE_A(0, 1, smem + BUF); PP_ISSUE_W(0, 1, smem + BUF);
   PP_VM(8);
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();            // the stagger
@@ -992,25 +635,25 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pq_kernel(GemmP p) {
 
   int t = 0;
   for (; t < nt - 2; ++t) {
-    const char* cur = smem + (t & 1) * BUF;
-    const int g = 4 * t;
-    PQ_PHASE(PQ_READ_A(0, cur); PQ_READ_W(wf0, 0, 0, cur), PQ_ISSUE(g + 6), PP_NOP, PQ_MMA(wf0, 0));
-    PQ_PHASE(PQ_READ_W(wf1, 0, 1, cur), PQ_ISSUE(g + 7), PP_VM(8), PQ_MMA(wf1, 1));
-    PQ_PHASE(PQ_READ_A(1, cur); PQ_READ_W(wf0, 1, 0, cur), PQ_ISSUE(g + 8), PP_NOP, PQ_MMA(wf0, 0));
-    PQ_PHASE(PQ_READ_W(wf1, 1, 1, cur), PQ_ISSUE(g + 9), PP_VM(8), PQ_MMA(wf1, 1));
+    char* cur = smem + (t & 1) * BUF;
+    char* oth = smem + ((t + 1) & 1) * BUF;
+    PP_PHASE(PP_READ_W(wf0, 0, cur); PP_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM(8), PP_MMA(wf0, 0, 0));
+    PP_PHASE(PP_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM(8), PP_MMA(wf1, 1, 0));
+    PP_PHASE(PP_READ_A(2, cur), PP_ISSUE_A(0, t + 2, cur), PP_NOP, PP_MMA(wf1, 1, 2));
+    PP_PHASE(PP_NOP, PP_ISSUE_W(0, t + 2, cur), PP_VM(8), PP_MMA(wf0, 0, 2));
   }
-  {   // K-tile nt-2: S[4nt-2], S[4nt-1] are the last issues, then the queue drains
-    const char* cur = smem + (t & 1) * BUF;
-    const int g = 4 * t;
-    PQ_PHASE(PQ_READ_A(0, cur); PQ_READ_W(wf0, 0, 0, cur), PQ_ISSUE(g + 6), PP_NOP, PQ_MMA(wf0, 0));
-    PQ_PHASE(PQ_READ_W(wf1, 0, 1, cur), PQ_ISSUE(g + 7), PP_VM(8), PQ_MMA(wf1, 1));
-    PQ_PHASE(PQ_READ_A(1, cur); PQ_READ_W(wf0, 1, 0, cur), PP_NOP, PP_NOP, PQ_MMA(wf0, 0));
-    PQ_PHASE(PQ_READ_W(wf1, 1, 1, cur), PP_NOP, PP_VM(4), PQ_MMA(wf1, 1));     // A_kh0, W_kh0 of the last K-tile landed
-    cur = smem + ((t + 1) & 1) * BUF;
-    PQ_PHASE(PQ_READ_A(0, cur); PQ_READ_W(wf0, 0, 0, cur), PP_NOP, PP_NOP, PQ_MMA(wf0, 0));
-    PQ_PHASE(PQ_READ_W(wf1, 0, 1, cur), PP_NOP, PP_VM(0), PQ_MMA(wf1, 1));     // A_kh1, W_kh1 landed
-    PQ_PHASE(PQ_READ_A(1, cur); PQ_READ_W(wf0, 1, 0, cur), PP_NOP, PP_NOP, PQ_MMA(wf0, 0));
-    PQ_PHASE(PQ_READ_W(wf1, 1, 1, cur), PP_NOP, PP_NOP, PQ_MMA(wf1, 1));
+  {   // K-tile nt-2: the last two half-tiles are issued, then the queue drains
+    char* cur = smem + (t & 1) * BUF;
+    char* oth = smem + ((t + 1) & 1) * BUF;
+    PP_PHASE(PP_READ_W(wf0, 0, cur); PP_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM(8), PP_MMA(wf0, 0, 0));
+    PP_PHASE(PP_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM(8), PP_MMA(wf1, 1, 0));
+    PP_PHASE(PP_READ_A(2, cur), PP_NOP, PP_NOP, PP_MMA(wf1, 1, 2));
+    PP_PHASE(PP_NOP, PP_NOP, PP_VM(4), PP_MMA(wf0, 0, 2));
+    cur = oth;   // K-tile nt-1
+    PP_PHASE(PP_READ_W(wf0, 0, cur); PP_READ_A(0, cur), PP_NOP, PP_VM(2), PP_MMA(wf0, 0, 0));
+    PP_PHASE(PP_READ_W(wf1, 1, cur), PP_NOP, PP_VM(0), PP_MMA(wf1, 1, 0));
+    PP_PHASE(PP_READ_A(2, cur), PP_NOP, PP_NOP, PP_MMA(wf1, 1, 2));
+    PP_PHASE(PP_NOP, PP_NOP, PP_NOP, PP_MMA(wf0, 0, 2));
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();            // re-join: every wave's reads and DMA are retired past this point
   epilogue_lds<OUT_F32, MI>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
@@ -1028,8 +671,8 @@ void llmseg_prof_begin(hipStream_t s);
 void llmseg_prof_end(hipStream_t s, double flops);
 void llmseg_prof_tag(long a, long b, long c, long d);
 
-// tuning knob: 0 = register staging 128x128; 1 = DMA 128x128 x2 buffers; 2 = DMA 128x128 x1; 3 = DMA 256x128 x1; 4 = DMA 256x128 x2;
-// 5 (default) = auto: 256x128 x1 when that still gives every CU >= 2 workgroups, else 128x128 x1
+// tuning knob (tools/gemm_bench.py): 0 = register staging 128x128; 2 = LDS-DMA 128x128; 8 = LDS-DMA 256x256 ping-pong;
+// 5 (default) = auto between 2 and 8.  Bits 4+ = XCD skew + 1.
 static int g_gemm_variant = 5, g_gemm_skew = 13;
 static int num_cus() {
   static int n = [] { int dev = 0, v = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
@@ -1067,20 +710,18 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   p.b_vec = ((p.bias == nullptr || (((uintptr_t)p.bias) & 7) == 0) && (p.gamma == nullptr || (((uintptr_t)p.gamma) & 7) == 0)) ? 1 : 0;
 
   p.skew = g_gemm_skew;
-  static const int dbg = getenv("LLMSEG_GEMM_DBG") ? atoi(getenv("LLMSEG_GEMM_DBG")) : 0;
-  p.dbg = dbg; p.batch_total = (int)batch;
   int variant = (p.K % BK == 0 && !ta && !tw) ? g_gemm_variant : 0;
-  if (variant >= 8 && p.K < 2 * BK) variant = 2;
+  if (variant != 0 && variant != 2 && variant != 8) variant = 5;
+  if (variant == 8 && p.K < 2 * BK) variant = 2;
   if (variant == 5) {
     // auto: the 256 x 256 ping-pong kernel (one workgroup per CU) when its tiles fill >= 70 % of whole rounds of the CUs (edge
     // tiles counted by their useful area); the 128 x 128 single-buffer DMA kernel (4 workgroups/CU) otherwise.  Measured with
     // tools/gemm_bench.py: +15..35 % on every hot-path shape that passes the test, -10 % on the 320-tile Llama N = 4096 shapes.
     const long tm = (p.M + 255) / 256, tn = (p.N + 255) / 256, tiles = tm * tn * batch, ncu = num_cus();
     const double fill = (double)tiles / (double)(((tiles + ncu - 1) / ncu) * ncu) * ((double)p.M * p.N / ((double)tm * 256 * tn * 256));
-    variant = fill >= 0.7 ? 8 : 2;
+    variant = (fill >= 0.7 && p.K >= 2 * BK) ? 8 : 2;
   }
-  const int bm = (variant == 3 || variant == 4 || variant >= 6) ? 256 : 128;
-  const int bn = variant >= 6 ? 256 : BN;
+  const int bm = variant == 8 ? 256 : 128, bn = variant == 8 ? 256 : BN;
   p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
   dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);
   hipStream_t s = (hipStream_t)stream;
@@ -1088,33 +729,10 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   llmseg_prof_tag(p.M, p.N, p.K, variant * 1000 + (ta ? 200 : 0) + (tw ? 100 : 0) + (p.res ? 20 : 0) + p.act * 2 + (a->out_f32 ? 1 : 0) + 40 * (batch > 1));
   const bool f = a->out_f32 != 0;
   switch (variant) {
-    case 1: f ? launch_glds<true, 2, 2>(p, grid, s) : launch_glds<false, 2, 2>(p, grid, s); break;
     case 2: f ? launch_glds<true, 2, 1>(p, grid, s) : launch_glds<false, 2, 1>(p, grid, s); break;
-    case 3: f ? launch_glds<true, 4, 1>(p, grid, s) : launch_glds<false, 4, 1>(p, grid, s); break;
-    case 4: f ? launch_glds<true, 4, 2>(p, grid, s) : launch_glds<false, 4, 2>(p, grid, s); break;
-    case 7:
-      if (f) hipLaunchKernelGGL(gemm_bf16_tn_ring_kernel<true>, grid, dim3(NTB), 0, s, p);
-      else hipLaunchKernelGGL(gemm_bf16_tn_ring_kernel<false>, grid, dim3(NTB), 0, s, p);
-      break;
     case 8:
-      if (f) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<true, false, false>), grid, dim3(NTB), 0, s, p);
-      else hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, false, false>), grid, dim3(NTB), 0, s, p);
-      break;
-    case 11:
-      if (f) hipLaunchKernelGGL(gemm_bf16_tn_pq_kernel<true>, grid, dim3(NTB), 0, s, p);
-      else hipLaunchKernelGGL(gemm_bf16_tn_pq_kernel<false>, grid, dim3(NTB), 0, s, p);
-      break;
-    case 10: hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, false, true>), grid, dim3(NTB), 0, s, p); break;
-    case 9: {
-      const long total = (long)p.tiles_m * p.tiles_n * batch;
-      dim3 pgrid((unsigned)std::min<long>(total, num_cus()));
-      if (f) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<true, true, false>), pgrid, dim3(NTB), 0, s, p);
-      else hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, true, false>), pgrid, dim3(NTB), 0, s, p);
-      break;
-    }
-    case 6:
-      if (f) hipLaunchKernelGGL(gemm_bf16_tn_big_kernel<true>, grid, dim3(NTB), 0, s, p);
-      else hipLaunchKernelGGL(gemm_bf16_tn_big_kernel<false>, grid, dim3(NTB), 0, s, p);
+      if (f) hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<true>, grid, dim3(NTB), 0, s, p);
+      else hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<false>, grid, dim3(NTB), 0, s, p);
       break;
     default: {
       const int key = (f ? 4 : 0) | (ta ? 2 : 0) | (tw ? 1 : 0);

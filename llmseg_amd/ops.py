@@ -330,7 +330,9 @@ def prof_enable(on):
 
 
 def prof_collect():
-    """-> dict(all=(ms, flops, launches), dominant=(ms, flops, launches)) of the GEMM launches since prof_enable(True)."""
+    """-> dict(all=(ms, flops, launches), dominant=(ms, flops, launches), dominant_kernel=name) of the GEMM launches since
+    prof_enable(True); dominant = the GEMM kernel class with the largest total time."""
     ms, fl, n, dms, dfl, dn = C.c_double(), C.c_double(), C.c_int64(), C.c_double(), C.c_double(), C.c_int64()
     _lib.load().llmseg_prof_collect(C.byref(ms), C.byref(fl), C.byref(n), C.byref(dms), C.byref(dfl), C.byref(dn))
-    return {"all": (ms.value, fl.value, n.value), "dominant": (dms.value, dfl.value, dn.value)}
+    name = _lib.load().llmseg_prof_dominant_kernel()
+    return {"all": (ms.value, fl.value, n.value), "dominant": (dms.value, dfl.value, dn.value), "dominant_kernel": (name or b"").decode()}

@@ -16,7 +16,7 @@ SHAPES = [  # (M, N, K, tag)  B=16 images
 RACE_REPEATS = int(os.environ.get("RACE_REPEATS", "0"))
 if os.environ.get("GEMM_SHAPES"):
     SHAPES = [SHAPES[int(i)] for i in os.environ["GEMM_SHAPES"].split(",")]
-variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["2", "6", "7"])]
+variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "2", "8"])]
 lib = _lib.load()
 torch.manual_seed(0)
 print("variants: v & 15 = kernel variant, (v >> 4) - 1 = XCD skew (none = default 13)")
