@@ -54,8 +54,8 @@ typedef struct {
   int64_t batch2, strideA2, strideW2, strideC2;   /* optional outer batch dimension (0/1 = none): entry (b1, b2) is at b1*stride + b2*stride2 */
 } llmseg_gemm_args;
 int llmseg_gemm_bf16(const llmseg_gemm_args* args, void* stream);
-/* tuning knob: staging variant for K % 64 == 0 shapes (0 = global->VGPR->LDS, 1 = LDS-DMA double buffer [default], 2 = LDS-DMA
- * single buffer).  Results are identical; only speed differs. */
+/* tuning knob: GEMM kernel for K % 64 == 0 shapes (0 = register staging 128x128, 2 = LDS-DMA 128x128, 8 = LDS-DMA 256x256
+ * ping-pong, 5 = auto [default]).  Results are identical; only speed differs. */
 int llmseg_gemm_set_variant(int variant);
 
 /* ---- fused attention forward -----------------------------------------------------------------
@@ -84,8 +84,37 @@ typedef struct {
   /* Fused variant for SAM's 14x14 windows (head_dim 80): instead of rel_h/rel_w pass the bf16 tables themselves,
    * [32][head_dim] with rows >= 27 zero; q . R^T is then computed inside the kernel (grid_h = grid_w = 14 still required). */
   const void* rel_tab_h; const void* rel_tab_w;
+  /* optional fp32 [batch][heads][Nq]: log2-sum-exp of every score row (max*scale*log2e + log2 sum), what llmseg_attn_bwd needs */
+  float* lse;
 } llmseg_attn_args;
 int llmseg_attn_fwd(const llmseg_attn_args* args, void* stream);
+
+/* ---- fused attention backward ----------------------------------------------------------------
+ * Gradients of O = softmax(scale * Q.K^T + mask) V w.r.t. Q, K, V (plain / causal / key_mask forms; no relative position:
+ * the SAM tower is frozen).  Scores are recomputed tile by tile from Q, K and the forward's `lse`; nothing of size Nq x Nk is
+ * written.  HF LlamaAttention backward (the LoRA gradients of training.py:218-226 flow through every layer's q/v) and the
+ * mask-selection head's self attention (model/transformer.py:319-341).  head_dim in {32, 64, 128}; causal needs Nq == Nk.
+ * Every tensor is addressed as base + b*stride_b + h*stride_h + row*stride_row (elements); dQ/dK/dV may be strided views of
+ * one packed buffer.  delta is an fp32 [batch][heads][Nq] workspace (rowsum(dO * O), written by the dQ pass). */
+typedef struct {
+  const void* Q; const void* K; const void* V; const void* O; const void* dO;
+  void* dQ; void* dK; void* dV;
+  int64_t q_stride_b, q_stride_h, q_stride_row;
+  int64_t k_stride_b, k_stride_h, k_stride_row;
+  int64_t v_stride_b, v_stride_h, v_stride_row;
+  int64_t o_stride_b, o_stride_h, o_stride_row;
+  int64_t do_stride_b, do_stride_h, do_stride_row;
+  int64_t dq_stride_b, dq_stride_h, dq_stride_row;
+  int64_t dk_stride_b, dk_stride_h, dk_stride_row;
+  int64_t dv_stride_b, dv_stride_h, dv_stride_row;
+  int32_t batch, heads, Nq, Nk, head_dim;
+  float scale;
+  int32_t causal;
+  const uint8_t* key_mask;   /* [batch][Nk] 1 = attend, or NULL */
+  const float* lse;
+  float* delta;
+} llmseg_attn_bwd_args;
+int llmseg_attn_bwd(const llmseg_attn_bwd_args* args, void* stream);
 
 /* ---- row-wise normalisation ------------------------------------------------------------------
  * y[row_map ? row_map[r] : r][:] = norm(x[r][:]) * w (+ b); statistics in fp32.

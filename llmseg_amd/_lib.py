@@ -33,7 +33,14 @@ class AttnArgs(C.Structure):
                 ("scale", C.c_float), ("causal", C.c_int32),
                 ("key_mask", C.c_void_p), ("rel_h", C.c_void_p), ("rel_w", C.c_void_p),
                 ("rel_ld", C.c_int32), ("grid_h", C.c_int32), ("grid_w", C.c_int32),
-                ("o_row_map", C.c_void_p), ("rel_tab_h", C.c_void_p), ("rel_tab_w", C.c_void_p)]
+                ("o_row_map", C.c_void_p), ("rel_tab_h", C.c_void_p), ("rel_tab_w", C.c_void_p), ("lse", C.c_void_p)]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("Q", "K", "V", "O", "dO", "dQ", "dK", "dV")] +
+                [(f"{t}_stride_{s}", C.c_int64) for t in ("q", "k", "v", "o", "do", "dq", "dk", "dv") for s in ("b", "h", "row")] +
+                [("batch", C.c_int32), ("heads", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("head_dim", C.c_int32),
+                 ("scale", C.c_float), ("causal", C.c_int32), ("key_mask", C.c_void_p), ("lse", C.c_void_p), ("delta", C.c_void_p)])
 
 
 _i64, _i32, _f32, _p = C.c_int64, C.c_int32, C.c_float, C.c_void_p
@@ -45,6 +52,7 @@ SIGNATURES = {
     "llmseg_gemm_bf16": [C.POINTER(GemmArgs), _p],
     "llmseg_gemm_set_variant": [C.c_int],
     "llmseg_attn_fwd": [C.POINTER(AttnArgs), _p],
+    "llmseg_attn_bwd": [C.POINTER(AttnBwdArgs), _p],
     "llmseg_norm": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _f32, C.c_int, _p, _p],
     "llmseg_rope": [_p, _p, _p, _i64, _i64, _i32, _i32, _i64, _p],
     "llmseg_swiglu": [_p, _p, _i64, _i64, _i64, _i64, _p],

@@ -189,18 +189,21 @@ def attention_backward(q, k, v, do, dq, dk, dv, *, batch, heads, Nq, Nk, hd, qs,
 
 
 class PackedAttnFn(Function):
-    """Self attention on a packed qkv [batch*n, 3*heads*hd] buffer (Llama causal+key-mask; head self-attention)."""
+    """Self attention on a packed qkv [batch*n, 3*heads*hd] buffer (Llama causal+key-mask; head self-attention).  Backward is
+    the fused recompute kernel (`llmseg_attn_bwd`) for head_dim 32/64/128, the materialised GEMM chain otherwise."""
 
     @staticmethod
     def forward(ctx, qkv, batch, n, heads, hd, causal, key_mask):
-        out = ops.attention_packed(qkv, batch, n, heads, hd, causal=causal, key_mask=key_mask)
+        fused = hd in (32, 64, 128)
+        lse = torch.empty((batch, heads, n), device=qkv.device, dtype=torch.float32) if fused else None
+        out = ops.attention_packed(qkv, batch, n, heads, hd, causal=causal, key_mask=key_mask, lse=lse)
         ctx.args = (batch, n, heads, hd, causal)
-        ctx.save_for_backward(qkv, key_mask)
+        ctx.save_for_backward(qkv, key_mask, out if fused else None, lse)
         return out
 
     @staticmethod
     def backward(ctx, do):
-        qkv, key_mask = ctx.saved_tensors
+        qkv, key_mask, out, lse = ctx.saved_tensors
         batch, n, heads, hd, causal = ctx.args
         D = heads * hd
         do = do.contiguous()
@@ -208,9 +211,14 @@ class PackedAttnFn(Function):
         ld = qkv.stride(0)
         st = (n * ld, hd, ld)
         dst = (n * D, hd, D)
-        attention_backward(qkv, qkv[:, D:], qkv[:, 2 * D:], do, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], batch=batch, heads=heads, Nq=n, Nk=n,
-                           hd=hd, qs=st, ks=st, vs=st, dos=dst, dqs=st, dks=st, dvs=st, scale=1.0 / math.sqrt(hd), causal=causal,
-                           key_mask=key_mask)
+        if lse is not None:
+            ops.attention_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], out, do, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], lse, batch=batch, heads=heads,
+                              Nq=n, Nk=n, head_dim=hd, q_strides=st, k_strides=st, v_strides=st, o_strides=(n * out.stride(0), hd, out.stride(0)),
+                              do_strides=dst, dq_strides=st, dk_strides=st, dv_strides=st, causal=causal, key_mask=key_mask)
+        else:
+            attention_backward(qkv, qkv[:, D:], qkv[:, 2 * D:], do, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], batch=batch, heads=heads, Nq=n, Nk=n,
+                               hd=hd, qs=st, ks=st, vs=st, dos=dst, dqs=st, dks=st, dvs=st, scale=1.0 / math.sqrt(hd), causal=causal,
+                               key_mask=key_mask)
         return dqkv, None, None, None, None, None, None
 
 

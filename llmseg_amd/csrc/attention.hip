@@ -32,6 +32,7 @@ struct AttnP {
   const uint8_t* key_mask;
   const float* rel_h; const float* rel_w; int rel_ld, gh, gw;
   const int32_t* o_row_map;
+  float* lse;                                   // optional [batch][heads][Nq]: row log2-sum-exp for llmseg_attn_bwd
   const bf16_t* rtab_h; const bf16_t* rtab_w;   // REL == 4: bf16 [32][head_dim] relative-position tables (rows >= 2*14-1 are zero)
 };
 
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnP p) {
   // ---- normalise and store: lane holds O[q][d..d+3] groups ------------------------------------------------------------
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
+  if (p.lse && half == 0 && q < p.Nq) p.lse[((long)b * p.heads + h) * p.Nq + q] = fmaf(m_run, p.scale_log2, __builtin_amdgcn_logf(l_tot));
   if (q < p.Nq) {
     bf16_t* orow;
     bool skip = false;
@@ -390,6 +392,7 @@ extern "C" int llmseg_attn_fwd(const llmseg_attn_args* a, void* stream) {
   p.causal = a->causal; p.key_mask = a->key_mask;
   p.rel_h = a->rel_h; p.rel_w = a->rel_w; p.rel_ld = a->rel_ld; p.gh = a->grid_h; p.gw = a->grid_w;
   p.o_row_map = a->o_row_map;
+  p.lse = a->lse;
   p.rtab_h = (const bf16_t*)a->rel_tab_h; p.rtab_w = (const bf16_t*)a->rel_tab_w;
   hipStream_t s = (hipStream_t)stream;
   switch (a->head_dim) {

@@ -10,7 +10,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_SIGMOID, ACT_SILU, AttnArgs, GemmArgs)
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_SIGMOID, ACT_SILU, AttnArgs, AttnBwdArgs, GemmArgs)
 
 BF16 = torch.bfloat16
 
@@ -65,7 +65,7 @@ def gemm_batched(a, w, out, M, N, K, lda, ldw, ldc, batch, sA, sW, sC, out_f32=T
 
 
 def attention(q, k, v, out, *, batch, heads, Nq, Nk, head_dim, q_strides, k_strides, v_strides, o_strides, scale=None,
-              causal=False, key_mask=None, rel_h=None, rel_w=None, rel_ld=0, grid_hw=(0, 0), o_row_map=None, rel_tab_h=None, rel_tab_w=None):
+              causal=False, key_mask=None, rel_h=None, rel_w=None, rel_ld=0, grid_hw=(0, 0), o_row_map=None, rel_tab_h=None, rel_tab_w=None, lse=None):
     """Strided fused attention.  *_strides = (batch, head, row) in elements relative to the given tensors' data_ptr."""
     a = AttnArgs(Q=q.data_ptr(), K=k.data_ptr(), V=v.data_ptr(), O=out.data_ptr(),
                  q_stride_b=q_strides[0], q_stride_h=q_strides[1], q_stride_row=q_strides[2],
@@ -78,7 +78,8 @@ def attention(q, k, v, out, *, batch, heads, Nq, Nk, head_dim, q_strides, k_stri
                  rel_h=None if rel_h is None else rel_h.data_ptr(), rel_w=None if rel_w is None else rel_w.data_ptr(),
                  rel_ld=rel_ld, grid_h=grid_hw[0], grid_w=grid_hw[1],
                  o_row_map=None if o_row_map is None else o_row_map.data_ptr(),
-                 rel_tab_h=None if rel_tab_h is None else rel_tab_h.data_ptr(), rel_tab_w=None if rel_tab_w is None else rel_tab_w.data_ptr())
+                 rel_tab_h=None if rel_tab_h is None else rel_tab_h.data_ptr(), rel_tab_w=None if rel_tab_w is None else rel_tab_w.data_ptr(),
+                 lse=None if lse is None else lse.data_ptr())
     _lib.check(_lib.load().llmseg_attn_fwd(C.byref(a), _stream()), "attn_fwd")
     return out
 
@@ -93,6 +94,22 @@ def attention_packed(qkv, batch, n_tok, heads, head_dim, out=None, **kw):
     st = (n_tok * ld, head_dim, ld)
     return attention(qkv, qkv[:, D:], qkv[:, 2 * D:], out, batch=batch, heads=heads, Nq=n_tok, Nk=n_tok, head_dim=head_dim,
                      q_strides=st, k_strides=st, v_strides=st, o_strides=(n_tok * out.stride(0), head_dim, out.stride(0)), **kw)
+
+
+def attention_bwd(q, k, v, o, do, dq, dk, dv, lse, *, batch, heads, Nq, Nk, head_dim, q_strides, k_strides, v_strides, o_strides, do_strides,
+                  dq_strides, dk_strides, dv_strides, scale=None, causal=False, key_mask=None):
+    """Fused attention backward (dq, dk, dv are written).  lse = the fp32 [batch, heads, Nq] row statistics the forward wrote."""
+    assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.numel() == batch * heads * Nq
+    delta = torch.empty_like(lse)
+    kw = {}
+    for name, st in (("q", q_strides), ("k", k_strides), ("v", v_strides), ("o", o_strides), ("do", do_strides), ("dq", dq_strides),
+                     ("dk", dk_strides), ("dv", dv_strides)):
+        kw[f"{name}_stride_b"], kw[f"{name}_stride_h"], kw[f"{name}_stride_row"] = st
+    a = AttnBwdArgs(Q=q.data_ptr(), K=k.data_ptr(), V=v.data_ptr(), O=o.data_ptr(), dO=do.data_ptr(), dQ=dq.data_ptr(), dK=dk.data_ptr(),
+                    dV=dv.data_ptr(), batch=batch, heads=heads, Nq=Nq, Nk=Nk, head_dim=head_dim,
+                    scale=(1.0 / math.sqrt(head_dim)) if scale is None else scale, causal=1 if causal else 0,
+                    key_mask=None if key_mask is None else key_mask.data_ptr(), lse=lse.data_ptr(), delta=delta.data_ptr(), **kw)
+    _lib.check(_lib.load().llmseg_attn_bwd(C.byref(a), _stream()), "attn_bwd")
 
 
 def norm(x, w, b=None, eps=1e-5, rms=False, out=None, row_map=None, out_rows=None):
