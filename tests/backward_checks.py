@@ -110,13 +110,13 @@ def check_autograd_ops():
     out += _grads(sa_ref, lambda t: ag.PackedAttnFn.apply(t, Cn, K, nh, hd, False, None), [qkv], ["attn head self", "qkv"])
     # the bench shape of the fused backward: T = 319 (three 128-row owner blocks, five 64-row tiles, causal tile skipping) with
     # right padding, and a plain hd = 64 case with ragged 200 rows
-    for (Nn, T, nh, hd, causal, pad) in ((2, 319, 2, 128, True, 300), (1, 200, 2, 64, False, None), (2, 130, 1, 32, True, None)):
-        qkv = rnd(Nn * T, 3 * nh * hd, seed=20 + hd, scale=0.5)
-        km = torch.ones(Nn, T, dtype=torch.uint8)
+    for (fN, fT, fh, fd, causal, pad) in ((2, 319, 2, 128, True, 300), (1, 200, 2, 64, False, None), (2, 130, 1, 32, True, None)):
+        qkv = rnd(fN * fT, 3 * fh * fd, seed=20 + fd, scale=0.5)
+        km = torch.ones(fN, fT, dtype=torch.uint8)
         if pad:
             km[1, pad:] = 0
 
-        def ref(t, Nn=Nn, T=T, nh=nh, hd=hd, causal=causal, km=km):
+        def ref(t, Nn=fN, T=fT, nh=fh, hd=fd, causal=causal, km=km):
             x = t.view(Nn, T, 3, nh, hd).permute(2, 0, 3, 1, 4)
             s = (x[0] @ x[1].transpose(-1, -2)) / math.sqrt(hd)
             m = (km != 0)[:, None, None, :].expand(Nn, 1, T, T)
@@ -125,8 +125,8 @@ def check_autograd_ops():
             p = torch.softmax(s.masked_fill(~m, -1e30), -1)
             return (p @ x[2]).transpose(1, 2).reshape(Nn * T, nh * hd)
         kmd = km.to(DEV) if pad else None
-        out += _grads(ref, lambda t, a=(Nn, T, nh, hd, causal, kmd): ag.PackedAttnFn.apply(t, *a), [qkv],
-                      [f"attn fused T={T} hd={hd}", "qkv"])
+        out += _grads(ref, lambda t, a=(fN, fT, fh, fd, causal, kmd): ag.PackedAttnFn.apply(t, *a), [qkv],
+                      [f"attn fused T={fT} hd={fd}", "qkv"])
     q, kv = rnd(Cn, D, seed=12), rnd(Cn * K, 2 * D, seed=13, scale=0.5)
 
     def ca_ref(q, kv):
