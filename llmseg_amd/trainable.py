@@ -208,12 +208,17 @@ class TrainableMixin:
     def _ln(self, x, name, F):
         return F.norm(x, self._w(name + ".weight", F), self._w(name + ".bias", F), 1e-5, False)
 
-    def _mask_head(self, pooled, text, F):
-        """LISA.py:363-391 for one image: pooled [K, D] bf16, text [C, D] bf16 -> (pred_iou [C*K] bf16, emb [C*K, D] bf16)."""
-        K, D = pooled.shape
+    def _mask_head(self, pooled, text, F, stacked=False):
+        """LISA.py:363-391: pooled [K, D] bf16 of one image, text [C, D] bf16 -> (pred_iou [C*K] bf16, emb [C*K, D] bf16).
+        stacked: `pooled` is already the [C*K, D] row matrix (row = c*K + k) of C conversations from several images."""
         Cn = text.shape[0]
+        D = pooled.shape[1]
+        K = pooled.shape[0] // Cn if stacked else pooled.shape[0]
         nh, hd = 8, D // 8
-        s = pooled.repeat(Cn, 1) if Cn > 1 else (pooled.clone() if not F.grad else pooled)     # row = c*K + k (LISA.py:372)
+        if stacked:
+            s = pooled
+        else:
+            s = pooled.repeat(Cn, 1) if Cn > 1 else (pooled.clone() if not F.grad else pooled)  # row = c*K + k (LISA.py:372)
         t = text.contiguous()
         lin = lambda x, p, act=ops.ACT_NONE, res=None: F.linear(x, self._w(p + ".weight", F), self._w(p + ".bias", F), act, res)
         for i in range(2):
@@ -301,21 +306,36 @@ class TrainableMixin:
             pred = torch.empty((0, c.out_dim), device=hidden.device, dtype=BF16)
         pred_embeddings = [pred[seg_off[b]:seg_off[b + 1]] for b in range(B)]
 
-        ious, embs = [], []
+        # mask pooling per image, then the mask-selection head ONCE per group of images with the same proposal count: the head's
+        # weights are shared, so its rows (image, conversation, proposal) are stacked into one matrix (the reference loops over
+        # images, LISA.py:355-391; per-image launches of M = K-row GEMMs leave 250 of the 256 CUs idle)
+        ious, embs = [None] * B, [None] * B
+        pooled_of, groups = {}, {}
         for b in range(B):
             segs = sam_segs_list[b].to(BF16).contiguous()
             S = segs.shape[-1]
             fb = feat[b * rows_per_img + row0: b * rows_per_img + row0 + g * g]
-            pooled = F.maskpool(fb, segs, g, S)
-            K = segs.shape[0]
             Cn = pred_embeddings[b].shape[0]
             if Cn == 0:
                 if not inference:
                     raise ValueError("number of rounds = 0")                          # LISA.py:435-437
-                ious.append(None); embs.append(None)
                 continue
-            iou, emb = self._mask_head(pooled, pred_embeddings[b], F)
-            ious.append(iou.view(Cn, K)); embs.append(emb.view(Cn, K, -1))
+            pooled_of[b] = F.maskpool(fb, segs, g, S)
+            groups.setdefault(segs.shape[0], []).append(b)
+        for K, members in groups.items():
+            if len(members) == 1:
+                b = members[0]
+                iou, emb = self._mask_head(pooled_of[b], pred_embeddings[b], F)
+            else:
+                s0 = torch.cat([pooled_of[b].repeat(pred_embeddings[b].shape[0], 1) if pred_embeddings[b].shape[0] > 1 else pooled_of[b]
+                                for b in members], 0)
+                iou, emb = self._mask_head(s0, torch.cat([pred_embeddings[b] for b in members], 0), F, stacked=True)
+            r0 = 0
+            for b in members:
+                Cn = pred_embeddings[b].shape[0]
+                ious[b] = iou[r0 * K:(r0 + Cn) * K].view(Cn, K)
+                embs[b] = emb[r0 * K:(r0 + Cn) * K].view(Cn, K, -1)
+                r0 += Cn
 
         if inference:
             sims = [ops.cosine_scores(pred_embeddings[b][0], embs[b][0])[None] for b in range(B)]
