@@ -26,8 +26,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   if (rl == 0 && col < N) atomicAdd(&out[col], red[0][c] + red[1][c] + red[2][c] + red[3][c]);
 }
 
-// LayerNorm / RMSNorm backward, one wave per row.  dw/db (fp32, may be NULL) are accumulated with atomics.
-__global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+// LayerNorm / RMSNorm backward, one wave per row.  dw/db (fp32, may be NULL) are accumulated with atomics.  CPL > 0: x and dy
+// (<= 64*CPL 16-byte chunks per row) are read once and kept in registers; CPL == 0: multi-pass fallback.
+template <int CPL>
+__global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                       bf16_t* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, long rows, int cols,
                                                       float eps, int rms) {
   const int lane = threadIdx.x & 63;
@@ -36,53 +38,66 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict_
   const bf16_t* xr = x + row * cols;
   const bf16_t* gr = dy + row * cols;
   const int nch = cols >> 3;
+  constexpr int NR = CPL > 0 ? CPL : 1;
+  uint4 xc[NR], gc[NR];
+  if constexpr (CPL > 0) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int c = lane + 64 * i;
+      const bool on = c < nch;
+      xc[i] = on ? *reinterpret_cast<const uint4*>(xr + c * 8) : make_uint4(0, 0, 0, 0);
+      gc[i] = on ? *reinterpret_cast<const uint4*>(gr + c * 8) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  // BODY sees chunk index c and the cached / freshly loaded 16-byte pieces xv (x) and gv (dy)
+#define LL_FOR_CHUNKS(...)                                                                       \
+  if constexpr (CPL > 0) {                                                                       \
+    _Pragma("unroll") for (int i = 0; i < NR; ++i) {                                             \
+      const int c = lane + 64 * i;                                                               \
+      if (c < nch) { const uint4 xv = xc[i], gv = gc[i]; __VA_ARGS__ }                             \
+    }                                                                                            \
+  } else {                                                                                       \
+    for (int c = lane; c < nch; c += 64) {                                                       \
+      const uint4 xv = *reinterpret_cast<const uint4*>(xr + c * 8), gv = *reinterpret_cast<const uint4*>(gr + c * 8); \
+      __VA_ARGS__                                                                                \
+    }                                                                                            \
+  }
   float f[8], g[8], ww[8];
   float s = 0.f;
   if (!rms) {
-    for (int c = lane; c < nch; c += 64) {
-      unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s += f[e];
-    }
+    LL_FOR_CHUNKS({ (void)gv; unpack8(xv, f); _Pragma("unroll") for (int e = 0; e < 8; ++e) s += f[e]; })
     s = wave_sum(s);
   }
   const float mean = rms ? 0.f : s / (float)cols;
   float v = 0.f;
-  for (int c = lane; c < nch; c += 64) {
-    unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; v += d * d; }
-  }
+  LL_FOR_CHUNKS({ (void)gv; unpack8(xv, f); _Pragma("unroll") for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; v += d * d; } })
   v = wave_sum(v);
   const float rstd = rsqrtf(v / (float)cols + eps);
   // c1 = mean(g), c2 = mean(g * xhat) with g = dy * w
   float c1 = 0.f, c2 = 0.f;
-  for (int c = lane; c < nch; c += 64) {
-    unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
-    unpack8(*reinterpret_cast<const uint4*>(gr + c * 8), g);
+  LL_FOR_CHUNKS({
+    unpack8(xv, f); unpack8(gv, g);
     unpack8(*reinterpret_cast<const uint4*>(w + c * 8), ww);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) {
       const float xh = (f[e] - mean) * rstd, gg = g[e] * ww[e];
       c1 += gg; c2 += gg * xh;
     }
-  }
+  })
   c1 = wave_sum(c1) / (float)cols; c2 = wave_sum(c2) / (float)cols;
   if (rms) c1 = 0.f;
-  for (int c = lane; c < nch; c += 64) {
+  LL_FOR_CHUNKS({
     float o[8];
-    unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
-    unpack8(*reinterpret_cast<const uint4*>(gr + c * 8), g);
+    unpack8(xv, f); unpack8(gv, g);
     unpack8(*reinterpret_cast<const uint4*>(w + c * 8), ww);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) {
       const float xh = (f[e] - mean) * rstd;
       o[e] = rstd * (g[e] * ww[e] - c1 - xh * c2);
       if (dw) atomicAdd(&dw[c * 8 + e], g[e] * xh);
       if (db) atomicAdd(&db[c * 8 + e], g[e]);
     }
     *reinterpret_cast<uint4*>(dx + row * cols + c * 8) = pack8(o);
-  }
+  })
+#undef LL_FOR_CHUNKS
 }
 
 // d_gu[r][c] = d_out * up * silu'(gate), d_gu[r][I+c] = d_out * silu(gate)
@@ -237,8 +252,13 @@ extern "C" int llmseg_colsum(const void* x, float* out, int64_t M, int64_t N, in
 extern "C" int llmseg_norm_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw, float* db, int64_t rows, int64_t cols, float eps,
                                int rms, void* stream) {
   LL_CHECK(dy && x && w && dx && rows > 0 && cols > 0 && (cols & 7) == 0 && AL16(dy) && AL16(x) && AL16(w) && AL16(dx), "norm_bwd: bad arguments");
-  hipLaunchKernelGGL(norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
-                     (const bf16_t*)w, (bf16_t*)dx, dw, db, (long)rows, (int)cols, eps, rms);
+  const int cpl = (int)(((cols >> 3) + 63) / 64);
+  const dim3 grid((unsigned)((rows + 3) / 4));
+#define LL_NORMB(C)                                                                                                                       \
+  hipLaunchKernelGGL(norm_bwd_kernel<C>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, \
+                     (bf16_t*)dx, dw, db, (long)rows, (int)cols, eps, rms)
+  if (cpl <= 1) LL_NORMB(1); else if (cpl <= 2) LL_NORMB(2); else if (cpl <= 4) LL_NORMB(4); else if (cpl <= 8) LL_NORMB(8); else LL_NORMB(0);
+#undef LL_NORMB
   LL_LAUNCH_CHECK("norm_bwd");
   return LLMSEG_OK;
 }

@@ -39,9 +39,9 @@ void llmseg_prof_begin(hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_mu);
   ProfRec r;
   if (!g_pool.empty()) { r = g_pool.back(); g_pool.pop_back(); }
-  else { hipEventCreate(&r.a); hipEventCreate(&r.b); }
+  else { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); }
   r.flops = 0;
-  hipEventRecord(r.a, s);
+  (void)hipEventRecord(r.a, s);
   g_recs.push_back(r);
 }
 
@@ -57,7 +57,7 @@ void llmseg_prof_end(hipStream_t s, double flops) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_recs.empty()) return;
   g_recs.back().flops = flops;
-  hipEventRecord(g_recs.back().b, s);
+  (void)hipEventRecord(g_recs.back().b, s);
 }
 
 extern "C" int llmseg_prof_enable(int on) {
@@ -74,9 +74,9 @@ extern "C" int llmseg_prof_collect(double* total_ms, double* total_flops, int64_
   std::map<long, std::array<double, 3>> by_class;                      // kernel class (staging variant, fp32-out) -> {ms, flops, count}
   std::map<std::array<long, 4>, std::array<double, 3>> by_shape;      // (M,N,K,variant) -> {ms, flops, count}
   for (auto& r : g_recs) {
-    hipEventSynchronize(r.b);
+    (void)hipEventSynchronize(r.b);
     float t = 0;
-    hipEventElapsedTime(&t, r.a, r.b);
+    (void)hipEventElapsedTime(&t, r.a, r.b);
     ms += t;
     fl += r.flops;
     auto& c = by_class[(r.tag[3] / 1000) * 2 + (r.tag[3] & 1)];

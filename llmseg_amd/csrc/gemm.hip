@@ -675,7 +675,7 @@ void llmseg_prof_tag(long a, long b, long c, long d);
 // 5 (default) = auto between 2 and 8.  Bits 4+ = XCD skew + 1.
 static int g_gemm_variant = 5, g_gemm_skew = 13;
 static int num_cus() {
-  static int n = [] { int dev = 0, v = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
+  static int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
   return n;
 }
 extern "C" int llmseg_gemm_set_variant(int v) { g_gemm_variant = v & 15; if (v >= 16) g_gemm_skew = (v >> 4) - 1; return LLMSEG_OK; }

@@ -7,7 +7,9 @@
 
 namespace {
 
-// ---- LayerNorm / RMSNorm: one wave per row, three L1-resident passes ----------------------------------------------
+// ---- LayerNorm / RMSNorm: one wave per row.  CPL > 0: the row (<= 64*CPL 16-byte chunks) is read ONCE and kept in registers
+// for the three reductions / the normalise pass; CPL == 0: generic multi-pass fallback for very wide rows. ------------------
+template <int CPL>
 __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                   const bf16_t* __restrict__ bias, bf16_t* __restrict__ y, long rows, int cols,
                                                   long ldx, long ldy, float eps, int rms, const int32_t* __restrict__ row_map) {
@@ -16,43 +18,78 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
   if (row >= rows) return;
   const bf16_t* xr = x + row * ldx;
   const int nch = cols >> 3;
+  constexpr int NR = CPL > 0 ? CPL : 1;
+  uint4 xc[NR];
   float f[8];
-  float s = 0.f;
-  if (!rms) {
-    for (int c = lane; c < nch; c += 64) {
-      unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
+  float s = 0.f, v = 0.f;
+  if (CPL > 0) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += f[e];
+    for (int i = 0; i < NR; ++i) {
+      const int c = lane + 64 * i;
+      xc[i] = c < nch ? *reinterpret_cast<const uint4*>(xr + c * 8) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  if (!rms) {
+    if (CPL > 0) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        unpack8(xc[i], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += f[e];
+      }
+    } else {
+      for (int c = lane; c < nch; c += 64) {
+        unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += f[e];
+      }
     }
     s = wave_sum(s);
   }
   const float mean = rms ? 0.f : s / (float)cols;
-  float v = 0.f;
-  for (int c = lane; c < nch; c += 64) {
-    unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
+  if (CPL > 0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; v += d * d; }
+    for (int i = 0; i < NR; ++i) {
+      if (lane + 64 * i < nch) {
+        unpack8(xc[i], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; v += d * d; }
+      }
+    }
+  } else {
+    for (int c = lane; c < nch; c += 64) {
+      unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; v += d * d; }
+    }
   }
   v = wave_sum(v);
   const float rstd = rsqrtf(v / (float)cols + eps);
   long orow = row;
   if (row_map) { orow = row_map[row]; if (orow < 0) return; }
   bf16_t* yr = y + orow * ldy;
-  for (int c = lane; c < nch; c += 64) {
-    float g[8], o[8];
-    unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
+  auto emit = [&](int c, const uint4& xv) {
+    float g[8], o[8], ff[8];
+    unpack8(xv, ff);
     unpack8(*reinterpret_cast<const uint4*>(w + c * 8), g);
     if (rms) {
       // HF LlamaRMSNorm rounds the normalised value to the activation dtype before the weight multiply
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = g[e] * bf2f(f2bf(f[e] * rstd));
+      for (int e = 0; e < 8; ++e) o[e] = g[e] * bf2f(f2bf(ff[e] * rstd));
     } else {
       float bb[8];
       if (bias) unpack8(*reinterpret_cast<const uint4*>(bias + c * 8), bb);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (f[e] - mean) * rstd * g[e] + (bias ? bb[e] : 0.f);
+      for (int e = 0; e < 8; ++e) o[e] = (ff[e] - mean) * rstd * g[e] + (bias ? bb[e] : 0.f);
     }
     *reinterpret_cast<uint4*>(yr + c * 8) = pack8(o);
+  };
+  if (CPL > 0) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      if (lane + 64 * i < nch) emit(lane + 64 * i, xc[i]);
+  } else {
+    for (int c = lane; c < nch; c += 64) emit(c, *reinterpret_cast<const uint4*>(xr + c * 8));
   }
 }
 
@@ -202,8 +239,14 @@ extern "C" int llmseg_norm(const void* x, const void* w, const void* b, void* y,
   LL_CHECK(x && w && y && rows > 0 && cols > 0, "norm: bad arguments");
   LL_CHECK((cols & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0, "norm: cols/ld must be multiples of 8");
   LL_CHECK(AL16(x) && AL16(w) && AL16(y) && (b == nullptr || AL16(b)), "norm: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(norm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w,
-                     (const bf16_t*)b, (bf16_t*)y, (long)rows, (int)cols, (long)ldx, (long)ldy, eps, rms, row_map);
+  const int cpl = (int)(((cols >> 3) + 63) / 64);
+  const dim3 grid((unsigned)((rows + 3) / 4));
+#define LL_NORM(C)                                                                                                                   \
+  hipLaunchKernelGGL(norm_kernel<C>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, \
+                     (bf16_t*)y, (long)rows, (int)cols, (long)ldx, (long)ldy, eps, rms, row_map)
+  if (cpl <= 1) LL_NORM(1); else if (cpl <= 2) LL_NORM(2); else if (cpl <= 3) LL_NORM(3); else if (cpl <= 4) LL_NORM(4);
+  else if (cpl <= 8) LL_NORM(8); else if (cpl <= 16) LL_NORM(16); else LL_NORM(0);
+#undef LL_NORM
   LL_LAUNCH_CHECK("norm");
   return LLMSEG_OK;
 }
