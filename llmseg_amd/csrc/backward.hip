@@ -1,6 +1,7 @@
 // Backward-pass and optimizer kernels for the trainable part of the LLM-Seg hot path (LoRA'd Llama stack, embed/lm_head,
 // text_hidden_fcs, mask-selection head).  All HBM-bound streaming kernels; GEMM-shaped gradients go through
 // llmseg_gemm_bf16 with trans_a / trans_w.  See include/llmseg_hip.h for the reference ops each one differentiates.
+#include <algorithm>
 #include "common.h"
 #include "llmseg_hip.h"
 
@@ -26,78 +27,105 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   if (rl == 0 && col < N) atomicAdd(&out[col], red[0][c] + red[1][c] + red[2][c] + red[3][c]);
 }
 
-// LayerNorm / RMSNorm backward, one wave per row.  dw/db (fp32, may be NULL) are accumulated with atomics.  CPL > 0: x and dy
-// (<= 64*CPL 16-byte chunks per row) are read once and kept in registers; CPL == 0: multi-pass fallback.
-template <int CPL>
+// LayerNorm / RMSNorm backward, one wave per row.  CPL > 0: x and dy (<= 64*CPL 16-byte chunks per row) are read once and kept
+// in registers; CPL == 0: multi-pass fallback.  Weight / bias gradients (fp32, dw may be NULL): ACC = true (narrow rows, CPL <= 2)
+// walks rows grid-stride with per-lane register partial sums and issues ONE atomic per column per wave at the end - per-element
+// atomics from 6144 rows onto 256 addresses took 1.1 ms per call; ACC = false keeps per-element atomics (wide trainable norms).
+template <int CPL, bool ACC>
 __global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                      bf16_t* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, long rows, int cols,
-                                                      float eps, int rms) {
+                                                         bf16_t* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, long rows, int cols,
+                                                         float eps, int rms) {
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const bf16_t* xr = x + row * cols;
-  const bf16_t* gr = dy + row * cols;
   const int nch = cols >> 3;
   constexpr int NR = CPL > 0 ? CPL : 1;
-  uint4 xc[NR], gc[NR];
-  if constexpr (CPL > 0) {
+  float aw[ACC ? NR : 1][8], ab[ACC ? NR : 1][8];
+  if constexpr (ACC) {
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int c = lane + 64 * i;
-      const bool on = c < nch;
-      xc[i] = on ? *reinterpret_cast<const uint4*>(xr + c * 8) : make_uint4(0, 0, 0, 0);
-      gc[i] = on ? *reinterpret_cast<const uint4*>(gr + c * 8) : make_uint4(0, 0, 0, 0);
-    }
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { aw[i][e] = 0.f; ab[i][e] = 0.f; }
   }
-  // BODY sees chunk index c and the cached / freshly loaded 16-byte pieces xv (x) and gv (dy)
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+    const bf16_t* xr = x + row * cols;
+    const bf16_t* gr = dy + row * cols;
+    uint4 xc[NR], gc[NR];
+    if constexpr (CPL > 0) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int c = lane + 64 * i;
+        const bool on = c < nch;
+        xc[i] = on ? *reinterpret_cast<const uint4*>(xr + c * 8) : make_uint4(0, 0, 0, 0);
+        gc[i] = on ? *reinterpret_cast<const uint4*>(gr + c * 8) : make_uint4(0, 0, 0, 0);
+      }
+    }
+    // the body sees chunk index c, cache slot i and the cached / freshly loaded 16-byte pieces xv (x) and gv (dy)
 #define LL_FOR_CHUNKS(...)                                                                       \
   if constexpr (CPL > 0) {                                                                       \
     _Pragma("unroll") for (int i = 0; i < NR; ++i) {                                             \
       const int c = lane + 64 * i;                                                               \
-      if (c < nch) { const uint4 xv = xc[i], gv = gc[i]; __VA_ARGS__ }                             \
+      if (c < nch) { const uint4 xv = xc[i], gv = gc[i]; __VA_ARGS__ }                           \
     }                                                                                            \
   } else {                                                                                       \
     for (int c = lane; c < nch; c += 64) {                                                       \
+      constexpr int i = 0;                                                                       \
       const uint4 xv = *reinterpret_cast<const uint4*>(xr + c * 8), gv = *reinterpret_cast<const uint4*>(gr + c * 8); \
       __VA_ARGS__                                                                                \
     }                                                                                            \
   }
-  float f[8], g[8], ww[8];
-  float s = 0.f;
-  if (!rms) {
-    LL_FOR_CHUNKS({ (void)gv; unpack8(xv, f); _Pragma("unroll") for (int e = 0; e < 8; ++e) s += f[e]; })
-    s = wave_sum(s);
-  }
-  const float mean = rms ? 0.f : s / (float)cols;
-  float v = 0.f;
-  LL_FOR_CHUNKS({ (void)gv; unpack8(xv, f); _Pragma("unroll") for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; v += d * d; } })
-  v = wave_sum(v);
-  const float rstd = rsqrtf(v / (float)cols + eps);
-  // c1 = mean(g), c2 = mean(g * xhat) with g = dy * w
-  float c1 = 0.f, c2 = 0.f;
-  LL_FOR_CHUNKS({
-    unpack8(xv, f); unpack8(gv, g);
-    unpack8(*reinterpret_cast<const uint4*>(w + c * 8), ww);
-    _Pragma("unroll") for (int e = 0; e < 8; ++e) {
-      const float xh = (f[e] - mean) * rstd, gg = g[e] * ww[e];
-      c1 += gg; c2 += gg * xh;
+    float f[8], g[8], ww[8];
+    float s = 0.f;
+    if (!rms) {
+      LL_FOR_CHUNKS({ (void)gv; (void)i; unpack8(xv, f); _Pragma("unroll") for (int e = 0; e < 8; ++e) s += f[e]; })
+      s = wave_sum(s);
     }
-  })
-  c1 = wave_sum(c1) / (float)cols; c2 = wave_sum(c2) / (float)cols;
-  if (rms) c1 = 0.f;
-  LL_FOR_CHUNKS({
-    float o[8];
-    unpack8(xv, f); unpack8(gv, g);
-    unpack8(*reinterpret_cast<const uint4*>(w + c * 8), ww);
-    _Pragma("unroll") for (int e = 0; e < 8; ++e) {
-      const float xh = (f[e] - mean) * rstd;
-      o[e] = rstd * (g[e] * ww[e] - c1 - xh * c2);
-      if (dw) atomicAdd(&dw[c * 8 + e], g[e] * xh);
-      if (db) atomicAdd(&db[c * 8 + e], g[e]);
-    }
-    *reinterpret_cast<uint4*>(dx + row * cols + c * 8) = pack8(o);
-  })
+    const float mean = rms ? 0.f : s / (float)cols;
+    float v = 0.f;
+    LL_FOR_CHUNKS({ (void)gv; (void)i; unpack8(xv, f); _Pragma("unroll") for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; v += d * d; } })
+    v = wave_sum(v);
+    const float rstd = rsqrtf(v / (float)cols + eps);
+    // c1 = mean(g), c2 = mean(g * xhat) with g = dy * w
+    float c1 = 0.f, c2 = 0.f;
+    LL_FOR_CHUNKS({
+      (void)i;
+      unpack8(xv, f); unpack8(gv, g);
+      unpack8(*reinterpret_cast<const uint4*>(w + c * 8), ww);
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) {
+        const float xh = (f[e] - mean) * rstd, gg = g[e] * ww[e];
+        c1 += gg; c2 += gg * xh;
+      }
+    })
+    c1 = wave_sum(c1) / (float)cols; c2 = wave_sum(c2) / (float)cols;
+    if (rms) c1 = 0.f;
+    LL_FOR_CHUNKS({
+      float o[8];
+      unpack8(xv, f); unpack8(gv, g);
+      unpack8(*reinterpret_cast<const uint4*>(w + c * 8), ww);
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) {
+        const float xh = (f[e] - mean) * rstd;
+        o[e] = rstd * (g[e] * ww[e] - c1 - xh * c2);
+        if constexpr (ACC) { aw[i][e] += g[e] * xh; ab[i][e] += g[e]; }
+        else {
+          if (dw) atomicAdd(&dw[c * 8 + e], g[e] * xh);
+          if (db) atomicAdd(&db[c * 8 + e], g[e]);
+        }
+      }
+      *reinterpret_cast<uint4*>(dx + row * cols + c * 8) = pack8(o);
+    })
 #undef LL_FOR_CHUNKS
+  }
+  if constexpr (ACC) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (dw) atomicAdd(&dw[c * 8 + e], aw[i][e]);
+          if (db) atomicAdd(&db[c * 8 + e], ab[i][e]);
+        }
+      }
+    }
+  }
 }
 
 // d_gu[r][c] = d_out * up * silu'(gate), d_gu[r][I+c] = d_out * silu(gate)
@@ -253,11 +281,15 @@ extern "C" int llmseg_norm_bwd(const void* dy, const void* x, const void* w, voi
                                int rms, void* stream) {
   LL_CHECK(dy && x && w && dx && rows > 0 && cols > 0 && (cols & 7) == 0 && AL16(dy) && AL16(x) && AL16(w) && AL16(dx), "norm_bwd: bad arguments");
   const int cpl = (int)(((cols >> 3) + 63) / 64);
-  const dim3 grid((unsigned)((rows + 3) / 4));
-#define LL_NORMB(C)                                                                                                                       \
-  hipLaunchKernelGGL(norm_bwd_kernel<C>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, \
+  const bool acc = (dw || db) && cpl <= 2;
+  const long wgs = (rows + 3) / 4;
+  const dim3 grid((unsigned)(acc ? std::min<long>(wgs, 256) : wgs));
+#define LL_NORMB(C, A)                                                                                                                       \
+  hipLaunchKernelGGL((norm_bwd_kernel<C, A>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, \
                      (bf16_t*)dx, dw, db, (long)rows, (int)cols, eps, rms)
-  if (cpl <= 1) LL_NORMB(1); else if (cpl <= 2) LL_NORMB(2); else if (cpl <= 4) LL_NORMB(4); else if (cpl <= 8) LL_NORMB(8); else LL_NORMB(0);
+  if (acc) { if (cpl <= 1) LL_NORMB(1, true); else LL_NORMB(2, true); }
+  else if (cpl <= 1) LL_NORMB(1, false); else if (cpl <= 2) LL_NORMB(2, false); else if (cpl <= 4) LL_NORMB(4, false);
+  else if (cpl <= 8) LL_NORMB(8, false); else LL_NORMB(0, false);
 #undef LL_NORMB
   LL_LAUNCH_CHECK("norm_bwd");
   return LLMSEG_OK;
@@ -332,62 +364,116 @@ extern "C" int llmseg_adamw(void* p, float* master, const void* grad, int grad_f
 namespace {
 constexpr int LR = 8;
 
-// y[m][r] = alpha * sum_k x[m][k] * W(r,k).  One wave per row.  w_kr = 0: W stored [8][K]; 1: W stored [K][8].
+// y[m][r] = alpha * sum_k x[m][k] * W(r,k).  One wave per FOUR rows (each W chunk is loaded once for the four).
+// w_kr = 0: W stored [8][K]; 1: W stored [K][8].
 __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
                                                        long M, int K, int w_kr, float alpha) {
+  constexpr int RW = 4;
   const int lane = threadIdx.x & 63;
-  const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= M) return;
-  float acc[LR];
+  const long m0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  if (m0 >= M) return;
+  float acc[RW][LR];
 #pragma unroll
-  for (int r = 0; r < LR; ++r) acc[r] = 0.f;
-  const bf16_t* xr = x + m * ldx;
+  for (int i = 0; i < RW; ++i)
+#pragma unroll
+    for (int r = 0; r < LR; ++r) acc[i][r] = 0.f;
+  const bf16_t* xr[RW];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) xr[i] = x + min(m0 + i, M - 1) * ldx;
   for (int k = lane * 8; k < K; k += 64 * 8) {
-    float xv[8], wv[8];
-    unpack8(*reinterpret_cast<const uint4*>(xr + k), xv);
+    float xv[RW][8], wv[8];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) unpack8(*reinterpret_cast<const uint4*>(xr[i] + k), xv[i]);
     if (w_kr) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         unpack8(*reinterpret_cast<const uint4*>(w + (long)(k + j) * LR), wv);
 #pragma unroll
-        for (int r = 0; r < LR; ++r) acc[r] += xv[j] * wv[r];
+        for (int i = 0; i < RW; ++i)
+#pragma unroll
+          for (int r = 0; r < LR; ++r) acc[i][r] += xv[i][j] * wv[r];
       }
     } else {
 #pragma unroll
       for (int r = 0; r < LR; ++r) {
         unpack8(*reinterpret_cast<const uint4*>(w + (long)r * K + k), wv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[r] += xv[j] * wv[j];
+        for (int i = 0; i < RW; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[i][r] += xv[i][j] * wv[j];
       }
     }
   }
 #pragma unroll
-  for (int r = 0; r < LR; ++r) acc[r] = wave_sum(acc[r]) * alpha;
-  if (lane == 0) *reinterpret_cast<uint4*>(y + m * LR) = pack8(acc);
+  for (int i = 0; i < RW; ++i) {
+#pragma unroll
+    for (int r = 0; r < LR; ++r) acc[i][r] = wave_sum(acc[i][r]) * alpha;
+    if (lane == 0 && m0 + i < M) *reinterpret_cast<uint4*>(y + (m0 + i) * LR) = pack8(acc[i]);
+  }
 }
 
 // out(n,r) += alpha * sum_m a[m][n] * b[m][r]  (fp32 atomics; caller zero-fills).  out_rn = 0: out [N][8]; 1: out [8][N].
+// Workgroup = 256 columns x one slice of rows: lane = (row-lane 0..7, column chunk 0..7), a wave reads 8 rows x 128 contiguous
+// bytes per step (16 B per lane, three steps in flight); the 8 row-lanes are folded with shuffles, so one set of atomics per
+// column per wave (the same atomic count as a column-per-thread layout, 20x the loads in flight).
 __global__ __launch_bounds__(256) void lora_outer_kernel(const bf16_t* __restrict__ a, long lda, const bf16_t* __restrict__ b, float* __restrict__ out,
                                                         long M, long N, int out_rn, float alpha) {
-  const long n = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cl = lane & 7, rl = lane >> 3;
+  const long n = ((long)blockIdx.x * 32 + wave * 8 + cl) * 8;
   const long per = (M + gridDim.y - 1) / gridDim.y;
   const long m0 = (long)blockIdx.y * per, m1 = min(M, m0 + per);
-  if (n >= N) return;
-  float a0[LR], a1[LR];
+  const bool on = n < N;
+  float acc[8][LR];
 #pragma unroll
-  for (int r = 0; r < LR; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
-  for (long m = m0; m < m1; ++m) {
-    const uint32_t av = *reinterpret_cast<const uint32_t*>(a + m * lda + n);
-    const float x0 = __uint_as_float(av << 16), x1 = __uint_as_float(av & 0xffff0000u);
-    float bv[8];
-    unpack8(*reinterpret_cast<const uint4*>(b + m * LR), bv);
+  for (int j = 0; j < 8; ++j)
 #pragma unroll
-    for (int r = 0; r < LR; ++r) { a0[r] += x0 * bv[r]; a1[r] += x1 * bv[r]; }
+    for (int r = 0; r < LR; ++r) acc[j][r] = 0.f;
+  if (on) {
+    long m = m0 + rl;
+    for (; m + 16 < m1; m += 24) {
+      uint4 av[3], bv[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        av[u] = *reinterpret_cast<const uint4*>(a + (m + 8 * u) * lda + n);
+        bv[u] = *reinterpret_cast<const uint4*>(b + (m + 8 * u) * LR);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        float x[8], y[8];
+        unpack8(av[u], x); unpack8(bv[u], y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int r = 0; r < LR; ++r) acc[j][r] = fmaf(x[j], y[r], acc[j][r]);
+      }
+    }
+    for (; m < m1; m += 8) {
+      float x[8], y[8];
+      unpack8(*reinterpret_cast<const uint4*>(a + m * lda + n), x);
+      unpack8(*reinterpret_cast<const uint4*>(b + m * LR), y);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < LR; ++r) acc[j][r] = fmaf(x[j], y[r], acc[j][r]);
+    }
   }
 #pragma unroll
-  for (int r = 0; r < LR; ++r) {
-    if (out_rn) { atomicAdd(&out[(long)r * N + n], a0[r] * alpha); atomicAdd(&out[(long)r * N + n + 1], a1[r] * alpha); }
-    else { atomicAdd(&out[n * LR + r], a0[r] * alpha); atomicAdd(&out[(n + 1) * LR + r], a1[r] * alpha); }
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int r = 0; r < LR; ++r) {
+      float v = acc[j][r];
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+      acc[j][r] = v * alpha;
+    }
+  if (on && rl == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < LR; ++r) {
+        if (out_rn) atomicAdd(&out[(long)r * N + n + j], acc[j][r]);
+        else atomicAdd(&out[(n + j) * LR + r], acc[j][r]);
+      }
   }
 }
 
@@ -424,16 +510,16 @@ __global__ __launch_bounds__(256) void lora_apply_kernel(bf16_t* __restrict__ y,
 
 extern "C" int llmseg_lora_down(const void* x, int64_t ldx, const void* w, void* y, int64_t M, int64_t K, int32_t w_kr, float alpha, void* stream) {
   LL_CHECK(x && w && y && M > 0 && K > 0 && (K & 7) == 0 && (ldx & 7) == 0 && AL16(x) && AL16(w) && AL16(y), "lora_down: bad arguments");
-  hipLaunchKernelGGL(lora_down_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ldx, (const bf16_t*)w,
+  hipLaunchKernelGGL(lora_down_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ldx, (const bf16_t*)w,
                      (bf16_t*)y, (long)M, (int)K, w_kr, alpha);
   LL_LAUNCH_CHECK("lora_down");
   return LLMSEG_OK;
 }
 
 extern "C" int llmseg_lora_outer(const void* a, int64_t lda, const void* b, float* out, int64_t M, int64_t N, int32_t out_rn, float alpha, void* stream) {
-  LL_CHECK(a && b && out && M > 0 && N > 0 && (N & 1) == 0 && (lda & 1) == 0 && AL16(b), "lora_outer: bad arguments");
+  LL_CHECK(a && b && out && M > 0 && N > 0 && (N & 7) == 0 && (lda & 7) == 0 && AL16(a) && AL16(b), "lora_outer: bad arguments (N, lda multiples of 8)");
   const unsigned gy = (unsigned)max((long)1, min((long)32, M / 64));
-  hipLaunchKernelGGL(lora_outer_kernel, dim3((unsigned)((N / 2 + 255) / 256), gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (long)lda,
+  hipLaunchKernelGGL(lora_outer_kernel, dim3((unsigned)((N + 255) / 256), gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (long)lda,
                      (const bf16_t*)b, out, (long)M, (long)N, out_rn, alpha);
   LL_LAUNCH_CHECK("lora_outer");
   return LLMSEG_OK;

@@ -1,0 +1,34 @@
+"""Tuning aid (GPU box): one training micro-step under torch.profiler; prints the PyTorch-side (non-library) ops by device time
+with input shapes, to find stray copies / casts in the host code."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
+from llmseg_amd import synthetic  # noqa: E402
+from llmseg_amd.lisa import LISAForCausalLM  # noqa: E402
+from llmseg_amd.params import LisaConfig, LlamaConfig  # noqa: E402
+from llmseg_amd.train import Trainer  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+dev = torch.device("cuda", 0)
+cfg = LisaConfig(backbone="sam", build_unused_towers=False)
+cfg.llama = LlamaConfig(lora_r=8)
+model = LISAForCausalLM(cfg, device=dev).init_random(seed=0)
+model.prepare()
+batch = synthetic.make_batch(B, img_size=1024, L=64, K=256, device=dev, seed=1234)
+model.set_trainable()
+trainer = Trainer(model, lr=3e-4, grad_accum=10)
+for _ in range(2):
+    trainer.micro_step(batch)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=False) as prof:
+    trainer.micro_step(batch)
+    torch.cuda.synchronize()
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.device_time_total > 0 and e.key.startswith("aten::")]
+rows.sort(key=lambda e: -e.device_time_total)
+print(f"{'op':28s} {'calls':>6s} {'dev ms':>9s}  shapes")
+for e in rows[:40]:
+    print(f"{e.key:28s} {e.count:6d} {e.device_time_total / 1e3:9.2f}  {str(e.input_shapes)[:150]}")
