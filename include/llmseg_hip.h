@@ -162,6 +162,9 @@ int llmseg_gather_rows(const void* x, const int64_t* idx, void* out, int64_t n, 
  * `segs` (K*S*S bf16, the only large operand) is read from HBM exactly once.  feat bf16 [g*g][C]; pooled bf16 [K][C].
  * ws: caller-provided bf16 [K][g*g] workspace (the normalised pulled-back masks; stage 2 is an MFMA GEMM over it).
  * Optional outputs for the backward pass (NULL = skip): pulled_back fp32 [K][g*g] = segs . U, wsum fp32 [K] = sum_p segs. */
+/* Stage 1 of the above alone: ws[k][:] = (segs[k] . U) / (sum_p segs[k][p] + 1e-8) as bf16 [K][g*g] (+ the optional fp32 outputs),
+ * so that a caller can pool several images with ONE strided-batched llmseg_gemm_bf16 (trans_w) over their feature maps. */
+int llmseg_mask_pullback(const void* segs, void* ws, float* pulled_back, float* wsum, int32_t K, int32_t g, int32_t S, void* stream);
 int llmseg_upsample_maskpool(const void* feat, const void* segs, void* pooled, void* ws, float* pulled_back, float* wsum, int32_t K,
                              int32_t C, int32_t g, int32_t S, void* stream);
 

@@ -61,6 +61,7 @@ SIGNATURES = {
     "llmseg_im2col3x3": [_p, _p, _i32, _i32, _i32, _i32, _p],
     "llmseg_embed_splice": [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i64, _i64, _p],
     "llmseg_gather_rows": [_p, _p, _p, _i64, _i64, _i64, _p],
+    "llmseg_mask_pullback": [_p, _p, _p, _p, _i32, _i32, _i32, _p],
     "llmseg_upsample_maskpool": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p],
     "llmseg_cosine_scores": [_p, _p, _p, _i32, _i32, _p],
     "llmseg_align_reg_loss": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _f32, _p],

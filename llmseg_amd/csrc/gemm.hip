@@ -45,16 +45,35 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case LLMSEG_ACT_RELU: return fmaxf(v, 0.f);
     case LLMSEG_ACT_GELU: {   // exact (erf) GELU; erf via Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7 (far below bf16 resolution)
       const float z = fabsf(v) * 0.70710678118654752f;
-      const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+      const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
       const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
       const float erfa = 1.f - poly * __expf(-z * z);
       return 0.5f * v * (1.f + copysignf(erfa, v));
     }
-    case LLMSEG_ACT_QUICKGELU: return v * __frcp_rn(1.f + __expf(-1.702f * v));
-    case LLMSEG_ACT_SILU: return v * __frcp_rn(1.f + __expf(-v));
-    case LLMSEG_ACT_SIGMOID: return __frcp_rn(1.f + __expf(-v));
+    case LLMSEG_ACT_QUICKGELU: return v * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v));
+    case LLMSEG_ACT_SILU: return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
+    case LLMSEG_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.f + __expf(-v));
     default: return v;
   }
+}
+
+// exact-erf GELU on a pair (packed fp32 VALU: v_pk_fma / v_pk_mul).  Same Abramowitz-Stegun 7.1.26 erf as apply_act, rearranged:
+// 0.5 v (1 + erf(v/sqrt2)) = max(v, 0) - 0.5|v| * t*poly(t) * exp(-v^2/2),  t = 1 / (1 + p|v|/sqrt2);  exp via exp2.
+__device__ __forceinline__ f32x2_t gelu2(f32x2_t v) {
+  const f32x2_t a = __builtin_elementwise_abs(v);
+  const f32x2_t den = __builtin_elementwise_fma(a, (f32x2_t)(0.3275911f * 0.70710678118654752f), (f32x2_t)(1.f));
+  f32x2_t t;
+  t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
+  f32x2_t p = __builtin_elementwise_fma(t, (f32x2_t)(1.061405429f), (f32x2_t)(-1.453152027f));
+  p = __builtin_elementwise_fma(p, t, (f32x2_t)(1.421413741f));
+  p = __builtin_elementwise_fma(p, t, (f32x2_t)(-0.284496736f));
+  p = __builtin_elementwise_fma(p, t, (f32x2_t)(0.254829592f));
+  const f32x2_t zs = a * 0.84932180028801907f;          // |v| * sqrt(log2(e) / 2): exp(-v^2/2) = exp2(-zs^2)
+  const f32x2_t nz2 = -(zs * zs);
+  f32x2_t e;
+  e.x = __builtin_amdgcn_exp2f(nz2.x); e.y = __builtin_amdgcn_exp2f(nz2.y);
+  const f32x2_t hp = (a * 0.5f) * (p * t);
+  return __builtin_elementwise_fma(-hp, e, __builtin_elementwise_max(v, (f32x2_t)(0.f)));
 }
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * (BK * 2) + (((chunk ^ (row >> 1)) & 7) << 4); }
@@ -291,7 +310,10 @@ __device__ __forceinline__ void epilogue_lds_body(const GemmP& p, const f32x16_t
     for (int it = 0; it < 8; ++it) {
       const float4 a4 = *reinterpret_cast<const float4*>(slab + roff[it & 3] + (it >> 2) * (16 * 64));
       float v[4] = {fmaf(a4.x, alpha, bs[0]), fmaf(a4.y, alpha, bs[1]), fmaf(a4.z, alpha, bs[2]), fmaf(a4.w, alpha, bs[3])};
-      if (ACT != LLMSEG_ACT_NONE) {
+      if (ACT == LLMSEG_ACT_GELU) {
+        const f32x2_t g0 = gelu2(f32x2_t{v[0], v[1]}), g1 = gelu2(f32x2_t{v[2], v[3]});
+        v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
+      } else if (ACT != LLMSEG_ACT_NONE) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], ACT);
       }

@@ -194,14 +194,21 @@ __global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logi
 
 }  // namespace
 
-extern "C" int llmseg_upsample_maskpool(const void* feat, const void* segs, void* pooled, void* ws, float* pulled_back, float* wsum, int32_t K,
-                                        int32_t C, int32_t g, int32_t S, void* stream) {
-  LL_CHECK(feat && segs && pooled && ws && K > 0 && C > 0 && g > 0 && S >= g, "upsample_maskpool: bad arguments");
-  LL_CHECK(256 % g == 0 && ((g * g) & 7) == 0 && (C & 7) == 0, "upsample_maskpool: feature grid %d must divide 256 (and C %% 8 == 0)", g);
+extern "C" int llmseg_mask_pullback(const void* segs, void* ws, float* pulled_back, float* wsum, int32_t K, int32_t g, int32_t S, void* stream) {
+  LL_CHECK(segs && ws && K > 0 && g > 0 && S >= g, "mask_pullback: bad arguments");
+  LL_CHECK(256 % g == 0 && ((g * g) & 7) == 0, "mask_pullback: feature grid %d must divide 256", g);
   const size_t lds = ((size_t)((S + 1) / 2) * g + (size_t)g * g + 16) * sizeof(float);
-  LL_CHECK(lds <= 64 * 1024, "upsample_maskpool: S=%d g=%d need %zu bytes of LDS", S, g, lds);
+  LL_CHECK(lds <= 64 * 1024, "mask_pullback: S=%d g=%d need %zu bytes of LDS", S, g, lds);
   hipLaunchKernelGGL(mask_pullback_kernel, dim3(K), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)segs, (bf16_t*)ws, pulled_back, wsum, g, S);
   LL_LAUNCH_CHECK("mask_pullback");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_upsample_maskpool(const void* feat, const void* segs, void* pooled, void* ws, float* pulled_back, float* wsum, int32_t K,
+                                        int32_t C, int32_t g, int32_t S, void* stream) {
+  LL_CHECK(feat && pooled && C > 0 && (C & 7) == 0, "upsample_maskpool: bad arguments");
+  const int rc = llmseg_mask_pullback(segs, ws, pulled_back, wsum, K, g, S, stream);
+  if (rc != LLMSEG_OK) return rc;
   // pooled[K][C] = wn[K][g*g] . feat[g*g][C]
   llmseg_gemm_args ga = {};
   ga.A = ws; ga.W = feat; ga.C = pooled;

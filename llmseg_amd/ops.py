@@ -196,6 +196,24 @@ def upsample_maskpool(feat_cl, segs, g, S, want_aux=False):
     return (out, pb, ws) if want_aux else out
 
 
+def maskpool_batched(feat_cl, rows_per_img, row0, segs_list, g, S):
+    """Mask pooling of several images with equal proposal count: feat_cl bf16 [B*rows_per_img, C] (the g*g patch rows of image b
+    start at row b*rows_per_img + row0), segs_list[b] bf16 [K, S, S] -> pooled bf16 [B, K, C].  One pull-back launch per image,
+    ONE strided-batched GEMM for all of them."""
+    B, K, Cc = len(segs_list), segs_list[0].shape[0], feat_cl.shape[1]
+    assert feat_cl.is_contiguous()
+    wn = torch.empty((B, K, g * g), device=feat_cl.device, dtype=BF16)
+    lib = _lib.load()
+    for b, segs in enumerate(segs_list):
+        _req(segs)
+        assert segs.is_contiguous() and segs.shape == (K, S, S)
+        _lib.check(lib.llmseg_mask_pullback(_ptr(segs), _ptr(wn[b]), None, None, K, g, S, _stream()), "mask_pullback")
+    out = torch.empty((B, K, Cc), device=feat_cl.device, dtype=BF16)
+    gemm_batched(wn, feat_cl[row0:], out, M=K, N=Cc, K=g * g, lda=g * g, ldw=Cc, ldc=Cc, batch=B, sA=K * g * g, sW=rows_per_img * Cc,
+                 sC=K * Cc, out_f32=False, trans_w=True)
+    return out
+
+
 def cosine_scores(t, e):
     K, D = e.shape
     out = torch.empty((K,), device=e.device, dtype=torch.float32)

@@ -311,17 +311,26 @@ class TrainableMixin:
         # images, LISA.py:355-391; per-image launches of M = K-row GEMMs leave 250 of the 256 CUs idle)
         ious, embs = [None] * B, [None] * B
         pooled_of, groups = {}, {}
+        segs_of = {}
         for b in range(B):
-            segs = sam_segs_list[b].to(BF16).contiguous()
-            S = segs.shape[-1]
-            fb = feat[b * rows_per_img + row0: b * rows_per_img + row0 + g * g]
             Cn = pred_embeddings[b].shape[0]
             if Cn == 0:
                 if not inference:
                     raise ValueError("number of rounds = 0")                          # LISA.py:435-437
                 continue
-            pooled_of[b] = F.maskpool(fb, segs, g, S)
-            groups.setdefault(segs.shape[0], []).append(b)
+            segs_of[b] = sam_segs_list[b].to(BF16).contiguous()
+            groups.setdefault(tuple(segs_of[b].shape), []).append(b)
+        for (K, S, _), members in groups.items():
+            if len(members) > 1 and not (F.grad and feat.requires_grad) and members == list(range(members[0], members[0] + len(members))):
+                # frozen feature map (SAM backbone): all images of the group pooled by one strided-batched GEMM
+                pooled = ops.maskpool_batched(feat[members[0] * rows_per_img:], rows_per_img, row0, [segs_of[b] for b in members], g, S)
+                for i, b in enumerate(members):
+                    pooled_of[b] = pooled[i]
+            else:
+                for b in members:
+                    fb = feat[b * rows_per_img + row0: b * rows_per_img + row0 + g * g]
+                    pooled_of[b] = F.maskpool(fb, segs_of[b], g, S)
+        groups = {K: [b for (k2, _, _), ms in groups.items() if k2 == K for b in ms] for K in sorted({k[0] for k in groups})}
         for K, members in groups.items():
             if len(members) == 1:
                 b = members[0]
