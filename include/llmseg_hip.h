@@ -229,6 +229,10 @@ int llmseg_scatter_add_rows(const void* src, const int64_t* idx, float* dst, int
 int llmseg_lora_down(const void* x, int64_t ldx, const void* w, void* y, int64_t M, int64_t K, int32_t w_kr, float alpha, void* stream);
 int llmseg_lora_outer(const void* a, int64_t lda, const void* b, float* out, int64_t M, int64_t N, int32_t out_rn, float alpha, void* stream);
 int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, const void* w, int64_t M, int64_t N, int32_t w_rn, float alpha, void* stream);
+/* out[c][r] = in[r][c] (bf16; in [rows][cols] with leading dimension ld_in, out [cols][ld_out]); rows r in [rows, rows_pad) of the
+ * source are taken as zero.  Lets the weight / input gradients of a wide trainable Linear (lm_head: dX = dY.W, dW = dY^T.X) run on
+ * the K-contiguous LDS-DMA GEMM kernels with the contraction dimension padded to a multiple of 64. */
+int llmseg_transpose_pad(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, int64_t rows_pad, void* stream);
 /* out[0] += sum x^2 (global gradient-norm clipping, training.py:301 "gradient_clipping": 1.0) */
 int llmseg_sumsq(const void* x, int64_t n, int is_f32, float* out, void* stream);
 /* Fused AdamW on fp32 master weights + bf16 model copy (DeepSpeed config training.py:292-332: betas (0.9, 0.95), wd 0).

@@ -14,6 +14,9 @@ from . import ops
 BF16 = torch.bfloat16
 
 
+BIG_LINEAR = 1 << 34          # M*N*K above which LinearFn.backward transposes/pads its operands for the LDS-DMA GEMM kernels
+
+
 def _pad8_cols(t):
     """[M, N] -> [M, roundup8(N)] zero-padded copy (tiny tensors only: N < 8 heads such as the 1-wide IoP head)."""
     M, N = t.shape
@@ -44,19 +47,35 @@ class LinearFn(Function):
         dy = dy.contiguous()
         dpre = ops.act_bwd(dy, y, ctx.act) if ctx.act != ops.ACT_NONE else dy
         N = w.shape[0]
+        M, Kin = x.shape
         dx = dw = db = None
-        if N % 8 != 0:                                   # tiny head (N = 1): pad the contraction/leading dims
-            dpre_p = _pad8_cols(dpre)
-            w_p = torch.zeros((dpre_p.shape[1], w.shape[1]), device=w.device, dtype=w.dtype)
-            w_p[:N] = w
+        if M * N * Kin >= BIG_LINEAR and Kin % 8 == 0 and (ctx.needs_input_grad[1] or ctx.wt is None or N % 8 != 0):
+            # wide trainable Linear (lm_head, [32004, 4096]): pad the contraction dims to multiples of 64 and transpose the
+            # operands once, so that both gradient GEMMs run on the K-contiguous LDS-DMA kernels instead of the
+            # transposed-operand register-staged one (3-4x slower at this size)
+            Np, Mp = (N + 63) // 64 * 64, (M + 63) // 64 * 64
+            if Np != N:
+                dpp = torch.zeros((M, Np), device=dpre.device, dtype=BF16)
+                dpp[:, :N] = dpre
+            else:
+                dpp = dpre
+            if ctx.needs_input_grad[0]:
+                dx = ops.gemm(dpp, ops.transpose_pad(w, Np))                             # [M, Np] @ [Np, Kin]   (W^T: [Kin, Np])
+            if ctx.needs_input_grad[1]:
+                dw = ops.gemm(ops.transpose_pad(dpp, Mp), ops.transpose_pad(x, Mp))[:N]   # [Np, Mp] @ [Mp, Kin]
         else:
-            dpre_p, w_p = dpre, w
-        if ctx.needs_input_grad[0]:
-            dx = ops.gemm(dpre, ctx.wt) if (ctx.wt is not None and N % 8 == 0) else ops.gemm(dpre_p, w_p, trans_w=True)   # [M,N] @ [N,K]
-        if ctx.needs_input_grad[1]:
-            dw = ops.gemm(dpre_p, x, trans_a=True, trans_w=True)[:N]      # [N,M] @ [M,K]
-            if dw.shape[0] != N or not dw.is_contiguous():
-                dw = dw.contiguous()
+            if N % 8 != 0:                                   # tiny head (N = 1): pad the contraction/leading dims
+                dpre_p = _pad8_cols(dpre)
+                w_p = torch.zeros((dpre_p.shape[1], w.shape[1]), device=w.device, dtype=w.dtype)
+                w_p[:N] = w
+            else:
+                dpre_p, w_p = dpre, w
+            if ctx.needs_input_grad[0]:
+                dx = ops.gemm(dpre, ctx.wt) if (ctx.wt is not None and N % 8 == 0) else ops.gemm(dpre_p, w_p, trans_w=True)   # [M,N] @ [N,K]
+            if ctx.needs_input_grad[1]:
+                dw = ops.gemm(dpre_p, x, trans_a=True, trans_w=True)[:N]      # [N,M] @ [M,K]
+                if dw.shape[0] != N or not dw.is_contiguous():
+                    dw = dw.contiguous()
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = ops.colsum(dpre).to(BF16)
         dres = dy if (ctx.has_res and ctx.needs_input_grad[4]) else None

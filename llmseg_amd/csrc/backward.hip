@@ -506,6 +506,33 @@ __global__ __launch_bounds__(256) void lora_apply_kernel(bf16_t* __restrict__ y,
     *reinterpret_cast<uint4*>(y + m * ldy + c * 8) = pack8(yv);
   }
 }
+// out[c][r] = in[r][c] for r < rows (zero for rows <= r < rows_pad): 64 x 64 tiles through LDS, 16-byte global accesses both ways.
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, long rows, long cols, long ld_in,
+                                                           long ld_out, long rows_pad) {
+  __shared__ bf16_t tile[64][66];
+  const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    const int r = idx >> 3, ch = idx & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < rows && c0 + ch * 8 < cols) v = *reinterpret_cast<const uint4*>(in + (r0 + r) * ld_in + c0 + ch * 8);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&tile[r][ch * 8]);
+    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    const int c = idx >> 3, rh = idx & 7;
+    if (c0 + c >= cols || r0 + rh * 8 >= rows_pad) continue;
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = (uint32_t)tile[rh * 8 + 2 * j][c] | ((uint32_t)tile[rh * 8 + 2 * j + 1][c] << 16);
+    *reinterpret_cast<uint4*>(out + (c0 + c) * ld_out + r0 + rh * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
 }  // namespace
 
 extern "C" int llmseg_lora_down(const void* x, int64_t ldx, const void* w, void* y, int64_t M, int64_t K, int32_t w_kr, float alpha, void* stream) {
@@ -530,5 +557,15 @@ extern "C" int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, const voi
   hipLaunchKernelGGL(lora_apply_kernel, dim3(grid_for(M * (N >> 3))), dim3(256), 0, (hipStream_t)stream, (bf16_t*)y, (long)ldy, (const bf16_t*)xa,
                      (const bf16_t*)w, (long)M, (long)N, w_rn, alpha);
   LL_LAUNCH_CHECK("lora_apply");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_transpose_pad(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, int64_t rows_pad, void* stream) {
+  LL_CHECK(in && out && rows > 0 && cols > 0 && rows_pad >= rows && ld_out >= rows_pad && ld_in >= cols, "transpose_pad: bad arguments");
+  LL_CHECK((cols & 7) == 0 && (ld_in & 7) == 0 && (ld_out & 7) == 0 && (rows_pad & 7) == 0 && AL16(in) && AL16(out),
+           "transpose_pad: cols, rows_pad and leading dimensions must be multiples of 8, pointers 16-byte aligned");
+  hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)((rows_pad + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)in, (bf16_t*)out, (long)rows, (long)cols, (long)ld_in, (long)ld_out, (long)rows_pad);
+  LL_LAUNCH_CHECK("transpose_pad");
   return LLMSEG_OK;
 }

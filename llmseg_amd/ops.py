@@ -360,6 +360,20 @@ def adamw_(p, master, grad, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=No
                                         lr, beta1, beta2, eps, wd, step, _ptr(grad_scale), _stream()), "adamw")
 
 
+def transpose_pad(x, rows_pad=None, out=None):
+    """x bf16 [R, C] (row stride any multiple of 8) -> out [C, rows_pad]: out[c][r] = x[r][c], zeros for R <= r < rows_pad.
+    `out` may be wider than rows_pad (its remaining columns are left untouched)."""
+    _req(x)
+    R, Cc = x.shape
+    rows_pad = (R + 7) // 8 * 8 if rows_pad is None else rows_pad
+    assert x.stride(1) == 1 and rows_pad >= R and rows_pad % 8 == 0
+    if out is None:
+        out = torch.empty((Cc, rows_pad), device=x.device, dtype=BF16)
+    assert out.shape[0] == Cc and out.shape[1] >= rows_pad and out.stride(1) == 1
+    _lib.check(_lib.load().llmseg_transpose_pad(_ptr(x), _ptr(out), R, Cc, x.stride(0), out.stride(0), rows_pad, _stream()), "transpose_pad")
+    return out
+
+
 def prof_enable(on):
     _lib.load().llmseg_prof_enable(1 if on else 0)
 

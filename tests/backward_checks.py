@@ -76,6 +76,14 @@ def check_autograd_ops():
     out += _grads(lambda x, w, b, r: F.linear(x, w, b) + r, lambda x, w, b, r: ag.linear(x, w, b, ops.ACT_NONE, r), [x, w, b, r],
                   ["linear+res", "x", "w", "b", "res"])
     out += _grads(lambda x, w, b: F.relu(F.linear(x, w, b)), lambda x, w, b: ag.linear(x, w, b, ops.ACT_RELU), [x, w, b], ["linear relu", "x", "w", "b"])
+    # the wide-Linear path (lm_head): operands transposed + padded to multiples of 64, forced here at a small size; N = 260 is
+    # neither a multiple of 8 nor of 64, M = 200 pads to 256
+    ag.BIG_LINEAR, keep = 0, ag.BIG_LINEAR
+    try:
+        wl = rnd(260, 256, seed=31, scale=1 / 16)
+        out += _grads(lambda x, w: F.linear(x, w), lambda x, w: ag.linear(x, w), [x, wl], ["linear wide-path", "x", "w"])
+    finally:
+        ag.BIG_LINEAR = keep
     w1, b1 = rnd(1, 256, seed=5, scale=1 / 16), rnd(1, seed=6)
     out += _grads(lambda x, w, b: torch.sigmoid(F.linear(x, w, b)), lambda x, w, b: ag.linear(x, w, b, ops.ACT_SIGMOID), [x, w1, b1],
                   ["linear N=1 sigmoid", "x", "w", "b"])
