@@ -245,14 +245,20 @@ def main():
             "model_tflop_per_image": model_flops / args.batch / 1e12,
             "model_mfma_frac": model_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
             "loss": loss,
+            "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
         }
         if fwd_only is not None:
             res["fwd_only"] = fwd_only
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(res), flush=True)
+    else:
+        res = None
     if dist:
-        dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()      # RCCL prints its version banner on teardown: keep the JSON line the LAST line of stdout
+    if res is not None:
+        sys.stdout.flush()
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

@@ -37,6 +37,7 @@ struct GemmP {
   int act;
   int tiles_m, tiles_n;
   int c_vec, r_vec, b_vec;   // host-verified alignment for vector C stores / residual loads / bias+gamma loads
+  int group_m;               // M-tiles per group of the ping-pong kernel's tile walk
   int skew;                  // per-XCD rotation of the tile walk (de-phases the 8 XCDs' HBM/MALL channel access)
 };
 
@@ -613,9 +614,9 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
     const int idx = ((bid >> 3) + xcd * p.skew) % len;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int per_group = GROUP_M * p.tiles_n;
-  const int first_m = (bid / per_group) * GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int per_group = p.group_m * p.tiles_n;
+  const int first_m = (bid / per_group) * p.group_m;
+  const int gsz = min(p.tiles_m - first_m, p.group_m);
   const int m0 = (first_m + (bid % per_group) % gsz) * BMB;
   const int n0 = ((bid % per_group) / gsz) * BNB;
 
@@ -732,6 +733,7 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   p.b_vec = ((p.bias == nullptr || (((uintptr_t)p.bias) & 7) == 0) && (p.gamma == nullptr || (((uintptr_t)p.gamma) & 7) == 0)) ? 1 : 0;
 
   p.skew = g_gemm_skew;
+  static const int group_m_env = getenv("LLMSEG_GEMM_GROUP_M") ? atoi(getenv("LLMSEG_GEMM_GROUP_M")) : 0;   // tuning override
   int variant = (p.K % BK == 0 && !ta && !tw) ? g_gemm_variant : 0;
   if (variant != 0 && variant != 2 && variant != 8) variant = 5;
   if (variant == 8 && p.K < 2 * BK) variant = 2;
@@ -745,6 +747,9 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   }
   const int bm = variant == 8 ? 256 : 128, bn = variant == 8 ? 256 : BN;
   p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
+  // ping-pong tile walk (tools/gemm_bench.py sweep): short matrices (Llama, <= 32 row tiles) keep all of M in one group so a
+  // W column tile is fetched once per XCD; tall ones (SAM, 384+ row tiles) walk 4 row tiles per group (+3..6 % at K = 5120)
+  p.group_m = group_m_env > 0 ? group_m_env : (p.tiles_m <= 32 ? p.tiles_m : 4);
   dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);
   hipStream_t s = (hipStream_t)stream;
   llmseg_prof_begin(s);
