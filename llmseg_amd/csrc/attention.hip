@@ -50,10 +50,16 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnP p) {
   constexpr int PV = (BKV + 4) * 2;           // Vt row pitch (bytes) = 136 = 8 * 17
   constexpr bool WIN = (REL == 3 || REL == 4);            // SAM 14x14 window; 4 = q.R^T computed here (no rel_h/rel_w arrays)
   constexpr int G_SLAB = 32 * 33;                          // per-wave fp32 [32 queries][33] slab per table (REL == 4)
-  __shared__ __attribute__((aligned(16))) char smem[BKV * PK + DT * 32 * PV + BKV * 4 + (REL == 4 ? 4 * 2 * G_SLAB * 4 : 0)];
-  char* Ks = smem;
+  // K/V tile buffers: two for the plain / global-grid paths (the next tile is written while the current one is read: ONE barrier per
+  // tile), one for the window paths (whose per-wave rel-pos slabs already take 34 KiB) and the generic-grid path (single lut)
+  constexpr bool DB = (REL == 0 || REL == 2);
+  constexpr int TILE_BYTES = BKV * PK + DT * 32 * PV;
+  __shared__ __attribute__((aligned(16))) char smem[(DB ? 2 : 1) * TILE_BYTES + BKV * 4 + (REL == 4 ? 4 * 2 * G_SLAB * 4 : 0)];
+  char* Ks = smem;                // tile being READ
   char* Vt = smem + BKV * PK;
-  uint32_t* lut = reinterpret_cast<uint32_t*>(smem + BKV * PK + DT * 32 * PV);
+  char* Ks_w = smem;              // tile being WRITTEN (== Ks unless DB)
+  char* Vt_w = smem + BKV * PK;
+  uint32_t* lut = reinterpret_cast<uint32_t*>(smem + (DB ? 2 : 1) * TILE_BYTES);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, half = lane >> 5;
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnP p) {
     // Fused decomposed rel-pos (image_encoder.py:354-392): G^T = R . Q^T on the matrix cores (R = the 27-row table, zero
     // padded to 32 rows; Q fragments are already in registers), bounced through a per-wave LDS slab because each lane needs the
     // entries at its own (qh - kh + 13) / (qw - kw + 13): replaces two skinny fp32 GEMM launches + 41 scattered loads per lane.
-    float* gs = reinterpret_cast<float*>(smem + BKV * PK + DT * 32 * PV + BKV * 4) + wave * (2 * G_SLAB);
+    float* gs = reinterpret_cast<float*>(smem + TILE_BYTES + BKV * 4) + wave * (2 * G_SLAB);
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb) {
       const bf16_t* tab = tb == 0 ? p.rtab_h : p.rtab_w;
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnP p) {
     const int idx = tid + IT * NT;                                                                  \
     if ((IT + 1) * NT <= BKV * CH || idx < BKV * CH) {                                              \
       const int key = idx / CH, c = idx - key * CH;                                                 \
-      *reinterpret_cast<uint4*>(Ks + key * PK + c * 16) = REG;                                      \
+      *reinterpret_cast<uint4*>(Ks_w + key * PK + c * 16) = REG;                                    \
     }                                                                                               \
   }
 #define LL_STAGE_LOAD(T)                                                                            \
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnP p) {
   {                                                                                                 \
     LL_K_STORE(0, kreg0) LL_K_STORE(1, kreg1) LL_K_STORE(2, kreg2) LL_K_STORE(3, kreg3)             \
     if (v_on) {                                                                                     \
-      char* dst = Vt + (8 * v_c) * PV + 8 * v_kq;                                                   \
+      char* dst = Vt_w + (8 * v_c) * PV + 8 * v_kq;                                                 \
       *reinterpret_cast<uint2*>(dst + 0 * PV) = make_uint2(perm_lo(vreg0.x, vreg1.x), perm_lo(vreg2.x, vreg3.x)); \
       *reinterpret_cast<uint2*>(dst + 1 * PV) = make_uint2(perm_hi(vreg0.x, vreg1.x), perm_hi(vreg2.x, vreg3.x)); \
       *reinterpret_cast<uint2*>(dst + 2 * PV) = make_uint2(perm_lo(vreg0.y, vreg1.y), perm_lo(vreg2.y, vreg3.y)); \
@@ -311,6 +317,15 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnP p) {
     LL_STAGE_LOAD(2) LL_TILE_BODY(1, 1) __syncthreads(); LL_STAGE_STORE(2) __syncthreads();
     LL_STAGE_LOAD(3) LL_TILE_BODY(2, 2) __syncthreads(); LL_STAGE_STORE(3) __syncthreads();
     LL_TILE_BODY(3, 3)
+  } else if constexpr (DB) {
+    for (int t = 0; t < ntiles; ++t) {
+      Ks = smem + (t & 1) * TILE_BYTES; Vt = Ks + BKV * PK;
+      Ks_w = smem + ((t + 1) & 1) * TILE_BYTES; Vt_w = Ks_w + BKV * PK;
+      if (t + 1 < ntiles) LL_STAGE_LOAD(t + 1)
+      LL_TILE_BODY(t, 0)
+      if (t + 1 < ntiles) LL_STAGE_STORE(t + 1)      // the other buffer: its last readers passed the barrier of iteration t-1
+      __syncthreads();
+    }
   } else {
     for (int t = 0; t < ntiles; ++t) {
       if (t + 1 < ntiles) LL_STAGE_LOAD(t + 1)
