@@ -50,5 +50,17 @@ for M, N, K, tag in SHAPES:
                 ops.gemm(a, w, bias=bias, out=out)
                 bad += int(not torch.equal(out, first))
             chk.append(float(bad))
-    print(f"{tag + f' {M}x{N}x{K}':32s} " + " ".join(f"{r:9.0f}" for r in res) + "   check " + " ".join(f"{c:.1e}" for c in chk), flush=True)
+    extra = ""
+    if os.environ.get("WITH_TORCH"):                       # hipBLASLt through torch.matmul (+ bias add), same data
+        for _ in range(3):
+            torch.addmm(bias, a, w.t(), out=out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            torch.addmm(bias, a, w.t(), out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        extra = f"   torch.addmm {2.0 * M * N * K / (e0.elapsed_time(e1) / 10) / 1e9:6.0f}"
+    print(f"{tag + f' {M}x{N}x{K}':32s} " + " ".join(f"{r:9.0f}" for r in res) + "   check " + " ".join(f"{c:.1e}" for c in chk) + extra, flush=True)
 lib.llmseg_gemm_set_variant(5)
