@@ -16,7 +16,8 @@
 // (lane -> LDS slot (row, cpos) -> global chunk cpos ^ ((row>>1)&7) of that row; the 8 lanes of a row still read one 128-byte
 // line).  Workgroup ids are remapped so that each of the 8 XCDs (private L2s) walks a contiguous, M-grouped range of tiles.
 // Kernels tried and dropped (numbers in DESIGN.md): 256 x 128 LDS-DMA tiles, a lock-step 256 x 256 two-stage kernel, a 4-stage
-// BK = 32 ring, a persistent ping-pong with the next tile's DMA issued before the epilogue, K-half ping-pong phases.
+// BK = 32 ring, a persistent ping-pong with the next tile's DMA issued before the epilogue, K-half ping-pong phases, a 4-wave
+// 128 x 128-per-wave kernel with in-wave fragment prefetch (LDS-DMA issue from the MFMA wave costs ~170 cycles per instruction).
 #include <algorithm>
 #include <cstdlib>
 #include "common.h"
