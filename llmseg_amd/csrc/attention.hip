@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int BQ = 128, BKV = 64, NT = 256;
+constexpr int BKV = 64;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG = -1.0e30f;
 
@@ -41,8 +41,11 @@ __device__ __forceinline__ uint32_t perm_hi(uint32_t a, uint32_t b) { return (a 
 
 // REL: 0 = no bias, 1 = generic grid (slow, general), 2 = grid_w == BKV (a K tile is exactly one key row: kh uniform,
 // kw = offset), 3 = SAM's 14x14 window (196 keys = 4 unrolled tiles, per-query bias rows live in 28 registers)
-template <int HD, int REL>
-__global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnP p) {
+// NW = waves per workgroup (32 queries each): 4 by default; 8 for long sequences (every workgroup re-reads ALL keys, so 256
+// queries per workgroup halve the L2 -> LDS traffic and the staging work per query; the K/V tile and LDS footprint are the same).
+template <int HD, int REL, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnP p) {
+  constexpr int NT = NW * 64, BQ = NW * 32;
   constexpr int KS = HD / 16;                 // k-steps of QK^T
   constexpr int DT = (HD + 31) / 32;          // 32-row blocks of O^T
   constexpr int CH = HD / 8;                  // 16-byte chunks per row
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnP p) {
   // tile), one for the window paths (whose per-wave rel-pos slabs already take 34 KiB) and the generic-grid path (single lut)
   constexpr bool DB = (REL == 0 || REL == 2);
   constexpr int TILE_BYTES = BKV * PK + DT * 32 * PV;
-  __shared__ __attribute__((aligned(16))) char smem[(DB ? 2 : 1) * TILE_BYTES + BKV * 4 + (REL == 4 ? 4 * 2 * G_SLAB * 4 : 0)];
+  __shared__ __attribute__((aligned(16))) char smem[(DB ? 2 : 1) * TILE_BYTES + BKV * 4 + (REL == 4 ? NW * 2 * G_SLAB * 4 : 0)];
   char* Ks = smem;                // tile being READ
   char* Vt = smem + BKV * PK;
   char* Ks_w = smem;              // tile being WRITTEN (== Ks unless DB)
@@ -366,12 +369,20 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnP p) {
 
 template <int HD>
 int launch_hd(const AttnP& p, hipStream_t s) {
-  dim3 grid((p.Nq + BQ - 1) / BQ, p.heads, p.batch);
-  if (p.rtab_h != nullptr) hipLaunchKernelGGL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 4 : 0>), grid, dim3(NT), 0, s, p);
-  else if (p.rel_h == nullptr) hipLaunchKernelGGL((attn_fwd_kernel<HD, 0>), grid, dim3(NT), 0, s, p);
-  else if (HD == 80 && p.gh == 14 && p.gw == 14 && p.Nk == 196 && !p.causal && !p.key_mask) hipLaunchKernelGGL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 3 : 1>), grid, dim3(NT), 0, s, p);
-  else if (p.gw == BKV && (p.Nk % BKV) == 0) hipLaunchKernelGGL((attn_fwd_kernel<HD, 2>), grid, dim3(NT), 0, s, p);
-  else hipLaunchKernelGGL((attn_fwd_kernel<HD, 1>), grid, dim3(NT), 0, s, p);
+  const bool wide = p.Nq >= 1024 && !p.causal;                       // long non-causal sequences: 256 queries per workgroup
+  const int bq = wide ? 256 : 128;
+  dim3 grid((p.Nq + bq - 1) / bq, p.heads, p.batch);
+  constexpr int NT4 = 256, NT8 = 512;
+  if (p.rtab_h != nullptr) hipLaunchKernelGGL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 4 : 0>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
+  else if (p.rel_h == nullptr) {
+    if (wide) hipLaunchKernelGGL((attn_fwd_kernel<HD, 0, 8>), grid, dim3(NT8), 0, s, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<HD, 0>), grid, dim3(NT4), 0, s, p);
+  } else if (HD == 80 && p.gh == 14 && p.gw == 14 && p.Nk == 196 && !p.causal && !p.key_mask)
+    hipLaunchKernelGGL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 3 : 1>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
+  else if (p.gw == BKV && (p.Nk % BKV) == 0) {
+    if (wide) hipLaunchKernelGGL((attn_fwd_kernel<HD, 2, 8>), grid, dim3(NT8), 0, s, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<HD, 2>), grid, dim3(NT4), 0, s, p);
+  } else hipLaunchKernelGGL((attn_fwd_kernel<HD, 1>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
   return 0;
 }
 

@@ -27,6 +27,11 @@ def test_tiny_train_losses(backbone):
     _assert(mc.check_tiny_train_losses(backbone))
 
 
+def test_tiny_train_losses_ragged_proposal_counts():
+    from tests import model_checks as mc
+    _assert(mc.check_tiny_train_losses("sam", ragged=True))
+
+
 def test_reference_api():
     from tests import model_checks as mc
     _assert(mc.check_reference_api())
