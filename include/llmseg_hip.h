@@ -52,6 +52,10 @@ typedef struct {
   int trans_a;   /* 1: A is stored [K][M] (M contiguous, lda >= M) -- used by the backward pass (dW = dY^T X) */
   int trans_w;   /* 1: W is stored [K][N] (N contiguous, ldw >= N) -- used by the backward pass (dX = dY W) */
   int64_t batch2, strideA2, strideW2, strideC2;   /* optional outer batch dimension (0/1 = none): entry (b1, b2) is at b1*stride + b2*stride2 */
+  /* optional 64-wide extension of the contraction: C = epi(alpha * (A.W^T + A2.W2^T)), A2 bf16 [M][64] (lda2), W2 bf16 [N][64]
+   * (ldw2); NULL = none.  Fuses low-rank updates (the r = 8 LoRA products of q_proj / v_proj, zero-padded to 64 columns) into the
+   * big GEMM as one more K-tile instead of a read-modify-write pass over C.  batch == 1, no trans_*. */
+  const void* A2; const void* W2; int64_t lda2, ldw2;
 } llmseg_gemm_args;
 int llmseg_gemm_bf16(const llmseg_gemm_args* args, void* stream);
 /* tuning knob: GEMM kernel for K % 64 == 0 shapes (0 = register staging 128x128, 2 = LDS-DMA 128x128, 8 = LDS-DMA 256x256

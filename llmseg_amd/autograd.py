@@ -86,21 +86,54 @@ def linear(x, w, b=None, act=ops.ACT_NONE, residual=None, wt=None):
     return LinearFn.apply(x, w, b, act, residual, wt)
 
 
+PARAM_EPOCH = 0            # bumped by the trainer after every optimizer step: parameters are updated in place by a HIP kernel, which
+#                            torch's version counters do not see
+
+
+def _ext_operand(cache, key, p1, p2, build):
+    """[N, 64] GEMM extension operand built from two LoRA matrices, cached in the MODEL's dict `cache` (None = no caching) and rebuilt
+    when the matrices change (optimizer step -> PARAM_EPOCH; load_state_dict -> version counters)."""
+    if cache is None:
+        return build()
+    stamp = (PARAM_EPOCH, p1._version, p2._version)
+    hit = cache.get(key)
+    if hit is None or hit[0] != stamp:
+        hit = (stamp, build())
+        cache[key] = hit
+    return hit[1]
+
+
+def _pack16(u, v):
+    """[M, 8], [M, 8] -> [M, 64] bf16 = [u | v | 0]: the extension operand of ops.gemm."""
+    out = torch.zeros((u.shape[0], 64), device=u.device, dtype=BF16)
+    out[:, :8] = u
+    out[:, 8:16] = v
+    return out
+
+
 class LoraQKVFn(Function):
     """qkv = x Wqkv^T with the LoRA deltas of q_proj and v_proj added in place:
     q += s (x Aq^T) Bq^T, v += s (x Av^T) Bv^T, s = alpha / r (peft 0.4.0 Linear; base weight frozen).  PARITY UNPINNED."""
 
     @staticmethod
-    def forward(ctx, x, wqkv, aq, bq, av, bv, s, wqkv_t=None):
+    def forward(ctx, x, wqkv, aq, bq, av, bv, s, wqkv_t=None, cache=None, key=None):
         ctx.wqkv_t = wqkv_t
+        ctx.cache, ctx.key = cache, key
         H = wqkv.shape[1]
-        qkv = ops.gemm(x, wqkv)
         ctx.fast = aq.shape[0] == 8                                      # rank-8 skinny kernels
         if ctx.fast:
+            # the two rank-8 updates ride in the qkv GEMM as one extra 64-wide K-tile: A2 = [x Aq^T | x Av^T | 0], W2 rows of the
+            # q block = [s Bq | 0], rows of the v block = [0 | s Bv | 0] (no read-modify-write pass over q and v)
             xaq, xav = ops.lora_down(x, aq), ops.lora_down(x, av)           # [M, 8]
-            ops.lora_apply_(qkv[:, :H], xaq, bq, alpha=s)
-            ops.lora_apply_(qkv[:, 2 * H:], xav, bv, alpha=s)
+            a2 = _pack16(xaq, xav)
+            def build():
+                w2 = torch.zeros((3 * H, 64), device=x.device, dtype=BF16)
+                w2[:H, :8] = bq * s
+                w2[2 * H:, 8:16] = bv * s
+                return w2
+            qkv = ops.gemm(x, wqkv, a2=a2, w2=_ext_operand(cache, (key, "B", s), bq, bv, build))
         else:
+            qkv = ops.gemm(x, wqkv)
             xaq, xav = ops.gemm(x, aq), ops.gemm(x, av)                   # [M, r]
             ops.gemm(xaq, bq, residual=qkv[:, :H], out=qkv[:, :H], alpha=s)
             ops.gemm(xav, bv, residual=qkv[:, 2 * H:], out=qkv[:, 2 * H:], alpha=s)
@@ -116,12 +149,20 @@ class LoraQKVFn(Function):
         dq, dv = d[:, :H], d[:, 2 * H:]
         if ctx.fast:
             tq, tv = ops.lora_down(dq, bq, w_kr=True, alpha=s), ops.lora_down(dv, bv, w_kr=True, alpha=s)   # [M, 8] = s dq Bq
-            dx = ops.gemm(d, ctx.wqkv_t) if ctx.wqkv_t is not None else ops.gemm(d, wqkv, trans_w=True)
-            ops.lora_apply_(dx, tq, aq, w_rn=True)
-            ops.lora_apply_(dx, tv, av, w_rn=True)
+            if ctx.wqkv_t is not None:                                    # dx = d Wqkv + tq Aq + tv Av in ONE GEMM
+                def build():
+                    w2 = torch.zeros((H, 64), device=d.device, dtype=BF16)
+                    w2[:, :8] = aq.t()
+                    w2[:, 8:16] = av.t()
+                    return w2
+                dx = ops.gemm(d, ctx.wqkv_t, a2=_pack16(tq, tv), w2=_ext_operand(ctx.cache, (ctx.key, "A"), aq, av, build))
+            else:
+                dx = ops.gemm(d, wqkv, trans_w=True)
+                ops.lora_apply_(dx, tq, aq, w_rn=True)
+                ops.lora_apply_(dx, tv, av, w_rn=True)
             dbq, dbv = ops.lora_outer(dq, xaq, alpha=s).to(BF16), ops.lora_outer(dv, xav, alpha=s).to(BF16)        # [H, 8]
             daq, dav = ops.lora_outer(x, tq, out_rn=True).to(BF16), ops.lora_outer(x, tv, out_rn=True).to(BF16)    # [8, H]
-            return dx, None, daq, dbq, dav, dbv, None, None
+            return dx, None, daq, dbq, dav, dbv, None, None, None, None
         tq = ops.gemm(dq, bq, trans_w=True, alpha=s)                      # [M, r] = s dq Bq
         tv = ops.gemm(dv, bv, trans_w=True, alpha=s)
         dx = ops.gemm(d, ctx.wqkv_t) if ctx.wqkv_t is not None else ops.gemm(d, wqkv, trans_w=True)
@@ -131,7 +172,7 @@ class LoraQKVFn(Function):
         dbv = ops.gemm(dv, xav, trans_a=True, trans_w=True, alpha=s)
         daq = ops.gemm(tq, x, trans_a=True, trans_w=True)                 # [r, H]
         dav = ops.gemm(tv, x, trans_a=True, trans_w=True)
-        return dx, None, daq, dbq, dav, dbv, None, None
+        return dx, None, daq, dbq, dav, dbv, None, None, None, None
 
 
 class NormFn(Function):

@@ -4,8 +4,9 @@
 //   Llama causal + key-padding (hd 128), CLIP/DINOv2 ViT global (hd 64), SAM ViT-H windowed/global with
 //   decomposed relative position (hd 80), mask-selection head (hd 32).
 //
-// CDNA4 mapping: workgroup = 4 wave64 = 128 query rows; each wave owns 32 queries and walks K/V in tiles of 64
-// keys staged through LDS.  Scores are computed TRANSPOSED, S^T = K . Q^T, with v_mfma_f32_32x32x16_bf16
+// CDNA4 mapping: workgroup = 4 wave64 = 128 query rows (8 waves = 256 rows for long non-causal sequences); each wave owns 32
+// queries and walks K/V in tiles of 64 keys staged through LDS (two tile buffers on the plain / global-grid paths: the next tile is
+// written while the current one is read, one barrier per tile).  Scores are computed TRANSPOSED, S^T = K . Q^T, with v_mfma_f32_32x32x16_bf16
 // (A = K fragment from LDS, B = Q fragment held in registers for the whole kernel), so that every lane owns
 // one query column: the online-softmax max/sum are in-lane reductions plus ONE cross-half exchange, and
 // the O rescale is a per-lane scalar.  The exponentiated scores are packed to bf16 in registers and fed back

@@ -38,6 +38,7 @@ struct GemmP {
   int act;
   int tiles_m, tiles_n;
   int c_vec, r_vec, b_vec;   // host-verified alignment for vector C stores / residual loads / bias+gamma loads
+  const bf16_t* A2; const bf16_t* W2; long lda2, ldw2;   // optional extension K-tile (64 wide): C += alpha * A2 . W2^T (ping-pong kernel)
   int group_m;               // M-tiles per group of the ping-pong kernel's tile walk
   int skew;                  // per-XCD rotation of the tile walk (de-phases the 8 XCDs' HBM/MALL channel access)
 };
@@ -564,6 +565,7 @@ __global__ __launch_bounds__(NT, NBUF == 2 ? (MI == 4 ? 1 : 2) : (MI == 4 ? 2 : 
 // lagging group's reads retire one barrier later).  Four half-tiles (64 KiB) stay in flight per workgroup.  K % 64 == 0, K >= 128.
 #define PP_DMA(src, i, tt, dst) \
   __builtin_amdgcn_global_load_lds((gbl_ptr_t)((src)[i] + (long)(tt) * BK), (lds_ptr_t)(dst), 16, 0, 0)
+#define PP_DMA_X(ptr, dst) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ptr), (lds_ptr_t)(dst), 16, 0, 0)
 #define PP_ISSUE_A(h, tt, base)                                                  \
   do {                                                                           \
     PP_DMA(a_src[h], 0, tt, (base) + ((h) * 64 + wave * 8) * 128);               \
@@ -573,6 +575,17 @@ __global__ __launch_bounds__(NT, NBUF == 2 ? (MI == 4 ? 1 : 2) : (MI == 4 ? 2 : 
   do {                                                                                                       \
     PP_DMA(w_src[h], 0, tt, (base) + OP_BYTES + (((wave >> 2)) * 64 + (h) * 32 + (wave & 3) * 8) * 128);     \
     PP_DMA(w_src[h], 1, tt, (base) + OP_BYTES + ((2 + (wave >> 2)) * 64 + (h) * 32 + (wave & 3) * 8) * 128); \
+  } while (0)
+// the optional extension tile (A2, W2) is K-tile 0, fetched in the prologue with the same lane -> (row, chunk) mapping
+#define PP_ISSUE_AX(h, base)                                                     \
+  do {                                                                           \
+    PP_DMA_X(ext_a(h, 0), (base) + ((h) * 64 + wave * 8) * 128);                 \
+    PP_DMA_X(ext_a(h, 1), (base) + (128 + (h) * 64 + wave * 8) * 128);           \
+  } while (0)
+#define PP_ISSUE_WX(h, base)                                                                                   \
+  do {                                                                                                         \
+    PP_DMA_X(ext_w(h, 0), (base) + OP_BYTES + (((wave >> 2)) * 64 + (h) * 32 + (wave & 3) * 8) * 128);         \
+    PP_DMA_X(ext_w(h, 1), (base) + OP_BYTES + ((2 + (wave >> 2)) * 64 + (h) * 32 + (wave & 3) * 8) * 128);     \
   } while (0)
 #define PP_READ_W(dst, j, base)                                                                                            \
   _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                       \
@@ -602,7 +615,7 @@ __global__ __launch_bounds__(NT, NBUF == 2 ? (MI == 4 ? 1 : 2) : (MI == 4 ? 2 : 
 
 constexpr int NTB = 512;
 
-template <bool OUT_F32>
+template <bool OUT_F32, bool EXT>
 __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
   constexpr int MI = 4, BMB = 256, BNB = 256;
   constexpr int OP_BYTES = 256 * BK * 2, BUF = 2 * OP_BYTES;     // 32 KiB per operand, 64 KiB per buffer
@@ -639,10 +652,20 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
     for (int i = 0; i < 2; ++i) {
       const int ra = i * 128 + h * 64 + wave * 8 + (lane >> 3);
       const int rw = (i * 2 + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + (lane >> 3);
-      a_src[h][i] = Ag + (long)min(m0 + ra, p.M - 1) * p.lda + (((lane & 7) ^ ((ra >> 1) & 7)) << 3);
-      w_src[h][i] = Wg + (long)min(n0 + rw, p.N - 1) * p.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) << 3);
+      // with an extension tile in front, main K-tile tt-1 is LDS tile tt: bias the pointers by one tile
+      a_src[h][i] = Ag + (long)min(m0 + ra, p.M - 1) * p.lda + (((lane & 7) ^ ((ra >> 1) & 7)) << 3) - (EXT ? BK : 0);
+      w_src[h][i] = Wg + (long)min(n0 + rw, p.N - 1) * p.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) << 3) - (EXT ? BK : 0);
     }
-  const int nt = p.K / BK;
+  const int nt_main = p.K / BK;
+  const int nt = nt_main + (EXT ? 1 : 0);
+  auto ext_a = [&](int h, int i) {
+    const int ra = i * 128 + h * 64 + wave * 8 + (lane >> 3);
+    return p.A2 + (long)min(m0 + ra, p.M - 1) * p.lda2 + (((lane & 7) ^ ((ra >> 1) & 7)) << 3);
+  };
+  auto ext_w = [&](int h, int i) {
+    const int rw = (i * 2 + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + (lane >> 3);
+    return p.W2 + (long)min(n0 + rw, p.N - 1) * p.ldw2 + (((lane & 7) ^ ((rw >> 1) & 7)) << 3);
+  };
 
   f32x16_t acc[2][MI];
   zero_acc<MI>(acc);
@@ -650,7 +673,8 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
   const int frow = lane & 31, fhalf = lane >> 5;
 
   // prologue: S[0..5] = A0(0) W0(0) W1(0) A1(0) A0(1) W0(1)
-  PP_ISSUE_A(0, 0, smem); PP_ISSUE_W(0, 0, smem); PP_ISSUE_W(1, 0, smem); PP_ISSUE_A(1, 0, smem);
+  if (EXT) { PP_ISSUE_AX(0, smem); PP_ISSUE_WX(0, smem); PP_ISSUE_WX(1, smem); PP_ISSUE_AX(1, smem); }
+  else { PP_ISSUE_A(0, 0, smem); PP_ISSUE_W(0, 0, smem); PP_ISSUE_W(1, 0, smem); PP_ISSUE_A(1, 0, smem); }
   PP_ISSUE_A(0, 1, smem + BUF); PP_ISSUE_W(0, 1, smem + BUF);
   PP_VM(8);
   __builtin_amdgcn_s_barrier();
@@ -734,10 +758,11 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   p.b_vec = ((p.bias == nullptr || (((uintptr_t)p.bias) & 7) == 0) && (p.gamma == nullptr || (((uintptr_t)p.gamma) & 7) == 0)) ? 1 : 0;
 
   p.skew = g_gemm_skew;
+  p.A2 = (const bf16_t*)a->A2; p.W2 = (const bf16_t*)a->W2; p.lda2 = a->lda2; p.ldw2 = a->ldw2;
   static const int group_m_env = getenv("LLMSEG_GEMM_GROUP_M") ? atoi(getenv("LLMSEG_GEMM_GROUP_M")) : 0;   // tuning override
   int variant = (p.K % BK == 0 && !ta && !tw) ? g_gemm_variant : 0;
   if (variant != 0 && variant != 2 && variant != 8) variant = 5;
-  if (variant == 8 && p.K < 2 * BK) variant = 2;
+  if (variant == 8 && p.K < (a->A2 ? BK : 2 * BK)) variant = 2;
   if (variant == 5) {
     // auto: the 256 x 256 ping-pong kernel (one workgroup per CU) when its tiles fill >= 70 % of whole rounds of the CUs (edge
     // tiles counted by their useful area); the 128 x 128 single-buffer DMA kernel (4 workgroups/CU) otherwise.  Measured with
@@ -745,6 +770,23 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
     const long tm = (p.M + 255) / 256, tn = (p.N + 255) / 256, tiles = tm * tn * batch, ncu = num_cus();
     const double fill = (double)tiles / (double)(((tiles + ncu - 1) / ncu) * ncu) * ((double)p.M * p.N / ((double)tm * 256 * tn * 256));
     variant = (fill >= 0.7 && p.K >= 2 * BK) ? 8 : 2;
+  }
+  if (p.A2) {
+    // C = epi(alpha * (A.W^T + A2.W2^T)), A2 [M][64], W2 [N][64]: fused as one more K-tile of the ping-pong kernel; any other
+    // kernel runs the product as a second launch that accumulates onto C (linear epilogues only)
+    LL_CHECK(p.W2 && batch == 1 && !ta && !tw && (p.lda2 & 7) == 0 && (p.ldw2 & 7) == 0 && p.lda2 >= 64 && p.ldw2 >= 64 &&
+                 (((uintptr_t)p.A2 | (uintptr_t)p.W2) & 15) == 0, "gemm: bad extension operands (A2 [M][64], W2 [N][64], 16-byte aligned rows)");
+    LL_CHECK(!a->out_f32, "gemm: extension operands need bf16 output");
+    if (variant != 8) {
+      LL_CHECK(a->act == LLMSEG_ACT_NONE && !a->gamma, "gemm: extension operands on this shape need a linear epilogue");
+      llmseg_gemm_args g1 = *a, g2 = *a;
+      g1.A2 = g1.W2 = nullptr;
+      int rc = llmseg_gemm_bf16(&g1, stream);
+      if (rc != LLMSEG_OK) return rc;
+      g2.A = a->A2; g2.W = a->W2; g2.lda = a->lda2; g2.ldw = a->ldw2; g2.K = 64; g2.bias = nullptr; g2.residual = a->C; g2.ldr = a->ldc;
+      g2.A2 = g2.W2 = nullptr;
+      return llmseg_gemm_bf16(&g2, stream);
+    }
   }
   const int bm = variant == 8 ? 256 : 128, bn = variant == 8 ? 256 : BN;
   p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
@@ -759,8 +801,9 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   switch (variant) {
     case 2: f ? launch_glds<true, 2, 1>(p, grid, s) : launch_glds<false, 2, 1>(p, grid, s); break;
     case 8:
-      if (f) hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<true>, grid, dim3(NTB), 0, s, p);
-      else hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<false>, grid, dim3(NTB), 0, s, p);
+      if (p.A2) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, true>), grid, dim3(NTB), 0, s, p);      // bf16 out only (checked above)
+      else if (f) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<true, false>), grid, dim3(NTB), 0, s, p);
+      else hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, false>), grid, dim3(NTB), 0, s, p);
       break;
     default: {
       const int key = (f ? 4 : 0) | (ta ? 2 : 0) | (tw ? 1 : 0);

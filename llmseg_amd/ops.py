@@ -28,9 +28,11 @@ def _req(t, dtype=BF16):
     return t
 
 
-def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alpha=1.0, out_f32=False, trans_a=False, trans_w=False):
+def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alpha=1.0, out_f32=False, trans_a=False, trans_w=False,
+         a2=None, w2=None):
     """out[M,N] = residual + gamma * act(alpha * A @ W^T + bias) with A = a [M,K] (or a^T when trans_a: a stored [K,M]) and
-    W = w [N,K] (or w^T when trans_w: w stored [K,N]).  2-D bf16 operands, last dim contiguous."""
+    W = w [N,K] (or w^T when trans_w: w stored [K,N]).  2-D bf16 operands, last dim contiguous.  a2 [M,64] / w2 [N,64]: optional
+    extension of the contraction (A @ W^T + a2 @ w2^T), e.g. zero-padded low-rank updates."""
     _req(a); _req(w)
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
@@ -47,6 +49,10 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alp
                  ldr=0 if residual is None else residual.stride(0),
                  batch=1, strideA=0, strideW=0, strideC=0, alpha=alpha, act=act, out_f32=1 if out_f32 else 0,
                  trans_a=1 if trans_a else 0, trans_w=1 if trans_w else 0)
+    if a2 is not None:
+        _req(a2); _req(w2)
+        assert a2.shape == (M, 64) and w2.shape == (N, 64) and a2.stride(1) == 1 and w2.stride(1) == 1
+        g.A2, g.W2, g.lda2, g.ldw2 = a2.data_ptr(), w2.data_ptr(), a2.stride(0), w2.stride(0)
     if residual is not None:
         assert residual.shape == (M, N) and residual.stride(1) == 1
     _lib.check(_lib.load().llmseg_gemm_bf16(C.byref(g), _stream()), "gemm")

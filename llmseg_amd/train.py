@@ -99,5 +99,7 @@ class Trainer:
         self.opt.step(lr, coef.reshape(1).float().contiguous())
         for p in self.params:
             p.grad = None
+        from . import autograd
+        autograd.PARAM_EPOCH += 1            # parameters changed in place: invalidate operand caches derived from them
         self.opt_steps += 1
         return float(lr)

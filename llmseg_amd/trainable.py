@@ -30,7 +30,7 @@ class _Direct:
     maskpool = staticmethod(lambda feat, segs, g, S: ops.upsample_maskpool(feat, segs, g, S))
 
     @staticmethod
-    def lora_qkv(x, wqkv, aq, bq, av, bv, s, wqkv_t=None):
+    def lora_qkv(x, wqkv, aq, bq, av, bv, s, wqkv_t=None, cache=None, key=None):
         H = wqkv.shape[1]
         qkv = ops.gemm(x, wqkv)
         if aq.shape[0] == 8:
@@ -77,7 +77,8 @@ class _Auto:
     embed_splice = staticmethod(lambda ids, emb, feats, P, fs: ag.EmbedSpliceFn.apply(ids, emb, feats, P, fs))
     gather_rows = staticmethod(lambda x, idx: ag.GatherRowsFn.apply(x, idx))
     maskpool = staticmethod(lambda feat, segs, g, S: ag.MaskPoolFn.apply(feat, segs, g, S))
-    lora_qkv = staticmethod(lambda x, wqkv, aq, bq, av, bv, s, wqkv_t=None: ag.LoraQKVFn.apply(x, wqkv, aq, bq, av, bv, s, wqkv_t))
+    lora_qkv = staticmethod(lambda x, wqkv, aq, bq, av, bv, s, wqkv_t=None, cache=None, key=None:
+                            ag.LoraQKVFn.apply(x, wqkv, aq, bq, av, bv, s, wqkv_t, cache, key))
     ce = staticmethod(lambda logits, labels: ag.CELossFn.apply(logits, labels))
     align_reg = staticmethod(lambda e, t, pred, gt_iou, gt_iop: ag.AlignRegFn.apply(e, t, pred, gt_iou, gt_iop))
     bcast_add = staticmethod(lambda s, add, Cn, K: ag.BcastAddFn.apply(s, add, Cn, K))
@@ -157,7 +158,8 @@ class TrainableMixin:
                 lp = p + "self_attn."
                 qkv = F.lora_qkv(h, self._w(p + "qkv", F), self._w(lp + "q_proj.lora_A.default.weight", F),
                                  self._w(lp + "q_proj.lora_B.default.weight", F), self._w(lp + "v_proj.lora_A.default.weight", F),
-                                 self._w(lp + "v_proj.lora_B.default.weight", F), s, self._wT(p + "qkv", F))
+                                 self._w(lp + "v_proj.lora_B.default.weight", F), s, self._wT(p + "qkv", F),
+                                 self.__dict__.setdefault("_lora_ext", {}), i)
             else:
                 mem = [p + f"self_attn.{n}_proj.weight" for n in "qkv"]
                 qkv = F.linear(h, self._wcat(p + "qkv", mem, F), None, ops.ACT_NONE, None, self._wT(p + "qkv", F) if self._frozen(mem) else None)

@@ -84,6 +84,14 @@ def check_gemm():
         out.append(("gemm ping-pong epilogue gelu", err(got, ref), tol_bf16(ref, 1.5)))
         ref = 0.5 * (a.float() @ w.float().t())
         out.append(("gemm ping-pong f32-out", err(ops.gemm(a.to(DEV), w.to(DEV), alpha=0.5, out_f32=True), ref), 1e-3))
+        # extension K-tile (fused low-rank update): C = A W^T + A2 W2^T + bias, incl. K = 64 (the extension is the second tile)
+        for M, N, K in ((513, 300, 192), (300, 520, 64)):
+            a, w, b = rnd(M, K, seed=71), rnd(N, K, seed=72, scale=1 / math.sqrt(K)), rnd(N, seed=73)
+            a2, w2 = rnd(M, 64, seed=74), rnd(N, 64, seed=75, scale=1 / 8)
+            a2[:, 16:] = 0
+            ref = a.float() @ w.float().t() + a2.float() @ w2.float().t() + b.float()
+            got = ops.gemm(a.to(DEV), w.to(DEV), bias=b.to(DEV), a2=a2.to(DEV), w2=w2.to(DEV))
+            out.append((f"gemm ping-pong + extension tile {M}x{N}x{K}", err(got, ref), tol_bf16(ref)))
         nb, M, N, K = 3, 260, 300, 128
         ab, wb = rnd(nb * M, K, seed=61), rnd(nb * N, K, seed=62, scale=1 / 8)
         ob = torch.zeros(nb, M, N, device=DEV, dtype=torch.float32)
@@ -92,6 +100,12 @@ def check_gemm():
         out.append(("gemm ping-pong batched", err(ob, ref), 1e-3))
     finally:
         lib.llmseg_gemm_set_variant(5)
+    # the same through the automatic dispatch on a small shape (128 x 128 kernel + accumulate launch)
+    M, N, K = 200, 264, 256
+    a, w = rnd(M, K, seed=81), rnd(N, K, seed=82, scale=1 / 16)
+    a2, w2 = rnd(M, 64, seed=83), rnd(N, 64, seed=84, scale=1 / 8)
+    ref = a.float() @ w.float().t() + a2.float() @ w2.float().t()
+    out.append(("gemm extension tile, fallback path", err(ops.gemm(a.to(DEV), w.to(DEV), a2=a2.to(DEV), w2=w2.to(DEV)), ref), tol_bf16(ref, 1.5)))
     return out
 
 
