@@ -103,6 +103,21 @@ def _ext_operand(cache, key, p1, p2, build):
     return hit[1]
 
 
+def lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, cache=None, key=None):
+    """qkv = x Wqkv^T + s (x Aq^T) Bq^T on the q block + s (x Av^T) Bv^T on the v block, rank 8.  The two updates ride in the qkv
+    GEMM as one extra 64-wide K-tile: A2 = [x Aq^T | x Av^T | 0], W2 rows of the q block = [s Bq | 0], rows of the v block =
+    [0 | s Bv | 0] (no read-modify-write pass over q and v).  -> (qkv, x Aq^T, x Av^T)"""
+    H = wqkv.shape[1]
+    xaq, xav = ops.lora_down(x, aq), ops.lora_down(x, av)           # [M, 8]
+
+    def build():
+        w2 = torch.zeros((3 * H, 64), device=x.device, dtype=BF16)
+        w2[:H, :8] = bq * s
+        w2[2 * H:, 8:16] = bv * s
+        return w2
+    return ops.gemm(x, wqkv, a2=_pack16(xaq, xav), w2=_ext_operand(cache, (key, "B", s), bq, bv, build)), xaq, xav
+
+
 def _pack16(u, v):
     """[M, 8], [M, 8] -> [M, 64] bf16 = [u | v | 0]: the extension operand of ops.gemm."""
     out = torch.zeros((u.shape[0], 64), device=u.device, dtype=BF16)
@@ -122,16 +137,7 @@ class LoraQKVFn(Function):
         H = wqkv.shape[1]
         ctx.fast = aq.shape[0] == 8                                      # rank-8 skinny kernels
         if ctx.fast:
-            # the two rank-8 updates ride in the qkv GEMM as one extra 64-wide K-tile: A2 = [x Aq^T | x Av^T | 0], W2 rows of the
-            # q block = [s Bq | 0], rows of the v block = [0 | s Bv | 0] (no read-modify-write pass over q and v)
-            xaq, xav = ops.lora_down(x, aq), ops.lora_down(x, av)           # [M, 8]
-            a2 = _pack16(xaq, xav)
-            def build():
-                w2 = torch.zeros((3 * H, 64), device=x.device, dtype=BF16)
-                w2[:H, :8] = bq * s
-                w2[2 * H:, 8:16] = bv * s
-                return w2
-            qkv = ops.gemm(x, wqkv, a2=a2, w2=_ext_operand(cache, (key, "B", s), bq, bv, build))
+            qkv, xaq, xav = lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, cache, key)
         else:
             qkv = ops.gemm(x, wqkv)
             xaq, xav = ops.gemm(x, aq), ops.gemm(x, av)                   # [M, r]

@@ -32,13 +32,11 @@ class _Direct:
     @staticmethod
     def lora_qkv(x, wqkv, aq, bq, av, bv, s, wqkv_t=None, cache=None, key=None):
         H = wqkv.shape[1]
-        qkv = ops.gemm(x, wqkv)
         if aq.shape[0] == 8:
-            ops.lora_apply_(qkv[:, :H], ops.lora_down(x, aq), bq, alpha=s)
-            ops.lora_apply_(qkv[:, 2 * H:], ops.lora_down(x, av), bv, alpha=s)
-        else:
-            ops.gemm(ops.gemm(x, aq), bq, residual=qkv[:, :H], out=qkv[:, :H], alpha=s)
-            ops.gemm(ops.gemm(x, av), bv, residual=qkv[:, 2 * H:], out=qkv[:, 2 * H:], alpha=s)
+            return ag.lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, cache, key)[0]
+        qkv = ops.gemm(x, wqkv)
+        ops.gemm(ops.gemm(x, aq), bq, residual=qkv[:, :H], out=qkv[:, :H], alpha=s)
+        ops.gemm(ops.gemm(x, av), bv, residual=qkv[:, 2 * H:], out=qkv[:, 2 * H:], alpha=s)
         return qkv
 
     @staticmethod
