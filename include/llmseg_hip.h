@@ -175,11 +175,12 @@ int llmseg_upsample_maskpool(const void* feat, const void* segs, void* pooled, v
 /* Cosine scoring (LISA.py:398-403): sim[k] = <t,e_k> / (|t||e_k|); t bf16 [D], e bf16 [K][D]; sim fp32 [K]. */
 int llmseg_cosine_scores(const void* t, const void* e, float* sim, int32_t K, int32_t D, void* stream);
 
-/* softmax_align_loss + iou_regression_loss (model/loss.py:50-94), one (image, round) per call, fp32 results:
- * out[0] = KL(softmax(gt_iou/tau) || softmax(cos(e_k,t)/tau)) summed; out[1] = mean((p-g)^2 exp(g-1)) * 50.
- * Optional gradients: d_e fp32 [K][D], d_t fp32 [D], d_pred fp32 [K] (of out[0] resp. out[1]; NULL = skip). */
+/* softmax_align_loss + iou_regression_loss (model/loss.py:50-94) for `items` (image, round) pairs with the same K, one workgroup
+ * each, every operand contiguous over items (e [items][K][D], t [items][D], gt_iou / pred_iou / gt_iop [items][K]); fp32 results:
+ * out[i][0] = KL(softmax(gt_iou/tau) || softmax(cos(e_k,t)/tau)) summed; out[i][1] = mean((p-g)^2 exp(g-1)) * 50.
+ * Optional gradients: d_e fp32 [items][K][D], d_t fp32 [items][D], d_pred fp32 [items][K] (of out[i][0] resp. out[i][1]; NULL = skip). */
 int llmseg_align_reg_loss(const void* e, const void* t, const float* gt_iou, const void* pred_iou, const float* gt_iop,
-                          float* out, float* d_e, float* d_t, float* d_pred, int32_t K, int32_t D, float tau, void* stream);
+                          float* out, float* d_e, float* d_t, float* d_pred, int32_t K, int32_t D, float tau, int32_t items, void* stream);
 
 /* dice_loss + sigmoid_ce_loss (model/loss.py:4-47; named by the north_star, no caller in the reference):
  * logits bf16/fp32-as-float [M][HW] given as fp32, targets fp32; out[0] = dice (scale 1000, eps 1e-6), out[1] = bce,

@@ -65,7 +65,7 @@ SIGNATURES = {
     "llmseg_mask_pullback": [_p, _p, _p, _p, _i32, _i32, _i32, _p],
     "llmseg_upsample_maskpool": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p],
     "llmseg_cosine_scores": [_p, _p, _p, _i32, _i32, _p],
-    "llmseg_align_reg_loss": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _f32, _p],
+    "llmseg_align_reg_loss": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
     "llmseg_dice_bce": [_p, _p, _p, _i32, _i64, _f32, _p],
     "llmseg_ce_loss": [_p, _p, _p, _i32, _i32, _i64, _i64, _p],
     "llmseg_intersection_union": [_p, _p, _i64, _i32, _p, _p],

@@ -387,7 +387,8 @@ class CELossFn(Function):
 
 
 class AlignRegFn(Function):
-    """softmax_align_loss + iou_regression_loss for one (image, round): returns fp32[2]; grads come from the same kernel."""
+    """softmax_align_loss + iou_regression_loss for one (image, round) -> fp32[2], or for R stacked items (e [R,K,D], t [R,D], pred /
+    gt [R,K]) -> fp32 [R, 2] in one launch; grads come from the same kernel."""
 
     @staticmethod
     def forward(ctx, e, t, pred, gt_iou, gt_iop):
@@ -399,6 +400,8 @@ class AlignRegFn(Function):
     def backward(ctx, g):
         d_e, d_t, d_p = ctx.saved_tensors
         g = g.float()
+        if g.dim() == 2:                                   # batched: g [R, 2]
+            return ((d_e * g[:, 0, None, None]).to(BF16), (d_t * g[:, 0, None]).to(BF16), (d_p * g[:, 1, None]).to(BF16), None, None)
         return (d_e * g[0]).to(BF16), (d_t * g[0]).to(BF16), (d_p * g[1]).to(BF16), None, None
 
 

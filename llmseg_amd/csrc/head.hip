@@ -94,13 +94,20 @@ __global__ __launch_bounds__(256) void cosine_kernel(const bf16_t* __restrict__ 
   if (lane == 0) sim[k] = dot / (sqrtf(ne) * sqrtf(ntt));
 }
 
-// ---- align (KL) + IoP regression losses for one (image, round); single workgroup --------------------------------------
+// ---- align (KL) + IoP regression losses: one workgroup per (image, round) item; items are contiguous in every operand -----
 __global__ __launch_bounds__(256) void align_reg_kernel(const bf16_t* __restrict__ e, const bf16_t* __restrict__ t, const float* __restrict__ gt_iou,
                                                        const bf16_t* __restrict__ pred, const float* __restrict__ gt_iop, float* __restrict__ out,
                                                        float* __restrict__ d_e, float* __restrict__ d_t, float* __restrict__ d_pred, int K, int D,
                                                        float tau) {
   extern __shared__ float sm[];                  // cos[K], enorm[K], gsoft[K], red[16]
   float* cs = sm; float* en = sm + K; float* gs = sm + 2 * K; float* red = sm + 3 * K;
+  {
+    const long it = blockIdx.x;
+    e += it * K * D; t += it * D; gt_iou += it * K; pred += it * K; gt_iop += it * K; out += it * 2;
+    if (d_e) d_e += it * K * D;
+    if (d_t) d_t += it * D;
+    if (d_pred) d_pred += it * K;
+  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
   float tn2 = 0.f;
   for (int d = threadIdx.x; d < D; d += blockDim.x) { const float a = bf2f(t[d]); tn2 += a * a; }
@@ -226,11 +233,11 @@ extern "C" int llmseg_cosine_scores(const void* t, const void* e, float* sim, in
 }
 
 extern "C" int llmseg_align_reg_loss(const void* e, const void* t, const float* gt_iou, const void* pred_iou, const float* gt_iop, float* out,
-                                     float* d_e, float* d_t, float* d_pred, int32_t K, int32_t D, float tau, void* stream) {
-  LL_CHECK(e && t && gt_iou && pred_iou && gt_iop && out && K > 0 && D > 0 && tau > 0.f, "align_reg_loss: bad arguments");
+                                     float* d_e, float* d_t, float* d_pred, int32_t K, int32_t D, float tau, int32_t items, void* stream) {
+  LL_CHECK(e && t && gt_iou && pred_iou && gt_iop && out && K > 0 && D > 0 && tau > 0.f && items > 0, "align_reg_loss: bad arguments");
   const size_t lds = ((size_t)3 * K + 16) * sizeof(float);
   LL_CHECK(lds <= 64 * 1024, "align_reg_loss: K=%d too large", K);
-  hipLaunchKernelGGL(align_reg_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)e, (const bf16_t*)t, gt_iou,
+  hipLaunchKernelGGL(align_reg_kernel, dim3(items), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)e, (const bf16_t*)t, gt_iou,
                      (const bf16_t*)pred_iou, gt_iop, out, d_e, d_t, d_pred, K, D, tau);
   LL_LAUNCH_CHECK("align_reg_loss");
   return LLMSEG_OK;

@@ -228,14 +228,22 @@ def cosine_scores(t, e):
 
 
 def align_reg_loss(e, t, gt_iou, pred_iou, gt_iop, tau=0.05, want_grads=False):
-    """-> out fp32[2] = (align KL, IoP regression) and optionally (d_e [K,D], d_t [D], d_pred [K]) fp32."""
-    K, D = e.shape
-    out = torch.empty((2,), device=e.device, dtype=torch.float32)
-    d_e = torch.empty((K, D), device=e.device, dtype=torch.float32) if want_grads else None
-    d_t = torch.empty((D,), device=e.device, dtype=torch.float32) if want_grads else None
-    d_p = torch.empty((K,), device=e.device, dtype=torch.float32) if want_grads else None
+    """One item: e bf16 [K, D], t [D], gt_iou / gt_iop fp32 [K], pred_iou bf16 [K] -> out fp32[2] = (align KL, IoP regression) and
+    optionally (d_e [K,D], d_t [D], d_pred [K]) fp32.  Batched: e [R, K, D], t [R, D], the K-vectors [R, K] -> out [R, 2] etc.,
+    one launch for all R items."""
+    batched = e.dim() == 3
+    R = e.shape[0] if batched else 1
+    K, D = e.shape[-2:]
+    for x in (e, t, gt_iou, pred_iou, gt_iop):
+        assert x.is_contiguous()
+    assert t.numel() == R * D and gt_iou.numel() == R * K and pred_iou.numel() == R * K and gt_iop.numel() == R * K
+    shp = (R,) if batched else ()
+    out = torch.empty(shp + (2,), device=e.device, dtype=torch.float32)
+    d_e = torch.empty(shp + (K, D), device=e.device, dtype=torch.float32) if want_grads else None
+    d_t = torch.empty(shp + (D,), device=e.device, dtype=torch.float32) if want_grads else None
+    d_p = torch.empty(shp + (K,), device=e.device, dtype=torch.float32) if want_grads else None
     _lib.check(_lib.load().llmseg_align_reg_loss(_ptr(e), _ptr(t), _ptr(gt_iou), _ptr(pred_iou), _ptr(gt_iop), _ptr(out), _ptr(d_e),
-                                                 _ptr(d_t), _ptr(d_p), K, D, tau, _stream()), "align_reg_loss")
+                                                 _ptr(d_t), _ptr(d_p), K, D, tau, R, _stream()), "align_reg_loss")
     return (out, d_e, d_t, d_p) if want_grads else out
 
 

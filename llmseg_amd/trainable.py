@@ -331,6 +331,7 @@ class TrainableMixin:
                     fb = feat[b * rows_per_img + row0: b * rows_per_img + row0 + g * g]
                     pooled_of[b] = F.maskpool(fb, segs_of[b], g, S)
         groups = {K: [b for (k2, _, _), ms in groups.items() if k2 == K for b in ms] for K in sorted({k[0] for k in groups})}
+        group_out = {}
         for K, members in groups.items():
             if len(members) == 1:
                 b = members[0]
@@ -339,6 +340,7 @@ class TrainableMixin:
                 s0 = torch.cat([pooled_of[b].repeat(pred_embeddings[b].shape[0], 1) if pred_embeddings[b].shape[0] > 1 else pooled_of[b]
                                 for b in members], 0)
                 iou, emb = self._mask_head(s0, torch.cat([pred_embeddings[b] for b in members], 0), F, stacked=True)
+            group_out[K] = (members, iou, emb)
             r0 = 0
             for b in members:
                 Cn = pred_embeddings[b].shape[0]
@@ -353,17 +355,19 @@ class TrainableMixin:
                 out.update(logits=logits, hidden=hidden, feats=feat, pred_embeddings=pred_embeddings)
             return out
 
+        # losses (LISA.py:416-466): every (image, round) item of a group in ONE launch; an image's rounds are averaged (1/(R+1e-8)),
+        # then the images
         align = torch.zeros((), device=hidden.device, dtype=torch.float32)
         reg = torch.zeros((), device=hidden.device, dtype=torch.float32)
-        for b in range(B):
-            R = pred_embeddings[b].shape[0]
-            a_r = torch.zeros_like(align); r_r = torch.zeros_like(reg)
-            for r in range(R):
-                o = F.align_reg(embs[b][r].contiguous(), pred_embeddings[b][r].contiguous(), ious[b][r].contiguous(),
-                                sam_ious_list[b][r].float().contiguous(), sam_iops_list[b][r].float().contiguous())
-                a_r = a_r + o[0]; r_r = r_r + o[1]
-            align = align + a_r / (R + 1e-8)
-            reg = reg + r_r / (R + 1e-8)
+        for K, (members, iou_s, emb_s) in group_out.items():
+            t_s = torch.cat([pred_embeddings[b] for b in members], 0).contiguous()
+            Rg = t_s.shape[0]
+            gi = torch.cat([sam_ious_list[b].float().reshape(-1, K) for b in members], 0).contiguous()
+            gp = torch.cat([sam_iops_list[b].float().reshape(-1, K) for b in members], 0).contiguous()
+            o = F.align_reg(emb_s.reshape(Rg, K, -1), t_s, iou_s.reshape(Rg, K), gi, gp)                    # [Rg, 2]
+            w = torch.cat([torch.full((pred_embeddings[b].shape[0],), 1.0 / (pred_embeddings[b].shape[0] + 1e-8)) for b in members]).to(o.device)
+            align = align + (o[:, 0] * w).sum()
+            reg = reg + (o[:, 1] * w).sum()
         align, reg = align / B, reg / B
         ce = ce * c.ce_loss_weight
         align = align * c.align_loss_weight

@@ -305,6 +305,17 @@ def check_head():
     out.append(("align d_e", err(d_e, ef.grad), 1e-3 * max(1e-3, ef.grad.abs().max().item())))
     out.append(("align d_t", err(d_t, tf.grad), 1e-3 * max(1e-3, tf.grad.abs().max().item())))
     out.append(("regression d_pred", err(d_p, pf.grad), 1e-3 * max(1e-3, pf.grad.abs().max().item())))
+    # batched form: three items in one launch == three single launches (bit for bit: same kernel, different block index)
+    R = 3
+    eb, tb = rnd(R * Kp, D, seed=13).view(R, Kp, D), rnd(R, D, seed=14)
+    gib, gpb, prb = torch.rand(R, Kp, generator=gen), torch.rand(R, Kp, generator=gen), torch.rand(R, Kp, generator=gen).to(BF)
+    ob, deb, dtb, dpb = ops.align_reg_loss(eb.to(DEV), tb.to(DEV), gib.to(DEV), prb.to(DEV), gpb.to(DEV), want_grads=True)
+    worst = 0.0
+    for r in range(R):
+        o1, de1, dt1, dp1 = ops.align_reg_loss(eb[r].contiguous().to(DEV), tb[r].contiguous().to(DEV), gib[r].contiguous().to(DEV),
+                                               prb[r].contiguous().to(DEV), gpb[r].contiguous().to(DEV), want_grads=True)
+        worst = max(worst, err(ob[r], o1.cpu()), err(deb[r], de1.cpu()), err(dtb[r], dt1.cpu()), err(dpb[r], dp1.cpu()))
+    out.append(("align/regression batched == single", worst, 0.0))
     x = torch.randn(3, 64, 64, generator=gen) * 3
     y = (torch.rand(3, 64, 64, generator=gen) > 0.5).float()
     o = ops.dice_bce(x.to(DEV), y.to(DEV), 3)
