@@ -563,18 +563,21 @@ __global__ __launch_bounds__(NT, NBUF == 2 ? (MI == 4 ? 1 : 2) : (MI == 4 ? 2 : 
 // Ordering rules (MI355X_MICROARCH.md "LDS-DMA"): a half-tile is read one phase AFTER the phase whose pre-barrier vmcnt retired
 // it (both groups' waits precede a barrier the reader has passed); a slot is re-issued >= 2 phases after its last read (the
 // lagging group's reads retire one barrier later).  Four half-tiles (64 KiB) stay in flight per workgroup.  K % 64 == 0, K >= 128.
-#define PP_DMA(src, i, tt, dst) \
-  __builtin_amdgcn_global_load_lds((gbl_ptr_t)((src)[i] + (long)(tt) * BK), (lds_ptr_t)(dst), 16, 0, 0)
+// LDS-DMA as `buffer_load_dwordx4 ... offen lds`: a raw buffer resource based at the tile's first row, tile-relative 32-bit per-lane
+// byte offsets, the K advance in the scalar offset (no 64-bit VALU address arithmetic per instruction, 8 fewer VGPRs than pointers)
+#define PP_KOFF(tt) ((int)(((tt) - (EXT ? 1 : 0)) * (BK * 2)))
 #define PP_DMA_X(ptr, dst) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ptr), (lds_ptr_t)(dst), 16, 0, 0)
-#define PP_ISSUE_A(h, tt, base)                                                  \
-  do {                                                                           \
-    PP_DMA(a_src[h], 0, tt, (base) + ((h) * 64 + wave * 8) * 128);               \
-    PP_DMA(a_src[h], 1, tt, (base) + (128 + (h) * 64 + wave * 8) * 128);         \
+#define PP_ISSUE_A(h, tt, base)                                                                                                   \
+  do {                                                                                                                            \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)((base) + ((h) * 64 + wave * 8) * 128), 16, a_off[h][0], PP_KOFF(tt), 0, 0);       \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)((base) + (128 + (h) * 64 + wave * 8) * 128), 16, a_off[h][1], PP_KOFF(tt), 0, 0); \
   } while (0)
-#define PP_ISSUE_W(h, tt, base)                                                                              \
-  do {                                                                                                       \
-    PP_DMA(w_src[h], 0, tt, (base) + OP_BYTES + (((wave >> 2)) * 64 + (h) * 32 + (wave & 3) * 8) * 128);     \
-    PP_DMA(w_src[h], 1, tt, (base) + OP_BYTES + ((2 + (wave >> 2)) * 64 + (h) * 32 + (wave & 3) * 8) * 128); \
+#define PP_ISSUE_W(h, tt, base)                                                                                                   \
+  do {                                                                                                                            \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)((base) + OP_BYTES + (((wave >> 2)) * 64 + (h) * 32 + (wave & 3) * 8) * 128), 16,     \
+                                             w_off[h][0], PP_KOFF(tt), 0, 0);                                                     \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)((base) + OP_BYTES + ((2 + (wave >> 2)) * 64 + (h) * 32 + (wave & 3) * 8) * 128), 16, \
+                                             w_off[h][1], PP_KOFF(tt), 0, 0);                                                     \
   } while (0)
 // the optional extension tile (A2, W2) is K-tile 0, fetched in the prologue with the same lane -> (row, chunk) mapping
 #define PP_ISSUE_AX(h, base)                                                     \
@@ -643,18 +646,18 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
   const bf16_t* __restrict__ Wg = p.W + b1 * p.sW + b2 * p.sW2;
 
   // per-lane DMA sources: [half][instruction]; the lane's LDS slot is (row0 + lane/8, chunk lane%8), it fetches global chunk
-  // (lane%8) ^ swizzle(row) of that row
-  const bf16_t* a_src[2][2];
-  const bf16_t* w_src[2][2];
+  // (lane%8) ^ swizzle(row) of that row.  Byte offsets relative to the tile's first row (rows past the matrix edge are clamped).
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ag + (long)m0 * p.lda), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Wg + (long)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
+  int a_off[2][2], w_off[2][2];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int ra = i * 128 + h * 64 + wave * 8 + (lane >> 3);
       const int rw = (i * 2 + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + (lane >> 3);
-      // with an extension tile in front, main K-tile tt-1 is LDS tile tt: bias the pointers by one tile
-      a_src[h][i] = Ag + (long)min(m0 + ra, p.M - 1) * p.lda + (((lane & 7) ^ ((ra >> 1) & 7)) << 3) - (EXT ? BK : 0);
-      w_src[h][i] = Wg + (long)min(n0 + rw, p.N - 1) * p.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) << 3) - (EXT ? BK : 0);
+      a_off[h][i] = (int)(((long)min(ra, p.M - 1 - m0) * p.lda + (((lane & 7) ^ ((ra >> 1) & 7)) << 3)) * 2);
+      w_off[h][i] = (int)(((long)min(rw, p.N - 1 - n0) * p.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) << 3)) * 2);
     }
   const int nt_main = p.K / BK;
   const int nt = nt_main + (EXT ? 1 : 0);
