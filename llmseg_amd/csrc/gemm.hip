@@ -5,8 +5,8 @@
 // Three kernels, one epilogue (the MFMA "A" operand is the WEIGHT fragment and the "B" operand the ACTIVATION fragment, so a
 // lane ends up holding 4 consecutive output columns of one output row: bias / activation / LayerScale / residual fuse into the
 // epilogue, which bounces through LDS so that stores and residual loads are whole 128-byte lines):
-//   Q  gemm_bf16_tn_pp_kernel    256 x 256 tile, 8 waves in two groups one barrier apart ("ping-pong"), half-tile LDS-DMA ring with
-//                                counted vmcnt, one workgroup per CU.  Used when the tile count fills whole rounds of the CUs.
+//   Q  gemm_bf16_tn_pp_kernel    256 x 256 tile, 8 waves in two groups one barrier apart ("ping-pong"), half-tile LDS-DMA ring
+//                                (buffer_load ... lds) with counted vmcnt, v_mfma_f32_16x16x32_bf16, one workgroup per CU.  Used when the tile count fills whole rounds of the CUs.
 //   G  gemm_bf16_tn_glds_kernel  128 x 128 tile, 4 waves, one LDS buffer filled by LDS-DMA, 4 workgroups per CU hide each other's
 //                                latency.  Used for everything else with K % 64 == 0.
 //   R  gemm_bf16_tn_kernel       128 x 128 tile, global -> VGPR -> LDS staging (double-buffered); any K % 8 == 0, zero-filled K
@@ -189,13 +189,45 @@ __device__ __forceinline__ void epilogue(const GemmP& p, const f32x16_t (&acc)[2
 }
 
 
+// Accumulator views: how a wave's (32*MI) x 64 fp32 sub-tile sits in registers, and how pass i (32 output rows) of it is written
+// into the per-wave 32 x 64 slab (row = output row m, 16-byte chunk = 4 consecutive n, chunk XOR (row & 15)).
+template <int MI>
+struct Acc32 {                       // v_mfma_f32_32x32x16: acc[j][i][4g+e] = C[n = 32j + 8g + 4*(lane>>5) + e][m = 32i + (lane&31)]
+  const f32x16_t (&a)[2][MI];
+  __device__ __forceinline__ void write(float* slab, int lane, int i) const {
+    const int frow = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int chunk = (j * 32 + 8 * g + 4 * fhalf) >> 2;
+        *reinterpret_cast<float4*>(slab + frow * 64 + ((chunk ^ (frow & 15)) << 2)) =
+            make_float4(a[j][i][4 * g], a[j][i][4 * g + 1], a[j][i][4 * g + 2], a[j][i][4 * g + 3]);
+      }
+  }
+};
+struct Acc16 {                       // v_mfma_f32_16x16x32: a[nb][mb][e] = C[n = 16nb + 4*(lane>>4) + e][m = 16mb + (lane&15)], nb < 4, mb < 8
+  const f32x4_t (&a)[4][8];
+  __device__ __forceinline__ void write(float* slab, int lane, int i) const {
+    const int r15 = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const int row = h * 16 + r15, chunk = nb * 4 + q;
+        *reinterpret_cast<float4*>(slab + row * 64 + ((chunk ^ (row & 15)) << 2)) =
+            make_float4(a[nb][2 * i + h][0], a[nb][2 * i + h][1], a[nb][2 * i + h][2], a[nb][2 * i + h][3]);
+      }
+  }
+};
+
 // Coalesced epilogue: the accumulator fragment (lane = one output row, 4 x 4 consecutive columns) is bounced through a
 // per-wave 32 x 64 fp32 LDS slab (XOR-swizzled 16-byte chunks: conflict-free both ways) so that afterwards 16 adjacent lanes
 // hold one output row's 64 consecutive columns: residual loads and C stores become full 128-byte lines instead of 8-byte
 // pieces scattered over 32 rows (measured on 32768x1280x1280 + bias + residual: 480 -> see profiles).  LDS ops of one wave
 // execute in order, so no barrier is needed; the slab aliases the (finished) operand tiles.
-template <bool OUT_F32, int MI>
-__device__ __forceinline__ void epilogue_lds_edge(const GemmP& p, const f32x16_t (&acc)[2][MI], char* smem, int wave, int m0, int n0, int wm, int wn,
+template <bool OUT_F32, int MI, class ACC>
+__device__ __forceinline__ void epilogue_lds_edge(const GemmP& p, const ACC& acc, char* smem, int wave, int m0, int n0, int wm, int wn,
                                                int lane, long bz) {
   float* slab = reinterpret_cast<float*>(smem) + wave * (32 * 64);
   const int frow = lane & 31, fhalf = lane >> 5;
@@ -218,14 +250,7 @@ __device__ __forceinline__ void epilogue_lds_edge(const GemmP& p, const f32x16_t
         rpre[it] = *reinterpret_cast<const uint2*>(p.res + bz + (long)m * p.ldr + n);
       }
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int chunk = (j * 32 + 8 * g + 4 * fhalf) >> 2;
-        *reinterpret_cast<float4*>(slab + frow * 64 + ((chunk ^ (frow & 15)) << 2)) =
-            make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
-      }
+    acc.write(slab, lane, i);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int row = it * 4 + rsub;
@@ -277,17 +302,15 @@ __device__ __forceinline__ void epilogue_lds_edge(const GemmP& p, const f32x16_t
 // straight-line code - no per-lane bounds or alignment branches, the activation resolved once per tile (ACT is a template
 // argument of the body), LDS offsets hoisted out of the pass loop, running 64-bit row pointers instead of a 64-bit multiply per
 // row.  The branchy edge version above costs ~10-18 us per 256 x 256 tile (instruction-bound with 2 waves/SIMD).
-template <bool OUT_F32, int MI, int ACT>
-__device__ __forceinline__ void epilogue_lds_body(const GemmP& p, const f32x16_t (&acc)[2][MI], float* slab, int mw, int nw, int lane, long bz) {
+template <bool OUT_F32, int MI, int ACT, class ACC>
+__device__ __forceinline__ void epilogue_lds_body(const GemmP& p, const ACC& acc, float* slab, int mw, int nw, int lane, long bz) {
   const int frow = lane & 31, fhalf = lane >> 5;
   const int c = lane & 15, rsub = lane >> 4;
   const int n = nw + c * 4;
   float bs[4] = {0.f, 0.f, 0.f, 0.f}, gm[4] = {1.f, 1.f, 1.f, 1.f};
   if (p.bias) ld4bf(p.bias + n, true, 4, bs);
   if (p.gamma) ld4bf(p.gamma + n, true, 4, gm);
-  int woff[8], roff[4];
-#pragma unroll
-  for (int jg = 0; jg < 8; ++jg) woff[jg] = frow * 64 + (((((jg >> 2) * 8 + (jg & 3) * 2 + fhalf)) ^ (frow & 15)) << 2);
+  int roff[4];
 #pragma unroll
   for (int it = 0; it < 4; ++it) roff[it] = (it * 4 + rsub) * 64 + ((c ^ ((it * 4 + rsub) & 15)) << 2);
   const long row0 = (long)(mw + rsub);
@@ -304,11 +327,7 @@ __device__ __forceinline__ void epilogue_lds_body(const GemmP& p, const f32x16_t
 #pragma unroll
       for (int it = 0; it < 8; ++it) { rpre[it] = *reinterpret_cast<const uint2*>(rp); rp += rstep; }
     }
-#pragma unroll
-    for (int jg = 0; jg < 8; ++jg) {
-      const int j = jg >> 2, g = jg & 3;
-      *reinterpret_cast<float4*>(slab + woff[jg]) = make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
-    }
+    acc.write(slab, lane, i);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const float4 a4 = *reinterpret_cast<const float4*>(slab + roff[it & 3] + (it >> 2) * (16 * 64));
@@ -335,23 +354,23 @@ __device__ __forceinline__ void epilogue_lds_body(const GemmP& p, const f32x16_t
   }
 }
 
-template <bool OUT_F32, int MI>
-__device__ __forceinline__ void epilogue_lds(const GemmP& p, const f32x16_t (&acc)[2][MI], char* smem, int wave, int m0, int n0, int wm, int wn,
+template <bool OUT_F32, int MI, class ACC>
+__device__ __forceinline__ void epilogue_lds(const GemmP& p, const ACC& acc, char* smem, int wave, int m0, int n0, int wm, int wn,
                                              int lane, long bz) {
   const int mw = m0 + wm * 32 * MI, nw = n0 + wn * 64;
   const bool interior = mw + 32 * MI <= p.M && nw + 64 <= p.N && p.c_vec && p.b_vec && (!p.res || p.r_vec);
   if (!interior) {
-    epilogue_lds_edge<OUT_F32, MI>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
+    epilogue_lds_edge<OUT_F32, MI, ACC>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
     return;
   }
   float* slab = reinterpret_cast<float*>(smem) + wave * (32 * 64);
   switch (p.act) {
-    case LLMSEG_ACT_NONE: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_NONE>(p, acc, slab, mw, nw, lane, bz); break;
-    case LLMSEG_ACT_GELU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_GELU>(p, acc, slab, mw, nw, lane, bz); break;
-    case LLMSEG_ACT_QUICKGELU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_QUICKGELU>(p, acc, slab, mw, nw, lane, bz); break;
-    case LLMSEG_ACT_SILU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_SILU>(p, acc, slab, mw, nw, lane, bz); break;
-    case LLMSEG_ACT_RELU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_RELU>(p, acc, slab, mw, nw, lane, bz); break;
-    default: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_SIGMOID>(p, acc, slab, mw, nw, lane, bz); break;
+    case LLMSEG_ACT_NONE: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_NONE, ACC>(p, acc, slab, mw, nw, lane, bz); break;
+    case LLMSEG_ACT_GELU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_GELU, ACC>(p, acc, slab, mw, nw, lane, bz); break;
+    case LLMSEG_ACT_QUICKGELU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_QUICKGELU, ACC>(p, acc, slab, mw, nw, lane, bz); break;
+    case LLMSEG_ACT_SILU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_SILU, ACC>(p, acc, slab, mw, nw, lane, bz); break;
+    case LLMSEG_ACT_RELU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_RELU, ACC>(p, acc, slab, mw, nw, lane, bz); break;
+    default: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_SIGMOID, ACC>(p, acc, slab, mw, nw, lane, bz); break;
   }
 }
 
@@ -475,7 +494,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_tn_kernel(GemmP p) {
     if (t + 1 < nt) { char* nb = smem + ((t + 1) & 1) * BUF; sa.store(nb); sw.store(nb + TILE); }
     __syncthreads();
   }
-  epilogue_lds<OUT_F32, MI>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
+  epilogue_lds<OUT_F32, MI>(p, Acc32<MI>{acc}, smem, wave, m0, n0, wm, wn, lane, bz);
 }
 
 // ---- variant G: direct global -> LDS DMA, K % 64 == 0 ---------------------------------------------------------------------
@@ -544,7 +563,7 @@ __global__ __launch_bounds__(NT, NBUF == 2 ? (MI == 4 ? 1 : 2) : (MI == 4 ? 2 : 
       __syncthreads();
     }
   }
-  epilogue_lds<OUT_F32, MI>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
+  epilogue_lds<OUT_F32, MI>(p, Acc32<MI>{acc}, smem, wave, m0, n0, wm, wn, lane, bz);
 }
 
 
@@ -557,7 +576,7 @@ __global__ __launch_bounds__(NT, NBUF == 2 ? (MI == 4 ? 1 : 2) : (MI == 4 ? 2 : 
 //   (sub-tile 0/1 of BOTH wave rows), W0/W1 = the first / second 32 rows of every 64-row wave column block.
 //   phase:        p0                p1               p2               p3
 //   reads         W0, A0 (12)       W1 (4)           A1 (8)           -
-//   MFMAs         acc[0][0..1]      acc[1][0..1]     acc[1][2..3]     acc[0][2..3]
+//   MFMAs (16 x v_mfma_f32_16x16x32_bf16 over 8 accumulators each)  W0 x A0 | W1 x A0 | W1 x A1 | W0 x A1
 //   DMA issue     W1(t+1)           A1(t+1)          A0(t+2)          W0(t+2)          (issue sequence S[g+6] at phase g)
 //   s_waitcnt     vmcnt(8)          vmcnt(8)         -                vmcnt(8)         (retires what phase g+1 reads)
 // Ordering rules (MI355X_MICROARCH.md "LDS-DMA"): a half-tile is read one phase AFTER the phase whose pre-barrier vmcnt retired
@@ -590,15 +609,6 @@ __global__ __launch_bounds__(NT, NBUF == 2 ? (MI == 4 ? 1 : 2) : (MI == 4 ? 2 : 
     PP_DMA_X(ext_w(h, 0), (base) + OP_BYTES + (((wave >> 2)) * 64 + (h) * 32 + (wave & 3) * 8) * 128);         \
     PP_DMA_X(ext_w(h, 1), (base) + OP_BYTES + ((2 + (wave >> 2)) * 64 + (h) * 32 + (wave & 3) * 8) * 128);     \
   } while (0)
-#define PP_READ_W(dst, j, base)                                                                                            \
-  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                       \
-      dst[ks] = *reinterpret_cast<const bf16x8_t*>((base) + OP_BYTES + lds_off(wn * 64 + (j) * 32 + frow, ks * 2 + fhalf))
-#define PP_READ_A(i0, base)                                                                                       \
-  _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)             \
-      af[ii][ks] = *reinterpret_cast<const bf16x8_t*>((base) + lds_off(wm * 128 + ((i0) + ii) * 32 + frow, ks * 2 + fhalf))
-#define PP_MMA(wfx, j, i0)                                                                \
-  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) \
-      acc[j][(i0) + ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfx[ks], af[ii][ks], acc[j][(i0) + ii], 0, 0, 0)
 #define PP_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define PP_NOP ((void)0)
 #define PP_PHASE(READS, ISSUE, WAIT, MMA)               \
@@ -617,6 +627,18 @@ __global__ __launch_bounds__(NT, NBUF == 2 ? (MI == 4 ? 1 : 2) : (MI == 4 ? 2 : 
   } while (0)
 
 constexpr int NTB = 512;
+
+// 16x16x32 fragments: lane -> (row lane&15, 16-byte k chunk lane>>4) of a 16-row block, two k-steps of 32 per K-tile
+#define P16_READ_W(dst, j, base)                                                                                              \
+  _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                         \
+      dst[nb][ks] = *reinterpret_cast<const bf16x8_t*>((base) + OP_BYTES + lds_off(wn * 64 + (j) * 32 + nb * 16 + frow, ks * 4 + fq))
+#define P16_READ_A(mb0, base)                                                                                                 \
+  _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                         \
+      af[mb][ks] = *reinterpret_cast<const bf16x8_t*>((base) + lds_off(wm * 128 + ((mb0) + mb) * 16 + frow, ks * 4 + fq))
+#define P16_MMA(wfx, nb0, mb0)                                                                                                \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                         \
+      _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                                        \
+          acc[(nb0) + nb][(mb0) + mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfx[nb][ks], af[mb][ks], acc[(nb0) + nb][(mb0) + mb], 0, 0, 0)
 
 template <bool OUT_F32, bool EXT>
 __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
@@ -670,10 +692,15 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
     return p.W2 + (long)min(n0 + rw, p.N - 1) * p.ldw2 + (((lane & 7) ^ ((rw >> 1) & 7)) << 3);
   };
 
-  f32x16_t acc[2][MI];
-  zero_acc<MI>(acc);
-  bf16x8_t af[2][4], wf0[4], wf1[4];
-  const int frow = lane & 31, fhalf = lane >> 5;
+  // v_mfma_f32_16x16x32_bf16: 16 MFMAs over EIGHT independent accumulators per phase (the 32x32x16 form alternates two, and a
+  // dependent MFMA issues only every ~42 cycles): acc[nb][mb] = C block (n = 16 nb.., m = 16 mb..), 4 x 8 blocks of f32x4
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t af[4][2], wf0[2][2], wf1[2][2];
+  const int frow = lane & 15, fq = lane >> 4;
 
   // prologue: S[0..5] = A0(0) W0(0) W1(0) A1(0) A0(1) W0(1)
   if (EXT) { PP_ISSUE_AX(0, smem); PP_ISSUE_WX(0, smem); PP_ISSUE_WX(1, smem); PP_ISSUE_AX(1, smem); }
@@ -688,26 +715,26 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
   for (; t < nt - 2; ++t) {
     char* cur = smem + (t & 1) * BUF;
     char* oth = smem + ((t + 1) & 1) * BUF;
-    PP_PHASE(PP_READ_W(wf0, 0, cur); PP_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM(8), PP_MMA(wf0, 0, 0));
-    PP_PHASE(PP_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM(8), PP_MMA(wf1, 1, 0));
-    PP_PHASE(PP_READ_A(2, cur), PP_ISSUE_A(0, t + 2, cur), PP_NOP, PP_MMA(wf1, 1, 2));
-    PP_PHASE(PP_NOP, PP_ISSUE_W(0, t + 2, cur), PP_VM(8), PP_MMA(wf0, 0, 2));
+    PP_PHASE(P16_READ_W(wf0, 0, cur); P16_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM(8), P16_MMA(wf0, 0, 0));
+    PP_PHASE(P16_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM(8), P16_MMA(wf1, 2, 0));
+    PP_PHASE(P16_READ_A(4, cur), PP_ISSUE_A(0, t + 2, cur), PP_NOP, P16_MMA(wf1, 2, 4));
+    PP_PHASE(PP_NOP, PP_ISSUE_W(0, t + 2, cur), PP_VM(8), P16_MMA(wf0, 0, 4));
   }
   {   // K-tile nt-2: the last two half-tiles are issued, then the queue drains
     char* cur = smem + (t & 1) * BUF;
     char* oth = smem + ((t + 1) & 1) * BUF;
-    PP_PHASE(PP_READ_W(wf0, 0, cur); PP_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM(8), PP_MMA(wf0, 0, 0));
-    PP_PHASE(PP_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM(8), PP_MMA(wf1, 1, 0));
-    PP_PHASE(PP_READ_A(2, cur), PP_NOP, PP_NOP, PP_MMA(wf1, 1, 2));
-    PP_PHASE(PP_NOP, PP_NOP, PP_VM(4), PP_MMA(wf0, 0, 2));
+    PP_PHASE(P16_READ_W(wf0, 0, cur); P16_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM(8), P16_MMA(wf0, 0, 0));
+    PP_PHASE(P16_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM(8), P16_MMA(wf1, 2, 0));
+    PP_PHASE(P16_READ_A(4, cur), PP_NOP, PP_NOP, P16_MMA(wf1, 2, 4));
+    PP_PHASE(PP_NOP, PP_NOP, PP_VM(4), P16_MMA(wf0, 0, 4));
     cur = oth;   // K-tile nt-1
-    PP_PHASE(PP_READ_W(wf0, 0, cur); PP_READ_A(0, cur), PP_NOP, PP_VM(2), PP_MMA(wf0, 0, 0));
-    PP_PHASE(PP_READ_W(wf1, 1, cur), PP_NOP, PP_VM(0), PP_MMA(wf1, 1, 0));
-    PP_PHASE(PP_READ_A(2, cur), PP_NOP, PP_NOP, PP_MMA(wf1, 1, 2));
-    PP_PHASE(PP_NOP, PP_NOP, PP_NOP, PP_MMA(wf0, 0, 2));
+    PP_PHASE(P16_READ_W(wf0, 0, cur); P16_READ_A(0, cur), PP_NOP, PP_VM(2), P16_MMA(wf0, 0, 0));
+    PP_PHASE(P16_READ_W(wf1, 1, cur), PP_NOP, PP_VM(0), P16_MMA(wf1, 2, 0));
+    PP_PHASE(P16_READ_A(4, cur), PP_NOP, PP_NOP, P16_MMA(wf1, 2, 4));
+    PP_PHASE(PP_NOP, PP_NOP, PP_NOP, P16_MMA(wf0, 0, 4));
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();            // re-join: every wave's reads and DMA are retired past this point
-  epilogue_lds<OUT_F32, MI>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
+  epilogue_lds<OUT_F32, MI>(p, Acc16{acc}, smem, wave, m0, n0, wm, wn, lane, bz);
 }
 
 template <bool OUT_F32, int MI, int NBUF>
