@@ -568,7 +568,7 @@ __global__ __launch_bounds__(NT, NBUF == 2 ? (MI == 4 ? 1 : 2) : (MI == 4 ? 2 : 
 
 
 // ---- variant Q: 256 x 256 tile, 8 waves in two groups that run ONE BARRIER APART ("ping-pong") ----------------------------
-// Each K-tile (BK = 64) is four phases; a phase is {LDS fragment reads + one half-tile of DMA issue} | barrier | {8 MFMAs} |
+// Each K-tile (BK = 64) is four phases; a phase is {LDS fragment reads + one half-tile of DMA issue} | barrier | {16 MFMAs} |
 // barrier.  Waves wm = 1 execute one extra barrier up front, so on every SIMD the wm = 0 wave's MFMA section overlaps the
 // wm = 1 wave's read/DMA section and vice versa: the matrix pipe sees back-to-back MFMAs while the partner hides LDS latency.
 //   operands per buffer (2 buffers x 64 KiB): A[256][64], W[256][64] bf16, 128-byte rows, chunk XOR (row>>1)&7
