@@ -269,9 +269,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnP p) {
     }                                                                                                               \
     f32x16_t s[2];                                                                                                  \
     LL_BIAS_INIT(TC)          /* raw-domain bias (or 0) is the C input of the QK^T MFMAs */                         \
-    _Pragma("unroll") for (int jb = 0; jb < 2; ++jb) {                                                              \
-      if (!(LAST_WIN && jb == 1)) {                                                                                 \
-        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                         \
+    /* k-step outer, key block inner: consecutive MFMAs alternate the two accumulators (a dependent MFMA issues late) */ \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                             \
+      _Pragma("unroll") for (int jb = 0; jb < 2; ++jb) {                                                            \
+        if (!(LAST_WIN && jb == 1)) {                                                                               \
           const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (jb * 32 + ql) * PK + (2 * ks + half) * 16);  \
           s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[jb], 0, 0, 0);                              \
         }                                                                                                           \

@@ -162,11 +162,14 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_kernel(BwdP p) {
 
     f32x16_t s[2], dp[2];
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
+    for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) { s[jb][e] = 0.f; dp[jb][e] = 0.f; }
+    // k-step outer: consecutive MFMAs cycle through the (up to four) accumulators
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
         const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(Y1 + (jb * 32 + ql) * PK + (2 * ks + half) * 16);
         s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xf1[ks], s[jb], 0, 0, 0);
         if (HAS2) {
@@ -174,7 +177,6 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_kernel(BwdP p) {
           dp[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xf2[ks], dp[jb], 0, 0, 0);
         }
       }
-    }
     // P (mode dV) or dS (modes dQ, dK), in place
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb)
