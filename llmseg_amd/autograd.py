@@ -95,7 +95,7 @@ def _ext_operand(cache, key, p1, p2, build):
     when the matrices change (optimizer step -> PARAM_EPOCH; load_state_dict -> version counters)."""
     if cache is None:
         return build()
-    stamp = (PARAM_EPOCH, p1._version, p2._version)
+    stamp = (PARAM_EPOCH, p1._version, p2._version, p1.data_ptr(), p2.data_ptr())
     hit = cache.get(key)
     if hit is None or hit[0] != stamp:
         hit = (stamp, build())
