@@ -56,10 +56,19 @@ typedef struct {
    * (ldw2); NULL = none.  Fuses low-rank updates (the r = 8 LoRA products of q_proj / v_proj, zero-padded to 64 columns) into the
    * big GEMM as one more K-tile instead of a read-modify-write pass over C.  batch == 1, no trans_*. */
   const void* A2; const void* W2; int64_t lda2, ldw2;
+  /* optional caller-owned scratch (fp32 partial tiles of the split-K path: short matrices with a long contraction, e.g. the
+   * Llama o / down projections and every dX GEMM at M = 2 x 319 rows, run as S K-slices + one reduce launch); NULL / too small =
+   * no split-K.  Must not be shared between streams that run concurrently. */
+  void* workspace; int64_t workspace_bytes;
+  /* out_f32 only: C += result instead of C = result (weight gradients accumulate over micro-steps in an fp32 arena, as the
+   * reference's DeepSpeed engine accumulates them: training.py:79-82 gradient_accumulation_steps, :292-332 bf16 config) */
+  int accumulate;
 } llmseg_gemm_args;
 int llmseg_gemm_bf16(const llmseg_gemm_args* args, void* stream);
-/* tuning knob: GEMM kernel for K % 64 == 0 shapes (0 = register staging 128x128, 2 = LDS-DMA 128x128, 8 = LDS-DMA 256x256
- * ping-pong, 5 = auto [default]).  Results are identical; only speed differs. */
+/* tuning knob (results are identical up to fp32 summation order of split-K; only speed differs):
+ * bits 0-3: GEMM kernel for K % 64 == 0 shapes: 0 = register staging 128x128, 2 = LDS-DMA 128x128, 8 = LDS-DMA 256x256 ping-pong,
+ *           9 = LDS-DMA 128x256 ping-pong, 5 = auto [default: a cost model picks kernel and split count];
+ * bits 4-7: XCD skew + 1 (0 = keep); bits 8-12: forced split-K slice count for variants 8 / 9 (0 = 1 slice). */
 int llmseg_gemm_set_variant(int variant);
 
 /* ---- fused attention forward -----------------------------------------------------------------

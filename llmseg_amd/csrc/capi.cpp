@@ -79,7 +79,7 @@ extern "C" int llmseg_prof_collect(double* total_ms, double* total_flops, int64_
     (void)hipEventElapsedTime(&t, r.a, r.b);
     ms += t;
     fl += r.flops;
-    auto& c = by_class[(r.tag[3] / 1000) * 2 + (r.tag[3] & 1)];
+    auto& c = by_class[((r.tag[3] % 10000) / 1000) * 2 + (r.tag[3] & 1)];    // tag = split * 10000 + variant * 1000 + flags
     c[0] += t; c[1] += r.flops; c[2] += 1;
     auto& e = by_shape[{r.tag[0], r.tag[1], r.tag[2], r.tag[3]}];
     e[0] += t; e[1] += r.flops; e[2] += 1;
@@ -89,10 +89,10 @@ extern "C" int llmseg_prof_collect(double* total_ms, double* total_flops, int64_
     std::vector<std::pair<double, std::array<long, 4>>> order;
     for (auto& kv : by_shape) order.push_back({-kv.second[0], kv.first});
     std::sort(order.begin(), order.end());
-    fprintf(stderr, "%8s %8s %8s %4s %8s %10s %9s %6s\n", "M", "N", "K", "var", "calls", "total_ms", "TFLOP/s", "%time");
+    fprintf(stderr, "%8s %8s %8s %6s %8s %10s %9s %6s\n", "M", "N", "K", "var", "calls", "total_ms", "TFLOP/s", "%time");
     for (size_t i = 0; i < order.size() && i < 40; ++i) {
       auto& e = by_shape[order[i].second];
-      fprintf(stderr, "%8ld %8ld %8ld %4ld %8.0f %10.2f %9.1f %6.1f\n", order[i].second[0], order[i].second[1], order[i].second[2], order[i].second[3],
+      fprintf(stderr, "%8ld %8ld %8ld %6ld %8.0f %10.2f %9.1f %6.1f\n", order[i].second[0], order[i].second[1], order[i].second[2], order[i].second[3],
               e[2], e[0], e[1] / (e[0] * 1e-3) / 1e12, 100.0 * e[0] / ms);
     }
   }
@@ -103,10 +103,10 @@ extern "C" int llmseg_prof_collect(double* total_ms, double* total_flops, int64_
   long dom = -1;
   for (auto& kv : by_class) if (dom < 0 || kv.second[0] > by_class[dom][0]) dom = kv.first;
   static const char* names[] = {"gemm_bf16_tn_kernel<*, ...> (register staging, 128x128)", "?", "gemm_bf16_tn_glds_kernel<*, 2, 1>", "?", "?", "?", "?", "?",
-                                "gemm_bf16_tn_pp_kernel<*, false>"};
+                                "gemm_bf16_tn_pp_kernel<*, false, 4>", "gemm_bf16_tn_pp_kernel<*, false, 2>"};
   if (dom >= 0) {
     const long v = dom / 2;
-    std::string nm = (v >= 0 && v < 9) ? names[v] : "?";
+    std::string nm = (v >= 0 && v < 10) ? names[v] : "?";
     const size_t star = nm.find('*');
     if (star != std::string::npos) nm.replace(star, 1, (dom & 1) ? "true" : "false");
     snprintf(g_dom_name, sizeof(g_dom_name), "%s", nm.c_str());

@@ -41,6 +41,8 @@ struct GemmP {
   const bf16_t* A2; const bf16_t* W2; long lda2, ldw2;   // optional extension K-tile (64 wide): C += alpha * A2 . W2^T (ping-pong kernel)
   int group_m;               // M-tiles per group of the ping-pong kernel's tile walk
   int skew;                  // per-XCD rotation of the tile walk (de-phases the 8 XCDs' HBM/MALL channel access)
+  int kt_total;              // split-K (ping-pong kernel): total K-tiles of the product; 0 = blockIdx.y is a batch index, K = whole contraction
+  int accum;                 // fp32 output only: C += result (gradient accumulation into an fp32 arena)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -131,64 +133,6 @@ __device__ __forceinline__ void ld4bf(const bf16_t* p, bool vec, int nv, float* 
   }
 }
 
-// lane holds C[m][n..n+3] for 4 column groups per accumulator
-template <bool OUT_F32, int MI>
-__device__ __forceinline__ void epilogue(const GemmP& p, const f32x16_t (&acc)[2][MI], int m0, int n0, int wm, int wn, int frow, int fhalf, long bz) {
-  const bool vec_ok = p.c_vec != 0, res_vec = p.r_vec != 0, b_vec = p.b_vec != 0;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * fhalf;
-      if (n >= p.N) continue;
-      const int nv = min(4, p.N - n);
-      float bs[4] = {0.f, 0.f, 0.f, 0.f}, gm[4] = {1.f, 1.f, 1.f, 1.f};
-      if (p.bias) ld4bf(p.bias + n, b_vec, nv, bs);
-      if (p.gamma) ld4bf(p.gamma + n, b_vec, nv, gm);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * 32 * MI + i * 32 + frow;
-        if (m >= p.M) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e] * p.alpha + bs[e];
-        if (p.act != LLMSEG_ACT_NONE) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
-        }
-        if (p.gamma) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= gm[e];
-        }
-        if (p.res) {
-          float rr[4];
-          ld4bf(p.res + bz + (long)m * p.ldr + n, res_vec, nv, rr);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += rr[e];
-        }
-        if (OUT_F32) {
-          float* cp = reinterpret_cast<float*>(p.C) + bz + (long)m * p.ldc + n;
-          if (vec_ok && nv == 4) {
-            *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (e < nv) cp[e] = v[e];
-          }
-        } else {
-          bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + bz + (long)m * p.ldc + n;
-          if (vec_ok && nv == 4) {
-            *reinterpret_cast<uint2*>(cp) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (e < nv) cp[e] = f2bf(v[e]);
-          }
-        }
-      }
-    }
-  }
-}
-
-
 // Accumulator views: how a wave's (32*MI) x 64 fp32 sub-tile sits in registers, and how pass i (32 output rows) of it is written
 // into the per-wave 32 x 64 slab (row = output row m, 16-byte chunk = 4 consecutive n, chunk XOR (row & 15)).
 template <int MI>
@@ -206,8 +150,9 @@ struct Acc32 {                       // v_mfma_f32_32x32x16: acc[j][i][4g+e] = C
       }
   }
 };
-struct Acc16 {                       // v_mfma_f32_16x16x32: a[nb][mb][e] = C[n = 16nb + 4*(lane>>4) + e][m = 16mb + (lane&15)], nb < 4, mb < 8
-  const f32x4_t (&a)[4][8];
+template <int MI>
+struct Acc16 {                       // v_mfma_f32_16x16x32: a[nb][mb][e] = C[n = 16nb + 4*(lane>>4) + e][m = 16mb + (lane&15)], nb < 4, mb < 2 MI
+  const f32x4_t (&a)[4][2 * MI];
   __device__ __forceinline__ void write(float* slab, int lane, int i) const {
     const int r15 = lane & 15, q = lane >> 4;
 #pragma unroll
@@ -279,6 +224,10 @@ __device__ __forceinline__ void epilogue_lds_edge(const GemmP& p, const ACC& acc
       }
       if (OUT_F32) {
         float* cp = reinterpret_cast<float*>(p.C) + bz + (long)m * p.ldc + n;
+        if (p.accum) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (e < nv) v[e] += cp[e];
+        }
         if (vec_ok && nv == 4) {
           *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
@@ -320,6 +269,7 @@ __device__ __forceinline__ void epilogue_lds_body(const GemmP& p, const ACC& acc
   const long rstep = 4 * p.ldr;
   const float alpha = p.alpha;
   const bool has_gamma = p.gamma != nullptr;
+  const bool accum = OUT_F32 && p.accum != 0;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     uint2 rpre[8];
@@ -347,8 +297,13 @@ __device__ __forceinline__ void epilogue_lds_body(const GemmP& p, const ACC& acc
         v[0] += __uint_as_float(rpre[it].x << 16); v[1] += __uint_as_float(rpre[it].x & 0xffff0000u);
         v[2] += __uint_as_float(rpre[it].y << 16); v[3] += __uint_as_float(rpre[it].y & 0xffff0000u);
       }
-      if (OUT_F32) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-      else *reinterpret_cast<uint2*>(cp) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      if (OUT_F32) {
+        if (accum) {
+          const float4 o4 = *reinterpret_cast<const float4*>(cp);
+          v[0] += o4.x; v[1] += o4.y; v[2] += o4.z; v[3] += o4.w;
+        }
+        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+      } else *reinterpret_cast<uint2*>(cp) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
       cp += cstep;
     }
   }
@@ -567,49 +522,64 @@ __global__ __launch_bounds__(NT, NBUF == 2 ? (MI == 4 ? 1 : 2) : (MI == 4 ? 2 : 
 }
 
 
-// ---- variant Q: 256 x 256 tile, 8 waves in two groups that run ONE BARRIER APART ("ping-pong") ----------------------------
-// Each K-tile (BK = 64) is four phases; a phase is {LDS fragment reads + one half-tile of DMA issue} | barrier | {16 MFMAs} |
+// ---- variant Q: (64 MI) x 256 tile, 8 waves in two groups that run ONE BARRIER APART ("ping-pong") -------------------------
+// MI = 4: 256 x 256 (waves 2 x 4, each 128 x 64); MI = 2: 128 x 256 (each wave 64 x 64) for short matrices (Llama at 2 images per
+// micro-step has M = 638 rows: five 128-row tiles waste 0.3 % of the rows, three 256-row tiles 17 %).
+// Each K-tile (BK = 64) is four phases; a phase is {LDS fragment reads + one half-tile of DMA issue} | barrier | {4 MI MFMAs} |
 // barrier.  Waves wm = 1 execute one extra barrier up front, so on every SIMD the wm = 0 wave's MFMA section overlaps the
 // wm = 1 wave's read/DMA section and vice versa: the matrix pipe sees back-to-back MFMAs while the partner hides LDS latency.
-//   operands per buffer (2 buffers x 64 KiB): A[256][64], W[256][64] bf16, 128-byte rows, chunk XOR (row>>1)&7
-//   half-tiles (16 KiB, one 2-instruction DMA issue by all 8 waves):  A0/A1 = rows {0..63, 128..191} / {64..127, 192..255}
-//   (sub-tile 0/1 of BOTH wave rows), W0/W1 = the first / second 32 rows of every 64-row wave column block.
+//   operands per buffer (2 buffers): A[64 MI][64], W[256][64] bf16, 128-byte rows, chunk XOR (row>>1)&7
+//   half-tiles (one DMA issue by all 8 waves: MI/2 instructions for A, 2 for W):  A0/A1 = the first / second half of BOTH wave
+//   rows' blocks, W0/W1 = the first / second 32 rows of every 64-row wave column block.
 //   phase:        p0                p1               p2               p3
-//   reads         W0, A0 (12)       W1 (4)           A1 (8)           -
-//   MFMAs (16 x v_mfma_f32_16x16x32_bf16 over 8 accumulators each)  W0 x A0 | W1 x A0 | W1 x A1 | W0 x A1
+//   reads         W0, A0            W1               A1               -
+//   MFMAs (4 MI x v_mfma_f32_16x16x32_bf16 over 2 MI accumulators each)  W0 x A0 | W1 x A0 | W1 x A1 | W0 x A1
 //   DMA issue     W1(t+1)           A1(t+1)          A0(t+2)          W0(t+2)          (issue sequence S[g+6] at phase g)
-//   s_waitcnt     vmcnt(8)          vmcnt(8)         -                vmcnt(8)         (retires what phase g+1 reads)
+//   s_waitcnt     vmcnt(MI + 4)     vmcnt(MI + 4)    -                vmcnt(MI + 4)    (retires what phase g+1 reads)
 // Ordering rules (MI355X_MICROARCH.md "LDS-DMA"): a half-tile is read one phase AFTER the phase whose pre-barrier vmcnt retired
 // it (both groups' waits precede a barrier the reader has passed); a slot is re-issued >= 2 phases after its last read (the
-// lagging group's reads retire one barrier later).  Four half-tiles (64 KiB) stay in flight per workgroup.  K % 64 == 0, K >= 128.
+// lagging group's reads retire one barrier later).  Four half-tiles stay in flight per workgroup.  K % 64 == 0, >= 2 K-tiles.
 // LDS-DMA as `buffer_load_dwordx4 ... offen lds`: a raw buffer resource based at the tile's first row, tile-relative 32-bit per-lane
 // byte offsets, the K advance in the scalar offset (no 64-bit VALU address arithmetic per instruction, 8 fewer VGPRs than pointers)
+// Split-K (p.kt_total > 0): blockIdx.y is the K-slice; slice s covers K-tiles [s q, min((s+1) q, kt_total)), q = p.K / 64, and
+// writes its fp32 partial tile to slab s of the workspace (plain OUT_F32 stores); splitk_reduce_kernel sums the slabs and applies
+// the epilogue.  Short matrices with a long contraction (Llama o / down and the dX GEMMs at M = 638: 48 tiles of 256 x 256)
+// otherwise leave 80 % of the CUs idle.
 #define PP_KOFF(tt) ((int)(((tt) - (EXT ? 1 : 0)) * (BK * 2)))
 #define PP_DMA_X(ptr, dst) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ptr), (lds_ptr_t)(dst), 16, 0, 0)
-#define PP_ISSUE_A(h, tt, base)                                                                                                   \
-  do {                                                                                                                            \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)((base) + ((h) * 64 + wave * 8) * 128), 16, a_off[h][0], PP_KOFF(tt), 0, 0);       \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)((base) + (128 + (h) * 64 + wave * 8) * 128), 16, a_off[h][1], PP_KOFF(tt), 0, 0); \
+// first LDS row of this wave's 8-row DMA group: A half h, instruction i (i < MI / 2); W half h, instruction i (i < 2)
+#define PP_AROW0(h, i) (MI == 4 ? ((i) * 128 + (h) * 64 + wave * 8) : ((wave >> 2) * 64 + (h) * 32 + (wave & 3) * 8))
+#define PP_WROW0(h, i) (((i) * 2 + (wave >> 2)) * 64 + (h) * 32 + (wave & 3) * 8)
+// NB: the LDS address handed to the DMA builtins must not be a value-dependent expression of a template parameter (hipcc 7.2 then
+// silently drops the kernel's host stub): the per-wave LDS offsets live in the runtime tables a_lds / w_lds.
+#define PP_BL(rs, dst, voff, tt) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst), 16, voff, PP_KOFF(tt), 0, 0)
+#define PP_ISSUE_A(h, tt, base)                                                  \
+  do {                                                                           \
+    PP_BL(rsrc_a, (base) + a_lds[h][0], a_off[h][0], tt);                        \
+    if constexpr (MI == 4) PP_BL(rsrc_a, (base) + a_lds[h][1], a_off[h][1], tt); \
   } while (0)
-#define PP_ISSUE_W(h, tt, base)                                                                                                   \
-  do {                                                                                                                            \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)((base) + OP_BYTES + (((wave >> 2)) * 64 + (h) * 32 + (wave & 3) * 8) * 128), 16,     \
-                                             w_off[h][0], PP_KOFF(tt), 0, 0);                                                     \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)((base) + OP_BYTES + ((2 + (wave >> 2)) * 64 + (h) * 32 + (wave & 3) * 8) * 128), 16, \
-                                             w_off[h][1], PP_KOFF(tt), 0, 0);                                                     \
+#define PP_ISSUE_W(h, tt, base)                                                  \
+  do {                                                                           \
+    PP_BL(rsrc_w, (base) + w_lds[h][0], w_off[h][0], tt);                        \
+    PP_BL(rsrc_w, (base) + w_lds[h][1], w_off[h][1], tt);                        \
   } while (0)
 // the optional extension tile (A2, W2) is K-tile 0, fetched in the prologue with the same lane -> (row, chunk) mapping
 #define PP_ISSUE_AX(h, base)                                                     \
   do {                                                                           \
-    PP_DMA_X(ext_a(h, 0), (base) + ((h) * 64 + wave * 8) * 128);                 \
-    PP_DMA_X(ext_a(h, 1), (base) + (128 + (h) * 64 + wave * 8) * 128);           \
+    PP_DMA_X(ext_a(h, 0), (base) + a_lds[h][0]);                                 \
+    if constexpr (MI == 4) PP_DMA_X(ext_a(h, 1), (base) + a_lds[h][1]);          \
   } while (0)
-#define PP_ISSUE_WX(h, base)                                                                                   \
-  do {                                                                                                         \
-    PP_DMA_X(ext_w(h, 0), (base) + OP_BYTES + (((wave >> 2)) * 64 + (h) * 32 + (wave & 3) * 8) * 128);         \
-    PP_DMA_X(ext_w(h, 1), (base) + OP_BYTES + ((2 + (wave >> 2)) * 64 + (h) * 32 + (wave & 3) * 8) * 128);     \
+#define PP_ISSUE_WX(h, base)                                                     \
+  do {                                                                           \
+    PP_DMA_X(ext_w(h, 0), (base) + w_lds[h][0]);                                 \
+    PP_DMA_X(ext_w(h, 1), (base) + w_lds[h][1]);                                 \
   } while (0)
-#define PP_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define PP_VMI(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// counted waits: FULL = four half-tiles may stay in flight (2 A + 2 W = MI + 4 instructions), then the drain ladder
+#define PP_VM_FULL do { if constexpr (MI == 4) PP_VMI(8); else PP_VMI(6); } while (0)
+#define PP_VM_WA do { if constexpr (MI == 4) PP_VMI(4); else PP_VMI(3); } while (0)     /* W + A half-tile in flight */
+#define PP_VM_A do { if constexpr (MI == 4) PP_VMI(2); else PP_VMI(1); } while (0)      /* one A half-tile in flight */
+#define PP_VM_0 PP_VMI(0)
 #define PP_NOP ((void)0)
 #define PP_PHASE(READS, ISSUE, WAIT, MMA)               \
   do {                                                  \
@@ -631,19 +601,19 @@ constexpr int NTB = 512;
 // 16x16x32 fragments: lane -> (row lane&15, 16-byte k chunk lane>>4) of a 16-row block, two k-steps of 32 per K-tile
 #define P16_READ_W(dst, j, base)                                                                                              \
   _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                         \
-      dst[nb][ks] = *reinterpret_cast<const bf16x8_t*>((base) + OP_BYTES + lds_off(wn * 64 + (j) * 32 + nb * 16 + frow, ks * 4 + fq))
+      dst[nb][ks] = *reinterpret_cast<const bf16x8_t*>((base) + A_BYTES + lds_off(wn * 64 + (j) * 32 + nb * 16 + frow, ks * 4 + fq))
 #define P16_READ_A(mb0, base)                                                                                                 \
-  _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                         \
-      af[mb][ks] = *reinterpret_cast<const bf16x8_t*>((base) + lds_off(wm * 128 + ((mb0) + mb) * 16 + frow, ks * 4 + fq))
+  _Pragma("unroll") for (int mb = 0; mb < MI; ++mb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                        \
+      af[mb][ks] = *reinterpret_cast<const bf16x8_t*>((base) + lds_off(wm * (32 * MI) + ((mb0) + mb) * 16 + frow, ks * 4 + fq))
 #define P16_MMA(wfx, nb0, mb0)                                                                                                \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                         \
-      _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                                        \
+      _Pragma("unroll") for (int mb = 0; mb < MI; ++mb)                                                                       \
           acc[(nb0) + nb][(mb0) + mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfx[nb][ks], af[mb][ks], acc[(nb0) + nb][(mb0) + mb], 0, 0, 0)
 
-template <bool OUT_F32, bool EXT>
+template <bool OUT_F32, bool EXT, int MI>
 __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
-  constexpr int MI = 4, BMB = 256, BNB = 256;
-  constexpr int OP_BYTES = 256 * BK * 2, BUF = 2 * OP_BYTES;     // 32 KiB per operand, 64 KiB per buffer
+  constexpr int BMB = 64 * MI, BNB = 256;
+  constexpr int A_BYTES = BMB * BK * 2, W_BYTES = BNB * BK * 2, BUF = A_BYTES + W_BYTES;     // 64 KiB (MI 4) / 48 KiB (MI 2) per buffer
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   int bid = blockIdx.x;
   const int nwg = p.tiles_m * p.tiles_n;
@@ -671,42 +641,47 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
   // (lane%8) ^ swizzle(row) of that row.  Byte offsets relative to the tile's first row (rows past the matrix edge are clamped).
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ag + (long)m0 * p.lda), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Wg + (long)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
-  int a_off[2][2], w_off[2][2];
+  int a_off[2][2], w_off[2][2];      // per-lane global byte offsets
+  int a_lds[2][2], w_lds[2][2];      // LDS byte offset of the wave's 8-row DMA group inside a buffer (wave-uniform)
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < 2; ++h) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int ra = i * 128 + h * 64 + wave * 8 + (lane >> 3);
-      const int rw = (i * 2 + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + (lane >> 3);
+      const int ra0 = i < MI / 2 ? PP_AROW0(h, i) : 0, ra = ra0 + (lane >> 3);
+      a_lds[h][i] = ra0 * 128;
       a_off[h][i] = (int)(((long)min(ra, p.M - 1 - m0) * p.lda + (((lane & 7) ^ ((ra >> 1) & 7)) << 3)) * 2);
+      const int rw0 = PP_WROW0(h, i), rw = rw0 + (lane >> 3);
+      w_lds[h][i] = A_BYTES + rw0 * 128;
       w_off[h][i] = (int)(((long)min(rw, p.N - 1 - n0) * p.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) << 3)) * 2);
     }
-  const int nt_main = p.K / BK;
+  }
+  int nt_main = p.K / BK;
+  if (p.kt_total > 0) nt_main = min(nt_main, p.kt_total - (int)b1 * nt_main);     // split-K: the last slice may be shorter
   const int nt = nt_main + (EXT ? 1 : 0);
   auto ext_a = [&](int h, int i) {
-    const int ra = i * 128 + h * 64 + wave * 8 + (lane >> 3);
+    const int ra = PP_AROW0(h, i) + (lane >> 3);
     return p.A2 + (long)min(m0 + ra, p.M - 1) * p.lda2 + (((lane & 7) ^ ((ra >> 1) & 7)) << 3);
   };
   auto ext_w = [&](int h, int i) {
-    const int rw = (i * 2 + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + (lane >> 3);
+    const int rw = PP_WROW0(h, i) + (lane >> 3);
     return p.W2 + (long)min(n0 + rw, p.N - 1) * p.ldw2 + (((lane & 7) ^ ((rw >> 1) & 7)) << 3);
   };
 
-  // v_mfma_f32_16x16x32_bf16: 16 MFMAs over EIGHT independent accumulators per phase (the 32x32x16 form alternates two, and a
-  // dependent MFMA issues only every ~42 cycles): acc[nb][mb] = C block (n = 16 nb.., m = 16 mb..), 4 x 8 blocks of f32x4
-  f32x4_t acc[4][8];
+  // v_mfma_f32_16x16x32_bf16: 4 MI MFMAs over 2 MI independent accumulators per phase (the 32x32x16 form alternates two, and a
+  // dependent MFMA issues only every ~42 cycles): acc[nb][mb] = C block (n = 16 nb.., m = 16 mb..), 4 x 2MI blocks of f32x4
+  f32x4_t acc[4][2 * MI];
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  bf16x8_t af[4][2], wf0[2][2], wf1[2][2];
+    for (int mb = 0; mb < 2 * MI; ++mb) acc[nb][mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t af[MI][2], wf0[2][2], wf1[2][2];
   const int frow = lane & 15, fq = lane >> 4;
 
   // prologue: S[0..5] = A0(0) W0(0) W1(0) A1(0) A0(1) W0(1)
   if (EXT) { PP_ISSUE_AX(0, smem); PP_ISSUE_WX(0, smem); PP_ISSUE_WX(1, smem); PP_ISSUE_AX(1, smem); }
   else { PP_ISSUE_A(0, 0, smem); PP_ISSUE_W(0, 0, smem); PP_ISSUE_W(1, 0, smem); PP_ISSUE_A(1, 0, smem); }
   PP_ISSUE_A(0, 1, smem + BUF); PP_ISSUE_W(0, 1, smem + BUF);
-  PP_VM(8);
+  PP_VM_FULL;
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();            // the stagger
   __builtin_amdgcn_sched_barrier(0);
@@ -715,26 +690,71 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
   for (; t < nt - 2; ++t) {
     char* cur = smem + (t & 1) * BUF;
     char* oth = smem + ((t + 1) & 1) * BUF;
-    PP_PHASE(P16_READ_W(wf0, 0, cur); P16_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM(8), P16_MMA(wf0, 0, 0));
-    PP_PHASE(P16_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM(8), P16_MMA(wf1, 2, 0));
-    PP_PHASE(P16_READ_A(4, cur), PP_ISSUE_A(0, t + 2, cur), PP_NOP, P16_MMA(wf1, 2, 4));
-    PP_PHASE(PP_NOP, PP_ISSUE_W(0, t + 2, cur), PP_VM(8), P16_MMA(wf0, 0, 4));
+    PP_PHASE(P16_READ_W(wf0, 0, cur); P16_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM_FULL, P16_MMA(wf0, 0, 0));
+    PP_PHASE(P16_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM_FULL, P16_MMA(wf1, 2, 0));
+    PP_PHASE(P16_READ_A(MI, cur), PP_ISSUE_A(0, t + 2, cur), PP_NOP, P16_MMA(wf1, 2, MI));
+    PP_PHASE(PP_NOP, PP_ISSUE_W(0, t + 2, cur), PP_VM_FULL, P16_MMA(wf0, 0, MI));
   }
   {   // K-tile nt-2: the last two half-tiles are issued, then the queue drains
     char* cur = smem + (t & 1) * BUF;
     char* oth = smem + ((t + 1) & 1) * BUF;
-    PP_PHASE(P16_READ_W(wf0, 0, cur); P16_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM(8), P16_MMA(wf0, 0, 0));
-    PP_PHASE(P16_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM(8), P16_MMA(wf1, 2, 0));
-    PP_PHASE(P16_READ_A(4, cur), PP_NOP, PP_NOP, P16_MMA(wf1, 2, 4));
-    PP_PHASE(PP_NOP, PP_NOP, PP_VM(4), P16_MMA(wf0, 0, 4));
+    PP_PHASE(P16_READ_W(wf0, 0, cur); P16_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM_FULL, P16_MMA(wf0, 0, 0));
+    PP_PHASE(P16_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM_FULL, P16_MMA(wf1, 2, 0));
+    PP_PHASE(P16_READ_A(MI, cur), PP_NOP, PP_NOP, P16_MMA(wf1, 2, MI));
+    PP_PHASE(PP_NOP, PP_NOP, PP_VM_WA, P16_MMA(wf0, 0, MI));
     cur = oth;   // K-tile nt-1
-    PP_PHASE(P16_READ_W(wf0, 0, cur); P16_READ_A(0, cur), PP_NOP, PP_VM(2), P16_MMA(wf0, 0, 0));
-    PP_PHASE(P16_READ_W(wf1, 1, cur), PP_NOP, PP_VM(0), P16_MMA(wf1, 2, 0));
-    PP_PHASE(P16_READ_A(4, cur), PP_NOP, PP_NOP, P16_MMA(wf1, 2, 4));
-    PP_PHASE(PP_NOP, PP_NOP, PP_NOP, P16_MMA(wf0, 0, 4));
+    PP_PHASE(P16_READ_W(wf0, 0, cur); P16_READ_A(0, cur), PP_NOP, PP_VM_A, P16_MMA(wf0, 0, 0));
+    PP_PHASE(P16_READ_W(wf1, 1, cur), PP_NOP, PP_VM_0, P16_MMA(wf1, 2, 0));
+    PP_PHASE(P16_READ_A(MI, cur), PP_NOP, PP_NOP, P16_MMA(wf1, 2, MI));
+    PP_PHASE(PP_NOP, PP_NOP, PP_NOP, P16_MMA(wf0, 0, MI));
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();            // re-join: every wave's reads and DMA are retired past this point
-  epilogue_lds<OUT_F32, MI>(p, Acc16{acc}, smem, wave, m0, n0, wm, wn, lane, bz);
+  epilogue_lds<OUT_F32, MI>(p, Acc16<MI>{acc}, smem, wave, m0, n0, wm, wn, lane, bz);
+}
+
+// Split-K tail: C = epi(alpha * sum_s slab[s]) with the GEMM's epilogue (bias, activation, LayerScale, residual, bf16 or fp32 out,
+// optional += into an fp32 C).  slab: fp32 [S][M][N] (dense), one thread per 4 consecutive columns (N % 4 == 0).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float* __restrict__ slab, int S, int out_f32) {
+  const long n4 = p.N >> 2, total = (long)p.M * n4, slab_sz = (long)p.M * p.N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / n4;
+    const int n = (int)(i - m * n4) * 4;
+    const float* sp = slab + m * p.N + n;
+    float4 a = *reinterpret_cast<const float4*>(sp);
+    for (int s = 1; s < S; ++s) {
+      const float4 b = *reinterpret_cast<const float4*>(sp + s * slab_sz);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float v[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
+    if (p.bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += bf2f(p.bias[n + e]);
+    }
+    if (p.act != LLMSEG_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+    }
+    if (p.gamma) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= bf2f(p.gamma[n + e]);
+    }
+    if (p.res) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += bf2f(p.res[m * p.ldr + n + e]);
+    }
+    if (out_f32) {
+      float* cp = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cp[e] = p.accum ? cp[e] + v[e] : v[e];
+    } else {
+      bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n;
+      if (p.c_vec) *reinterpret_cast<uint2*>(cp) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cp[e] = f2bf(v[e]);
+      }
+    }
+  }
 }
 
 template <bool OUT_F32, int MI, int NBUF>
@@ -749,14 +769,48 @@ void llmseg_prof_begin(hipStream_t s);
 void llmseg_prof_end(hipStream_t s, double flops);
 void llmseg_prof_tag(long a, long b, long c, long d);
 
-// tuning knob (tools/gemm_bench.py): 0 = register staging 128x128; 2 = LDS-DMA 128x128; 8 = LDS-DMA 256x256 ping-pong;
-// 5 (default) = auto between 2 and 8.  Bits 4+ = XCD skew + 1.
-static int g_gemm_variant = 5, g_gemm_skew = 13;
+// tuning knob (tools/gemm_bench.py): bits 0-3 kernel (0 = register staging 128x128; 2 = LDS-DMA 128x128; 8 / 9 = LDS-DMA ping-pong
+// 256x256 / 128x256; 5 (default) = cost model), bits 4-7 = XCD skew + 1, bits 8-12 = forced split-K slice count for 8 / 9.
+static int g_gemm_variant = 5, g_gemm_skew = 13, g_gemm_split = 0;
 static int num_cus() {
   static int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
   return n;
 }
-extern "C" int llmseg_gemm_set_variant(int v) { g_gemm_variant = v & 15; if (v >= 16) g_gemm_skew = (v >> 4) - 1; return LLMSEG_OK; }
+extern "C" int llmseg_gemm_set_variant(int v) {
+  g_gemm_variant = v & 15;
+  if ((v >> 4) & 15) g_gemm_skew = ((v >> 4) & 15) - 1;
+  g_gemm_split = (v >> 8) & 31;
+  return LLMSEG_OK;
+}
+
+namespace {
+// Cost model of the K % 64 == 0 kernels (microseconds; constants fitted to tools/gemm_bench.py on MI355X, profiles/r02*_gemm*.txt).
+// One ping-pong workgroup owns a CU: a K-tile of the 256 x 256 kernel takes ~1.7 us (1.25 PF/s over 256 CUs), of the 128 x 256
+// kernel ~1.0 us; prologue + epilogue ~7 / 4.5 us.  The 128 x 128 kernel shares a CU between up to 4 workgroups (2.4 us per K-tile
+// each when all four are resident, latency-bound 1.3 us when alone).
+struct GemmPlan { int variant, split; double us; };
+inline double pp_cost(long M, long N, int nt, int mi, int S, long ncu, bool f32out) {
+  const long tiles = ((M + 64 * mi - 1) / (64 * mi)) * ((N + 255) / 256);
+  const long rounds = (tiles * S + ncu - 1) / ncu;
+  const int q = (nt + S - 1) / S;
+  const double it = mi == 4 ? 1.7 : 1.0, fix = (mi == 4 ? 7.0 : 4.5) + ((S > 1 || f32out) ? 1.0 : 0.0);
+  double us = (double)rounds * (q * it + fix);
+  if (S > 1) us += 2.5 + ((double)(S + 1) * M * N * 4.0) / 4.0e6;     // reduce launch: slabs read once (mostly from the Infinity Cache)
+  return us;
+}
+inline double glds_cost(long M, long N, int nt, long ncu) {
+  const long tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  const long full = tiles / (4 * ncu), rem = tiles - full * 4 * ncu;
+  double us = (double)full * (nt * 2.4 + 4.0);
+  if (rem > 0) { const double w = (double)((rem + ncu - 1) / ncu); us += nt * std::max(1.3, 0.6 * w) + 4.0; }
+  return us;
+}
+inline bool split_ok(int nt, int S) {       // every slice needs >= 2 K-tiles (the kernel's pipeline depth)
+  if (S <= 1) return S == 1;
+  const int q = (nt + S - 1) / S;
+  return q >= 2 && nt - (S - 1) * q >= 2;
+}
+}  // namespace
 
 extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   LL_CHECK(a && a->A && a->W && a->C, "gemm: null pointer");
@@ -770,6 +824,7 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   LL_CHECK((!ta || a->lda >= a->M) && (!tw || a->ldw >= a->N), "gemm: transposed operand needs ld >= rows");
   LL_CHECK((((uintptr_t)a->A) & 15) == 0 && (((uintptr_t)a->W) & 15) == 0, "gemm: A/W must be 16-byte aligned");
   LL_CHECK(((a->strideA | a->strideW | a->strideA2 | a->strideW2) & 7) == 0, "gemm: batch strides of A/W must be multiples of 8");
+  LL_CHECK(!a->accumulate || a->out_f32, "gemm: accumulate needs fp32 output");
   const int esz = a->out_f32 ? 4 : 2;
   GemmP p;
   p.A = (const bf16_t*)a->A; p.W = (const bf16_t*)a->W; p.C = a->C;
@@ -782,6 +837,7 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   p.sA = a->strideA; p.sW = a->strideW; p.sC = a->strideC;
   p.sA2 = a->strideA2; p.sW2 = a->strideW2; p.sC2 = a->strideC2;
   p.alpha = a->alpha; p.act = a->act;
+  p.kt_total = 0; p.accum = a->accumulate ? 1 : 0;
   // vector stores/loads need 4-element alignment of every row start; otherwise the kernel goes element-wise
   p.c_vec = ((((uintptr_t)a->C) % (4 * esz)) == 0 && (a->ldc & 3) == 0 && ((a->strideC | a->strideC2) & 3) == 0) ? 1 : 0;
   p.r_vec = (p.res && (((uintptr_t)p.res) & 7) == 0 && (p.ldr & 3) == 0 && ((a->strideC | a->strideC2) & 3) == 0) ? 1 : 0;
@@ -790,16 +846,33 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   p.skew = g_gemm_skew;
   p.A2 = (const bf16_t*)a->A2; p.W2 = (const bf16_t*)a->W2; p.lda2 = a->lda2; p.ldw2 = a->ldw2;
   static const int group_m_env = getenv("LLMSEG_GEMM_GROUP_M") ? atoi(getenv("LLMSEG_GEMM_GROUP_M")) : 0;   // tuning override
+  const int nt = p.K / BK;
+  const long ncu = num_cus();
   int variant = (p.K % BK == 0 && !ta && !tw) ? g_gemm_variant : 0;
-  if (variant != 0 && variant != 2 && variant != 8) variant = 5;
-  if (variant == 8 && p.K < (a->A2 ? BK : 2 * BK)) variant = 2;
+  if (variant != 0 && variant != 2 && variant != 8 && variant != 9) variant = 5;
+  if ((variant == 8 || variant == 9) && nt < (a->A2 ? 1 : 2)) variant = 2;
+  // split-K needs a dense-enough problem for the slab layout [S][M][N], 4-column alignment and room in the caller's workspace
+  const bool can_split = batch == 1 && (p.N & 3) == 0 && (p.ldc & 3) == 0 && a->workspace != nullptr &&
+                         (((uintptr_t)a->workspace) & 15) == 0 && (!p.res || (p.ldr & 3) == 0);
+  auto ws_fits = [&](int S) { return (double)(S + (a->A2 ? 1 : 0)) * p.M * p.N * 4.0 <= (double)a->workspace_bytes; };   // + the extension product's slab
+  int split = 1;
   if (variant == 5) {
-    // auto: the 256 x 256 ping-pong kernel (one workgroup per CU) when its tiles fill >= 70 % of whole rounds of the CUs (edge
-    // tiles counted by their useful area); the 128 x 128 single-buffer DMA kernel (4 workgroups/CU) otherwise.  Measured with
-    // tools/gemm_bench.py: +15..35 % on every hot-path shape that passes the test, -10 % on the 320-tile Llama N = 4096 shapes.
-    const long tm = (p.M + 255) / 256, tn = (p.N + 255) / 256, tiles = tm * tn * batch, ncu = num_cus();
-    const double fill = (double)tiles / (double)(((tiles + ncu - 1) / ncu) * ncu) * ((double)p.M * p.N / ((double)tm * 256 * tn * 256));
-    variant = (fill >= 0.7 && p.K >= 2 * BK) ? 8 : 2;
+    // auto: minimum of the cost model over {128 x 128 DMA kernel, ping-pong 256 x 256 / 128 x 256 with 1..16 K-slices}
+    GemmPlan best{2, 1, glds_cost(p.M, p.N, nt, ncu) * (double)batch};
+    if (nt >= (a->A2 ? 1 : 2)) {
+      for (int mi = 4; mi >= 2; mi -= 2) {
+        for (int S = 1; S <= 16; ++S) {
+          if (S > 1 && (!can_split || !split_ok(nt, S) || !ws_fits(S))) continue;
+          if (S > 1 && ((p.M + 64 * mi - 1) / (64 * mi)) * ((p.N + 255) / 256) * S > ncu) break;     // slices only to fill ONE round of the CUs
+          const double us = pp_cost(p.M, p.N, nt, mi, S, ncu, a->out_f32 != 0) * (double)batch;
+          if (us < best.us * 0.97 || (us < best.us && S == 1)) best = GemmPlan{mi == 4 ? 8 : 9, S, us};
+        }
+      }
+    }
+    variant = best.variant; split = best.split;
+  } else if (variant == 8 || variant == 9) {
+    split = g_gemm_split > 1 ? g_gemm_split : 1;
+    if (split > 1) LL_CHECK(can_split && split_ok(nt, split) && ws_fits(split), "gemm: forced split-K %d not possible for this call", split);
   }
   if (p.A2) {
     // C = epi(alpha * (A.W^T + A2.W2^T)), A2 [M][64], W2 [N][64]: fused as one more K-tile of the ping-pong kernel; any other
@@ -807,7 +880,15 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
     LL_CHECK(p.W2 && batch == 1 && !ta && !tw && (p.lda2 & 7) == 0 && (p.ldw2 & 7) == 0 && p.lda2 >= 64 && p.ldw2 >= 64 &&
                  (((uintptr_t)p.A2 | (uintptr_t)p.W2) & 15) == 0, "gemm: bad extension operands (A2 [M][64], W2 [N][64], 16-byte aligned rows)");
     LL_CHECK(!a->out_f32, "gemm: extension operands need bf16 output");
-    if (variant != 8) {
+    if ((variant == 8 || variant == 9) && split > 1) {
+      // split-K: the extension product is one more fp32 slab (a K = 64 launch of its own), summed by the reduce kernel
+      llmseg_gemm_args g2 = *a;
+      g2.A = a->A2; g2.W = a->W2; g2.lda = a->lda2; g2.ldw = a->ldw2; g2.K = 64; g2.A2 = g2.W2 = nullptr;
+      g2.bias = g2.gamma = g2.residual = nullptr; g2.alpha = 1.f; g2.act = LLMSEG_ACT_NONE; g2.out_f32 = 1; g2.accumulate = 0;
+      g2.C = (float*)a->workspace + (long)split * p.M * p.N; g2.ldc = p.N; g2.workspace = nullptr; g2.workspace_bytes = 0;
+      const int rc = llmseg_gemm_bf16(&g2, stream);
+      if (rc != LLMSEG_OK) return rc;
+    } else if (variant != 8 && variant != 9) {
       LL_CHECK(a->act == LLMSEG_ACT_NONE && !a->gamma, "gemm: extension operands on this shape need a linear epilogue");
       llmseg_gemm_args g1 = *a, g2 = *a;
       g1.A2 = g1.W2 = nullptr;
@@ -818,34 +899,58 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
       return llmseg_gemm_bf16(&g2, stream);
     }
   }
-  const int bm = variant == 8 ? 256 : 128, bn = variant == 8 ? 256 : BN;
+  const bool pp = variant == 8 || variant == 9;
+  const int bm = variant == 8 ? 256 : 128, bn = pp ? 256 : BN;
   p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
   // ping-pong tile walk (tools/gemm_bench.py sweep): short matrices (Llama, <= 32 row tiles) keep all of M in one group so a
   // W column tile is fetched once per XCD; tall ones (SAM, 384+ row tiles) walk 4 row tiles per group (+3..6 % at K = 5120)
   p.group_m = group_m_env > 0 ? group_m_env : (p.tiles_m <= 32 ? p.tiles_m : 4);
-  dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);
   hipStream_t s = (hipStream_t)stream;
   llmseg_prof_begin(s);
-  llmseg_prof_tag(p.M, p.N, p.K, variant * 1000 + (ta ? 200 : 0) + (tw ? 100 : 0) + (p.res ? 20 : 0) + p.act * 2 + (a->out_f32 ? 1 : 0) + 40 * (batch > 1));
+  llmseg_prof_tag(p.M, p.N, p.K, variant * 1000 + (ta ? 200 : 0) + (tw ? 100 : 0) + (p.res ? 20 : 0) + p.act * 2 + (a->out_f32 ? 1 : 0) + 40 * (batch > 1) +
+                  10000 * (split > 1 ? split : 0));
   const bool f = a->out_f32 != 0;
-  switch (variant) {
-    case 2: f ? launch_glds<true, 2, 1>(p, grid, s) : launch_glds<false, 2, 1>(p, grid, s); break;
-    case 8:
-      if (p.A2) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, true>), grid, dim3(NTB), 0, s, p);      // bf16 out only (checked above)
-      else if (f) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<true, false>), grid, dim3(NTB), 0, s, p);
-      else hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, false>), grid, dim3(NTB), 0, s, p);
-      break;
-    default: {
-      const int key = (f ? 4 : 0) | (ta ? 2 : 0) | (tw ? 1 : 0);
-      switch (key) {
-        case 0: hipLaunchKernelGGL((gemm_bf16_tn_kernel<false, false, false>), grid, dim3(NT), 0, s, p); break;
-        case 1: hipLaunchKernelGGL((gemm_bf16_tn_kernel<false, false, true>), grid, dim3(NT), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((gemm_bf16_tn_kernel<false, true, false>), grid, dim3(NT), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((gemm_bf16_tn_kernel<false, true, true>), grid, dim3(NT), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, false, false>), grid, dim3(NT), 0, s, p); break;
-        case 5: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, false, true>), grid, dim3(NT), 0, s, p); break;
-        case 6: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, true, false>), grid, dim3(NT), 0, s, p); break;
-        default: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, true, true>), grid, dim3(NT), 0, s, p); break;
+  if (pp && split > 1) {
+    // K-slices as the batch dimension of the ping-pong kernel: slice s reads A / W columns [s q 64, ...), writes fp32 slab s
+    GemmP ps = p;
+    const int q = (nt + split - 1) / split;
+    ps.K = q * BK; ps.kt_total = nt; ps.batch1 = split;
+    ps.sA = ps.sW = (long)q * BK; ps.sA2 = ps.sW2 = ps.sC2 = 0;
+    ps.C = a->workspace; ps.ldc = p.N; ps.sC = (long)p.M * p.N;
+    ps.bias = ps.gamma = ps.res = nullptr; ps.ldr = 0; ps.alpha = 1.f; ps.act = LLMSEG_ACT_NONE; ps.accum = 0;
+    ps.c_vec = 1; ps.r_vec = 0; ps.b_vec = 1; ps.A2 = ps.W2 = nullptr;
+    dim3 grid(p.tiles_m * p.tiles_n, (unsigned)split);
+    if (variant == 8) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<true, false, 4>), grid, dim3(NTB), 0, s, ps);
+    else hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<true, false, 2>), grid, dim3(NTB), 0, s, ps);
+    const long total4 = (long)p.M * (p.N >> 2);
+    const unsigned rg = (unsigned)std::min<long>((total4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, s, p, (const float*)a->workspace, split + (p.A2 ? 1 : 0), f ? 1 : 0);
+  } else {
+    dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);
+    switch (variant) {
+      case 2: f ? launch_glds<true, 2, 1>(p, grid, s) : launch_glds<false, 2, 1>(p, grid, s); break;
+      case 8:
+        if (p.A2) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, true, 4>), grid, dim3(NTB), 0, s, p);      // bf16 out only (checked above)
+        else if (f) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<true, false, 4>), grid, dim3(NTB), 0, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, false, 4>), grid, dim3(NTB), 0, s, p);
+        break;
+      case 9:
+        if (p.A2) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, true, 2>), grid, dim3(NTB), 0, s, p);
+        else if (f) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<true, false, 2>), grid, dim3(NTB), 0, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, false, 2>), grid, dim3(NTB), 0, s, p);
+        break;
+      default: {
+        const int key = (f ? 4 : 0) | (ta ? 2 : 0) | (tw ? 1 : 0);
+        switch (key) {
+          case 0: hipLaunchKernelGGL((gemm_bf16_tn_kernel<false, false, false>), grid, dim3(NT), 0, s, p); break;
+          case 1: hipLaunchKernelGGL((gemm_bf16_tn_kernel<false, false, true>), grid, dim3(NT), 0, s, p); break;
+          case 2: hipLaunchKernelGGL((gemm_bf16_tn_kernel<false, true, false>), grid, dim3(NT), 0, s, p); break;
+          case 3: hipLaunchKernelGGL((gemm_bf16_tn_kernel<false, true, true>), grid, dim3(NT), 0, s, p); break;
+          case 4: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, false, false>), grid, dim3(NT), 0, s, p); break;
+          case 5: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, false, true>), grid, dim3(NT), 0, s, p); break;
+          case 6: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, true, false>), grid, dim3(NT), 0, s, p); break;
+          default: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, true, true>), grid, dim3(NT), 0, s, p); break;
+        }
       }
     }
   }

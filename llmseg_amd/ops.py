@@ -28,19 +28,37 @@ def _req(t, dtype=BF16):
     return t
 
 
+WS_BYTES = 192 << 20
+_WS = {}
+
+
+def _workspace(dev, stream):
+    """Per-(device, stream) scratch of the split-K GEMM path (fp32 partial tiles), allocated on first use and kept."""
+    key = (dev.index, stream)
+    ws = _WS.get(key)
+    if ws is None:
+        ws = _WS[key] = torch.empty(WS_BYTES, device=dev, dtype=torch.uint8)
+    return ws
+
+
 def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alpha=1.0, out_f32=False, trans_a=False, trans_w=False,
-         a2=None, w2=None):
+         a2=None, w2=None, accumulate=False):
     """out[M,N] = residual + gamma * act(alpha * A @ W^T + bias) with A = a [M,K] (or a^T when trans_a: a stored [K,M]) and
     W = w [N,K] (or w^T when trans_w: w stored [K,N]).  2-D bf16 operands, last dim contiguous.  a2 [M,64] / w2 [N,64]: optional
-    extension of the contraction (A @ W^T + a2 @ w2^T), e.g. zero-padded low-rank updates."""
+    extension of the contraction (A @ W^T + a2 @ w2^T), e.g. zero-padded low-rank updates.  accumulate (fp32 `out` only):
+    out += result (gradient accumulation)."""
     _req(a); _req(w)
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
     N, Kw = (w.shape[1], w.shape[0]) if trans_w else w.shape
     assert K == Kw, (a.shape, w.shape, trans_a, trans_w)
     if out is None:
+        assert not accumulate
         out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else BF16)
-    assert out.shape == (M, N) and out.stride(1) == 1
+    else:
+        out_f32 = out.dtype == torch.float32
+    assert out.shape == (M, N) and out.stride(1) == 1 and (out_f32 or not accumulate)
+    stream = torch.cuda.current_stream().cuda_stream
     g = GemmArgs(A=a.data_ptr(), W=w.data_ptr(), C=out.data_ptr(),
                  bias=None if bias is None else _req(bias).data_ptr(),
                  gamma=None if gamma is None else _req(gamma).data_ptr(),
@@ -48,14 +66,17 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alp
                  M=M, N=N, K=K, lda=a.stride(0), ldw=w.stride(0), ldc=out.stride(0),
                  ldr=0 if residual is None else residual.stride(0),
                  batch=1, strideA=0, strideW=0, strideC=0, alpha=alpha, act=act, out_f32=1 if out_f32 else 0,
-                 trans_a=1 if trans_a else 0, trans_w=1 if trans_w else 0)
+                 trans_a=1 if trans_a else 0, trans_w=1 if trans_w else 0, accumulate=1 if accumulate else 0)
     if a2 is not None:
         _req(a2); _req(w2)
         assert a2.shape == (M, 64) and w2.shape == (N, 64) and a2.stride(1) == 1 and w2.stride(1) == 1
         g.A2, g.W2, g.lda2, g.ldw2 = a2.data_ptr(), w2.data_ptr(), a2.stride(0), w2.stride(0)
+    if K >= 1024 and K % 64 == 0 and not (trans_a or trans_w):          # split-K candidates: hand the scratch over
+        ws = _workspace(a.device, stream)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
     if residual is not None:
         assert residual.shape == (M, N) and residual.stride(1) == 1
-    _lib.check(_lib.load().llmseg_gemm_bf16(C.byref(g), _stream()), "gemm")
+    _lib.check(_lib.load().llmseg_gemm_bf16(C.byref(g), C.c_void_p(stream)), "gemm")
     return out
 
 

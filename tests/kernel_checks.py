@@ -100,6 +100,75 @@ def check_gemm():
         out.append(("gemm ping-pong batched", err(ob, ref), 1e-3))
     finally:
         lib.llmseg_gemm_set_variant(5)
+    # the 128 x 256 ping-pong kernel (variant 9): same cases as the 256 x 256 one (its half-tile DMA ring holds MI + 4 = 6 instructions)
+    lib.llmseg_gemm_set_variant(9)
+    try:
+        for i, (M, N, K) in enumerate([(1000, 520, 128), (257, 300, 192), (638, 512, 1280), (129, 256, 4096)]):
+            a, w = rnd(M, K, seed=140 + i), rnd(N, K, seed=150 + i, scale=1 / math.sqrt(K))
+            ref = a.float() @ w.float().t()
+            out.append((f"gemm ping-pong 128x256 {M}x{N}x{K}", err(ops.gemm(a.to(DEV), w.to(DEV)), ref), tol_bf16(ref)))
+        M, N, K = 300, 520, 256
+        a, w, b, g, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / 16), rnd(N, seed=3), rnd(N, seed=4), rnd(M, N, seed=5)
+        ref = r.float() + g.float() * F.gelu(a.float() @ w.float().t() + b.float())
+        got = ops.gemm(a.to(DEV), w.to(DEV), bias=b.to(DEV), act=ops.ACT_GELU, residual=r.to(DEV), gamma=g.to(DEV))
+        out.append(("gemm ping-pong 128x256 epilogue gelu", err(got, ref), tol_bf16(ref, 1.5)))
+        for M, N, K in ((513, 300, 192), (300, 520, 64)):
+            a, w, b = rnd(M, K, seed=71), rnd(N, K, seed=72, scale=1 / math.sqrt(K)), rnd(N, seed=73)
+            a2, w2 = rnd(M, 64, seed=74), rnd(N, 64, seed=75, scale=1 / 8)
+            a2[:, 16:] = 0
+            ref = a.float() @ w.float().t() + a2.float() @ w2.float().t() + b.float()
+            got = ops.gemm(a.to(DEV), w.to(DEV), bias=b.to(DEV), a2=a2.to(DEV), w2=w2.to(DEV))
+            out.append((f"gemm ping-pong 128x256 + extension tile {M}x{N}x{K}", err(got, ref), tol_bf16(ref)))
+    finally:
+        lib.llmseg_gemm_set_variant(5)
+    # split-K (K-slices write fp32 slabs into the workspace, one reduce launch applies the epilogue): forced slice counts incl. an
+    # uneven last slice (K = 1344 = 21 tiles in 4 slices of 6, 6, 6, 3), both tile heights, bf16 / fp32 / accumulating output
+    M, N, K = 638, 520, 1344
+    a, w, b, r = rnd(M, K, seed=91), rnd(N, K, seed=92, scale=1 / math.sqrt(K)), rnd(N, seed=93), rnd(M, N, seed=94)
+    ref = r.float() + F.relu(a.float() @ w.float().t() + b.float())
+    for v, S in ((8, 4), (9, 4), (9, 7), (8, 2)):
+        lib.llmseg_gemm_set_variant(v | (S << 8))
+        try:
+            got = ops.gemm(a.to(DEV), w.to(DEV), bias=b.to(DEV), act=ops.ACT_RELU, residual=r.to(DEV))
+            out.append((f"gemm split-K variant {v} x{S} bias+relu+residual", err(got, ref), tol_bf16(ref, 1.5)))
+            c32 = torch.full((M, N), 2.0, device=DEV, dtype=torch.float32)
+            ops.gemm(a.to(DEV), w.to(DEV), out=c32, accumulate=True, alpha=0.5)
+            out.append((f"gemm split-K variant {v} x{S} fp32 +=", err(c32, 2.0 + 0.5 * (a.float() @ w.float().t())), 2e-3))
+        finally:
+            lib.llmseg_gemm_set_variant(5)
+    # split-K + extension K-tile (the LoRA dX GEMM at M = 2 x 319: the rank-8 products are one more slab)
+    M, N, K = 638, 512, 4096
+    a, w = rnd(M, K, seed=95), rnd(N, K, seed=96, scale=1 / math.sqrt(K))
+    a2, w2 = rnd(M, 64, seed=97), rnd(N, 64, seed=98, scale=1 / 8)
+    a2[:, 16:] = 0
+    ref = a.float() @ w.float().t() + a2.float() @ w2.float().t()
+    for v, S in ((9, 5), (8, 3), (5, 0)):
+        lib.llmseg_gemm_set_variant(v | (S << 8))
+        try:
+            out.append((f"gemm split-K variant {v} x{S} + extension tile", err(ops.gemm(a.to(DEV), w.to(DEV), a2=a2.to(DEV), w2=w2.to(DEV)), ref), tol_bf16(ref, 1.5)))
+        finally:
+            lib.llmseg_gemm_set_variant(5)
+    # automatic dispatch on the short-and-long shapes of BASELINE configs[2] (M = 2 x 319): whatever the cost model picks must agree
+    for i, (M, N, K) in enumerate([(638, 4096, 4096), (638, 1024, 11008), (514, 1024, 4096), (638, 12288, 1024)]):
+        a, w = rnd(M, K, seed=160 + i), rnd(N, K, seed=170 + i, scale=1 / math.sqrt(K))
+        ref = a.float() @ w.float().t()
+        out.append((f"gemm auto {M}x{N}x{K}", err(ops.gemm(a.to(DEV), w.to(DEV)), ref), tol_bf16(ref)))
+    # fp32 accumulate (gradient arena): every kernel family, incl. the transposed-operand layouts of dW = dY^T X
+    M, N, K = 200, 264, 256
+    a, w = rnd(M, K, seed=181), rnd(N, K, seed=182, scale=1 / 16)
+    for v in (0, 2, 8, 9):
+        lib.llmseg_gemm_set_variant(v)
+        try:
+            c32 = torch.full((M, N), -1.0, device=DEV, dtype=torch.float32)
+            ops.gemm(a.to(DEV), w.to(DEV), out=c32, accumulate=True)
+            ops.gemm(a.to(DEV), w.to(DEV), out=c32, accumulate=True)
+            out.append((f"gemm fp32 += (variant {v}, twice)", err(c32, -1.0 + 2.0 * (a.float() @ w.float().t())), 2e-3))
+        finally:
+            lib.llmseg_gemm_set_variant(5)
+    dy, x = rnd(300, 136, seed=183), rnd(300, 72, seed=184)               # dW [136, 72] += dY^T X
+    c32 = torch.full((136, 72), 0.5, device=DEV, dtype=torch.float32)
+    ops.gemm(dy.to(DEV), x.to(DEV), out=c32, trans_a=True, trans_w=True, accumulate=True)
+    out.append(("gemm fp32 += transposed operands", err(c32, 0.5 + dy.float().t() @ x.float()), 2e-3))
     # the same through the automatic dispatch on a small shape (128 x 128 kernel + accumulate launch)
     M, N, K = 200, 264, 256
     a, w = rnd(M, K, seed=81), rnd(N, K, seed=82, scale=1 / 16)

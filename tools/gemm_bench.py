@@ -13,14 +13,26 @@ SHAPES = [  # (M, N, K, tag)  B=16 images
     (5104, 12288, 4096, "llama qkv"), (5104, 4096, 4096, "llama o"), (5104, 22016, 4096, "llama gate_up"), (5104, 4096, 11008, "llama down"),
     (5104, 32004, 4096, "lm_head"), (4112, 3072, 1024, "clip qkv"), (1000, 520, 128, "edge"), (4096, 4096, 4096, "4096^3"), (8192, 8192, 8192, "8192^3"),
 ]
+if os.environ.get("GEMM_SET") == "b2":   # BASELINE configs[2]: 2 images per micro-step (Llama M = 2 x 319, SAM M = 2 x 4096 / 2 x 4900)
+    SHAPES = [(8192, 3840, 1280, "sam qkv (global)"), (9800, 3840, 1280, "sam qkv (windows)"), (8192, 1280, 1280, "sam proj"),
+              (8192, 5120, 1280, "sam lin1"), (8192, 1280, 5120, "sam lin2"),
+              (638, 12288, 4096, "llama qkv"), (638, 4096, 4096, "llama o"), (638, 22016, 4096, "llama gate_up"), (638, 4096, 11008, "llama down"),
+              (638, 4096, 12288, "llama dx(qkv)"), (638, 4096, 22016, "llama dx(gate_up)"), (638, 11008, 4096, "llama dx(down)"),
+              (638, 32004, 4096, "lm_head"), (638, 4096, 32064, "lm_head dx"), (32064, 4096, 640, "lm_head dw"), (514, 3072, 1024, "clip qkv"),
+              (514, 4096, 1024, "clip fc1")]
 RACE_REPEATS = int(os.environ.get("RACE_REPEATS", "0"))
 if os.environ.get("GEMM_SHAPES"):
     SHAPES = [SHAPES[int(i)] for i in os.environ["GEMM_SHAPES"].split(",")]
-variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "2", "8"])]
+def _variant(spec):          # "8" | "9:3" (kernel 9, 3 K-slices) | "5" (auto)
+    v, _, sp = spec.partition(":")
+    return int(v) | (int(sp) << 8 if sp else 0)
+
+
+variants = [_variant(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "2", "8"])]
 lib = _lib.load()
 torch.manual_seed(0)
 print("variants: v & 15 = kernel variant, (v >> 4) - 1 = XCD skew (none = default 13)")
-print(f"{'shape':32s} " + " ".join(f"v{v:>8d}" for v in variants) + "   (TFLOP/s; check = max|v - v0|)")
+print(f"{'shape':32s} " + " ".join(f"{'v%d:%d' % (v & 15, v >> 8):>9s}" for v in variants) + "   (TFLOP/s; check = max|v - v0|)")
 for M, N, K, tag in SHAPES:
     a = (torch.rand(M, K, device="cuda") * 2 - 1).to(torch.bfloat16)
     w = (torch.rand(N, K, device="cuda") * 2 - 1).to(torch.bfloat16)
@@ -29,8 +41,12 @@ for M, N, K, tag in SHAPES:
     res, ref, chk = [], None, []
     for v in variants:
         lib.llmseg_gemm_set_variant(v)
-        for _ in range(3):
-            ops.gemm(a, w, bias=bias, out=out)
+        try:
+            for _ in range(3):
+                ops.gemm(a, w, bias=bias, out=out)
+        except RuntimeError:
+            res.append(0.0); chk.append(-1.0)
+            continue
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 10
