@@ -236,13 +236,30 @@ int llmseg_ce_bwd(const void* logits, const int64_t* labels, const float* coef, 
                   int64_t ldl, void* stream);
 /* dst[idx[i]][:] += src[i][:] in fp32 (embedding / row-gather gradients; idx < 0 skipped) */
 int llmseg_scatter_add_rows(const void* src, const int64_t* idx, float* dst, int64_t n, int64_t cols, void* stream);
-/* Rank-8 LoRA products (peft==0.4.0 Linear with r = 8, training.py:218-226) -- skinny shapes a tiled GEMM cannot fill:
- *   lora_down:  y[M][8]  = alpha * x[M][K] . W^T      (W stored [8][K], or [K][8] when w_kr)          fwd x.A^T, bwd dq.B
- *   lora_outer: out(n,r) += alpha * sum_m a[m][n] b[m][r]  (fp32 [N][8], or [8][N] when out_rn; caller zero-fills)   dB, dA
- *   lora_apply: y[M][N] += alpha * xa[M][8] . W^T     (W stored [N][8], or [8][N] when w_rn)           fwd +s.xa.B^T, bwd +tq.A */
-int llmseg_lora_down(const void* x, int64_t ldx, const void* w, void* y, int64_t M, int64_t K, int32_t w_kr, float alpha, void* stream);
-int llmseg_lora_outer(const void* a, int64_t lda, const void* b, float* out, int64_t M, int64_t N, int32_t out_rn, float alpha, void* stream);
-int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, const void* w, int64_t M, int64_t N, int32_t w_rn, float alpha, void* stream);
+/* Rank-8 LoRA products (peft==0.4.0 Linear with r = 8, lora_dropout 0.05: training.py:91,218-226) -- skinny shapes a tiled GEMM
+ * cannot fill:
+ *   lora_down:  y[m][0..7] = alpha * drop(x)[M][K] . W^T  (W stored [8][K], or [K][8] when w_kr), rows of y at pitch ldy, the
+ *               following zero_cols columns of each row zero-filled                                  fwd drop(x).A^T, bwd dq.B
+ *   lora_outer: out(n,r) += alpha * sum_m drop(a)[m][n] b[m][r]  (fp32 [N][8], or [8][N] when out_rn; accumulates)   dB, dA
+ *   lora_apply: y[M][N] += alpha * mask * (xa[M][8] . W^T)  (W stored [N][8], or [8][N] when w_rn)    bwd dx += mask * (tq.A)
+ *   lora_pack:  the two [*][64] extension operands of llmseg_gemm_args (A2 / W2) for a LoRA'd q|k|v projection, from the current
+ *               LoRA matrices: w2b [3H][64] = rows [s Bq | 0], 0, [0 | s Bv | 0];  w2a [H][64] = rows [Aq[:,h] | Av[:,h] | 0]
+ * Dropout (NULL = none, as in eval mode) is counter-based, nothing is stored: Philox4x32-10 with key = rng_state[0] (seed), counter
+ * = (element index / 8, stream, rng_state[1] (offset)); the 16-bit field j of the 128-bit output decides element 8 idx + j, kept
+ * when field >= drop_thr (= round(p * 65536)) and scaled by 65536 / (65536 - drop_thr); element index = row * width + column of
+ * the dense [M][width] activation.  rng_state is DEVICE memory (a captured hipGraph reads a fresh offset on every replay). */
+typedef struct {
+  const uint64_t* rng_state;   /* device: {seed, offset} */
+  uint32_t stream;             /* which dropout module (layer * 2 + {q = 0, v = 1}) */
+  uint32_t drop_thr;           /* round(p * 65536); 0 = no dropout */
+} llmseg_dropout;
+int llmseg_lora_down(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t M, int64_t K, int32_t w_kr, float alpha,
+                     int32_t zero_cols, const llmseg_dropout* drop, void* stream);
+int llmseg_lora_outer(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t M, int64_t N, int32_t out_rn, float alpha,
+                      const llmseg_dropout* drop, void* stream);
+int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, int64_t ldxa, const void* w, int64_t M, int64_t N, int32_t w_rn, float alpha,
+                      const llmseg_dropout* drop, void* stream);
+int llmseg_lora_pack(const void* aq, const void* bq, const void* av, const void* bv, void* w2b, void* w2a, int64_t H, float s, void* stream);
 /* out[c][r] = in[r][c] (bf16; in [rows][cols] with leading dimension ld_in, out [cols][ld_out]); rows r in [rows, rows_pad) of the
  * source are taken as zero.  Lets the weight / input gradients of a wide trainable Linear (lm_head: dX = dY.W, dW = dY^T.X) run on
  * the K-contiguous LDS-DMA GEMM kernels with the contraction dimension padded to a multiple of 64. */

@@ -45,7 +45,12 @@ class AttnBwdArgs(C.Structure):
                  ("scale", C.c_float), ("causal", C.c_int32), ("key_mask", C.c_void_p), ("lse", C.c_void_p), ("delta", C.c_void_p)])
 
 
+class Dropout(C.Structure):
+    _fields_ = [("rng_state", C.c_void_p), ("stream", C.c_uint32), ("drop_thr", C.c_uint32)]
+
+
 _i64, _i32, _f32, _p = C.c_int64, C.c_int32, C.c_float, C.c_void_p
+_dp = C.POINTER(Dropout)
 
 # name -> argtypes (restype is int unless noted); must list EVERY symbol of include/llmseg_hip.h
 SIGNATURES = {
@@ -79,9 +84,10 @@ SIGNATURES = {
     "llmseg_attn_ds": [_p, _p, _p, _i64, _i32, _i32, _f32, _p],
     "llmseg_ce_bwd": [_p, _p, _p, _p, _i32, _i32, _i64, _i64, _p],
     "llmseg_scatter_add_rows": [_p, _p, _p, _i64, _i64, _p],
-    "llmseg_lora_down": [_p, _i64, _p, _p, _i64, _i64, _i32, _f32, _p],
-    "llmseg_lora_outer": [_p, _i64, _p, _p, _i64, _i64, _i32, _f32, _p],
-    "llmseg_lora_apply": [_p, _i64, _p, _p, _i64, _i64, _i32, _f32, _p],
+    "llmseg_lora_down": [_p, _i64, _p, _p, _i64, _i64, _i64, _i32, _f32, _i32, _dp, _p],
+    "llmseg_lora_outer": [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _f32, _dp, _p],
+    "llmseg_lora_apply": [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _f32, _dp, _p],
+    "llmseg_lora_pack": [_p, _p, _p, _p, _p, _p, _i64, _f32, _p],
     "llmseg_transpose_pad": [_p, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "llmseg_sumsq": [_p, _i64, C.c_int, _p, _p],
     "llmseg_adamw": [_p, _p, _p, C.c_int, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _p, _p],

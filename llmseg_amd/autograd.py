@@ -1,8 +1,15 @@
 """torch.autograd.Function wrappers: forward AND backward of every op on the trainable part of the path run in
 libllmseg_hip.so (the autograd engine is only the graph plumbing).  Frozen towers (CLIP, SAM, DINOv2) never come here.
 
-Backward GEMMs use the transposed-operand modes of `llmseg_gemm_bf16` (dX = dY W, dW = dY^T X); attention backward
-materialises the (small: T<=~512) probability matrices with batched GEMMs + `llmseg_softmax_rows` / `llmseg_attn_ds`.
+Backward GEMMs use the transposed-operand modes of `llmseg_gemm_bf16` (dX = dY W, dW = dY^T X); attention backward is the fused
+recompute kernel (`llmseg_attn_bwd`; the single-query cross attentions of the head keep a small materialised chain).
+
+Parameter gradients have two destinations:
+  * arena mode (training, `llmseg_amd.train.GradArena`): a parameter tensor carries `_g32`, an fp32 view into the trainer's flat
+    gradient arena; the backward kernels ACCUMULATE into it (`C += ...` GEMM epilogue, fp32 atomics) and the Function returns None
+    for that input, so gradients are summed over micro-steps in fp32 (the reference's DeepSpeed engine accumulates
+    `gradient_accumulation_steps` micro-batches, training.py:79-82,292-332) and no bf16 `.grad` round trip exists;
+  * plain autograd: without `_g32` the Function returns a bf16 gradient and autograd fills `.grad` as usual (parity tests).
 """
 import math
 
@@ -15,6 +22,11 @@ BF16 = torch.bfloat16
 
 
 BIG_LINEAR = 1 << 34          # M*N*K above which LinearFn.backward transposes/pads its operands for the LDS-DMA GEMM kernels
+
+
+def g32_of(t):
+    """fp32 gradient-arena view attached to a parameter tensor (None outside arena mode)."""
+    return getattr(t, "_g32", None)
 
 
 def _pad8_cols(t):
@@ -34,8 +46,9 @@ class LinearFn(Function):
         y = ops.gemm(x, w, bias=b, act=act, residual=residual)
         ctx.wt = wt
         ctx.act = act
-        ctx.has_b = b is not None
         ctx.has_res = residual is not None
+        ctx.gw, ctx.gb = g32_of(w), (g32_of(b) if b is not None else None)
+        ctx.b_needs = b is not None and b.requires_grad
         assert not (act != ops.ACT_NONE and residual is not None)
         assert act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_SIGMOID), "only relu/sigmoid epilogues are differentiated"
         ctx.save_for_backward(x, w, y if act != ops.ACT_NONE else None)
@@ -49,7 +62,9 @@ class LinearFn(Function):
         N = w.shape[0]
         M, Kin = x.shape
         dx = dw = db = None
-        if M * N * Kin >= BIG_LINEAR and Kin % 8 == 0 and (ctx.needs_input_grad[1] or ctx.wt is None or N % 8 != 0):
+        gw = ctx.gw
+        need_w = gw is not None or ctx.needs_input_grad[1]
+        if M * N * Kin >= BIG_LINEAR and Kin % 8 == 0 and (need_w or ctx.wt is None or N % 8 != 0):
             # wide trainable Linear (lm_head, [32004, 4096]): pad the contraction dims to multiples of 64 and transpose the
             # operands once, so that both gradient GEMMs run on the K-contiguous LDS-DMA kernels instead of the
             # transposed-operand register-staged one (3-4x slower at this size)
@@ -61,8 +76,12 @@ class LinearFn(Function):
                 dpp = dpre
             if ctx.needs_input_grad[0]:
                 dx = ops.gemm(dpp, ops.transpose_pad(w, Np))                             # [M, Np] @ [Np, Kin]   (W^T: [Kin, Np])
-            if ctx.needs_input_grad[1]:
-                dw = ops.gemm(ops.transpose_pad(dpp, Mp), ops.transpose_pad(x, Mp))[:N]   # [Np, Mp] @ [Mp, Kin]
+            if need_w:
+                dT, xT = ops.transpose_pad(dpp, Mp), ops.transpose_pad(x, Mp)            # [Np, Mp], [Kin, Mp]
+                if gw is not None:
+                    ops.gemm(dT[:N], xT, out=gw, accumulate=True)                         # fp32 arena += dY^T X
+                else:
+                    dw = ops.gemm(dT, xT)[:N]
         else:
             if N % 8 != 0:                                   # tiny head (N = 1): pad the contraction/leading dims
                 dpre_p = _pad8_cols(dpre)
@@ -72,11 +91,15 @@ class LinearFn(Function):
                 dpre_p, w_p = dpre, w
             if ctx.needs_input_grad[0]:
                 dx = ops.gemm(dpre, ctx.wt) if (ctx.wt is not None and N % 8 == 0) else ops.gemm(dpre_p, w_p, trans_w=True)   # [M,N] @ [N,K]
-            if ctx.needs_input_grad[1]:
+            if gw is not None:
+                ops.gemm(dpre_p[:, :N], x, out=gw, trans_a=True, trans_w=True, accumulate=True)   # [N,M] @ [M,K] -> fp32 arena
+            elif need_w:
                 dw = ops.gemm(dpre_p, x, trans_a=True, trans_w=True)[:N]      # [N,M] @ [M,K]
                 if dw.shape[0] != N or not dw.is_contiguous():
                     dw = dw.contiguous()
-        if ctx.has_b and ctx.needs_input_grad[2]:
+        if ctx.gb is not None:
+            ops.colsum(dpre, out=ctx.gb)
+        elif ctx.b_needs and ctx.needs_input_grad[2]:
             db = ops.colsum(dpre).to(BF16)
         dres = dy if (ctx.has_res and ctx.needs_input_grad[4]) else None
         return dx, dw, db, None, dres, None
@@ -86,59 +109,47 @@ def linear(x, w, b=None, act=ops.ACT_NONE, residual=None, wt=None):
     return LinearFn.apply(x, w, b, act, residual, wt)
 
 
-PARAM_EPOCH = 0            # bumped by the trainer after every optimizer step: parameters are updated in place by a HIP kernel, which
-#                            torch's version counters do not see
-
-
-def _ext_operand(cache, key, p1, p2, build):
-    """[N, 64] GEMM extension operand built from two LoRA matrices, cached in the MODEL's dict `cache` (None = no caching) and rebuilt
-    when the matrices change (optimizer step -> PARAM_EPOCH; load_state_dict -> version counters)."""
-    if cache is None:
-        return build()
-    stamp = (PARAM_EPOCH, p1._version, p2._version, p1.data_ptr(), p2.data_ptr())
-    hit = cache.get(key)
-    if hit is None or hit[0] != stamp:
-        hit = (stamp, build())
-        cache[key] = hit
-    return hit[1]
-
-
-def lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, cache=None, key=None):
-    """qkv = x Wqkv^T + s (x Aq^T) Bq^T on the q block + s (x Av^T) Bv^T on the v block, rank 8.  The two updates ride in the qkv
-    GEMM as one extra 64-wide K-tile: A2 = [x Aq^T | x Av^T | 0], W2 rows of the q block = [s Bq | 0], rows of the v block =
-    [0 | s Bv | 0] (no read-modify-write pass over q and v).  -> (qkv, x Aq^T, x Av^T)"""
+def lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, drop=None):
+    """qkv = x Wqkv^T + s (drop_q(x) Aq^T) Bq^T on the q block + s (drop_v(x) Av^T) Bv^T on the v block, rank 8.  The two updates
+    ride in the qkv GEMM as one extra 64-wide K-tile: A2 = [x Aq^T | x Av^T | 0], W2 rows of the q block = [s Bq | 0], rows of the
+    v block = [0 | s Bv | 0] (no read-modify-write pass over q and v).  Both operands are rebuilt from the current LoRA matrices
+    on every call (two small kernels): nothing is cached, so an in-place optimizer update or a load_state_dict cannot leave a
+    stale operand behind.  drop = (rng_state, layer, p) or None.  -> (qkv, A2)"""
     H = wqkv.shape[1]
-    xaq, xav = ops.lora_down(x, aq), ops.lora_down(x, av)           # [M, 8]
+    M = x.shape[0]
+    dq, dv = _drops(drop)
+    a2 = torch.empty((M, 64), device=x.device, dtype=BF16)
+    ops.lora_down(x, aq, out=a2[:, :8], drop=dq)
+    ops.lora_down(x, av, out=a2[:, 8:16], zero_cols=48, drop=dv)
+    w2b = torch.empty((3 * H, 64), device=x.device, dtype=BF16)
+    ops.lora_pack(aq, bq, av, bv, s, w2b=w2b)
+    return ops.gemm(x, wqkv, a2=a2, w2=w2b), a2
 
-    def build():
-        w2 = torch.zeros((3 * H, 64), device=x.device, dtype=BF16)
-        w2[:H, :8] = bq * s
-        w2[2 * H:, 8:16] = bv * s
-        return w2
-    return ops.gemm(x, wqkv, a2=_pack16(xaq, xav), w2=_ext_operand(cache, (key, "B", s), bq, bv, build)), xaq, xav
 
-
-def _pack16(u, v):
-    """[M, 8], [M, 8] -> [M, 64] bf16 = [u | v | 0]: the extension operand of ops.gemm."""
-    out = torch.zeros((u.shape[0], 64), device=u.device, dtype=BF16)
-    out[:, :8] = u
-    out[:, 8:16] = v
-    return out
+def _drops(drop):
+    if drop is None or drop[2] <= 0.0:
+        return None, None
+    rng, layer, p = drop
+    return (rng, 2 * layer, p), (rng, 2 * layer + 1, p)
 
 
 class LoraQKVFn(Function):
     """qkv = x Wqkv^T with the LoRA deltas of q_proj and v_proj added in place:
-    q += s (x Aq^T) Bq^T, v += s (x Av^T) Bv^T, s = alpha / r (peft 0.4.0 Linear; base weight frozen).  PARITY UNPINNED."""
+    q += s (drop(x) Aq^T) Bq^T, v += s (drop(x) Av^T) Bv^T, s = alpha / r, independent dropout masks on the two LoRA branch inputs
+    (peft 0.4.0 Linear: `lora_B(lora_A(lora_dropout(x))) * scaling`; base weight frozen).  PARITY UNPINNED (peft absent)."""
 
     @staticmethod
-    def forward(ctx, x, wqkv, aq, bq, av, bv, s, wqkv_t=None, cache=None, key=None):
+    def forward(ctx, x, wqkv, aq, bq, av, bv, s, wqkv_t=None, drop=None):
         ctx.wqkv_t = wqkv_t
-        ctx.cache, ctx.key = cache, key
         H = wqkv.shape[1]
         ctx.fast = aq.shape[0] == 8                                      # rank-8 skinny kernels
+        ctx.drop = drop if (drop is not None and drop[2] > 0.0) else None
+        ctx.g = tuple(g32_of(t) for t in (aq, bq, av, bv))
         if ctx.fast:
-            qkv, xaq, xav = lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, cache, key)
+            qkv, a2 = lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, ctx.drop)
+            xaq, xav = a2[:, :8], a2[:, 8:16]
         else:
+            assert ctx.drop is None, "LoRA dropout is implemented for rank 8"
             qkv = ops.gemm(x, wqkv)
             xaq, xav = ops.gemm(x, aq), ops.gemm(x, av)                   # [M, r]
             ops.gemm(xaq, bq, residual=qkv[:, :H], out=qkv[:, :H], alpha=s)
@@ -152,33 +163,42 @@ class LoraQKVFn(Function):
         x, wqkv, aq, bq, av, bv, xaq, xav = ctx.saved_tensors
         s, H = ctx.s, wqkv.shape[1]
         d = d.contiguous()
+        M = d.shape[0]
         dq, dv = d[:, :H], d[:, 2 * H:]
+        gaq, gbq, gav, gbv = ctx.g
         if ctx.fast:
-            tq, tv = ops.lora_down(dq, bq, w_kr=True, alpha=s), ops.lora_down(dv, bv, w_kr=True, alpha=s)   # [M, 8] = s dq Bq
-            if ctx.wqkv_t is not None:                                    # dx = d Wqkv + tq Aq + tv Av in ONE GEMM
-                def build():
-                    w2 = torch.zeros((H, 64), device=d.device, dtype=BF16)
-                    w2[:, :8] = aq.t()
-                    w2[:, 8:16] = av.t()
-                    return w2
-                dx = ops.gemm(d, ctx.wqkv_t, a2=_pack16(tq, tv), w2=_ext_operand(ctx.cache, (ctx.key, "A"), aq, av, build))
-            else:
-                dx = ops.gemm(d, wqkv, trans_w=True)
-                ops.lora_apply_(dx, tq, aq, w_rn=True)
-                ops.lora_apply_(dx, tv, av, w_rn=True)
-            dbq, dbv = ops.lora_outer(dq, xaq, alpha=s).to(BF16), ops.lora_outer(dv, xav, alpha=s).to(BF16)        # [H, 8]
-            daq, dav = ops.lora_outer(x, tq, out_rn=True).to(BF16), ops.lora_outer(x, tv, out_rn=True).to(BF16)    # [8, H]
-            return dx, None, daq, dbq, dav, dbv, None, None, None, None
+            drq, drv = _drops(ctx.drop)
+            t2 = torch.empty((M, 64), device=d.device, dtype=BF16)       # [s dq Bq | s dv Bv | 0]
+            tq, tv = t2[:, :8], t2[:, 8:16]
+            ops.lora_down(dq, bq, w_kr=True, alpha=s, out=tq)
+            ops.lora_down(dv, bv, w_kr=True, alpha=s, out=tv, zero_cols=48)
+            if ctx.wqkv_t is not None and ctx.drop is None:               # dx = d Wqkv + tq Aq + tv Av in ONE GEMM
+                w2a = torch.empty((H, 64), device=d.device, dtype=BF16)
+                ops.lora_pack(aq, bq, av, bv, s, w2a=w2a)
+                dx = ops.gemm(d, ctx.wqkv_t, a2=t2, w2=w2a)
+            else:                                                         # dropout masks the LoRA branch's dx element-wise
+                dx = ops.gemm(d, ctx.wqkv_t) if ctx.wqkv_t is not None else ops.gemm(d, wqkv, trans_w=True)
+                ops.lora_apply_(dx, tq, aq, w_rn=True, drop=drq)
+                ops.lora_apply_(dx, tv, av, w_rn=True, drop=drv)
+            dbq = ops.lora_outer(dq, xaq, alpha=s, out=gbq)                                   # [H, 8]
+            dbv = ops.lora_outer(dv, xav, alpha=s, out=gbv)
+            daq = ops.lora_outer(x, tq, out_rn=True, out=gaq, drop=drq)                       # [8, H] = tq^T drop(x)
+            dav = ops.lora_outer(x, tv, out_rn=True, out=gav, drop=drv)
+            outs = [None if g is not None else t.to(BF16) for g, t in ((gaq, daq), (gbq, dbq), (gav, dav), (gbv, dbv))]
+            return dx, None, outs[0], outs[1], outs[2], outs[3], None, None, None
         tq = ops.gemm(dq, bq, trans_w=True, alpha=s)                      # [M, r] = s dq Bq
         tv = ops.gemm(dv, bv, trans_w=True, alpha=s)
         dx = ops.gemm(d, ctx.wqkv_t) if ctx.wqkv_t is not None else ops.gemm(d, wqkv, trans_w=True)
         ops.gemm(tq, aq, trans_w=True, residual=dx, out=dx)
         ops.gemm(tv, av, trans_w=True, residual=dx, out=dx)
-        dbq = ops.gemm(dq, xaq, trans_a=True, trans_w=True, alpha=s)      # [H, r]
-        dbv = ops.gemm(dv, xav, trans_a=True, trans_w=True, alpha=s)
-        daq = ops.gemm(tq, x, trans_a=True, trans_w=True)                 # [r, H]
-        dav = ops.gemm(tv, x, trans_a=True, trans_w=True)
-        return dx, None, daq, dbq, dav, dbv, None, None, None, None
+        grads = []
+        for g, a_, b_, al in ((gaq, tq, x, 1.0), (gbq, dq, xaq, s), (gav, tv, x, 1.0), (gbv, dv, xav, s)):   # dA = t^T x, dB = s d^T (xA)
+            if g is not None:
+                ops.gemm(a_, b_, out=g, trans_a=True, trans_w=True, alpha=al, accumulate=True)
+                grads.append(None)
+            else:
+                grads.append(ops.gemm(a_, b_, trans_a=True, trans_w=True, alpha=al))
+        return dx, None, grads[0], grads[1], grads[2], grads[3], None, None, None
 
 
 class NormFn(Function):
@@ -186,12 +206,16 @@ class NormFn(Function):
     def forward(ctx, x, w, b, eps, rms):
         x = x.contiguous()
         ctx.eps, ctx.rms, ctx.has_b = eps, rms, b is not None
+        ctx.gw, ctx.gb = g32_of(w), (g32_of(b) if b is not None else None)
         ctx.save_for_backward(x, w)
         return ops.norm(x, w, b, eps=eps, rms=rms)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
+        if ctx.gw is not None:                                   # arena mode: the kernel adds into the fp32 arena views
+            dx = ops.norm_bwd(dy.contiguous(), x, w, ctx.eps, ctx.rms, ctx.gw, ctx.gb)
+            return dx, None, None, None, None
         need_w = ctx.needs_input_grad[1]
         dw = torch.zeros(w.shape, device=w.device, dtype=torch.float32) if need_w else None
         db = torch.zeros(w.shape, device=w.device, dtype=torch.float32) if (need_w and ctx.has_b) else None
@@ -201,28 +225,6 @@ class NormFn(Function):
 
 def norm(x, w, b=None, eps=1e-5, rms=False):
     return NormFn.apply(x, w, b, eps, rms)
-
-
-class RopeFn(Function):
-    """In-place rotate-half RoPE on the q|k part of a packed qkv buffer; backward is the inverse rotation."""
-
-    @staticmethod
-    def forward(ctx, qkv, cos, sin, rows, T, heads, hd, ld):
-        ops.rope_(qkv, cos, sin, rows, T, heads, hd, ld)
-        ctx.mark_dirty(qkv)
-        ctx.args = (rows, T, heads, hd, ld)
-        ctx.save_for_backward(cos, sin)
-        return qkv
-
-    @staticmethod
-    def backward(ctx, d):
-        cos, sin = ctx.saved_tensors
-        rows, T, heads, hd, ld = ctx.args
-        # The incoming gradient is the freshly allocated dqkv of PackedAttnFn.backward (qkv has exactly one consumer), so the
-        # inverse rotation is applied in place instead of on a 60 MB clone per layer.
-        d = d if d.is_contiguous() else d.contiguous()
-        ops.rope_(d, cos, (-sin).contiguous(), rows, T, heads, hd, ld)
-        return d, None, None, None, None, None, None, None
 
 
 def attention_backward(q, k, v, do, dq, dk, dv, *, batch, heads, Nq, Nk, hd, qs, ks, vs, dos, dqs, dks, dvs, scale, causal=False,
@@ -255,20 +257,31 @@ def attention_backward(q, k, v, do, dq, dk, dv, *, batch, heads, Nq, Nk, hd, qs,
 
 
 class PackedAttnFn(Function):
-    """Self attention on a packed qkv [batch*n, 3*heads*hd] buffer (Llama causal+key-mask; head self-attention).  Backward is
-    the fused recompute kernel (`llmseg_attn_bwd`) for head_dim 32/64/128, the materialised GEMM chain otherwise."""
+    """Self attention on a packed qkv [batch*n, 3*heads*hd] buffer (Llama causal+key-mask; head self-attention), optionally with
+    the rotate-half RoPE of the q|k part applied first (in place on qkv; positions = row % n).  Backward is the fused recompute
+    kernel (`llmseg_attn_bwd`) for head_dim 32/64/128, the materialised GEMM chain otherwise, followed by the inverse rotation on
+    the gradient buffer this node itself allocated (RoPE and attention are ONE autograd node, so no other node ever sees the
+    buffer that is rotated in place)."""
 
     @staticmethod
-    def forward(ctx, qkv, batch, n, heads, hd, causal, key_mask):
+    def forward(ctx, qkv, batch, n, heads, hd, causal, key_mask, rope=None):
+        """rope = (cos, sin, -sin) fp32 [n, hd/2] tables or None."""
+        D = heads * hd
+        if rope is not None:
+            ops.rope_(qkv, rope[0], rope[1], batch * n, n, 2 * heads, hd, qkv.stride(0))
+            ctx.mark_dirty(qkv)
+            ctx.set_materialize_grads(False)          # the rotated qkv output has no consumer: its gradient stays None
         fused = hd in (32, 64, 128)
         lse = torch.empty((batch, heads, n), device=qkv.device, dtype=torch.float32) if fused else None
         out = ops.attention_packed(qkv, batch, n, heads, hd, causal=causal, key_mask=key_mask, lse=lse)
         ctx.args = (batch, n, heads, hd, causal)
+        ctx.rope = rope
         ctx.save_for_backward(qkv, key_mask, out if fused else None, lse)
-        return out
+        return (qkv, out) if rope is not None else out
 
     @staticmethod
-    def backward(ctx, do):
+    def backward(ctx, *grads):
+        do = grads[-1]
         qkv, key_mask, out, lse = ctx.saved_tensors
         batch, n, heads, hd, causal = ctx.args
         D = heads * hd
@@ -285,7 +298,15 @@ class PackedAttnFn(Function):
             attention_backward(qkv, qkv[:, D:], qkv[:, 2 * D:], do, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], batch=batch, heads=heads, Nq=n, Nk=n,
                                hd=hd, qs=st, ks=st, vs=st, dos=dst, dqs=st, dks=st, dvs=st, scale=1.0 / math.sqrt(hd), causal=causal,
                                key_mask=key_mask)
-        return dqkv, None, None, None, None, None, None
+        if ctx.rope is not None:
+            assert grads[0] is None, "the rotated qkv buffer must not be consumed outside this node"
+            ops.rope_(dqkv, ctx.rope[0], ctx.rope[2], batch * n, n, 2 * heads, hd, ld)
+        return dqkv, None, None, None, None, None, None, None
+
+
+def rope_attention(qkv, rope, batch, n, heads, hd, causal, key_mask):
+    """RoPE (in place on the q|k part of qkv) + attention as one autograd node -> attention output."""
+    return PackedAttnFn.apply(qkv, batch, n, heads, hd, causal, key_mask, rope)[1]
 
 
 class CrossAttn1QFn(Function):
@@ -328,32 +349,44 @@ class SwigluFn(Function):
         return ops.swiglu_bwd(gu, d.contiguous(), ctx.inter), None
 
 
+def embed_token_index(ids, P):
+    """Embedding row that receives the gradient of every spliced position ([N, T] int64): text positions -> token id, the image
+    span -> -1 (CLIP + mm_projector are frozen).  Index plumbing of the splice (llava_arch.py:185-208)."""
+    N, L = ids.shape
+    T = L - 1 + P
+    pos = (ids == -200).int().argmax(1)
+    ar = torch.arange(T, device=ids.device)[None]
+    src = torch.where(ar < pos[:, None], ar, (ar - P + 1).clamp(min=0)).clamp(max=L - 1)
+    tok = torch.gather(ids, 1, src)
+    return torch.where((ar >= pos[:, None]) & (ar < pos[:, None] + P), torch.full_like(tok, -1), tok).contiguous()
+
+
 class EmbedSpliceFn(Function):
     """LLaVA splice; gradient flows to the embedding table only (CLIP + mm_projector are frozen, training.py:173-176)."""
 
     @staticmethod
-    def forward(ctx, ids, embed, img_feats, P, fstride):
+    def forward(ctx, ids, embed, img_feats, P, fstride, tok_index=None):
         out = ops.embed_splice(ids, embed, img_feats, P, feats_stride_n=fstride)
         ctx.P = P
         ctx.vocab = embed.shape
-        ctx.save_for_backward(ids)
+        ctx.g = g32_of(embed)
+        ctx.save_for_backward(ids, tok_index)
         return out
 
     @staticmethod
     def backward(ctx, d):
-        (ids,) = ctx.saved_tensors
+        ids, tok = ctx.saved_tensors
         N, L = ids.shape
-        P = ctx.P
-        T = L - 1 + P
-        # destination row of every output position: text positions -> token id, image span -> -1
-        pos = (ids == -200).int().argmax(1)
-        ar = torch.arange(T, device=ids.device)[None]
-        src = torch.where(ar < pos[:, None], ar, (ar - P + 1).clamp(min=0)).clamp(max=L - 1)
-        tok = torch.gather(ids, 1, src)
-        tok = torch.where((ar >= pos[:, None]) & (ar < pos[:, None] + P), torch.full_like(tok, -1), tok)
+        T = L - 1 + ctx.P
+        if tok is None:
+            tok = embed_token_index(ids, ctx.P)
+        src = d.contiguous().view(N * T, -1)
+        if ctx.g is not None:
+            ops.scatter_add_rows(src, tok.reshape(-1), ctx.g)
+            return None, None, None, None, None, None
         g32 = torch.zeros(ctx.vocab, device=d.device, dtype=torch.float32)
-        ops.scatter_add_rows(d.contiguous().view(N * T, -1), tok.reshape(-1).contiguous(), g32)
-        return None, g32.to(BF16), None, None, None
+        ops.scatter_add_rows(src, tok.reshape(-1).contiguous(), g32)
+        return None, g32.to(BF16), None, None, None, None
 
 
 class GatherRowsFn(Function):

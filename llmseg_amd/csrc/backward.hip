@@ -364,10 +364,13 @@ extern "C" int llmseg_adamw(void* p, float* master, const void* grad, int grad_f
 namespace {
 constexpr int LR = 8;
 
-// y[m][r] = alpha * sum_k x[m][k] * W(r,k).  One wave per FOUR rows (each W chunk is loaded once for the four).
-// w_kr = 0: W stored [8][K]; 1: W stored [K][8].
+struct DropP { const unsigned long* rng; uint32_t stream, thr; float scale; };     // thr == 0: no dropout
+
+// y[m][r] = alpha * sum_k drop(x)[m][k] * W(r,k), written at row pitch ldy; `zero_cols` further columns of each row are zero-filled
+// (the [M][64] extension operand of the qkv GEMM is [x Aq^T | x Av^T | 0]).  One wave per FOUR rows (each W chunk is loaded once for
+// the four).  w_kr = 0: W stored [8][K]; 1: W stored [K][8].  drop(x) = x * mask / (1 - p), mask element index m K + k.
 __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
-                                                       long M, int K, int w_kr, float alpha) {
+                                                       long ldy, long M, int K, int w_kr, float alpha, int zero_cols, DropP dp) {
   constexpr int RW = 4;
   const int lane = threadIdx.x & 63;
   const long m0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
@@ -383,7 +386,10 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict
   for (int k = lane * 8; k < K; k += 64 * 8) {
     float xv[RW][8], wv[8];
 #pragma unroll
-    for (int i = 0; i < RW; ++i) unpack8(*reinterpret_cast<const uint4*>(xr[i] + k), xv[i]);
+    for (int i = 0; i < RW; ++i) {
+      unpack8(*reinterpret_cast<const uint4*>(xr[i] + k), xv[i]);
+      if (dp.thr) dropout8(xv[i], ((unsigned long)min(m0 + i, M - 1) * (unsigned long)K + (unsigned long)k) >> 3, dp.stream, dp.rng, dp.thr, dp.scale);
+    }
     if (w_kr) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -408,16 +414,21 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict
   for (int i = 0; i < RW; ++i) {
 #pragma unroll
     for (int r = 0; r < LR; ++r) acc[i][r] = wave_sum(acc[i][r]) * alpha;
-    if (lane == 0 && m0 + i < M) *reinterpret_cast<uint4*>(y + (m0 + i) * LR) = pack8(acc[i]);
+    if (m0 + i < M) {
+      bf16_t* yr = y + (m0 + i) * ldy;
+      if (lane == 0) *reinterpret_cast<uint4*>(yr) = pack8(acc[i]);
+      else if (lane * 8 <= zero_cols) *reinterpret_cast<uint4*>(yr + lane * 8) = make_uint4(0, 0, 0, 0);
+    }
   }
 }
 
-// out(n,r) += alpha * sum_m a[m][n] * b[m][r]  (fp32 atomics; caller zero-fills).  out_rn = 0: out [N][8]; 1: out [8][N].
+// out(n,r) += alpha * sum_m drop(a)[m][n] * b[m][r]  (fp32 atomics onto `out`: the caller zero-fills it or accumulates into a
+// gradient arena).  out_rn = 0: out [N][8]; 1: out [8][N].  b has row pitch ldb.
 // Workgroup = 256 columns x one slice of rows: lane = (row-lane 0..7, column chunk 0..7), a wave reads 8 rows x 128 contiguous
 // bytes per step (16 B per lane, three steps in flight); the 8 row-lanes are folded with shuffles, so one set of atomics per
 // column per wave (the same atomic count as a column-per-thread layout, 20x the loads in flight).
-__global__ __launch_bounds__(256) void lora_outer_kernel(const bf16_t* __restrict__ a, long lda, const bf16_t* __restrict__ b, float* __restrict__ out,
-                                                        long M, long N, int out_rn, float alpha) {
+__global__ __launch_bounds__(256) void lora_outer_kernel(const bf16_t* __restrict__ a, long lda, const bf16_t* __restrict__ b, long ldb,
+                                                        float* __restrict__ out, long M, long N, int out_rn, float alpha, DropP dp) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cl = lane & 7, rl = lane >> 3;
   const long n = ((long)blockIdx.x * 32 + wave * 8 + cl) * 8;
@@ -436,12 +447,13 @@ __global__ __launch_bounds__(256) void lora_outer_kernel(const bf16_t* __restric
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         av[u] = *reinterpret_cast<const uint4*>(a + (m + 8 * u) * lda + n);
-        bv[u] = *reinterpret_cast<const uint4*>(b + (m + 8 * u) * LR);
+        bv[u] = *reinterpret_cast<const uint4*>(b + (m + 8 * u) * ldb);
       }
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         float x[8], y[8];
         unpack8(av[u], x); unpack8(bv[u], y);
+        if (dp.thr) dropout8(x, ((unsigned long)(m + 8 * u) * (unsigned long)N + (unsigned long)n) >> 3, dp.stream, dp.rng, dp.thr, dp.scale);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -451,7 +463,8 @@ __global__ __launch_bounds__(256) void lora_outer_kernel(const bf16_t* __restric
     for (; m < m1; m += 8) {
       float x[8], y[8];
       unpack8(*reinterpret_cast<const uint4*>(a + m * lda + n), x);
-      unpack8(*reinterpret_cast<const uint4*>(b + m * LR), y);
+      unpack8(*reinterpret_cast<const uint4*>(b + m * ldb), y);
+      if (dp.thr) dropout8(x, ((unsigned long)m * (unsigned long)N + (unsigned long)n) >> 3, dp.stream, dp.rng, dp.thr, dp.scale);
 #pragma unroll
       for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -477,21 +490,24 @@ __global__ __launch_bounds__(256) void lora_outer_kernel(const bf16_t* __restric
   }
 }
 
-// y[m][n..n+7] += alpha * sum_r xa[m][r] * W(n,r).  w_rn = 0: W stored [N][8]; 1: W stored [8][N].
-__global__ __launch_bounds__(256) void lora_apply_kernel(bf16_t* __restrict__ y, long ldy, const bf16_t* __restrict__ xa, const bf16_t* __restrict__ w,
-                                                        long M, long N, int w_rn, float alpha) {
+// y[m][n..n+7] += alpha * mask(m, n..) * sum_r xa[m][r] * W(n,r).  w_rn = 0: W stored [N][8]; 1: W stored [8][N].  xa row pitch ldxa.
+// With dropout the product is masked like the forward input was (dX of the LoRA branch: ((dq Bq) Aq) * mask / (1 - p)).
+__global__ __launch_bounds__(256) void lora_apply_kernel(bf16_t* __restrict__ y, long ldy, const bf16_t* __restrict__ xa, long ldxa,
+                                                        const bf16_t* __restrict__ w, long M, long N, int w_rn, float alpha, DropP dp) {
   const long nch = N >> 3, total = M * nch;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long m = i / nch, c = i % nch;
-    float yv[8], xv[8], wv[8];
+    float yv[8], xv[8], wv[8], dv[8];
     unpack8(*reinterpret_cast<const uint4*>(y + m * ldy + c * 8), yv);
-    unpack8(*reinterpret_cast<const uint4*>(xa + m * LR), xv);
+    unpack8(*reinterpret_cast<const uint4*>(xa + m * ldxa), xv);
     if (w_rn) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dv[j] = 0.f;
 #pragma unroll
       for (int r = 0; r < LR; ++r) {
         unpack8(*reinterpret_cast<const uint4*>(w + (long)r * N + c * 8), wv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) yv[j] += alpha * xv[r] * wv[j];
+        for (int j = 0; j < 8; ++j) dv[j] += xv[r] * wv[j];
       }
     } else {
 #pragma unroll
@@ -500,10 +516,44 @@ __global__ __launch_bounds__(256) void lora_apply_kernel(bf16_t* __restrict__ y,
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < LR; ++r) s += xv[r] * wv[r];
-        yv[j] += alpha * s;
+        dv[j] = s;
       }
     }
+    if (dp.thr) dropout8(dv, (unsigned long)i, dp.stream, dp.rng, dp.thr, dp.scale);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) yv[j] += alpha * dv[j];
     *reinterpret_cast<uint4*>(y + m * ldy + c * 8) = pack8(yv);
+  }
+}
+
+// The two [*, 64] extension operands of a LoRA'd q|k|v projection (llmseg_gemm_args.A2 / W2), rebuilt from the CURRENT LoRA
+// matrices on every call (no cache to go stale when the optimizer updates them in place):
+//   w2b [3H][64]: rows of the q block = [s Bq | 0], k block = 0, v block = [0 | s Bv | 0]     (forward: qkv += [xAq | xAv | 0] . w2b^T)
+//   w2a [H][64]:  row h = [Aq[:, h] | Av[:, h] | 0]                                             (backward: dx += [tq | tv | 0] . w2a^T)
+__global__ __launch_bounds__(256) void lora_pack_kernel(const bf16_t* __restrict__ aq, const bf16_t* __restrict__ bq, const bf16_t* __restrict__ av,
+                                                       const bf16_t* __restrict__ bv, bf16_t* __restrict__ w2b, bf16_t* __restrict__ w2a, long H, float s) {
+  const long total = 4 * H * 8;                                      // (3H + H) rows x 8 chunks of 8 columns
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i >> 3;
+    const int ch = (int)(i & 7);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (row < 3 * H) {
+      if (w2b == nullptr) continue;
+      if (row < H && ch == 0) { unpack8(*reinterpret_cast<const uint4*>(bq + row * LR), v); }
+      else if (row >= 2 * H && ch == 1) { unpack8(*reinterpret_cast<const uint4*>(bv + (row - 2 * H) * LR), v); }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= s;
+      *reinterpret_cast<uint4*>(w2b + row * 64 + ch * 8) = pack8(v);
+    } else {
+      if (w2a == nullptr) continue;
+      const long h = row - 3 * H;
+      if (ch < 2) {
+        const bf16_t* src = ch == 0 ? aq : av;
+#pragma unroll
+        for (int r = 0; r < LR; ++r) v[r] = bf2f(src[(long)r * H + h]);
+      }
+      *reinterpret_cast<uint4*>(w2a + h * 64 + ch * 8) = pack8(v);
+    }
   }
 }
 // out[c][r] = in[r][c] for r < rows (zero for rows <= r < rows_pad): 64 x 64 tiles through LDS, 16-byte global accesses both ways.
@@ -535,28 +585,54 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16_t* __rest
 
 }  // namespace
 
-extern "C" int llmseg_lora_down(const void* x, int64_t ldx, const void* w, void* y, int64_t M, int64_t K, int32_t w_kr, float alpha, void* stream) {
-  LL_CHECK(x && w && y && M > 0 && K > 0 && (K & 7) == 0 && (ldx & 7) == 0 && AL16(x) && AL16(w) && AL16(y), "lora_down: bad arguments");
+static DropP make_drop(const llmseg_dropout* d) {
+  DropP dp{nullptr, 0u, 0u, 1.f};
+  if (d && d->rng_state && d->drop_thr > 0) {
+    dp.rng = (const unsigned long*)d->rng_state; dp.stream = d->stream; dp.thr = d->drop_thr;
+    dp.scale = 65536.f / (65536.f - (float)d->drop_thr);
+  }
+  return dp;
+}
+#define LL_DROP_OK(d) (!(d) || (d)->drop_thr < 65536u)
+
+extern "C" int llmseg_lora_down(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t M, int64_t K, int32_t w_kr, float alpha,
+                                int32_t zero_cols, const llmseg_dropout* drop, void* stream) {
+  LL_CHECK(x && w && y && M > 0 && K > 0 && (K & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0 && ldy >= 8 + zero_cols && zero_cols >= 0 &&
+               (zero_cols & 7) == 0 && zero_cols <= 504 && AL16(x) && AL16(w) && AL16(y) && LL_DROP_OK(drop), "lora_down: bad arguments");
   hipLaunchKernelGGL(lora_down_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ldx, (const bf16_t*)w,
-                     (bf16_t*)y, (long)M, (int)K, w_kr, alpha);
+                     (bf16_t*)y, (long)ldy, (long)M, (int)K, w_kr, alpha, zero_cols, make_drop(drop));
   LL_LAUNCH_CHECK("lora_down");
   return LLMSEG_OK;
 }
 
-extern "C" int llmseg_lora_outer(const void* a, int64_t lda, const void* b, float* out, int64_t M, int64_t N, int32_t out_rn, float alpha, void* stream) {
-  LL_CHECK(a && b && out && M > 0 && N > 0 && (N & 7) == 0 && (lda & 7) == 0 && AL16(a) && AL16(b), "lora_outer: bad arguments (N, lda multiples of 8)");
+extern "C" int llmseg_lora_outer(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t M, int64_t N, int32_t out_rn, float alpha,
+                                 const llmseg_dropout* drop, void* stream) {
+  LL_CHECK(a && b && out && M > 0 && N > 0 && (N & 7) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && AL16(a) && AL16(b) && LL_DROP_OK(drop),
+           "lora_outer: bad arguments (N, lda, ldb multiples of 8)");
   const unsigned gy = (unsigned)max((long)1, min((long)32, M / 64));
   hipLaunchKernelGGL(lora_outer_kernel, dim3((unsigned)((N + 255) / 256), gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (long)lda,
-                     (const bf16_t*)b, out, (long)M, (long)N, out_rn, alpha);
+                     (const bf16_t*)b, (long)ldb, out, (long)M, (long)N, out_rn, alpha, make_drop(drop));
   LL_LAUNCH_CHECK("lora_outer");
   return LLMSEG_OK;
 }
 
-extern "C" int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, const void* w, int64_t M, int64_t N, int32_t w_rn, float alpha, void* stream) {
-  LL_CHECK(y && xa && w && M > 0 && N > 0 && (N & 7) == 0 && (ldy & 7) == 0 && AL16(y) && AL16(xa) && AL16(w), "lora_apply: bad arguments");
+extern "C" int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, int64_t ldxa, const void* w, int64_t M, int64_t N, int32_t w_rn, float alpha,
+                                 const llmseg_dropout* drop, void* stream) {
+  LL_CHECK(y && xa && w && M > 0 && N > 0 && (N & 7) == 0 && (ldy & 7) == 0 && (ldxa & 7) == 0 && AL16(y) && AL16(xa) && AL16(w) && LL_DROP_OK(drop),
+           "lora_apply: bad arguments");
+  LL_CHECK(!(drop && drop->drop_thr) || ldy == N, "lora_apply: the dropout mask indexes y as a dense [M][N] matrix");
   hipLaunchKernelGGL(lora_apply_kernel, dim3(grid_for(M * (N >> 3))), dim3(256), 0, (hipStream_t)stream, (bf16_t*)y, (long)ldy, (const bf16_t*)xa,
-                     (const bf16_t*)w, (long)M, (long)N, w_rn, alpha);
+                     (long)ldxa, (const bf16_t*)w, (long)M, (long)N, w_rn, alpha, make_drop(drop));
   LL_LAUNCH_CHECK("lora_apply");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_lora_pack(const void* aq, const void* bq, const void* av, const void* bv, void* w2b, void* w2a, int64_t H, float s, void* stream) {
+  LL_CHECK(aq && bq && av && bv && (w2b || w2a) && H > 0 && (H & 7) == 0 && AL16(aq) && AL16(bq) && AL16(av) && AL16(bv) && AL16(w2b) && AL16(w2a),
+           "lora_pack: bad arguments");
+  hipLaunchKernelGGL(lora_pack_kernel, dim3(grid_for(4 * H * 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)aq, (const bf16_t*)bq, (const bf16_t*)av,
+                     (const bf16_t*)bv, (bf16_t*)w2b, (bf16_t*)w2a, (long)H, s);
+  LL_LAUNCH_CHECK("lora_pack");
   return LLMSEG_OK;
 }
 

@@ -68,6 +68,34 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return t;
 }
 
+// ---- counter-based RNG for LoRA dropout (peft Linear: dropout(p = 0.05) on the LoRA branch input, reference training.py:91,218-226) ----
+// Philox4x32-10 (Salmon et al. 2011): counter = (idx_lo, idx_hi, stream, offset), key = (seed_lo, seed_hi).  One call yields the
+// keep bits of EIGHT consecutive elements: element e = 8 * idx + j uses the 16-bit field j of the 128-bit output (field j = bits
+// 16 (j & 1) .. +15 of word j >> 1) and is KEPT when field >= drop_thr (drop_thr = round(p * 65536)); kept values are scaled by
+// 65536 / (65536 - drop_thr).  Nothing is stored: forward and backward regenerate the mask from (seed, offset, stream, idx).
+// rng_state points at device memory {seed, offset} (uint64 each) so that a replayed hipGraph sees a fresh offset every micro-step.
+struct Philox8 { uint32_t w[4]; };
+__device__ __forceinline__ Philox8 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Philox8{{c0, c1, c2, c3}};
+}
+// multiplies f[0..7] (elements 8 idx .. 8 idx + 7) by the dropout mask * scale
+__device__ __forceinline__ void dropout8(float* f, unsigned long idx, uint32_t stream, const unsigned long* rng, uint32_t thr, float scale) {
+  const unsigned long seed = rng[0], off = rng[1];
+  const Philox8 r = philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), stream, (uint32_t)off, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t field = (r.w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+    f[j] = field >= thr ? f[j] * scale : 0.f;
+  }
+}
+
 void llmseg_set_error(const char* fmt, ...);
 #define LL_CHECK(cond, ...)                 \
   do {                                      \

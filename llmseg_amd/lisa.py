@@ -71,15 +71,21 @@ class LISAForCausalLM(TrainableMixin, nn.Module):
             for n, p in own.items():
                 if n in sd:
                     p.copy_(sd[n].to(device=p.device, dtype=p.dtype))
-        self._derived = None
-        self.__dict__.pop("_wt_cache", None)
+        self._invalidate_derived()
         return missing, unexpected
 
     def init_random(self, seed=0):
         init_random_(self.params, self.shapes, seed)
+        self._invalidate_derived()
+        return self
+
+    def _invalidate_derived(self):
+        """Weights changed wholesale (checkpoint load / re-init): drop every tensor derived from them (re-laid-out conv / position
+        tables, transposed copies of frozen weights) and tell an attached optimizer to re-read its fp32 master copies."""
         self._derived = None
         self.__dict__.pop("_wt_cache", None)
-        return self
+        for hook in self.__dict__.get("_weight_hooks", []):
+            hook()
 
     def get_model(self):
         return self
@@ -134,7 +140,8 @@ class LISAForCausalLM(TrainableMixin, nn.Module):
             c = self.config.llama
             inv = 1.0 / (c.theta ** (torch.arange(0, c.head_dim, 2, dtype=torch.float32, device=self.device_) / c.head_dim))
             ang = torch.outer(torch.arange(T, dtype=torch.float32, device=self.device_), inv)
-            self._maps[key] = (ang.cos().contiguous(), ang.sin().contiguous())
+            sin = ang.sin().contiguous()
+            self._maps[key] = (ang.cos().contiguous(), sin, (-sin).contiguous())      # (cos, sin, -sin): forward and inverse rotation
         return self._maps[key]
 
     def _window_maps(self, B, g, ws):

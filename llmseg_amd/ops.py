@@ -362,27 +362,52 @@ def scatter_add_rows(src, idx, dst):
     return dst
 
 
-def lora_down(x, w, w_kr=False, alpha=1.0):
-    """y [M, 8] = alpha * x [M, K] @ W^T; W stored [8, K] (or [K, 8] when w_kr).  x may be a column view (row stride = ld)."""
+def _drop(drop):
+    """drop = (rng_state int64[2] device tensor, stream id, p) or None -> ctypes pointer (or None)."""
+    if drop is None or drop[2] <= 0.0:
+        return None
+    rng, stream, p = drop
+    assert rng.is_cuda and rng.dtype == torch.int64 and rng.numel() == 2
+    return C.byref(_lib.Dropout(rng_state=rng.data_ptr(), stream=int(stream), drop_thr=int(round(p * 65536))))
+
+
+def lora_down(x, w, w_kr=False, alpha=1.0, out=None, zero_cols=0, drop=None):
+    """y [M, 8] = alpha * drop(x) [M, K] @ W^T; W stored [8, K] (or [K, 8] when w_kr).  x may be a column view (row stride = ld).
+    `out` may be 8 columns of a wider row (e.g. buf[:, 8:16]); `zero_cols` further columns of every row are zero-filled."""
     M, K = x.shape
-    y = torch.empty((M, 8), device=x.device, dtype=BF16)
-    _lib.check(_lib.load().llmseg_lora_down(_ptr(x), x.stride(0), _ptr(w), _ptr(y), M, K, 1 if w_kr else 0, alpha, _stream()), "lora_down")
+    y = torch.empty((M, 8), device=x.device, dtype=BF16) if out is None else out
+    assert y.shape[0] == M and y.stride(1) == 1
+    _lib.check(_lib.load().llmseg_lora_down(_ptr(x), x.stride(0), _ptr(w), _ptr(y), y.stride(0), M, K, 1 if w_kr else 0, alpha, zero_cols,
+                                            _drop(drop), _stream()), "lora_down")
     return y
 
 
-def lora_outer(a, b, out_rn=False, alpha=1.0):
-    """out [N, 8] (or [8, N] when out_rn) = alpha * a[M, N]^T @ b[M, 8], fp32."""
+def lora_outer(a, b, out_rn=False, alpha=1.0, out=None, drop=None):
+    """out [N, 8] (or [8, N] when out_rn) += alpha * drop(a)[M, N]^T @ b[M, 8], fp32 (a fresh zero buffer unless `out` is given)."""
     M, N = a.shape
-    out = torch.zeros((8, N) if out_rn else (N, 8), device=a.device, dtype=torch.float32)
-    _lib.check(_lib.load().llmseg_lora_outer(_ptr(a), a.stride(0), _ptr(b), _ptr(out), M, N, 1 if out_rn else 0, alpha, _stream()), "lora_outer")
+    if out is None:
+        out = torch.zeros((8, N) if out_rn else (N, 8), device=a.device, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == 8 * N and b.stride(1) == 1
+    _lib.check(_lib.load().llmseg_lora_outer(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), M, N, 1 if out_rn else 0, alpha, _drop(drop),
+                                             _stream()), "lora_outer")
     return out
 
 
-def lora_apply_(y, xa, w, w_rn=False, alpha=1.0):
-    """y [M, N] += alpha * xa [M, 8] @ W^T in place; W stored [N, 8] (or [8, N] when w_rn).  y may be a column view."""
+def lora_apply_(y, xa, w, w_rn=False, alpha=1.0, drop=None):
+    """y [M, N] += alpha * mask * (xa [M, 8] @ W^T) in place; W stored [N, 8] (or [8, N] when w_rn).  y may be a column view."""
     M, N = y.shape
-    _lib.check(_lib.load().llmseg_lora_apply(_ptr(y), y.stride(0), _ptr(xa), _ptr(w), M, N, 1 if w_rn else 0, alpha, _stream()), "lora_apply")
+    _lib.check(_lib.load().llmseg_lora_apply(_ptr(y), y.stride(0), _ptr(xa), xa.stride(0), _ptr(w), M, N, 1 if w_rn else 0, alpha, _drop(drop),
+                                             _stream()), "lora_apply")
     return y
+
+
+def lora_pack(aq, bq, av, bv, s, w2b=None, w2a=None):
+    """Extension operands of the LoRA'd qkv GEMMs from the current LoRA matrices (aq/av [8, H], bq/bv [H, 8]):
+    w2b [3H, 64] (forward) and/or w2a [H, 64] (backward dX); written in place."""
+    H = aq.shape[1]
+    for t in (aq, bq, av, bv):
+        assert t.is_contiguous()
+    _lib.check(_lib.load().llmseg_lora_pack(_ptr(aq), _ptr(bq), _ptr(av), _ptr(bv), _ptr(w2b), _ptr(w2a), H, s, _stream()), "lora_pack")
 
 
 def sumsq(x, out):

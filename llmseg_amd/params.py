@@ -22,6 +22,7 @@ class LlamaConfig:
     theta: float = 10000.0
     lora_r: int = 0
     lora_alpha: float = 16.0
+    lora_dropout: float = 0.0      # reference: 0.05 (training.py:91); active in training-mode forwards under autograd only
 
     @property
     def head_dim(self):

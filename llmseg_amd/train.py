@@ -1,17 +1,26 @@
-"""Data-parallel training step for the hot path: plain torch DDP over RCCL/xGMI in place of the reference's DeepSpeed
-ZeRO-2 engine (reference `training.py:292-332` config, `:480-602` loop).
+"""Data-parallel training step for the hot path: torch.distributed over RCCL/xGMI in place of the reference's DeepSpeed ZeRO-2 engine
+(reference `training.py:292-332` config, `:480-602` loop).
 
-What is kept from the reference's recipe: micro-batches with gradient accumulation (`no_sync()` on all but the last
-micro-step, so ONE bucketed all-reduce of the ~0.58 GB trainable-gradient set per optimizer step), AdamW(betas, wd 0) on fp32
-master weights with bf16 model copies, global-norm clipping at 1.0, WarmupDecayLR (linear 0 -> lr over 100 steps, then linear
-decay to 0 at total_steps).  ZeRO sharding is dropped on purpose: optimizer state for the trainable set is ~3.5 GB on a
-288 GB device.  DeepSpeed itself is not installed here: PARITY UNPINNED for optimizer/schedule details (published formulas).
+What is kept from the reference's recipe: micro-batches with gradient accumulation, ONE all-reduce of the trainable-gradient set per
+optimizer step (nothing is reduced on the other accumulation micro-steps -- DDP's `no_sync()`), AdamW(betas, wd 0) on fp32 master
+weights with bf16 model copies, global-norm clipping at 1.0, WarmupDecayLR (linear 0 -> lr over 100 steps, then linear decay to 0 at
+total_steps).  ZeRO sharding is dropped on purpose: optimizer state for the trainable set is ~3.5 GB on a 288 GB device.  DeepSpeed
+itself is not installed here: PARITY UNPINNED for optimizer/schedule details (published formulas).
 
-The optimizer / clipping arithmetic runs in libllmseg_hip.so (`llmseg_adamw`, `llmseg_sumsq`); `opt_step` can be replaced
+MI355X-first structure:
+  * `GradArena`: ONE flat fp32 buffer holds the gradient of every trainable tensor.  The backward kernels accumulate into it directly
+    (`C += dY^T X` GEMM epilogue, fp32 atomics of the skinny LoRA / norm / bias / embedding kernels), so accumulation over micro-steps is
+    fp32 end to end, there is no per-parameter bf16 `.grad`, the global norm is ONE reduction kernel and the data-parallel exchange is ONE
+    `all_reduce` on a contiguous 1.2 GB buffer (what DDP's reducer does with its buckets, minus the copy into them).
+  * `use_graph`: the whole fwd+bwd micro-step (~3000 kernel launches) is captured once per batch structure in a hipGraph and replayed;
+    inputs are copied into the graph's static buffers, the dropout offset lives in device memory, the optimizer step and the collective
+    stay outside the graph.
+  * `ddp_wrapper=True` keeps the plain `torch.nn.parallel.DistributedDataParallel` wrapper (bf16 `.grad`, reducer buckets) as an alternative.
+
+The optimizer / clipping arithmetic runs in libllmseg_hip.so (`llmseg_adamw`, `llmseg_sumsq`); `optimizer` can be replaced
 (tests inject a CPU restatement to exercise the distributed/accumulation logic under gloo).
 """
 import contextlib
-import math
 
 import torch
 import torch.distributed as dist
@@ -25,8 +34,87 @@ def warmup_decay_lr(step, lr, warmup=100, total=5000):
     return lr * max(0.0, (total - step) / max(1.0, total - warmup))
 
 
+class GradArena:
+    """Flat fp32 gradient storage of a `LISAForCausalLM`'s trainable tensors.  Every trainable Parameter gets `p._g32`, an fp32 view of
+    its block; fused weight groups (q|k|v of the head attentions) occupy ONE block laid out like the fused tensor, whose backing
+    tensor gets the fused view, so a fused forward GEMM has a fused weight-gradient GEMM."""
+
+    ALIGN = 64          # elements: every block starts 256-byte aligned (vector accesses of the GEMM epilogue)
+
+    def __init__(self, model):
+        from .params import fused_groups
+        self.model = model
+        flat = model.params.flat
+        groups = {g: [m for m in members if m in flat] for g, members in fused_groups(model.config) if g in flat}
+        member_of = {m: g for g, ms in groups.items() for m in ms}
+        blocks, seen, total = [], set(), 0
+        self.params = []
+        for name, p in model.params.named_parameters():
+            if not p.requires_grad:
+                continue
+            self.params.append(p)
+            key = member_of.get(name, name)
+            if key in seen:
+                continue
+            seen.add(key)
+            n = flat[key].numel() if key in groups else p.numel()
+            blocks.append((key, total, n))
+            total += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        dev = self.params[0].device
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.numel = sum(p.numel() for p in self.params)
+        self._touched, views = [], {}
+        for key, off, n in blocks:
+            if key in groups:
+                buf = flat[key]
+                gv = self.flat[off:off + n].view(buf.shape)
+                self._attach(buf, gv, make_leaf=True)
+                r = 0
+                for m in groups[key]:
+                    rows = flat[m].shape[0]
+                    self._attach(flat[m], gv[r:r + rows])
+                    r += rows
+                if key.endswith("cross_attn_image_to_token.qkv.weight") or key.endswith("cross_attn_image_to_token.qkv.bias"):
+                    # the k|v half as one operand (rows D.. of the fused tensor): a leaf view that carries its arena block
+                    D = buf.shape[0] // 3
+                    with torch.no_grad():
+                        kv = buf[D:]
+                    self._attach(kv, gv[D:], make_leaf=True)
+                    views[key.replace("qkv.", "kv.")] = kv
+            else:
+                p = flat[key]
+                self._attach(p, self.flat[off:off + n].view(p.shape))
+                if key == "model.lisa_dino_conv.weight":
+                    with torch.no_grad():
+                        w2d = p.view(p.shape[0], p.shape[1])
+                    self._attach(w2d, p._g32.view(p.shape[0], p.shape[1]), make_leaf=True)
+                    views["model.lisa_dino_conv.weight2d"] = w2d
+        model.__dict__["_arena_views"] = views
+
+    def _attach(self, t, view, make_leaf=False):
+        t._g32 = view
+        if make_leaf and not t.requires_grad:
+            t.requires_grad_(True)           # so that an autograd Function whose other inputs are frozen still runs its backward
+            self._touched.append((t, True))
+        else:
+            self._touched.append((t, False))
+
+    def detach(self):
+        for t, was_made_leaf in self._touched:
+            if hasattr(t, "_g32"):
+                del t._g32
+            if was_made_leaf:
+                t.requires_grad_(False)
+        self.model.__dict__.pop("_arena_views", None)
+        self._touched = []
+
+    def zero_(self):
+        self.flat.zero_()
+
+
 class HipAdamW:
-    """fp32 master / m / v per trainable parameter; fused update + bf16 write-back in one kernel per parameter."""
+    """fp32 master / m / v per trainable parameter; fused update + bf16 write-back in one kernel per parameter.  Gradients are read
+    from the parameter's arena view (`p._g32`, fp32) when it has one, else from `p.grad`."""
 
     def __init__(self, params, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0):
         from . import ops
@@ -38,20 +126,33 @@ class HipAdamW:
         self.v = [torch.zeros_like(t) for t in self.master]
         self.t = 0
 
+    def resync_master(self):
+        """Re-read the fp32 master copies from the (bf16) parameters: call after loading weights into the model."""
+        with torch.no_grad():
+            for w, p in zip(self.master, self.params):
+                w.copy_(p.detach().float())
+
+    @staticmethod
+    def _grad(p):
+        g = getattr(p, "_g32", None)
+        return g if g is not None else p.grad
+
     def grad_sumsq(self):
         acc = torch.zeros(1, device=self.params[0].device, dtype=torch.float32)
         for p in self.params:
-            if p.grad is not None:
-                self.ops.sumsq(p.grad.contiguous(), acc)
+            g = self._grad(p)
+            if g is not None:
+                self.ops.sumsq(g.contiguous(), acc)
         return acc
 
     def step(self, lr, grad_scale):
         """grad_scale: device fp32 scalar multiplying every gradient (1/accum x clip coefficient)."""
         self.t += 1
         for p, w, m, v in zip(self.params, self.master, self.m, self.v):
-            if p.grad is None:
+            g = self._grad(p)
+            if g is None:
                 continue
-            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            g = g if g.is_contiguous() else g.contiguous()
             if p.is_contiguous():
                 self.ops.adamw_(p.data, w, g, m, v, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale)
             else:   # parameter is a strided view: update a contiguous copy and write it back
@@ -59,47 +160,166 @@ class HipAdamW:
                 self.ops.adamw_(tmp, w, g, m, v, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale)
                 p.data.copy_(tmp)
 
+    def state_dict(self):
+        return {"t": self.t, "master": self.master, "m": self.m, "v": self.v}
+
+    def load_state_dict(self, sd):
+        self.t = int(sd["t"])
+        with torch.no_grad():
+            for dst, src in ((self.master, sd["master"]), (self.m, sd["m"]), (self.v, sd["v"])):
+                for d, s in zip(dst, src):
+                    d.copy_(s)
+
+
+def _clone_batch(batch):
+    def c(v):
+        if torch.is_tensor(v):
+            return v.clone()
+        if isinstance(v, (list, tuple)):
+            return [c(x) for x in v]
+        return v
+    return {k: c(v) for k, v in batch.items()}
+
+
+def _copy_batch(dst, src):
+    for k, v in src.items():
+        d = dst[k]
+        if torch.is_tensor(v):
+            if d.data_ptr() != v.data_ptr():
+                d.copy_(v, non_blocking=True)
+        elif isinstance(v, (list, tuple)):
+            for dd, vv in zip(d, v):
+                if torch.is_tensor(vv) and dd.data_ptr() != vv.data_ptr():
+                    dd.copy_(vv, non_blocking=True)
+
 
 class Trainer:
-    """One process per GPU.  `module(**batch)` must return a dict with a scalar "loss"."""
+    """One process per GPU.  `module(**batch)` must return a dict with a scalar "loss".
+
+    Default (HIP model): gradient arena + optional hipGraph micro-step.  `ddp_wrapper=True`, or a module that is not a
+    `LISAForCausalLM` (the gloo tests' toy modules), uses plain `.grad` tensors and torch DDP."""
 
     def __init__(self, module, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.0, clip=1.0, grad_accum=10, warmup=100, total_steps=5000,
-                 optimizer=None, device_ids=None, force_ddp=False):
+                 optimizer=None, device_ids=None, force_ddp=False, ddp_wrapper=False, use_graph=False, graph_warmup=2):
         self.module = module
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.ddp = None
-        if self.world > 1 or (force_ddp and dist.is_initialized()):
-            self.ddp = torch.nn.parallel.DistributedDataParallel(module, device_ids=device_ids, broadcast_buffers=False,
-                                                               gradient_as_bucket_view=False)
-        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.arena = None
+        arena_ok = hasattr(module, "params") and hasattr(module, "make_plan") and optimizer is None and not ddp_wrapper
+        if arena_ok:
+            self.arena = GradArena(module)
+            self.params = self.arena.params
+        else:
+            if self.world > 1 or (force_ddp and dist.is_initialized()):
+                self.ddp = torch.nn.parallel.DistributedDataParallel(module, device_ids=device_ids, broadcast_buffers=False,
+                                                                   gradient_as_bucket_view=False)
+            self.params = [p for p in module.parameters() if p.requires_grad]
         self.opt = optimizer if optimizer is not None else HipAdamW(self.params, betas, weight_decay=weight_decay)
+        if hasattr(self.opt, "resync_master") and hasattr(module, "__dict__"):
+            module.__dict__.setdefault("_weight_hooks", []).append(self.opt.resync_master)
         self.lr, self.clip, self.accum, self.warmup, self.total = lr, clip, grad_accum, warmup, total_steps
         self.micro = 0
         self.opt_steps = 0
+        self.use_graph = bool(use_graph) and self.arena is not None
+        self.graph_warmup = graph_warmup
+        self._graphs = {}
+        self.graph_error = None
 
-    def micro_step(self, batch):
-        """Forward + backward of one micro-batch; runs the optimizer on every `grad_accum`-th call.  Returns the loss dict."""
+    def close(self):
+        """Detach from the model: arena views, weight hooks, captured graphs (a model can then be handed to another Trainer)."""
+        if self.arena is not None:
+            self.arena.detach()
+        hooks = getattr(self.module, "__dict__", {}).get("_weight_hooks", [])
+        if hasattr(self.opt, "resync_master") and self.opt.resync_master in hooks:
+            hooks.remove(self.opt.resync_master)
+        self._graphs = {}
+
+    # ------------------------------------------------------------------------------------------------ micro-step
+    def micro_step(self, batch, plan=None):
+        """Forward + backward of one micro-batch; runs the optimizer on every `grad_accum`-th call.  Returns the loss dict.
+        `plan` (HIP model only): the batch's `BatchPlan`; built here when absent (one device synchronisation)."""
         last = (self.micro + 1) % self.accum == 0
-        fwd = self.ddp if self.ddp is not None else self.module
-        sync_ctx = contextlib.nullcontext() if (last or self.ddp is None) else self.ddp.no_sync()
-        with sync_ctx:
-            out = fwd(**batch)
-            out["loss"].backward()
+        if self.arena is not None:
+            if getattr(self.module.config.llama, "lora_dropout", 0.0) > 0:
+                self.module.advance_dropout()
+            if plan is None:
+                plan = self.module.make_plan(**batch)
+            out = self._graph_step(batch, plan) if self.use_graph else self._eager_step(batch, plan)
+        else:
+            fwd = self.ddp if self.ddp is not None else self.module
+            sync_ctx = contextlib.nullcontext() if (last or self.ddp is None) else self.ddp.no_sync()
+            with sync_ctx:
+                out = fwd(**batch)
+                out["loss"].backward()
         self.micro += 1
         if last:
             self.optimizer_step()
         return out
 
+    def _eager_step(self, batch, plan):
+        out = self.module.model_forward(**batch, plan=plan)
+        out["loss"].backward()
+        return out
+
+    def _graph_step(self, batch, plan):
+        ent = self._graphs.setdefault(plan.sig, {"calls": 0, "graph": None})
+        if ent["graph"] is None and (ent["calls"] < self.graph_warmup or self.graph_error is not None):
+            ent["calls"] += 1
+            return self._eager_step(batch, plan)       # eager warm-up (lazy caches, workspace) -- also a real micro-step
+        if ent["graph"] is None:
+            try:
+                self._capture(ent, batch, plan)
+            except Exception as e:                       # noqa: BLE001 -- fall back to eager launches, keep training
+                self.graph_error = repr(e)
+                torch.cuda.synchronize()
+                ent["graph"] = None
+                return self._eager_step(batch, plan)
+        _copy_batch(ent["batch"], batch)
+        ent["plan"].copy_tensors_from(plan)
+        ent["graph"].replay()
+        return ent["out"]
+
+    def _capture(self, ent, batch, plan):
+        from .trainable import BatchPlan
+        sb = _clone_batch(batch)
+        sp = BatchPlan()
+        sp.__dict__.update({k: v for k, v in plan.__dict__.items() if k != "tensors"})
+        sp.tensors = {k: (None if v is None else v.clone()) for k, v in plan.tensors.items()}
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self.module.model_forward(**sb, plan=sp)
+            out["loss"].backward()
+        ent.update(graph=g, batch=sb, plan=sp, out={k: v.detach() for k, v in out.items() if torch.is_tensor(v)})
+
+    # ------------------------------------------------------------------------------------------------ optimizer step
     def optimizer_step(self):
         lr = warmup_decay_lr(self.opt_steps, self.lr, self.warmup, self.total)
-        # gradients hold the SUM over `accum` micro-steps (DDP already averaged over ranks): scale by 1/accum, then clip
-        ss = self.opt.grad_sumsq()
-        norm = torch.sqrt(ss) / self.accum
-        coef = torch.clamp(self.clip / (norm + 1e-6), max=1.0) / self.accum if self.clip and self.clip > 0 else torch.full_like(norm, 1.0 / self.accum)
+        scale = 1.0 / self.accum
+        if self.arena is not None:
+            if self.world > 1:                           # the data-parallel exchange: one all-reduce of the flat fp32 gradient arena
+                dist.all_reduce(self.arena.flat)
+                scale /= self.world
+            ss = torch.zeros(1, device=self.arena.flat.device, dtype=torch.float32)
+            self.opt.ops.sumsq(self.arena.flat, ss)                                      # global gradient norm: ONE reduction over the arena
+        else:
+            ss = self.opt.grad_sumsq()                  # gradients hold the SUM over `accum` micro-steps (DDP already averaged over ranks)
+        norm = torch.sqrt(ss) * scale
+        coef = torch.clamp(self.clip / (norm + 1e-6), max=1.0) * scale if self.clip and self.clip > 0 else torch.full_like(norm, scale)
         self.opt.step(lr, coef.reshape(1).float().contiguous())
-        for p in self.params:
-            p.grad = None
-        from . import autograd
-        autograd.PARAM_EPOCH += 1            # parameters changed in place: invalidate operand caches derived from them
+        if self.arena is not None:
+            self.arena.zero_()
+        else:
+            for p in self.params:
+                p.grad = None
         self.opt_steps += 1
         return float(lr)
+
+    # ------------------------------------------------------------------------------------------------ checkpoint (reference: training.py:404-421, 460-477)
+    def state_dict(self):
+        return {"opt": self.opt.state_dict() if hasattr(self.opt, "state_dict") else None, "micro": self.micro, "opt_steps": self.opt_steps}
+
+    def load_state_dict(self, sd):
+        if sd.get("opt") is not None and hasattr(self.opt, "load_state_dict"):
+            self.opt.load_state_dict(sd["opt"])
+        self.micro, self.opt_steps = int(sd["micro"]), int(sd["opt_steps"])

@@ -6,6 +6,10 @@ Every op goes through a small namespace `F`: `_Direct` calls the kernels straigh
 same calls through the autograd Functions of `autograd.py` so that `loss.backward()` runs the HIP backward kernels.
 What is trainable follows the reference (`training.py:183-241`): LoRA A/B on every q_proj/v_proj, `embed_tokens`,
 `lm_head`, `text_hidden_fcs`, every `lisa_*` module; CLIP, mm_projector, SAM, DINOv2 and the Llama base weights are frozen.
+
+Host-side index plumbing (where the `<image>` token sits, which hidden rows are `[SEG]`, how conversations map to images, the
+spliced labels) is computed ONCE per batch into a `BatchPlan` (`make_plan`); `model_forward(..., plan=plan)` then issues kernels only --
+no device->host synchronisation, so a whole fwd+bwd micro-step can be captured in a hipGraph (`llmseg_amd/train.py`).
 """
 import torch
 
@@ -21,19 +25,23 @@ class _Direct:
     grad = False
     linear = staticmethod(lambda x, w, b=None, act=ops.ACT_NONE, residual=None, wt=None: ops.gemm(x, w, bias=b, act=act, residual=residual))
     norm = staticmethod(lambda x, w, b=None, eps=1e-5, rms=False: ops.norm(x, w, b, eps=eps, rms=rms))
-    rope = staticmethod(lambda qkv, cos, sin, rows, T, heads, hd, ld: ops.rope_(qkv, cos, sin, rows, T, heads, hd, ld))
     attn_packed = staticmethod(lambda qkv, batch, n, heads, hd, causal=False, key_mask=None:
                                ops.attention_packed(qkv, batch, n, heads, hd, causal=causal, key_mask=key_mask))
     swiglu = staticmethod(lambda gu, inter: ops.swiglu(gu, inter))
-    embed_splice = staticmethod(lambda ids, emb, feats, P, fs: ops.embed_splice(ids, emb, feats, P, feats_stride_n=fs))
+    embed_splice = staticmethod(lambda ids, emb, feats, P, fs, tok=None: ops.embed_splice(ids, emb, feats, P, feats_stride_n=fs))
     gather_rows = staticmethod(lambda x, idx: ops.gather_rows(x, idx))
     maskpool = staticmethod(lambda feat, segs, g, S: ops.upsample_maskpool(feat, segs, g, S))
 
     @staticmethod
-    def lora_qkv(x, wqkv, aq, bq, av, bv, s, wqkv_t=None, cache=None, key=None):
+    def rope_attn(qkv, rope, batch, n, heads, hd, causal, key_mask):
+        ops.rope_(qkv, rope[0], rope[1], batch * n, n, 2 * heads, hd, qkv.stride(0))
+        return ops.attention_packed(qkv, batch, n, heads, hd, causal=causal, key_mask=key_mask)
+
+    @staticmethod
+    def lora_qkv(x, wqkv, aq, bq, av, bv, s, wqkv_t=None, drop=None):
         H = wqkv.shape[1]
         if aq.shape[0] == 8:
-            return ag.lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, cache, key)[0]
+            return ag.lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, None)[0]
         qkv = ops.gemm(x, wqkv)
         ops.gemm(ops.gemm(x, aq), bq, residual=qkv[:, :H], out=qkv[:, :H], alpha=s)
         ops.gemm(ops.gemm(x, av), bv, residual=qkv[:, 2 * H:], out=qkv[:, 2 * H:], alpha=s)
@@ -68,19 +76,41 @@ class _Auto:
     grad = True
     linear = staticmethod(ag.linear)
     norm = staticmethod(ag.norm)
-    rope = staticmethod(lambda qkv, cos, sin, rows, T, heads, hd, ld: ag.RopeFn.apply(qkv, cos, sin, rows, T, heads, hd, ld))
     attn_packed = staticmethod(lambda qkv, batch, n, heads, hd, causal=False, key_mask=None:
-                               ag.PackedAttnFn.apply(qkv, batch, n, heads, hd, causal, key_mask))
+                               ag.PackedAttnFn.apply(qkv, batch, n, heads, hd, causal, key_mask, None))
+    rope_attn = staticmethod(ag.rope_attention)
     swiglu = staticmethod(lambda gu, inter: ag.SwigluFn.apply(gu, inter))
-    embed_splice = staticmethod(lambda ids, emb, feats, P, fs: ag.EmbedSpliceFn.apply(ids, emb, feats, P, fs))
+    embed_splice = staticmethod(lambda ids, emb, feats, P, fs, tok=None: ag.EmbedSpliceFn.apply(ids, emb, feats, P, fs, tok))
     gather_rows = staticmethod(lambda x, idx: ag.GatherRowsFn.apply(x, idx))
     maskpool = staticmethod(lambda feat, segs, g, S: ag.MaskPoolFn.apply(feat, segs, g, S))
-    lora_qkv = staticmethod(lambda x, wqkv, aq, bq, av, bv, s, wqkv_t=None, cache=None, key=None:
-                            ag.LoraQKVFn.apply(x, wqkv, aq, bq, av, bv, s, wqkv_t, cache, key))
+    lora_qkv = staticmethod(lambda x, wqkv, aq, bq, av, bv, s, wqkv_t=None, drop=None:
+                            ag.LoraQKVFn.apply(x, wqkv, aq, bq, av, bv, s, wqkv_t, drop))
     ce = staticmethod(lambda logits, labels: ag.CELossFn.apply(logits, labels))
     align_reg = staticmethod(lambda e, t, pred, gt_iou, gt_iop: ag.AlignRegFn.apply(e, t, pred, gt_iou, gt_iop))
     bcast_add = staticmethod(lambda s, add, Cn, K: ag.BcastAddFn.apply(s, add, Cn, K))
     cross_attn_1q = staticmethod(lambda q, kv, Cn, K, heads, hd: ag.CrossAttn1QFn.apply(q, kv, Cn, K, heads, hd))
+
+
+class BatchPlan:
+    """Index plumbing of one batch, computed on the host once (`TrainableMixin.make_plan`): python structure (`sig`: everything that
+    shapes the kernel sequence) + small device index tensors (`tensors`: their VALUES may change from batch to batch while `sig`
+    stays the same, which is what lets a captured hipGraph be replayed on new data after `copy_tensors_from`)."""
+
+    def __init__(self):
+        self.tensors = {}
+        self.sig = None
+
+    def __getattr__(self, k):
+        t = self.__dict__.get("tensors", {})
+        if k in t:
+            return t[k]
+        raise AttributeError(k)
+
+    def copy_tensors_from(self, other):
+        assert self.sig == other.sig, "batch structure changed: capture a new graph"
+        for k, v in other.tensors.items():
+            if v is not None:
+                self.tensors[k].copy_(v, non_blocking=True)
 
 
 class TrainableMixin:
@@ -112,10 +142,12 @@ class TrainableMixin:
         return t.data if isinstance(t, torch.nn.Parameter) else t
 
     def _wcat(self, fused, members, F):
-        """Fused [q|k|v]-style operand: the single backing tensor, or a cat of the member Parameters when they train."""
-        if F.grad and any(self.params.flat[m].requires_grad for m in members):
+        """Fused [q|k|v]-style operand: the single backing tensor (frozen members, or arena mode where its gradient block is fused
+        too), else a cat of the member Parameters so that plain autograd reaches each of them."""
+        buf = self.params.flat[fused]
+        if F.grad and ag.g32_of(buf) is None and any(self.params.flat[m].requires_grad for m in members):
             return torch.cat([self.params.flat[m] for m in members], 0)
-        return self.params.flat[fused]
+        return buf
 
     def _wT(self, name, F):
         """Cached [K, N] transposed copy of a FROZEN [N, K] weight (one-time re-layout): lets dX = dY W use the fast TN kernel."""
@@ -138,6 +170,84 @@ class TrainableMixin:
         names_b = [p + f"{n}_proj.bias" for n in "qkv"]
         return self._wcat(p + "qkv.weight", names_w, F), self._wcat(p + "qkv.bias", names_b, F)
 
+    def _kv_wb(self, pc, F, D):
+        """k|v projection of a head attention as ONE operand (rows D.. of the fused q|k|v tensor)."""
+        views = self.__dict__.get("_arena_views", {})
+        if F.grad and (pc + "kv.weight") in views:                                   # arena mode: slice views carrying their arena block
+            return views[pc + "kv.weight"], views[pc + "kv.bias"]
+        if F.grad and self.params.flat[pc + "k_proj.weight"].requires_grad:
+            return (torch.cat([self.params.flat[pc + "k_proj.weight"], self.params.flat[pc + "v_proj.weight"]], 0),
+                    torch.cat([self.params.flat[pc + "k_proj.bias"], self.params.flat[pc + "v_proj.bias"]], 0))
+        return self.params[pc + "qkv.weight"][D:], self.params[pc + "qkv.bias"][D:]
+
+    # LoRA dropout state (peft lora_dropout, training.py:91): device {seed, offset}; the trainer advances `offset` every micro-step
+    def dropout_state(self):
+        st = self.__dict__.get("_rng_state")
+        if st is None:
+            st = self.__dict__["_rng_state"] = torch.tensor([0x5EED, 0], device=self.device_, dtype=torch.int64)
+        return st
+
+    def set_dropout_seed(self, seed, offset=0):
+        self.dropout_state().copy_(torch.tensor([int(seed), int(offset)], dtype=torch.int64))
+
+    def advance_dropout(self):
+        self.dropout_state()[1:].add_(1)
+
+    # ------------------------------------------------------------------------------------------------ batch plan
+    def make_plan(self, input_ids, labels, attention_masks, offset, sam_segs_list=None, inference=False, **_):
+        """Host-side index plumbing of a batch -> BatchPlan (the only place that synchronises with the device)."""
+        c = self.config
+        dev = self.device_
+        ids = input_ids.detach().cpu()
+        N, L = ids.shape
+        Pn = c.n_img_tokens
+        T = L - 1 + Pn
+        off = [int(v) for v in (offset.tolist() if torch.is_tensor(offset) else offset)]
+        B = len(off) - 1
+        is_img = ids == IMAGE_TOKEN_INDEX
+        assert bool((is_img.sum(1) == 1).all()), "exactly one <image> per sequence (the reference's seg_token_mask assumes it too)"
+        pos = is_img.int().argmax(1)
+        am = attention_masks.detach().cpu().bool()
+        key_mask = torch.cat([torch.ones((N, T - L), dtype=torch.bool), am], 1).to(torch.uint8)
+        if inference:
+            clip_index = torch.zeros((N,), dtype=torch.int64)                               # LISA.py:271-276: one image, expanded
+        else:
+            clip_index = torch.tensor([i for i in range(B) for _ in range(off[i + 1] - off[i])], dtype=torch.int64)   # LISA.py:293-303
+        new_labels = None
+        if labels is not None:                                                          # label splice (llava_arch.py:242-251)
+            lab = labels.detach().cpu()
+            ar = torch.arange(T)[None]
+            src = torch.where(ar < pos[:, None], ar, (ar - Pn + 1).clamp(min=0))
+            new_labels = torch.gather(lab, 1, src.clamp(max=L - 1))
+            new_labels = torch.where((ar >= pos[:, None]) & (ar < pos[:, None] + Pn), torch.full_like(new_labels, IGNORE_INDEX), new_labels)
+        tok = ag.embed_token_index(ids, Pn)
+        # [SEG] rows: mask shifted by one and by the P-1 extra image tokens (LISA.py:254-266)
+        segm = torch.zeros((N, T), dtype=torch.bool)
+        segm[:, Pn - 1:Pn - 1 + L - 1] = ids[:, 1:] == self.seg_token_idx
+        seg_idx = segm.view(-1).nonzero().flatten()
+        cnt = [0] + segm.sum(1).cumsum(0).tolist()
+        seg_off = [int(cnt[o]) for o in off]
+        rounds = [seg_off[b + 1] - seg_off[b] for b in range(B)]
+        plan = BatchPlan()
+        segs_shapes = tuple(tuple(s.shape) for s in sam_segs_list) if sam_segs_list is not None else None
+        plan.sig = (N, L, T, B, tuple(off), tuple(seg_off), bool(inference), labels is not None, segs_shapes)
+        plan.N, plan.L, plan.T, plan.B, plan.off, plan.seg_off, plan.rounds = N, L, T, B, off, seg_off, rounds
+        # groups of images with the same proposal count (the head runs once per group), and the loss weights 1 / (R + 1e-8) of
+        # every (image, round) item in group order (LISA.py:452-455)
+        plan.groups, loss_w = {}, {}
+        if sam_segs_list is not None:
+            for b in range(B):
+                if rounds[b] > 0:
+                    plan.groups.setdefault(int(sam_segs_list[b].shape[0]), []).append(b)
+            plan.groups = {K: plan.groups[K] for K in sorted(plan.groups)}
+            for K, members in plan.groups.items():
+                loss_w[K] = torch.tensor([1.0 / (rounds[b] + 1e-8) for b in members for _ in range(rounds[b])], dtype=torch.float32)
+        plan.tensors = dict(key_mask=key_mask.contiguous().to(dev), clip_index=clip_index.to(dev), tok_index=tok.reshape(-1).to(dev),
+                            seg_idx=seg_idx.to(dev), new_labels=None if new_labels is None else new_labels.contiguous().to(dev))
+        for K, w in loss_w.items():
+            plan.tensors[f"loss_w{K}"] = w.to(dev)
+        return plan
+
     # ------------------------------------------------------------------------------------------------ language
     def _llama(self, embeds, key_mask_u8, F):
         """32 x [RMSNorm -> q|k|v GEMM (+LoRA) -> RoPE -> causal attention -> o_proj(+res) -> RMSNorm -> gate|up GEMM ->
@@ -147,8 +257,10 @@ class TrainableMixin:
         c = self.config.llama
         N, T, H = embeds.shape
         x = embeds.reshape(N * T, H)
-        cos, sin = self._rope(T)
+        rope = self._rope(T)
         s = c.lora_alpha / c.lora_r if c.lora_r > 0 else 0.0
+        p_drop = c.lora_dropout if (F.grad and self.training) else 0.0
+        rng = self.dropout_state() if p_drop > 0 else None
         for i in range(c.layers):
             p = f"model.layers.{i}."
             h = F.norm(x, self._w(p + "input_layernorm.weight", F), None, c.eps, True)
@@ -157,12 +269,11 @@ class TrainableMixin:
                 qkv = F.lora_qkv(h, self._w(p + "qkv", F), self._w(lp + "q_proj.lora_A.default.weight", F),
                                  self._w(lp + "q_proj.lora_B.default.weight", F), self._w(lp + "v_proj.lora_A.default.weight", F),
                                  self._w(lp + "v_proj.lora_B.default.weight", F), s, self._wT(p + "qkv", F),
-                                 self.__dict__.setdefault("_lora_ext", {}), i)
+                                 (rng, i, p_drop) if p_drop > 0 else None)
             else:
                 mem = [p + f"self_attn.{n}_proj.weight" for n in "qkv"]
                 qkv = F.linear(h, self._wcat(p + "qkv", mem, F), None, ops.ACT_NONE, None, self._wT(p + "qkv", F) if self._frozen(mem) else None)
-            qkv = F.rope(qkv, cos, sin, N * T, T, 2 * c.heads, c.head_dim, 3 * H)
-            a = F.attn_packed(qkv, N, T, c.heads, c.head_dim, causal=True, key_mask=key_mask_u8)
+            a = F.rope_attn(qkv, rope, N, T, c.heads, c.head_dim, True, key_mask_u8)
             x = F.linear(a, self._w(p + "self_attn.o_proj.weight", F), None, ops.ACT_NONE, x, self._wT(p + "self_attn.o_proj.weight", F))
             h = F.norm(x, self._w(p + "post_attention_layernorm.weight", F), None, c.eps, True)
             mem = [p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"]
@@ -170,32 +281,23 @@ class TrainableMixin:
             x = F.linear(F.swiglu(gu, c.inter), self._w(p + "mlp.down_proj.weight", F), None, ops.ACT_NONE, x, self._wT(p + "mlp.down_proj.weight", F))
         return F.norm(x, self._w("model.norm.weight", F), None, c.eps, True).view(N, T, H)
 
-    def llava_forward(self, images_clip, attention_mask, input_ids, labels=None, want_logits=True):
+    def llava_forward(self, images_clip, input_ids, plan, want_logits=True):
         """LlavaLlamaForCausalLM.forward (llava_llama.py:55-135): splice, decoder stack, lm_head, shifted CE.
-        -> (ce_loss | None, logits | None, final-norm hidden [N,T,H])."""
+        `images_clip` already holds one image per sequence.  -> (ce_loss | None, logits | None, final-norm hidden [N,T,H])."""
         c = self.config
         F = self._F()
-        N, L = input_ids.shape
-        n_img = (input_ids == IMAGE_TOKEN_INDEX).sum(1)
-        assert bool((n_img == 1).all()), "exactly one <image> per sequence (the reference's seg_token_mask assumes it too)"
+        N, T = plan.N, plan.T
         Pn = c.n_img_tokens
         with torch.no_grad():                                              # CLIP + mm_projector are frozen
             proj = self.encode_images(images_clip)                         # [N*(P+1), H]
         H = c.llama.hidden
-        embeds = F.embed_splice(input_ids.contiguous(), self._w("model.embed_tokens.weight", F), proj[1:], Pn, (Pn + 1) * H)
-        T = L - 1 + Pn
-        mask = torch.cat([torch.ones((N, T - L), dtype=torch.bool, device=input_ids.device), attention_mask.bool()], 1)
-        hidden = self._llama(embeds, mask.to(torch.uint8).contiguous(), F)
+        embeds = F.embed_splice(input_ids.contiguous(), self._w("model.embed_tokens.weight", F), proj[1:], Pn, (Pn + 1) * H, plan.tok_index)
+        hidden = self._llama(embeds, plan.key_mask, F)
         logits, loss = None, None
-        if want_logits or labels is not None:
+        if want_logits or plan.new_labels is not None:
             logits = F.linear(hidden.view(N * T, H), self._w("lm_head.weight", F)).view(N, T, -1)
-        if labels is not None:
-            pos = (input_ids == IMAGE_TOKEN_INDEX).int().argmax(1)          # index plumbing for the label splice
-            ar = torch.arange(T, device=labels.device)[None]
-            src = torch.where(ar < pos[:, None], ar, (ar - Pn + 1).clamp(min=0))
-            new_labels = torch.gather(labels, 1, src.clamp(max=L - 1))
-            new_labels = torch.where((ar >= pos[:, None]) & (ar < pos[:, None] + Pn), torch.full_like(new_labels, IGNORE_INDEX), new_labels)
-            loss = F.ce(logits, new_labels.contiguous())
+        if plan.new_labels is not None:
+            loss = F.ce(logits, plan.new_labels)
         return loss, logits, hidden
 
     # ------------------------------------------------------------------------------------------------------ head
@@ -231,11 +333,7 @@ class TrainableMixin:
             # image -> token: q = text (1 query per conversation), k = v = mask features
             pc = p + "cross_attn_image_to_token."
             q = lin(t, pc + "q_proj")
-            if F.grad and self.params.flat[pc + "k_proj.weight"].requires_grad:
-                kvw = torch.cat([self.params.flat[pc + "k_proj.weight"], self.params.flat[pc + "v_proj.weight"]], 0)
-                kvb = torch.cat([self.params.flat[pc + "k_proj.bias"], self.params.flat[pc + "v_proj.bias"]], 0)
-            else:
-                kvw, kvb = self.params[pc + "qkv.weight"][D:], self.params[pc + "qkv.bias"][D:]
+            kvw, kvb = self._kv_wb(pc, F, D)
             kv = F.linear(s, kvw, kvb)                                                      # [C*K, 2D] = k | v
             o = F.cross_attn_1q(q, kv, Cn, K, nh, hd)
             t = self._ln(lin(o, pc + "out_proj", res=t), p + "norm4", F)
@@ -254,8 +352,12 @@ class TrainableMixin:
             x, n_tok, (gh, gw) = self._dinov2_tokens(images)
         assert gh == gw
         d = self.prepare()
-        w = self._w("model.lisa_dino_conv.weight", F)
-        w = w.reshape(c.out_dim, c.dino.dim) if F.grad else d["dino.conv_w"]
+        views = self.__dict__.get("_arena_views", {})
+        if F.grad and "model.lisa_dino_conv.weight2d" in views:
+            w = views["model.lisa_dino_conv.weight2d"]
+        else:
+            w = self._w("model.lisa_dino_conv.weight", F)
+            w = w.reshape(c.out_dim, c.dino.dim) if F.grad else d["dino.conv_w"]
         y = F.linear(x, w, self._w("model.lisa_dino_conv.bias", F))                          # 1x1 conv (LISA.py:245)
         return y, n_tok, 1, gh
 
@@ -264,42 +366,34 @@ class TrainableMixin:
 
     def model_forward(self, images, images_clip, input_ids, labels, attention_masks, offset, masks_list=None, label_list=None,
                       resize_list=None, sam_segs_list=None, sam_ious_list=None, sam_iops_list=None, inference=False,
-                      return_aux=False, **kwargs):
+                      return_aux=False, plan=None, **kwargs):
+        """Same arguments and return keys as the reference (model/LISA.py:225-474).  `plan` (optional): the BatchPlan of this batch
+        (`make_plan`); without it the plan is built here, which synchronises with the device once."""
+        if plan is None:
+            plan = self.make_plan(input_ids, None if inference else labels, attention_masks, offset, sam_segs_list, inference)
         if inference:
             with torch.no_grad():
-                return self._model_forward(images, images_clip, input_ids, labels, attention_masks, offset, masks_list, sam_segs_list,
-                                           sam_ious_list, sam_iops_list, True, return_aux)
-        return self._model_forward(images, images_clip, input_ids, labels, attention_masks, offset, masks_list, sam_segs_list, sam_ious_list,
-                                   sam_iops_list, False, return_aux)
+                return self._model_forward(images, images_clip, input_ids, masks_list, sam_segs_list, sam_ious_list, sam_iops_list, True,
+                                           return_aux, plan)
+        return self._model_forward(images, images_clip, input_ids, masks_list, sam_segs_list, sam_ious_list, sam_iops_list, False, return_aux, plan)
 
-    def _model_forward(self, images, images_clip, input_ids, labels, attention_masks, offset, masks_list, sam_segs_list, sam_ious_list,
-                       sam_iops_list, inference, return_aux):
+    def _model_forward(self, images, images_clip, input_ids, masks_list, sam_segs_list, sam_ious_list, sam_iops_list, inference, return_aux, plan):
         c = self.config
         F = self._F()
         images, images_clip = images.to(BF16), images_clip.to(BF16)
         feat, rows_per_img, row0, g = self.visual_features_cl(images.contiguous(), F)
         B = images.shape[0]
-        assert B == len(offset) - 1
-        Pn = c.n_img_tokens
-        off = offset.tolist()
+        assert B == plan.B
         if inference:
             assert images_clip.shape[0] == 1                                             # LISA.py:271
-            clip_in = images_clip.expand(input_ids.shape[0], -1, -1, -1).contiguous()
-            ce, logits, hidden = self.llava_forward(clip_in, attention_masks, input_ids, None, want_logits=return_aux)
-        else:
-            reps = torch.tensor([off[i + 1] - off[i] for i in range(B)], device=images_clip.device)
-            clip_in = images_clip.repeat_interleave(reps, 0).contiguous()                # LISA.py:293-303
-            ce, logits, hidden = self.llava_forward(clip_in, attention_masks, input_ids, labels)
+        clip_in = images_clip.index_select(0, plan.clip_index)                          # one CLIP image per sequence (LISA.py:271-303)
+        ce, logits, hidden = self.llava_forward(clip_in.contiguous(), input_ids, plan, want_logits=return_aux or not inference)
 
-        # [SEG] rows: mask shifted by one and by the P-1 extra image tokens (LISA.py:254-266); gather first, then the MLP
+        # [SEG] rows: gather first, then the MLP (identical to the reference's MLP-on-everything + boolean gather, LISA.py:318-323)
         N, T, H = hidden.shape
-        segm = torch.zeros((N, T), dtype=torch.bool, device=input_ids.device)
-        segm[:, Pn - 1:Pn - 1 + input_ids.shape[1] - 1] = input_ids[:, 1:] == self.seg_token_idx
-        idx = segm.view(-1).nonzero().flatten()
-        seg_off = [0] + segm.sum(1).cumsum(0).tolist()
-        seg_off = [seg_off[o] for o in off]
-        if idx.numel():
-            hs = F.gather_rows(hidden.view(N * T, H), idx)
+        seg_off = plan.seg_off
+        if plan.seg_idx.numel():
+            hs = F.gather_rows(hidden.view(N * T, H), plan.seg_idx)
             hs = F.linear(hs, self._w("model.text_hidden_fcs.0.0.weight", F), self._w("model.text_hidden_fcs.0.0.bias", F), ops.ACT_RELU)
             pred = F.linear(hs, self._w("model.text_hidden_fcs.0.2.weight", F), self._w("model.text_hidden_fcs.0.2.bias", F))
         else:
@@ -310,17 +404,16 @@ class TrainableMixin:
         # weights are shared, so its rows (image, conversation, proposal) are stacked into one matrix (the reference loops over
         # images, LISA.py:355-391; per-image launches of M = K-row GEMMs leave 250 of the 256 CUs idle)
         ious, embs = [None] * B, [None] * B
-        pooled_of, groups = {}, {}
+        pooled_of, pool_groups = {}, {}
         segs_of = {}
         for b in range(B):
-            Cn = pred_embeddings[b].shape[0]
-            if Cn == 0:
+            if plan.rounds[b] == 0:
                 if not inference:
                     raise ValueError("number of rounds = 0")                          # LISA.py:435-437
                 continue
             segs_of[b] = sam_segs_list[b].to(BF16).contiguous()
-            groups.setdefault(tuple(segs_of[b].shape), []).append(b)
-        for (K, S, _), members in groups.items():
+            pool_groups.setdefault(tuple(segs_of[b].shape), []).append(b)
+        for (K, S, _), members in pool_groups.items():
             if len(members) > 1 and not (F.grad and feat.requires_grad) and members == list(range(members[0], members[0] + len(members))):
                 # frozen feature map (SAM backbone): all images of the group pooled by one strided-batched GEMM
                 pooled = ops.maskpool_batched(feat[members[0] * rows_per_img:], rows_per_img, row0, [segs_of[b] for b in members], g, S)
@@ -330,20 +423,18 @@ class TrainableMixin:
                 for b in members:
                     fb = feat[b * rows_per_img + row0: b * rows_per_img + row0 + g * g]
                     pooled_of[b] = F.maskpool(fb, segs_of[b], g, S)
-        groups = {K: [b for (k2, _, _), ms in groups.items() if k2 == K for b in ms] for K in sorted({k[0] for k in groups})}
         group_out = {}
-        for K, members in groups.items():
+        for K, members in plan.groups.items():
             if len(members) == 1:
                 b = members[0]
                 iou, emb = self._mask_head(pooled_of[b], pred_embeddings[b], F)
             else:
-                s0 = torch.cat([pooled_of[b].repeat(pred_embeddings[b].shape[0], 1) if pred_embeddings[b].shape[0] > 1 else pooled_of[b]
-                                for b in members], 0)
+                s0 = torch.cat([pooled_of[b].repeat(plan.rounds[b], 1) if plan.rounds[b] > 1 else pooled_of[b] for b in members], 0)
                 iou, emb = self._mask_head(s0, torch.cat([pred_embeddings[b] for b in members], 0), F, stacked=True)
             group_out[K] = (members, iou, emb)
             r0 = 0
             for b in members:
-                Cn = pred_embeddings[b].shape[0]
+                Cn = plan.rounds[b]
                 ious[b] = iou[r0 * K:(r0 + Cn) * K].view(Cn, K)
                 embs[b] = emb[r0 * K:(r0 + Cn) * K].view(Cn, K, -1)
                 r0 += Cn
@@ -360,12 +451,12 @@ class TrainableMixin:
         align = torch.zeros((), device=hidden.device, dtype=torch.float32)
         reg = torch.zeros((), device=hidden.device, dtype=torch.float32)
         for K, (members, iou_s, emb_s) in group_out.items():
-            t_s = torch.cat([pred_embeddings[b] for b in members], 0).contiguous()
+            t_s = torch.cat([pred_embeddings[b] for b in members], 0).contiguous() if len(members) > 1 else pred_embeddings[members[0]].contiguous()
             Rg = t_s.shape[0]
             gi = torch.cat([sam_ious_list[b].float().reshape(-1, K) for b in members], 0).contiguous()
             gp = torch.cat([sam_iops_list[b].float().reshape(-1, K) for b in members], 0).contiguous()
             o = F.align_reg(emb_s.reshape(Rg, K, -1), t_s, iou_s.reshape(Rg, K), gi, gp)                    # [Rg, 2]
-            w = torch.cat([torch.full((pred_embeddings[b].shape[0],), 1.0 / (pred_embeddings[b].shape[0] + 1e-8)) for b in members]).to(o.device)
+            w = plan.tensors[f"loss_w{K}"]
             align = align + (o[:, 0] * w).sum()
             reg = reg + (o[:, 1] * w).sum()
         align, reg = align / B, reg / B

@@ -88,11 +88,11 @@ def splice(sd, cfg, input_ids, attention_mask, labels, image_features):
     return embeds, mask, new_labels
 
 
-def llava_forward(sd, cfg, images_clip, attention_mask, input_ids, labels=None):
+def llava_forward(sd, cfg, images_clip, attention_mask, input_ids, labels=None, dropout_state=None):
     """-> (loss | None, logits [N,T,V], final-norm hidden [N,T,H])."""
     feats = encode_images(sd, cfg, images_clip)
     embeds, mask, new_labels = splice(sd, cfg, input_ids, attention_mask, labels, feats)
-    hs = _llama.llama_model(sd, "model.", embeds, mask, cfg.llama)
+    hs = _llama.llama_model(sd, "model.", embeds, mask, cfg.llama, dropout_state)
     logits = F.linear(hs[-1], sd["lm_head.weight"])
     loss = _llama.shifted_ce(logits, new_labels, logits.shape[-1]) if labels is not None else None
     return loss, logits, hs[-1]
@@ -121,7 +121,8 @@ def visual_features(sd, cfg, images):
 
 def model_forward(sd, cfg: LisaCfg, images, images_clip, input_ids, labels, attention_masks, offset,
                   sam_segs_list, sam_ious_list=None, sam_iops_list=None, masks_list=None, inference=False,
-                  return_aux=False):
+                  return_aux=False, dropout_state=None):
+    """dropout_state = (seed, offset) turns the LoRA dropout on (training-mode forward, training.py:91); None = eval."""
     feats = visual_features(sd, cfg, images)
     B = feats.shape[0]
     assert B == len(offset) - 1
@@ -134,7 +135,7 @@ def model_forward(sd, cfg: LisaCfg, images, images_clip, input_ids, labels, atte
     else:
         reps = (offset[1:] - offset[:-1]).tolist()
         clip_in = torch.cat([images_clip[i:i + 1].expand(r, -1, -1, -1) for i, r in enumerate(reps)], 0)
-        ce, logits, hidden = llava_forward(sd, cfg, clip_in, attention_masks, input_ids, labels)
+        ce, logits, hidden = llava_forward(sd, cfg, clip_in, attention_masks, input_ids, labels, dropout_state)
 
     h = F.relu(F.linear(hidden, sd["model.text_hidden_fcs.0.0.weight"], sd["model.text_hidden_fcs.0.0.bias"]))
     h = F.linear(h, sd["model.text_hidden_fcs.0.2.weight"], sd["model.text_hidden_fcs.0.2.bias"])

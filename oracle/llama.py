@@ -26,6 +26,7 @@ class LlamaCfg:
     theta: float = 10000.0
     lora_r: int = 0          # 0 = no LoRA
     lora_alpha: float = 16.0
+    lora_dropout: float = 0.0   # reference: 0.05 (training.py:91); applied only when a dropout state is passed (training mode)
 
     @property
     def head_dim(self):
@@ -54,13 +55,18 @@ def apply_rope(x, cos, sin):
     return (x.float() * cos + rot.float() * sin).to(x.dtype)
 
 
-def lora_linear(x, sd, name, cfg):
-    """y = x W^T (+ (alpha/r) B A x when LoRA tensors exist; dropout = identity at eval)."""
+def lora_linear(x, sd, name, cfg, drop=None):
+    """y = x W^T (+ (alpha/r) B A dropout(x) when LoRA tensors exist; dropout = identity at eval).
+    drop = (seed, offset, stream) of the counter-based mask (oracle/dropout.py) or None."""
     y = F.linear(x, sd[name + ".weight"])
     a = sd.get(name + ".lora_A.default.weight")
     if a is not None and cfg.lora_r > 0:
         b = sd[name + ".lora_B.default.weight"]
-        y = y + (cfg.lora_alpha / cfg.lora_r) * F.linear(F.linear(x, a), b)
+        xd = x
+        if drop is not None and cfg.lora_dropout > 0:
+            from . import dropout as _do
+            xd = _do.apply(x.reshape(-1, x.shape[-1]), drop[0], drop[1], drop[2], cfg.lora_dropout).reshape(x.shape)
+        y = y + (cfg.lora_alpha / cfg.lora_r) * F.linear(F.linear(xd, a), b)
     return y
 
 
@@ -74,13 +80,16 @@ def additive_mask(attention_mask, T, dtype, device):
     return m
 
 
-def decoder_layer(sd, p, h, mask, cos, sin, cfg):
+def decoder_layer(sd, p, h, mask, cos, sin, cfg, drop=None):
+    """drop = (seed, offset, layer index) -> dropout streams 2 layer (q_proj) and 2 layer + 1 (v_proj)."""
     N, T, H = h.shape
     nh, hd = cfg.heads, cfg.head_dim
     x = rmsnorm(h, sd[p + "input_layernorm.weight"], cfg.eps)
-    q = lora_linear(x, sd, p + "self_attn.q_proj", cfg).view(N, T, nh, hd).transpose(1, 2)
+    dq = None if drop is None else (drop[0], drop[1], 2 * drop[2])
+    dv = None if drop is None else (drop[0], drop[1], 2 * drop[2] + 1)
+    q = lora_linear(x, sd, p + "self_attn.q_proj", cfg, dq).view(N, T, nh, hd).transpose(1, 2)
     k = lora_linear(x, sd, p + "self_attn.k_proj", cfg).view(N, T, nh, hd).transpose(1, 2)
-    v = lora_linear(x, sd, p + "self_attn.v_proj", cfg).view(N, T, nh, hd).transpose(1, 2)
+    v = lora_linear(x, sd, p + "self_attn.v_proj", cfg, dv).view(N, T, nh, hd).transpose(1, 2)
     q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
     s = q @ k.transpose(-1, -2) / math.sqrt(hd) + mask
     s = torch.max(s, torch.tensor(torch.finfo(s.dtype).min, dtype=s.dtype))
@@ -93,8 +102,9 @@ def decoder_layer(sd, p, h, mask, cos, sin, cfg):
     return h + F.linear(F.silu(g) * u, sd[p + "mlp.down_proj.weight"])
 
 
-def llama_model(sd, pfx, inputs_embeds, attention_mask, cfg):
-    """Returns the HF `hidden_states` tuple: input of each layer, then the final-norm output."""
+def llama_model(sd, pfx, inputs_embeds, attention_mask, cfg, dropout_state=None):
+    """Returns the HF `hidden_states` tuple: input of each layer, then the final-norm output.
+    dropout_state = (seed, offset): LoRA dropout active (training mode), None = eval."""
     N, T, _ = inputs_embeds.shape
     cos, sin = rope_tables(T, cfg.head_dim, cfg.theta, inputs_embeds.device)
     mask = additive_mask(attention_mask, T, inputs_embeds.dtype, inputs_embeds.device)
@@ -102,7 +112,7 @@ def llama_model(sd, pfx, inputs_embeds, attention_mask, cfg):
     hs = []
     for i in range(cfg.layers):
         hs.append(h)
-        h = decoder_layer(sd, f"{pfx}layers.{i}.", h, mask, cos, sin, cfg)
+        h = decoder_layer(sd, f"{pfx}layers.{i}.", h, mask, cos, sin, cfg, None if dropout_state is None else (dropout_state[0], dropout_state[1], i))
     hs.append(rmsnorm(h, sd[pfx + "norm.weight"], cfg.eps))
     return hs
 

@@ -144,19 +144,23 @@ def check_autograd_ops():
         p = torch.softmax((qq @ kk.transpose(-1, -2)) / math.sqrt(hd), -1)
         return (p @ vv).transpose(1, 2).reshape(Cn, D)
     out += _grads(ca_ref, lambda q, kv: ag.CrossAttn1QFn.apply(q, kv, Cn, K, nh, hd), [q, kv], ["attn head 1q", "q", "kv"])
-    # rope
+    # RoPE + causal attention as ONE autograd node (the inverse rotation runs on the node's own gradient buffer)
     T, nh, hd, N = 19, 2, 128, 2
-    qkv = rnd(N * T, 3 * nh * hd, seed=14)
+    qkv = rnd(N * T, 3 * nh * hd, seed=14, scale=0.5)
     inv = 1.0 / (10000 ** (torch.arange(0, hd, 2).float() / hd))
     ang = torch.outer(torch.arange(T).float(), inv)
     cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
 
-    def rope_ref(t):
+    def rope_attn_ref(t):
         x = t.view(N, T, 3, nh, hd)
         c2, s2 = torch.cat([cos, cos], -1)[None, :, None], torch.cat([sin, sin], -1)[None, :, None]
         rot = lambda u: torch.cat([-u[..., hd // 2:], u[..., :hd // 2]], -1)
-        return torch.stack([x[:, :, 0] * c2 + rot(x[:, :, 0]) * s2, x[:, :, 1] * c2 + rot(x[:, :, 1]) * s2, x[:, :, 2]], 2).reshape(N * T, -1)
-    out += _grads(rope_ref, lambda t: ag.RopeFn.apply(t.clone(), cos.to(DEV), sin.to(DEV), N * T, T, 2 * nh, hd, 3 * nh * hd), [qkv], ["rope", "qkv"])
+        q, k, v = (x[:, :, 0] * c2 + rot(x[:, :, 0]) * s2).transpose(1, 2), (x[:, :, 1] * c2 + rot(x[:, :, 1]) * s2).transpose(1, 2), x[:, :, 2].transpose(1, 2)
+        sc = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+        p = torch.softmax(sc.masked_fill(~torch.ones(T, T, dtype=torch.bool).tril()[None, None], -1e30), -1)
+        return (p @ v).transpose(1, 2).reshape(N * T, nh * hd)
+    rope_tabs = (cos.to(DEV), sin.to(DEV), (-sin).to(DEV))
+    out += _grads(rope_attn_ref, lambda t: ag.rope_attention(t.clone(), rope_tabs, N, T, nh, hd, True, None), [qkv], ["rope+attn", "qkv"])
     # CE
     Nn, T, V = 2, 7, 1000
     logits = rnd(Nn, T, V, seed=15, scale=2.0)
@@ -200,6 +204,126 @@ def check_autograd_ops():
     out += _grads(pool_ref, lambda f: ag.MaskPoolFn.apply(f, segs.to(DEV), g, S), [feat], ["maskpool", "feat"])
     s, add = rnd(2 * 10, 64, seed=26), rnd(2, 64, seed=27)
     out += _grads(lambda s, a: s + a.repeat_interleave(10, 0), lambda s, a: ag.BcastAddFn.apply(s, a, 2, 10), [s, add], ["bcast_add", "s", "add"])
+    return out
+
+
+def _oracle_drop(x, stream, st, p):
+    from oracle import dropout as odrop
+    return odrop.apply(x, st[0], st[1], stream, p)
+
+
+def check_lora_paths():
+    """The LoRA'd qkv projection on the paths the training step really takes: rank-8 kernels + extension K-tile with the
+    pre-transposed frozen weight (dX in ONE GEMM), the same under dropout (masked dX through lora_apply), gradients accumulated
+    into fp32 arena views over two backward passes, at a shape that dispatches to the ping-pong GEMM."""
+    out = []
+    H, r, M, s_ = 512, 8, 700, 2.0
+    x, wq = rnd(M, H, seed=16), rnd(3 * H, H, seed=17, scale=1 / 22)
+    aq, bq, av, bv = rnd(r, H, seed=18, scale=1 / 22), rnd(H, r, seed=19, scale=0.3), rnd(r, H, seed=20, scale=1 / 22), rnd(H, r, seed=21, scale=0.3)
+    wqd = wq.to(DEV)
+    wqt = wqd.t().contiguous()
+    st = (0xABCDEF12345, 3)
+    rng = torch.tensor(list(st), device=DEV, dtype=torch.int64)
+    for p_drop in (0.0, 0.25):
+        def lora_ref(x, aq, bq, av, bv, p_drop=p_drop):
+            y = F.linear(x, wq.float())
+            xq = _oracle_drop(x, 2 * 5, st, p_drop) if p_drop > 0 else x
+            xv = _oracle_drop(x, 2 * 5 + 1, st, p_drop) if p_drop > 0 else x
+            dq, dv = s_ * F.linear(F.linear(xq, aq), bq), s_ * F.linear(F.linear(xv, av), bv)
+            return torch.cat([y[:, :H] + dq, y[:, H:2 * H], y[:, 2 * H:] + dv], 1)
+        drop = (rng, 5, p_drop) if p_drop > 0 else None
+        tag = f"lora qkv ext-tile{' + dropout' if p_drop else ''}"
+        out += _grads(lora_ref, lambda x, aq, bq, av, bv, drop=drop: ag.LoraQKVFn.apply(x, wqd, aq, bq, av, bv, s_, wqt, drop), [x, aq, bq, av, bv],
+                      [tag, "x", "Aq", "Bq", "Av", "Bv"])
+        # arena mode: two backward passes accumulate 2 x the gradient in fp32, nothing lands in .grad
+        xs = [t.float().clone().requires_grad_(True) for t in (x, aq, bq, av, bv)]
+        y = lora_ref(*xs)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(BF)
+        y.backward(gy.float())
+        prm = [t.to(DEV).clone().requires_grad_(True) for t in (aq, bq, av, bv)]
+        for t in prm:
+            t._g32 = torch.zeros(t.shape, device=DEV, dtype=torch.float32)
+        for _ in range(2):
+            xd = x.to(DEV).clone().requires_grad_(True)
+            ag.LoraQKVFn.apply(xd, wqd, *prm, s_, wqt, drop).backward(gy.to(DEV))
+        for n, t, ref in zip(("Aq", "Bq", "Av", "Bv"), prm, xs[1:]):
+            assert t.grad is None
+            out.append((f"{tag} arena d{n} (2 passes)", err(t._g32 / 2, ref.grad), rel_tol(ref.grad, 2.0 ** -6)))
+    # the bit-exact mask: lora_down with all-ones weights row 0 counts the kept elements of every row
+    Mm, Hh, p_drop = 37, 256, 0.05
+    from oracle import dropout as odrop
+    ones = torch.ones(Mm, Hh).to(BF)
+    wsel = torch.zeros(8, Hh).to(BF)
+    wsel[0] = 1
+    got = ops.lora_down(ones.to(DEV), wsel.to(DEV), drop=(rng, 9, p_drop))[:, 0].float().cpu()
+    keep = odrop.keep_mask(Mm, Hh, st[0], st[1], 9, p_drop)
+    ref = keep.float().sum(1) * odrop.drop_scale(p_drop)
+    out.append(("dropout mask: kept count per row vs the Philox oracle", (got - ref).abs().max().item(), 2.0 ** -8 * ref.max().item()))
+    out.append(("dropout keep rate", abs(keep.float().mean().item() - (1 - p_drop)), 0.02))
+    # exact positions: lora_apply adds mask * scale * 1 onto zeros
+    yz = torch.zeros(Mm, Hh, device=DEV, dtype=BF)
+    xa1, wn1 = torch.zeros(Mm, 8).to(BF), torch.zeros(Hh, 8).to(BF)
+    xa1[:, 0] = 1
+    wn1[:, 0] = 1
+    ops.lora_apply_(yz, xa1.to(DEV), wn1.to(DEV), drop=(rng, 9, p_drop))
+    out.append(("dropout mask positions (lora_apply) vs the Philox oracle: mismatching elements", float(((yz.cpu() != 0) != keep).sum()), 0.0))
+    a_ones = torch.ones(Mm, Hh).to(BF)
+    b_sel = torch.zeros(Mm, 8).to(BF)
+    b_sel[:, 0] = 1
+    colcnt = ops.lora_outer(a_ones.to(DEV), b_sel.to(DEV), drop=(rng, 9, p_drop))[:, 0].cpu()
+    out.append(("dropout mask column counts (lora_outer)", (colcnt - keep.float().sum(0) * odrop.drop_scale(p_drop)).abs().max().item(), 1e-3))
+    return out
+
+
+def check_arena_ops():
+    """Parameter gradients accumulated by the kernels into fp32 `_g32` views (two passes = 2 x grad), per autograd Function."""
+    out = []
+
+    def run(name, fn_ref, fn_hip, acts, prms):
+        """acts / prms: bf16 CPU tensors; fn_*(acts..., prms...)."""
+        xs = [t.float().clone().requires_grad_(True) for t in acts + prms]
+        y = fn_ref(*xs)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).to(BF)
+        y.backward(gy.float())
+        pd = [t.to(DEV).clone().requires_grad_(True) for t in prms]
+        for t in pd:
+            t._g32 = torch.full(t.shape, 0.0, device=DEV, dtype=torch.float32)
+        for _ in range(2):
+            ad = [t.to(DEV).clone().requires_grad_(True) for t in acts]
+            fn_hip(*ad, *pd).backward(gy.to(DEV))
+        for i, (t, ref) in enumerate(zip(pd, xs[len(acts):])):
+            assert t.grad is None, name
+            out.append((f"arena {name} dparam{i}", err(t._g32 / 2, ref.grad), rel_tol(ref.grad, 2.0 ** -6)))
+        out.append((f"arena {name} dx", err(ad[0].grad, xs[0].grad), rel_tol(xs[0].grad, 2.0 ** -5)))
+
+    x, w, b = rnd(200, 256, seed=1), rnd(264, 256, seed=2, scale=1 / 16), rnd(264, seed=3)
+    run("linear", lambda x, w, b: F.linear(x, w, b), lambda x, w, b: ag.linear(x, w, b), [x], [w, b])
+    run("linear relu", lambda x, w, b: F.relu(F.linear(x, w, b)), lambda x, w, b: ag.linear(x, w, b, ops.ACT_RELU), [x], [w, b])
+    w1, b1 = rnd(1, 256, seed=5, scale=1 / 16), rnd(1, seed=6)
+    run("linear N=1 sigmoid", lambda x, w, b: torch.sigmoid(F.linear(x, w, b)), lambda x, w, b: ag.linear(x, w, b, ops.ACT_SIGMOID), [x], [w1, b1])
+    ag.BIG_LINEAR, keep = 0, ag.BIG_LINEAR
+    try:
+        wl = rnd(260, 256, seed=31, scale=1 / 16)
+        run("linear wide-path", lambda x, w: F.linear(x, w), lambda x, w: ag.linear(x, w), [x], [wl])
+    finally:
+        ag.BIG_LINEAR = keep
+    g, bb = rnd(256, seed=7), rnd(256, seed=8)
+    run("layernorm", lambda x, g, b: F.layer_norm(x, (256,), g, b, 1e-5), lambda x, g, b: ag.norm(x, g, b, 1e-5, False), [x], [g, bb])
+    Nn, L, P, Hd, V = 2, 9, 4, 64, 50
+    ids = torch.randint(0, V, (Nn, L), generator=torch.Generator().manual_seed(2))
+    ids[:, 2] = -200
+    ids[0, 5] = ids[0, 6]
+    emb, feats = rnd(V, Hd, seed=22), rnd(Nn, P, Hd, seed=23)
+    e32 = emb.float().clone().requires_grad_(True)
+    y = torch.stack([torch.cat([e32[ids[n, :2]], feats[n].float(), e32[ids[n, 3:]]]) for n in range(Nn)])
+    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(8)).to(BF)
+    y.backward(gy.float())
+    ed = emb.to(DEV).clone().requires_grad_(True)
+    ed._g32 = torch.zeros(ed.shape, device=DEV, dtype=torch.float32)
+    tok = ag.embed_token_index(ids, P).reshape(-1).to(DEV)
+    for _ in range(2):
+        ag.EmbedSpliceFn.apply(ids.to(DEV), ed, feats.to(DEV), P, P * Hd, tok).backward(gy.to(DEV))
+    out.append(("arena embed_splice (precomputed token index)", err(ed._g32 / 2, e32.grad), rel_tol(e32.grad, 2.0 ** -6)))
     return out
 
 
@@ -268,4 +392,144 @@ def check_model_grads(golden_loader=None):
     return res
 
 
-ALL = [check_gemm_layouts, check_autograd_ops, check_adamw]
+def _lora_case(backbone="sam", p_drop=0.05):
+    from oracle import cases
+    from tests import model_checks as mc
+    cfg = cases.tiny_lisa_cfg(backbone, lora_r=8)
+    cfg.llama.lora_dropout = p_drop
+    m, sd = mc.build_pair(cfg)
+    m.set_trainable()
+    img = 896 if backbone == "dinov2" else cfg.sam.img
+    batch = mc._round_batch(cases.tiny_lisa_batch(img_size=img))
+    return cfg, m, sd, batch
+
+
+def check_model_grads_lora(backbone="sam"):
+    """The configuration the benchmark times, at tiny size: LoRA r = 8 (random B) with dropout 0.05 on q/v, trainable embed / lm_head /
+    text_hidden_fcs / lisa_*, gradients accumulated by the kernels into the fp32 arena over TWO micro-steps -- against autograd through the
+    fp32 oracle with the same dropout masks.  Covers the extension K-tile GEMMs, the rank-8 kernels, the fused weight-gradient blocks."""
+    from llmseg_amd.train import GradArena
+    from oracle import lisa as olisa
+    from tests import model_checks as mc
+    cfg, m, sd, batch = _lora_case(backbone)
+    names = [n for n, p in m.params.named_parameters() if p.requires_grad]
+    for n in names:
+        sd[n].requires_grad_(True)
+    seed, off = 0x1234ABCD, 7
+    ref = olisa.model_forward(sd, cfg, **batch, inference=False, dropout_state=(seed, off))
+    ref["loss"].backward()
+    sd_lo = {k: v.detach().to(BF) for k, v in sd.items()}
+    for n in names:
+        sd_lo[n].requires_grad_(True)
+    lo = olisa.model_forward(sd_lo, cfg, **mc._bf16_batch(batch), inference=False, dropout_state=(seed, off))
+    lo["loss"].backward()
+    arena = GradArena(m)
+    m.set_dropout_seed(seed, off)
+    db = mc._dev(batch)
+    plan = m.make_plan(**db)
+    for _ in range(2):
+        out = m.model_forward(**db, inference=False, plan=plan)
+        out["loss"].backward()
+    res = []
+    for k in ("ce_loss", "align_loss", "regression_loss", "loss"):
+        r = float(ref[k])
+        res.append((f"lora+dropout train {k} (ref {r:.4f})", abs(float(out[k]) - r), max(5e-3 * max(1.0, abs(r)), 3.0 * abs(float(lo[k]) - r))))
+    prm = dict(m.params.named_parameters())
+    pick = [n for n in names if any(t in n for t in ("layers.0.self_attn.q_proj.lora_A", "layers.1.self_attn.q_proj.lora_B", "layers.1.self_attn.v_proj.lora_A",
+                                                     "layers.0.self_attn.v_proj.lora_B", "embed_tokens", "lm_head", "text_hidden_fcs.0.0.weight",
+                                                     "text_hidden_fcs.0.2.bias", "lisa_attention_layers.0.self_attn.k_proj.weight",
+                                                     "lisa_attention_layers.1.self_attn.v_proj.bias", "cross_attn_image_to_token.v_proj.weight",
+                                                     "cross_attn_image_to_token.q_proj.weight", "lisa_final_attn.v_proj.weight", "lisa_attention_layers.0.norm2.weight",
+                                                     "lisa_iou_head.2.weight", "lisa_embedding_head.0.bias"))]
+    assert len(pick) >= 16, pick
+    for n in pick:
+        assert prm[n].grad is None, n
+        got, r = prm[n]._g32 / 2, sd[n].grad
+        lo_e = (sd_lo[n].grad.float() - r).abs().max().item()
+        # floor 1e-4: a tensor whose true gradient vanishes (k-projections: softmax is shift-invariant) holds rounding noise only
+        res.append((f"arena grad {n} (bf16-CPU err {lo_e:.2e}, |ref| {r.abs().max().item():.2e})", err(got.reshape(r.shape), r),
+                    max(0.06 * r.abs().max().item(), 3.0 * lo_e, 1e-4)))
+    arena.detach()
+    return res
+
+
+def check_trainer(use_graph=False, opt_steps=3, accum=2):
+    """`Trainer` on the HIP model (arena, HipAdamW, clip, WarmupDecayLR, LoRA + dropout; optionally the hipGraph micro-step) against an
+    fp32 oracle-side loop with the same recipe: per-micro-step losses (they depend on the updated parameters) and the parameter updates."""
+    from llmseg_amd.train import Trainer, warmup_decay_lr
+    from oracle import lisa as olisa
+    from tests import model_checks as mc
+    cfg, m, sd, batch = _lora_case("sam")
+    names = [n for n, p in m.params.named_parameters() if p.requires_grad]
+    lr, clip, betas, eps, seed = 2e-3, 1.0, (0.9, 0.95), 1e-8, 99
+    tr = Trainer(m, lr=lr, betas=betas, clip=clip, grad_accum=accum, warmup=1, total_steps=10, use_graph=use_graph, graph_warmup=1)
+    m.set_dropout_seed(seed, 0)
+    db = mc._dev(batch)
+    plan = m.make_plan(**db)
+    p0 = {n: dict(m.params.named_parameters())[n].detach().float().cpu().clone() for n in names}
+    hip_losses = []
+    for _ in range(opt_steps * accum):
+        hip_losses.append(float(tr.micro_step(db, plan)["loss"]))
+    if use_graph:
+        assert tr.graph_error is None, tr.graph_error
+        assert any(e["graph"] is not None for e in tr._graphs.values()), "the hipGraph path was never taken"
+    # oracle loop: fp32 master weights, bf16-rounded copies in the forward, fp32 gradient accumulation
+    master = {n: sd[n].detach().clone() for n in names}
+    mom = {n: torch.zeros_like(master[n]) for n in names}
+    var = {n: torch.zeros_like(master[n]) for n in names}
+    ref_losses, offset, gmax, gsig = [], 0, {n: 0.0 for n in names}, {n: None for n in names}
+    for step in range(opt_steps):
+        w = {n: master[n].to(BF).float().requires_grad_(True) for n in names}
+        sdw = {**sd, **w}
+        for _ in range(accum):
+            offset += 1
+            o = olisa.model_forward(sdw, cfg, **batch, inference=False, dropout_state=(seed, offset))
+            o["loss"].backward()
+            ref_losses.append(float(o["loss"]))
+        g = {n: w[n].grad / accum for n in names}
+        for n in names:
+            gmax[n] = max(gmax[n], g[n].abs().max().item())
+            gsig[n] = g[n].abs() if gsig[n] is None else torch.minimum(gsig[n], g[n].abs())
+        norm = torch.sqrt(sum((v.double() ** 2).sum() for v in g.values())).float()
+        coef = min(1.0, clip / (float(norm) + 1e-6))
+        lr_t = warmup_decay_lr(step, lr, 1, 10)
+        t = step + 1
+        for n in names:
+            gn = g[n] * coef
+            mom[n] = betas[0] * mom[n] + (1 - betas[0]) * gn
+            var[n] = betas[1] * var[n] + (1 - betas[1]) * gn * gn
+            master[n] = master[n] - lr_t * ((mom[n] / (1 - betas[0] ** t)) / ((var[n] / (1 - betas[1] ** t)).sqrt() + eps))
+    tag = "graph" if use_graph else "eager"
+    res = [(f"trainer[{tag}] loss at micro-step {i} (ref {r:.4f})", abs(h - r), 2e-2 * max(1.0, abs(r))) for i, (h, r) in enumerate(zip(hip_losses, ref_losses))]
+    res.append((f"trainer[{tag}] the loss moved (|first - last| = {abs(ref_losses[0] - ref_losses[-1]):.3f})", 0.0 if abs(ref_losses[0] - ref_losses[-1]) > 0.05 else 1.0, 0.5))
+    hip_master = {n: w.detach().cpu() for n, w in zip(names, tr.opt.master)}
+    worst = (1.0, "")
+    for n in names:
+        if gmax[n] < 1e-3 * max(gmax.values()):      # AdamW normalises a vanishing gradient's rounding noise to +-lr
+            continue
+        sig = (gsig[n] > 0.1 * gmax[n]).flatten()      # elements whose gradient stands clear of the bf16 noise in EVERY step (Adam keeps only the sign)
+        if int(sig.sum()) < 4:
+            continue
+        d_h, d_r = (hip_master[n] - p0[n]).flatten().double()[sig], (master[n] - p0[n]).flatten().double()[sig]
+        if d_r.norm() == 0:
+            continue
+        cosv = float((d_h @ d_r) / (d_h.norm() * d_r.norm() + 1e-30))
+        worst = min(worst, (cosv, n))
+    res.append((f"trainer[{tag}] update direction on the significant elements: worst cosine over {len(names)} tensors = {worst[0]:.3f} ({worst[1]})",
+                1.0 - worst[0], 0.25))
+    for n in ("lm_head.weight", "model.layers.0.self_attn.q_proj.lora_B.default.weight", "model.text_hidden_fcs.0.2.weight"):
+        d_h, d_r = (hip_master[n] - p0[n]).flatten().double(), (master[n] - p0[n]).flatten().double()
+        res.append((f"trainer[{tag}] update cosine {n}", 1.0 - float((d_h @ d_r) / (d_h.norm() * d_r.norm() + 1e-30)), 0.1))
+    tr.close()
+    return res, hip_losses
+
+
+def check_trainer_graph_vs_eager():
+    r_e, l_e = check_trainer(False)
+    r_g, l_g = check_trainer(True)
+    res = r_e + r_g
+    res.append(("trainer graph vs eager: max loss difference over the micro-steps", max(abs(a - b) for a, b in zip(l_e, l_g)), 5e-3))
+    return res
+
+
+ALL = [check_gemm_layouts, check_autograd_ops, check_lora_paths, check_arena_ops, check_adamw]

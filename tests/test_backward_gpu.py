@@ -19,6 +19,16 @@ def test_autograd_ops():
     _assert(bc.check_autograd_ops())
 
 
+def test_lora_paths():
+    from tests import backward_checks as bc
+    _assert(bc.check_lora_paths())
+
+
+def test_arena_ops():
+    from tests import backward_checks as bc
+    _assert(bc.check_arena_ops())
+
+
 def test_adamw():
     from tests import backward_checks as bc
     _assert(bc.check_adamw())
@@ -27,3 +37,13 @@ def test_adamw():
 def test_model_grads(golden):
     from tests import backward_checks as bc
     _assert(bc.check_model_grads(golden))
+
+
+def test_model_grads_lora_arena():
+    from tests import backward_checks as bc
+    _assert(bc.check_model_grads_lora("sam"))
+
+
+def test_trainer_eager_and_graph():
+    from tests import backward_checks as bc
+    _assert(bc.check_trainer_graph_vs_eager())

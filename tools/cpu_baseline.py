@@ -1,0 +1,149 @@
+"""CPU baseline of the hot path for bench.py: the oracle's `model_forward` (oracle/lisa.py -- the CPU restatement of the reference's
+arithmetic, pinned to the imported reference by oracle/make_goldens.py) timed on the host cores of the GPU box.
+
+What is timed: the WHOLE restated `model_forward` (SAM ViT-H encoder -> CLIP-L -> splice -> Llama stack -> lm_head + CE -> [SEG] MLP ->
+upsample + mask pooling -> mask-selection head -> align / IoP losses) on ONE synthetic image of the benchmark's shape (1024 x 1024, 64-token
+prompt, 256 candidate masks), full width, at REDUCED DEPTH so that the default bench run stays within minutes: `DEPTH` layers of each tower
+are run end to end, the remaining layers are accounted for by per-layer times measured in the same process (one Llama layer, one windowed
+and one global SAM block, one CLIP layer -- every layer of a tower is the same arithmetic).  fp32: >= 3 timed forwards + one timed
+forward+backward (LoRA r = 8 + the reference's trainable set); bf16 (the reference's dtype): forwards within the remaining time budget.
+The only consumer is bench.py's `cpu_baseline` leg; nothing here is on the product path."""
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+DEPTH = dict(llama=2, sam_windowed=2, sam_global=1, clip=2)         # layers run end to end in the timed whole-path sample
+FULL = dict(llama=32, sam_windowed=28, sam_global=4, clip=23)       # the benchmark's model (CLIP: hidden_states[-2] = 23 layers)
+
+
+def _fill(shapes, dtype, gen):
+    sd = {}
+    for k, v in shapes.items():
+        if ("norm" in k or "layrnorm" in k or ".neck.1." in k or ".neck.3." in k) and k.endswith("weight"):
+            sd[k] = torch.ones(v, dtype=dtype)
+        else:
+            fan = 1
+            for d in v[1:]:
+                fan *= d
+            sd[k] = (torch.randn(v, generator=gen) * (0.02 if len(v) < 2 else 1.0 / max(fan, 1) ** 0.5)).to(dtype)
+    return sd
+
+
+def _time(fn, reps):
+    fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2], ts
+
+
+def run(threads=None, budget_s=45.0):
+    from oracle import lisa as olisa, llama as ol, sam_encoder as osam, seeded, vit as ovit
+    if threads:
+        torch.set_num_threads(threads)
+    cores = torch.get_num_threads()
+    gen = torch.Generator().manual_seed(0)
+    cfg = olisa.LisaCfg(
+        llama=ol.LlamaCfg(layers=DEPTH["llama"], lora_r=8),
+        clip=ovit.VitCfg(layers=DEPTH["clip"] + 1, eps=1e-5, img=224),      # select_layer -2 runs layers - 1 blocks
+        sam=osam.SamCfg(depth=DEPTH["sam_windowed"] + DEPTH["sam_global"], global_idx=(DEPTH["sam_windowed"],)),
+        backbone="sam")
+    sd = _fill(seeded.lisa_shapes(cfg), torch.float32, gen)
+    L, K = 64, 256
+    ids = torch.randint(3, 31999, (1, L), generator=gen)
+    ids[0, 0], ids[0, 1], ids[0, 2], ids[0, 3], ids[0, L - 3] = 1, 32001, -200, 32002, 32000
+    labels = ids.clone()
+    labels[:, :L // 2] = -100
+    batch = dict(images=torch.randn(1, 3, 1024, 1024, generator=gen), images_clip=torch.randn(1, 3, 224, 224, generator=gen), input_ids=ids,
+                 labels=labels, attention_masks=torch.ones(1, L, dtype=torch.bool), offset=torch.tensor([0, 1]),
+                 sam_segs_list=[(torch.rand(K, 256, 256, generator=gen) > 0.7).float()],
+                 sam_ious_list=[torch.rand(1, K, generator=gen).double()], sam_iops_list=[torch.rand(1, K, generator=gen).double()])
+
+    t_start = time.perf_counter()          # the budget counts timed work, not the weight generation above
+
+    def fwd(sd_, b_):
+        with torch.no_grad():
+            return olisa.model_forward(sd_, cfg, **b_, inference=False)
+    t_whole, runs = _time(lambda: fwd(sd, batch), 3)
+    # per-layer increments (same process, same threads)
+    with torch.no_grad():
+        x = torch.randn(1, 64, 64, 1280, generator=gen)
+        sp = "model.visual_model.image_encoder."
+        t_win, _ = _time(lambda: osam.sam_block(sd, sp + "blocks.0.", x, cfg.sam, 14), 1)
+        t_glob, _ = _time(lambda: osam.sam_block(sd, sp + f"blocks.{DEPTH['sam_windowed']}.", x, cfg.sam, 0), 1)
+        h = torch.randn(1, 319, 4096, generator=gen)
+        cos, sin = ol.rope_tables(319, 128, 1e4, "cpu")
+        mask = ol.additive_mask(torch.ones(1, 319, dtype=torch.bool), 319, torch.float32, "cpu")
+        t_llama, _ = _time(lambda: ol.decoder_layer(sd, "model.layers.0.", h, mask, cos, sin, cfg.llama), 1)
+        ic = torch.randn(1, 3, 224, 224, generator=gen)
+        vp = "model.vision_tower.vision_tower."
+        c1 = ovit.VitCfg(layers=2, eps=1e-5, img=224)
+        c2 = ovit.VitCfg(layers=3, eps=1e-5, img=224)
+        ta, _ = _time(lambda: ovit.clip_vision_features(sd, vp, ic, c1, select_layer=-2), 2)
+        tb, _ = _time(lambda: ovit.clip_vision_features(sd, vp, ic, c2, select_layer=-2), 2)
+        t_clip = max(tb - ta, 1e-4)
+    rest = ((FULL["llama"] - DEPTH["llama"]) * t_llama + (FULL["sam_windowed"] - DEPTH["sam_windowed"]) * t_win +
+            (FULL["sam_global"] - DEPTH["sam_global"]) * t_glob + (FULL["clip"] - DEPTH["clip"]) * t_clip)
+    t_full_fp32 = t_whole + rest
+    # one forward + backward (fp32): LoRA + embed / lm_head / text_hidden_fcs / lisa_* trainable, as training.py:183-241 leaves it
+    t_fb = None
+    if time.perf_counter() - t_start < budget_s:
+        names = [k for k in sd if any(t in k for t in ("lora_", "embed_tokens", "lm_head", "text_hidden_fcs", "lisa_"))]
+        sdg = dict(sd)
+        for k in names:
+            sdg[k] = sd[k].clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        out = olisa.model_forward(sdg, cfg, **batch, inference=False, dropout_state=(1, 1))
+        out["loss"].backward()
+        t_fb = time.perf_counter() - t0
+        del sdg, out
+    # bf16 (what the reference runs under DeepSpeed): forwards while the budget lasts
+    t_bf16, n_bf16 = None, 0
+    if time.perf_counter() - t_start < budget_s:
+        sdb = {k: v.to(torch.bfloat16) for k, v in sd.items()}
+        bb = {k: (v.to(torch.bfloat16) if torch.is_tensor(v) and v.dtype == torch.float32 else
+                  ([t.to(torch.bfloat16) if t.dtype == torch.float32 else t for t in v] if isinstance(v, list) else v)) for k, v in batch.items()}
+        ts = []
+        while n_bf16 < 3 and (n_bf16 == 0 or time.perf_counter() - t_start < budget_s):
+            t0 = time.perf_counter(); fwd(sdb, bb); ts.append(time.perf_counter() - t0); n_bf16 += 1
+        t_bf16 = min(ts)
+    bwd_ratio = (t_fb / t_whole) if t_fb else None
+    res = {"value": 1.0 / t_full_fp32, "unit": "images/s", "cores": cores, "kind": "port (reduced depth, scaled per layer)",
+           "cpu_model": _cpu_model(),
+           "sample": ("oracle.lisa.model_forward end to end on 1 image (1024x1024, 64-token prompt, 256 masks), full width, depth Llama %d/32 + SAM-H %d+%d/28+4 "
+                      "+ CLIP-L %d/23 layers: fp32 forward %.2f s (median of 3 after 1 warm-up: %s); + per-layer times x the remaining layers "
+                      "(Llama %.3f s, SAM windowed %.3f s, SAM global %.3f s, CLIP %.3f s) = %.1f s per image fp32 forward" % (
+                          DEPTH["llama"], DEPTH["sam_windowed"], DEPTH["sam_global"], DEPTH["clip"], t_whole, ", ".join("%.2f" % t for t in runs),
+                          t_llama, t_win, t_glob, t_clip, t_full_fp32)),
+           "fwd_fp32_s_per_image": t_full_fp32}
+    if t_fb:
+        # the measured reduced-depth fwd+bwd, plus the remaining layers: Llama forward + dX, frozen towers forward only
+        t_fb_full = t_fb + (FULL["llama"] - DEPTH["llama"]) * t_llama * 2.0 + rest - (FULL["llama"] - DEPTH["llama"]) * t_llama
+        res["fwd_bwd_fp32"] = {"value": 1.0 / t_fb_full, "unit": "images/s", "reduced_depth_s": t_fb, "ratio_to_fwd_at_reduced_depth": bwd_ratio,
+                               "note": "1 timed forward+backward at the reduced depth; remaining Llama layers counted at 2 x their forward time (frozen base weights: dX only, no recompute), frozen towers at 1 x"}
+    if t_bf16:
+        res["fwd_bf16"] = {"reduced_depth_s": t_bf16, "runs": n_bf16, "ratio_to_fp32": t_bf16 / t_whole,
+                           "value": 1.0 / (t_full_fp32 * t_bf16 / t_whole), "unit": "images/s",
+                           "note": "bf16 CPU forward at the reduced depth; full-depth figure scaled by the measured bf16/fp32 ratio"}
+    res["cpu_seconds"] = time.perf_counter() - t_start
+    return res
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+if __name__ == "__main__":
+    import json
+    print(json.dumps(run(budget_s=float(sys.argv[1]) if len(sys.argv) > 1 else 25.0), indent=1))
