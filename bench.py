@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--mode", default="train", choices=["fwd", "train"],
                     help="train (default; BASELINE metric 'fwd+bwd'): fwd+bwd with LoRA r=8, optimizer step every --accum steps, and a "
                          "forward-only pass (BASELINE configs[1]) reported under 'fwd_only'; fwd: forward only")
+    ap.add_argument("--no-overlap", action="store_true", help="issue the frozen backbone on the main stream instead of its own HIP stream")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--ddp-wrapper", action="store_true", help="torch DDP wrapper + bf16 .grad instead of the fp32 gradient arena")
     ap.add_argument("--force-ddp", action="store_true", help="with --ddp-wrapper: wrap in DDP even at world size 1")
@@ -199,6 +200,7 @@ def main():
         cfg.clip = VitConfig(layers=3)
     model = LISAForCausalLM(cfg, device=dev).init_random(seed=0)
     model.prepare()
+    model.overlap_towers = not args.no_overlap
     if train:
         model.set_trainable()
     use_graph = train and not args.no_graph and not args.ddp_wrapper

@@ -237,11 +237,12 @@ int llmseg_ce_bwd(const void* logits, const int64_t* labels, const float* coef, 
 /* dst[idx[i]][:] += src[i][:] in fp32 (embedding / row-gather gradients; idx < 0 skipped) */
 int llmseg_scatter_add_rows(const void* src, const int64_t* idx, float* dst, int64_t n, int64_t cols, void* stream);
 /* Rank-8 LoRA products (peft==0.4.0 Linear with r = 8, lora_dropout 0.05: training.py:91,218-226) -- skinny shapes a tiled GEMM
- * cannot fill:
- *   lora_down:  y[m][0..7] = alpha * drop(x)[M][K] . W^T  (W stored [8][K], or [K][8] when w_kr), rows of y at pitch ldy, the
- *               following zero_cols columns of each row zero-filled                                  fwd drop(x).A^T, bwd dq.B
- *   lora_outer: out(n,r) += alpha * sum_m drop(a)[m][n] b[m][r]  (fp32 [N][8], or [8][N] when out_rn; accumulates)   dB, dA
- *   lora_apply: y[M][N] += alpha * mask * (xa[M][8] . W^T)  (W stored [N][8], or [8][N] when w_rn)    bwd dx += mask * (tq.A)
+ * cannot fill.  Every kernel handles the q AND the v branch of one layer in one launch (second operand set NULL = one branch);
+ * branch b uses dropout stream drop->stream + b:
+ *   lora_down:  y[m][8b..8b+7] = alpha * drop_b(x_b)[M][K] . W_b^T  (W stored [8][K], or [K][8] when w_kr), rows of y at pitch ldy,
+ *               the following zero_cols columns of each row zero-filled                            fwd drop(x).A^T, bwd dq.Bq | dv.Bv
+ *   lora_outer: out_b(n,r) += alpha * sum_m drop_b(a_b)[m][n] b_b[m][r]  (fp32 [N][8], or [8][N] when out_rn; accumulates)   dB, dA
+ *   lora_apply: y[M][N] += alpha * sum_b mask_b * (xa[M][8b..8b+7] . W_b^T)  (W stored [N][8], or [8][N] when w_rn)   bwd dx of the LoRA branches
  *   lora_pack:  the two [*][64] extension operands of llmseg_gemm_args (A2 / W2) for a LoRA'd q|k|v projection, from the current
  *               LoRA matrices: w2b [3H][64] = rows [s Bq | 0], 0, [0 | s Bv | 0];  w2a [H][64] = rows [Aq[:,h] | Av[:,h] | 0]
  * Dropout (NULL = none, as in eval mode) is counter-based, nothing is stored: Philox4x32-10 with key = rng_state[0] (seed), counter
@@ -253,12 +254,12 @@ typedef struct {
   uint32_t stream;             /* which dropout module (layer * 2 + {q = 0, v = 1}) */
   uint32_t drop_thr;           /* round(p * 65536); 0 = no dropout */
 } llmseg_dropout;
-int llmseg_lora_down(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t M, int64_t K, int32_t w_kr, float alpha,
-                     int32_t zero_cols, const llmseg_dropout* drop, void* stream);
-int llmseg_lora_outer(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t M, int64_t N, int32_t out_rn, float alpha,
-                      const llmseg_dropout* drop, void* stream);
-int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, int64_t ldxa, const void* w, int64_t M, int64_t N, int32_t w_rn, float alpha,
-                      const llmseg_dropout* drop, void* stream);
+int llmseg_lora_down(const void* x0, const void* x1, int64_t ldx, const void* w0, const void* w1, void* y, int64_t ldy, int64_t M, int64_t K,
+                     int32_t w_kr, float alpha, int32_t zero_cols, const llmseg_dropout* drop, void* stream);
+int llmseg_lora_outer(const void* a0, const void* a1, int64_t lda, const void* b0, const void* b1, int64_t ldb, float* out0, float* out1, int64_t M,
+                      int64_t N, int32_t out_rn, float alpha, const llmseg_dropout* drop, void* stream);
+int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, int64_t ldxa, const void* w0, const void* w1, int64_t M, int64_t N, int32_t w_rn,
+                      float alpha, const llmseg_dropout* drop, void* stream);
 int llmseg_lora_pack(const void* aq, const void* bq, const void* av, const void* bv, void* w2b, void* w2a, int64_t H, float s, void* stream);
 /* out[c][r] = in[r][c] (bf16; in [rows][cols] with leading dimension ld_in, out [cols][ld_out]); rows r in [rows, rows_pad) of the
  * source are taken as zero.  Lets the weight / input gradients of a wide trainable Linear (lm_head: dX = dY.W, dW = dY^T.X) run on

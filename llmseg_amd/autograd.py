@@ -117,10 +117,8 @@ def lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, drop=None):
     stale operand behind.  drop = (rng_state, layer, p) or None.  -> (qkv, A2)"""
     H = wqkv.shape[1]
     M = x.shape[0]
-    dq, dv = _drops(drop)
     a2 = torch.empty((M, 64), device=x.device, dtype=BF16)
-    ops.lora_down(x, aq, out=a2[:, :8], drop=dq)
-    ops.lora_down(x, av, out=a2[:, 8:16], zero_cols=48, drop=dv)
+    ops.lora_down(x, aq, out=a2, zero_cols=48, drop=_drops(drop)[0], x2=x, w2=av)      # [x Aq^T | x Av^T | 0], x read once
     w2b = torch.empty((3 * H, 64), device=x.device, dtype=BF16)
     ops.lora_pack(aq, bq, av, bv, s, w2b=w2b)
     return ops.gemm(x, wqkv, a2=a2, w2=w2b), a2
@@ -167,23 +165,19 @@ class LoraQKVFn(Function):
         dq, dv = d[:, :H], d[:, 2 * H:]
         gaq, gbq, gav, gbv = ctx.g
         if ctx.fast:
-            drq, drv = _drops(ctx.drop)
+            drq = _drops(ctx.drop)[0]                                        # stream of the q branch; the v branch is stream + 1
             t2 = torch.empty((M, 64), device=d.device, dtype=BF16)       # [s dq Bq | s dv Bv | 0]
+            ops.lora_down(dq, bq, w_kr=True, alpha=s, out=t2, zero_cols=48, x2=dv, w2=bv)
             tq, tv = t2[:, :8], t2[:, 8:16]
-            ops.lora_down(dq, bq, w_kr=True, alpha=s, out=tq)
-            ops.lora_down(dv, bv, w_kr=True, alpha=s, out=tv, zero_cols=48)
             if ctx.wqkv_t is not None and ctx.drop is None:               # dx = d Wqkv + tq Aq + tv Av in ONE GEMM
                 w2a = torch.empty((H, 64), device=d.device, dtype=BF16)
                 ops.lora_pack(aq, bq, av, bv, s, w2a=w2a)
                 dx = ops.gemm(d, ctx.wqkv_t, a2=t2, w2=w2a)
-            else:                                                         # dropout masks the LoRA branch's dx element-wise
+            else:                                                         # dropout masks the LoRA branches' dx element-wise
                 dx = ops.gemm(d, ctx.wqkv_t) if ctx.wqkv_t is not None else ops.gemm(d, wqkv, trans_w=True)
-                ops.lora_apply_(dx, tq, aq, w_rn=True, drop=drq)
-                ops.lora_apply_(dx, tv, av, w_rn=True, drop=drv)
-            dbq = ops.lora_outer(dq, xaq, alpha=s, out=gbq)                                   # [H, 8]
-            dbv = ops.lora_outer(dv, xav, alpha=s, out=gbv)
-            daq = ops.lora_outer(x, tq, out_rn=True, out=gaq, drop=drq)                       # [8, H] = tq^T drop(x)
-            dav = ops.lora_outer(x, tv, out_rn=True, out=gav, drop=drv)
+                ops.lora_apply_(dx, t2, aq, w_rn=True, drop=drq, w2=av)
+            dbq, dbv = ops.lora_outer(dq, xaq, alpha=s, out=gbq, a2=dv, b2=xav, out2=gbv)               # [H, 8] = s d^T (drop(x) A^T)
+            daq, dav = ops.lora_outer(x, tq, out_rn=True, out=gaq, drop=drq, a2=x, b2=tv, out2=gav)      # [8, H] = t^T drop(x)
             outs = [None if g is not None else t.to(BF16) for g, t in ((gaq, daq), (gbq, dbq), (gav, dav), (gbv, dbv))]
             return dx, None, outs[0], outs[1], outs[2], outs[3], None, None, None
         tq = ops.gemm(dq, bq, trans_w=True, alpha=s)                      # [M, r] = s dq Bq

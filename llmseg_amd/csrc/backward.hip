@@ -366,69 +366,93 @@ constexpr int LR = 8;
 
 struct DropP { const unsigned long* rng; uint32_t stream, thr; float scale; };     // thr == 0: no dropout
 
-// y[m][r] = alpha * sum_k drop(x)[m][k] * W(r,k), written at row pitch ldy; `zero_cols` further columns of each row are zero-filled
-// (the [M][64] extension operand of the qkv GEMM is [x Aq^T | x Av^T | 0]).  One wave per FOUR rows (each W chunk is loaded once for
-// the four).  w_kr = 0: W stored [8][K]; 1: W stored [K][8].  drop(x) = x * mask / (1 - p), mask element index m K + k.
-__global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
-                                                       long ldy, long M, int K, int w_kr, float alpha, int zero_cols, DropP dp) {
-  constexpr int RW = 4;
+// Two rank-8 down-projections in ONE launch (q and v branches of a LoRA'd q|k|v projection):
+//   y[m][0..7] = alpha * drop0(x0)[m][:] . W0^T,   y[m][8..15] = alpha * drop1(x1)[m][:] . W1^T,   y[m][16..16+zero_cols) = 0
+// rows of y at pitch ldy (the [M][64] extension operand of the qkv GEMM is [x Aq^T | x Av^T | 0]); x0 == x1 in the forward pass (one
+// load feeds both branches, each with its own dropout stream), two column blocks of dY in the backward pass.  w_kr = 0: W stored
+// [8][K]; 1: W stored [K][8].  drop(x) = x * mask / (1 - p), mask element index m K + k.  nb = 1 computes the first branch only.
+// RW rows per wave: 4 for tall activations (each W chunk is loaded once for four rows), 1 for short ones (M = 2 x 319: four times the
+// waves in flight -- the kernel is latency-bound there).
+template <int RW>
+__global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1, long ldx, const bf16_t* __restrict__ w0,
+                                                       const bf16_t* __restrict__ w1, bf16_t* __restrict__ y, long ldy, long M, int K, int w_kr, float alpha,
+                                                       int zero_cols, int nb, DropP dp) {
   const int lane = threadIdx.x & 63;
   const long m0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
   if (m0 >= M) return;
-  float acc[RW][LR];
+  float acc[2][RW][LR];
 #pragma unroll
-  for (int i = 0; i < RW; ++i)
+  for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int r = 0; r < LR; ++r) acc[i][r] = 0.f;
-  const bf16_t* xr[RW];
+    for (int i = 0; i < RW; ++i)
 #pragma unroll
-  for (int i = 0; i < RW; ++i) xr[i] = x + min(m0 + i, M - 1) * ldx;
+      for (int r = 0; r < LR; ++r) acc[b][i][r] = 0.f;
+  const bool same = x0 == x1;
+#pragma unroll 2
   for (int k = lane * 8; k < K; k += 64 * 8) {
-    float xv[RW][8], wv[8];
 #pragma unroll
-    for (int i = 0; i < RW; ++i) {
-      unpack8(*reinterpret_cast<const uint4*>(xr[i] + k), xv[i]);
-      if (dp.thr) dropout8(xv[i], ((unsigned long)min(m0 + i, M - 1) * (unsigned long)K + (unsigned long)k) >> 3, dp.stream, dp.rng, dp.thr, dp.scale);
-    }
-    if (w_kr) {
+    for (int b = 0; b < 2; ++b) {
+      if (b >= nb) break;
+      const bf16_t* xb = b == 0 ? x0 : x1;
+      const bf16_t* wb = b == 0 ? w0 : w1;
+      float xv[RW][8], wv[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        unpack8(*reinterpret_cast<const uint4*>(w + (long)(k + j) * LR), wv);
-#pragma unroll
-        for (int i = 0; i < RW; ++i)
-#pragma unroll
-          for (int r = 0; r < LR; ++r) acc[i][r] += xv[i][j] * wv[r];
+      for (int i = 0; i < RW; ++i) {
+        const long m = min(m0 + i, M - 1);
+        unpack8(*reinterpret_cast<const uint4*>(xb + m * ldx + k), xv[i]);
+        if (dp.thr) dropout8(xv[i], ((unsigned long)m * (unsigned long)K + (unsigned long)k) >> 3, dp.stream + b, dp.rng, dp.thr, dp.scale);
       }
-    } else {
+      (void)same;
+      if (w_kr) {
 #pragma unroll
-      for (int r = 0; r < LR; ++r) {
-        unpack8(*reinterpret_cast<const uint4*>(w + (long)r * K + k), wv);
+        for (int j = 0; j < 8; ++j) {
+          unpack8(*reinterpret_cast<const uint4*>(wb + (long)(k + j) * LR), wv);
 #pragma unroll
-        for (int i = 0; i < RW; ++i)
+          for (int i = 0; i < RW; ++i)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[i][r] += xv[i][j] * wv[j];
+            for (int r = 0; r < LR; ++r) acc[b][i][r] += xv[i][j] * wv[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < LR; ++r) {
+          unpack8(*reinterpret_cast<const uint4*>(wb + (long)r * K + k), wv);
+#pragma unroll
+          for (int i = 0; i < RW; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[b][i][r] += xv[i][j] * wv[j];
+        }
       }
     }
   }
 #pragma unroll
   for (int i = 0; i < RW; ++i) {
 #pragma unroll
-    for (int r = 0; r < LR; ++r) acc[i][r] = wave_sum(acc[i][r]) * alpha;
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < LR; ++r) acc[b][i][r] = wave_sum(acc[b][i][r]) * alpha;
     if (m0 + i < M) {
       bf16_t* yr = y + (m0 + i) * ldy;
-      if (lane == 0) *reinterpret_cast<uint4*>(yr) = pack8(acc[i]);
-      else if (lane * 8 <= zero_cols) *reinterpret_cast<uint4*>(yr + lane * 8) = make_uint4(0, 0, 0, 0);
+      if (lane == 0) *reinterpret_cast<uint4*>(yr) = pack8(acc[0][i]);
+      else if (lane == 1 && nb > 1) *reinterpret_cast<uint4*>(yr + 8) = pack8(acc[1][i]);
+      else if (lane >= nb && (lane - nb) * 8 < zero_cols) *reinterpret_cast<uint4*>(yr + lane * 8) = make_uint4(0, 0, 0, 0);
     }
   }
 }
 
 // out(n,r) += alpha * sum_m drop(a)[m][n] * b[m][r]  (fp32 atomics onto `out`: the caller zero-fills it or accumulates into a
-// gradient arena).  out_rn = 0: out [N][8]; 1: out [8][N].  b has row pitch ldb.
+// gradient arena).  out_rn = 0: out [N][8]; 1: out [8][N].  b has row pitch ldb.  blockIdx.z selects one of up to two independent
+// products that share the shapes (the q and v branches of one layer: dAq / dAv read the same activation with their own dropout streams,
+// dBq / dBv two column blocks of dY).
 // Workgroup = 256 columns x one slice of rows: lane = (row-lane 0..7, column chunk 0..7), a wave reads 8 rows x 128 contiguous
 // bytes per step (16 B per lane, three steps in flight); the 8 row-lanes are folded with shuffles, so one set of atomics per
 // column per wave (the same atomic count as a column-per-thread layout, 20x the loads in flight).
-__global__ __launch_bounds__(256) void lora_outer_kernel(const bf16_t* __restrict__ a, long lda, const bf16_t* __restrict__ b, long ldb,
-                                                        float* __restrict__ out, long M, long N, int out_rn, float alpha, DropP dp) {
+struct OuterP { const bf16_t* a[2]; const bf16_t* b[2]; float* out[2]; };
+__global__ __launch_bounds__(256) void lora_outer_kernel(OuterP q, long lda, long ldb, long M, long N, int out_rn, float alpha, DropP dp) {
+  const int z = blockIdx.z;
+  const bf16_t* __restrict__ a = q.a[z];
+  const bf16_t* __restrict__ b = q.b[z];
+  float* __restrict__ out = q.out[z];
+  const uint32_t dstream = dp.stream + z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cl = lane & 7, rl = lane >> 3;
   const long n = ((long)blockIdx.x * 32 + wave * 8 + cl) * 8;
@@ -453,7 +477,7 @@ __global__ __launch_bounds__(256) void lora_outer_kernel(const bf16_t* __restric
       for (int u = 0; u < 3; ++u) {
         float x[8], y[8];
         unpack8(av[u], x); unpack8(bv[u], y);
-        if (dp.thr) dropout8(x, ((unsigned long)(m + 8 * u) * (unsigned long)N + (unsigned long)n) >> 3, dp.stream, dp.rng, dp.thr, dp.scale);
+        if (dp.thr) dropout8(x, ((unsigned long)(m + 8 * u) * (unsigned long)N + (unsigned long)n) >> 3, dstream, dp.rng, dp.thr, dp.scale);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -464,7 +488,7 @@ __global__ __launch_bounds__(256) void lora_outer_kernel(const bf16_t* __restric
       float x[8], y[8];
       unpack8(*reinterpret_cast<const uint4*>(a + m * lda + n), x);
       unpack8(*reinterpret_cast<const uint4*>(b + m * ldb), y);
-      if (dp.thr) dropout8(x, ((unsigned long)m * (unsigned long)N + (unsigned long)n) >> 3, dp.stream, dp.rng, dp.thr, dp.scale);
+      if (dp.thr) dropout8(x, ((unsigned long)m * (unsigned long)N + (unsigned long)n) >> 3, dstream, dp.rng, dp.thr, dp.scale);
 #pragma unroll
       for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -490,38 +514,44 @@ __global__ __launch_bounds__(256) void lora_outer_kernel(const bf16_t* __restric
   }
 }
 
-// y[m][n..n+7] += alpha * mask(m, n..) * sum_r xa[m][r] * W(n,r).  w_rn = 0: W stored [N][8]; 1: W stored [8][N].  xa row pitch ldxa.
-// With dropout the product is masked like the forward input was (dX of the LoRA branch: ((dq Bq) Aq) * mask / (1 - p)).
+// y[m][n..n+7] += alpha * sum over nb branches of mask_b(m, n..) * sum_r xa[m][8 b + r] * W_b(n,r).  w_rn = 0: W stored [N][8]; 1: W
+// stored [8][N].  xa row pitch ldxa (branch b reads columns 8 b .. 8 b + 7).  With dropout the product is masked like the forward input
+// was (dX of the LoRA branches: ((dq Bq) Aq) * mask_q / (1 - p) + ((dv Bv) Av) * mask_v / (1 - p)) -- one pass over y for both.
 __global__ __launch_bounds__(256) void lora_apply_kernel(bf16_t* __restrict__ y, long ldy, const bf16_t* __restrict__ xa, long ldxa,
-                                                        const bf16_t* __restrict__ w, long M, long N, int w_rn, float alpha, DropP dp) {
+                                                        const bf16_t* __restrict__ w0, const bf16_t* __restrict__ w1, long M, long N, int w_rn,
+                                                        float alpha, int nb, DropP dp) {
   const long nch = N >> 3, total = M * nch;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long m = i / nch, c = i % nch;
-    float yv[8], xv[8], wv[8], dv[8];
+    float yv[8], wv[8];
     unpack8(*reinterpret_cast<const uint4*>(y + m * ldy + c * 8), yv);
-    unpack8(*reinterpret_cast<const uint4*>(xa + m * ldxa), xv);
-    if (w_rn) {
+    for (int b = 0; b < nb; ++b) {
+      const bf16_t* w = b == 0 ? w0 : w1;
+      float xv[8], dv[8];
+      unpack8(*reinterpret_cast<const uint4*>(xa + m * ldxa + 8 * b), xv);
+      if (w_rn) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dv[j] = 0.f;
+        for (int j = 0; j < 8; ++j) dv[j] = 0.f;
 #pragma unroll
-      for (int r = 0; r < LR; ++r) {
-        unpack8(*reinterpret_cast<const uint4*>(w + (long)r * N + c * 8), wv);
+        for (int r = 0; r < LR; ++r) {
+          unpack8(*reinterpret_cast<const uint4*>(w + (long)r * N + c * 8), wv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dv[j] += xv[r] * wv[j];
+          for (int j = 0; j < 8; ++j) dv[j] += xv[r] * wv[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          unpack8(*reinterpret_cast<const uint4*>(w + (c * 8 + j) * LR), wv);
+          float s = 0.f;
+#pragma unroll
+          for (int r = 0; r < LR; ++r) s += xv[r] * wv[r];
+          dv[j] = s;
+        }
       }
-    } else {
+      if (dp.thr) dropout8(dv, (unsigned long)i, dp.stream + b, dp.rng, dp.thr, dp.scale);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        unpack8(*reinterpret_cast<const uint4*>(w + (c * 8 + j) * LR), wv);
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < LR; ++r) s += xv[r] * wv[r];
-        dv[j] = s;
-      }
+      for (int j = 0; j < 8; ++j) yv[j] += alpha * dv[j];
     }
-    if (dp.thr) dropout8(dv, (unsigned long)i, dp.stream, dp.rng, dp.thr, dp.scale);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) yv[j] += alpha * dv[j];
     *reinterpret_cast<uint4*>(y + m * ldy + c * 8) = pack8(yv);
   }
 }
@@ -595,34 +625,44 @@ static DropP make_drop(const llmseg_dropout* d) {
 }
 #define LL_DROP_OK(d) (!(d) || (d)->drop_thr < 65536u)
 
-extern "C" int llmseg_lora_down(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t M, int64_t K, int32_t w_kr, float alpha,
-                                int32_t zero_cols, const llmseg_dropout* drop, void* stream) {
-  LL_CHECK(x && w && y && M > 0 && K > 0 && (K & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0 && ldy >= 8 + zero_cols && zero_cols >= 0 &&
-               (zero_cols & 7) == 0 && zero_cols <= 504 && AL16(x) && AL16(w) && AL16(y) && LL_DROP_OK(drop), "lora_down: bad arguments");
-  hipLaunchKernelGGL(lora_down_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ldx, (const bf16_t*)w,
-                     (bf16_t*)y, (long)ldy, (long)M, (int)K, w_kr, alpha, zero_cols, make_drop(drop));
+extern "C" int llmseg_lora_down(const void* x0, const void* x1, int64_t ldx, const void* w0, const void* w1, void* y, int64_t ldy, int64_t M, int64_t K,
+                                int32_t w_kr, float alpha, int32_t zero_cols, const llmseg_dropout* drop, void* stream) {
+  const int nb = (x1 && w1) ? 2 : 1;
+  LL_CHECK(x0 && w0 && y && (!x1) == (!w1) && M > 0 && K > 0 && (K & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0 && ldy >= 8 * nb + zero_cols &&
+               zero_cols >= 0 && (zero_cols & 7) == 0 && zero_cols <= 480 && AL16(x0) && AL16(x1) && AL16(w0) && AL16(w1) && AL16(y) && LL_DROP_OK(drop),
+           "lora_down: bad arguments");
+  const DropP dp = make_drop(drop);
+  if (M <= 2048)
+    hipLaunchKernelGGL(lora_down_kernel<1>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x0, (const bf16_t*)(x1 ? x1 : x0),
+                       (long)ldx, (const bf16_t*)w0, (const bf16_t*)(w1 ? w1 : w0), (bf16_t*)y, (long)ldy, (long)M, (int)K, w_kr, alpha, zero_cols, nb, dp);
+  else
+    hipLaunchKernelGGL(lora_down_kernel<4>, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x0, (const bf16_t*)(x1 ? x1 : x0),
+                       (long)ldx, (const bf16_t*)w0, (const bf16_t*)(w1 ? w1 : w0), (bf16_t*)y, (long)ldy, (long)M, (int)K, w_kr, alpha, zero_cols, nb, dp);
   LL_LAUNCH_CHECK("lora_down");
   return LLMSEG_OK;
 }
 
-extern "C" int llmseg_lora_outer(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t M, int64_t N, int32_t out_rn, float alpha,
-                                 const llmseg_dropout* drop, void* stream) {
-  LL_CHECK(a && b && out && M > 0 && N > 0 && (N & 7) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && AL16(a) && AL16(b) && LL_DROP_OK(drop),
-           "lora_outer: bad arguments (N, lda, ldb multiples of 8)");
+extern "C" int llmseg_lora_outer(const void* a0, const void* a1, int64_t lda, const void* b0, const void* b1, int64_t ldb, float* out0, float* out1, int64_t M,
+                                 int64_t N, int32_t out_rn, float alpha, const llmseg_dropout* drop, void* stream) {
+  const int nz = (a1 && b1 && out1) ? 2 : 1;
+  LL_CHECK(a0 && b0 && out0 && ((!a1) == (!b1)) && ((!a1) == (!out1)) && M > 0 && N > 0 && (N & 7) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && AL16(a0) &&
+               AL16(a1) && AL16(b0) && AL16(b1) && LL_DROP_OK(drop), "lora_outer: bad arguments (N, lda, ldb multiples of 8)");
   const unsigned gy = (unsigned)max((long)1, min((long)32, M / 64));
-  hipLaunchKernelGGL(lora_outer_kernel, dim3((unsigned)((N + 255) / 256), gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (long)lda,
-                     (const bf16_t*)b, (long)ldb, out, (long)M, (long)N, out_rn, alpha, make_drop(drop));
+  OuterP q;
+  q.a[0] = (const bf16_t*)a0; q.a[1] = (const bf16_t*)a1; q.b[0] = (const bf16_t*)b0; q.b[1] = (const bf16_t*)b1; q.out[0] = out0; q.out[1] = out1;
+  hipLaunchKernelGGL(lora_outer_kernel, dim3((unsigned)((N + 255) / 256), gy, nz), dim3(256), 0, (hipStream_t)stream, q, (long)lda, (long)ldb, (long)M, (long)N,
+                     out_rn, alpha, make_drop(drop));
   LL_LAUNCH_CHECK("lora_outer");
   return LLMSEG_OK;
 }
 
-extern "C" int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, int64_t ldxa, const void* w, int64_t M, int64_t N, int32_t w_rn, float alpha,
-                                 const llmseg_dropout* drop, void* stream) {
-  LL_CHECK(y && xa && w && M > 0 && N > 0 && (N & 7) == 0 && (ldy & 7) == 0 && (ldxa & 7) == 0 && AL16(y) && AL16(xa) && AL16(w) && LL_DROP_OK(drop),
-           "lora_apply: bad arguments");
+extern "C" int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, int64_t ldxa, const void* w0, const void* w1, int64_t M, int64_t N, int32_t w_rn,
+                                 float alpha, const llmseg_dropout* drop, void* stream) {
+  LL_CHECK(y && xa && w0 && M > 0 && N > 0 && (N & 7) == 0 && (ldy & 7) == 0 && (ldxa & 7) == 0 && ldxa >= (w1 ? 16 : 8) && AL16(y) && AL16(xa) && AL16(w0) &&
+               AL16(w1) && LL_DROP_OK(drop), "lora_apply: bad arguments");
   LL_CHECK(!(drop && drop->drop_thr) || ldy == N, "lora_apply: the dropout mask indexes y as a dense [M][N] matrix");
   hipLaunchKernelGGL(lora_apply_kernel, dim3(grid_for(M * (N >> 3))), dim3(256), 0, (hipStream_t)stream, (bf16_t*)y, (long)ldy, (const bf16_t*)xa,
-                     (long)ldxa, (const bf16_t*)w, (long)M, (long)N, w_rn, alpha, make_drop(drop));
+                     (long)ldxa, (const bf16_t*)w0, (const bf16_t*)w1, (long)M, (long)N, w_rn, alpha, w1 ? 2 : 1, make_drop(drop));
   LL_LAUNCH_CHECK("lora_apply");
   return LLMSEG_OK;
 }

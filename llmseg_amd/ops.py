@@ -371,32 +371,43 @@ def _drop(drop):
     return C.byref(_lib.Dropout(rng_state=rng.data_ptr(), stream=int(stream), drop_thr=int(round(p * 65536))))
 
 
-def lora_down(x, w, w_kr=False, alpha=1.0, out=None, zero_cols=0, drop=None):
+def lora_down(x, w, w_kr=False, alpha=1.0, out=None, zero_cols=0, drop=None, x2=None, w2=None):
     """y [M, 8] = alpha * drop(x) [M, K] @ W^T; W stored [8, K] (or [K, 8] when w_kr).  x may be a column view (row stride = ld).
-    `out` may be 8 columns of a wider row (e.g. buf[:, 8:16]); `zero_cols` further columns of every row are zero-filled."""
+    With (x2, w2) the second branch lands in columns 8..15 of the same rows (its dropout stream is drop's + 1; x2 may be x).  `out`
+    may be the leading columns of a wider row; `zero_cols` further columns of every row are zero-filled."""
     M, K = x.shape
-    y = torch.empty((M, 8), device=x.device, dtype=BF16) if out is None else out
-    assert y.shape[0] == M and y.stride(1) == 1
-    _lib.check(_lib.load().llmseg_lora_down(_ptr(x), x.stride(0), _ptr(w), _ptr(y), y.stride(0), M, K, 1 if w_kr else 0, alpha, zero_cols,
-                                            _drop(drop), _stream()), "lora_down")
+    nb = 1 if w2 is None else 2
+    y = torch.empty((M, 8 * nb), device=x.device, dtype=BF16) if out is None else out
+    assert y.shape[0] == M and y.stride(1) == 1 and (x2 is None or (x2.shape == x.shape and x2.stride(0) == x.stride(0)))
+    _lib.check(_lib.load().llmseg_lora_down(_ptr(x), _ptr(x2 if w2 is not None and x2 is not None else (x if w2 is not None else None)), x.stride(0),
+                                            _ptr(w), _ptr(w2), _ptr(y), y.stride(0), M, K, 1 if w_kr else 0, alpha, zero_cols, _drop(drop), _stream()),
+               "lora_down")
     return y
 
 
-def lora_outer(a, b, out_rn=False, alpha=1.0, out=None, drop=None):
-    """out [N, 8] (or [8, N] when out_rn) += alpha * drop(a)[M, N]^T @ b[M, 8], fp32 (a fresh zero buffer unless `out` is given)."""
+def lora_outer(a, b, out_rn=False, alpha=1.0, out=None, drop=None, a2=None, b2=None, out2=None):
+    """out [N, 8] (or [8, N] when out_rn) += alpha * drop(a)[M, N]^T @ b[M, 8], fp32 (a fresh zero buffer unless `out` is given).
+    With (a2, b2) a second, independent product of the same shapes runs in the same launch (dropout stream + 1) -> (out, out2)."""
     M, N = a.shape
+    shape = (8, N) if out_rn else (N, 8)
     if out is None:
-        out = torch.zeros((8, N) if out_rn else (N, 8), device=a.device, dtype=torch.float32)
+        out = torch.zeros(shape, device=a.device, dtype=torch.float32)
     assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == 8 * N and b.stride(1) == 1
-    _lib.check(_lib.load().llmseg_lora_outer(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), M, N, 1 if out_rn else 0, alpha, _drop(drop),
-                                             _stream()), "lora_outer")
-    return out
+    if b2 is not None:
+        a2 = a if a2 is None else a2
+        if out2 is None:
+            out2 = torch.zeros(shape, device=a.device, dtype=torch.float32)
+        assert a2.shape == a.shape and a2.stride(0) == a.stride(0) and b2.stride(0) == b.stride(0) and out2.is_contiguous() and out2.numel() == 8 * N
+    _lib.check(_lib.load().llmseg_lora_outer(_ptr(a), _ptr(a2 if b2 is not None else None), a.stride(0), _ptr(b), _ptr(b2), b.stride(0), _ptr(out),
+                                             _ptr(out2 if b2 is not None else None), M, N, 1 if out_rn else 0, alpha, _drop(drop), _stream()), "lora_outer")
+    return out if b2 is None else (out, out2)
 
 
-def lora_apply_(y, xa, w, w_rn=False, alpha=1.0, drop=None):
-    """y [M, N] += alpha * mask * (xa [M, 8] @ W^T) in place; W stored [N, 8] (or [8, N] when w_rn).  y may be a column view."""
+def lora_apply_(y, xa, w, w_rn=False, alpha=1.0, drop=None, w2=None):
+    """y [M, N] += alpha * mask * (xa [M, 8] @ W^T) in place; W stored [N, 8] (or [8, N] when w_rn).  y may be a column view.
+    With w2: + alpha * mask2 * (xa[:, 8:16] @ W2^T) in the same pass (dropout stream + 1)."""
     M, N = y.shape
-    _lib.check(_lib.load().llmseg_lora_apply(_ptr(y), y.stride(0), _ptr(xa), xa.stride(0), _ptr(w), M, N, 1 if w_rn else 0, alpha, _drop(drop),
+    _lib.check(_lib.load().llmseg_lora_apply(_ptr(y), y.stride(0), _ptr(xa), xa.stride(0), _ptr(w), _ptr(w2), M, N, 1 if w_rn else 0, alpha, _drop(drop),
                                              _stream()), "lora_apply")
     return y
 

@@ -171,16 +171,6 @@ class HipAdamW:
                     d.copy_(s)
 
 
-def _clone_batch(batch):
-    def c(v):
-        if torch.is_tensor(v):
-            return v.clone()
-        if isinstance(v, (list, tuple)):
-            return [c(x) for x in v]
-        return v
-    return {k: c(v) for k, v in batch.items()}
-
-
 def _copy_batch(dst, src):
     for k, v in src.items():
         d = dst[k]
@@ -275,22 +265,22 @@ class Trainer:
                 ent["graph"] = None
                 return self._eager_step(batch, plan)
         _copy_batch(ent["batch"], batch)
-        ent["plan"].copy_tensors_from(plan)
+        if plan is not ent["plan"]:
+            ent["plan"].copy_tensors_from(plan)
         ent["graph"].replay()
         return ent["out"]
 
     def _capture(self, ent, batch, plan):
-        from .trainable import BatchPlan
-        sb = _clone_batch(batch)
-        sp = BatchPlan()
-        sp.__dict__.update({k: v for k, v in plan.__dict__.items() if k != "tensors"})
-        sp.tensors = {k: (None if v is None else v.clone()) for k, v in plan.tensors.items()}
+        """Capture fwd+bwd of one micro-step.  The graph reads its inputs from the tensors of THIS call (`batch`, `plan`): a caller that
+        keeps feeding the same tensor objects (a loader writing each micro-batch into fixed device buffers, the benchmark's resident
+        batch) pays no copy; any other tensor passed later is copied into them."""
+        sb = {k: ([x for x in v] if isinstance(v, (list, tuple)) else v) for k, v in batch.items()}
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            out = self.module.model_forward(**sb, plan=sp)
+            out = self.module.model_forward(**sb, plan=plan)
             out["loss"].backward()
-        ent.update(graph=g, batch=sb, plan=sp, out={k: v.detach() for k, v in out.items() if torch.is_tensor(v)})
+        ent.update(graph=g, batch=sb, plan=plan, out={k: v.detach() for k, v in out.items() if torch.is_tensor(v)})
 
     # ------------------------------------------------------------------------------------------------ optimizer step
     def optimizer_step(self):

@@ -343,6 +343,14 @@ class TrainableMixin:
         return iou.view(Cn * K), emb
 
     # ------------------------------------------------------------------------------------------------ model_forward
+    overlap_towers = True          # issue the frozen segmentation backbone on its own HIP stream (class default; set False to serialise)
+
+    def _tower_stream(self):
+        st = self.__dict__.get("_side_stream")
+        if st is None:
+            st = self.__dict__["_side_stream"] = torch.cuda.Stream(device=self.device_)
+        return st
+
     def visual_features_cl(self, images, F):
         """-> (channels-last feature rows bf16, rows per image, row offset of the first patch, grid)."""
         c = self.config
@@ -380,14 +388,28 @@ class TrainableMixin:
     def _model_forward(self, images, images_clip, input_ids, masks_list, sam_segs_list, sam_ious_list, sam_iops_list, inference, return_aux, plan):
         c = self.config
         F = self._F()
-        images, images_clip = images.to(BF16), images_clip.to(BF16)
-        feat, rows_per_img, row0, g = self.visual_features_cl(images.contiguous(), F)
+        images, images_clip = images.to(BF16).contiguous(), images_clip.to(BF16)
         B = images.shape[0]
         assert B == plan.B
         if inference:
             assert images_clip.shape[0] == 1                                             # LISA.py:271
+        # The frozen segmentation backbone (SAM ViT-H / DINOv2) and the CLIP -> Llama chain do not depend on each other until the mask
+        # pooling: they are issued on two HIP streams, so the short-matrix Llama GEMMs (M = N_seq x 319 rows leaves CUs idle) and the
+        # backbone's kernels share the chip.  Inside a captured micro-step the two streams become parallel branches of the hipGraph.
+        side = self._tower_stream() if (self.overlap_towers and (c.backbone == "sam" or not F.grad)) else None   # (DINOv2's 1x1 conv trains: keep autograd on one stream)
+        if side is not None:
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                feat, rows_per_img, row0, g = self.visual_features_cl(images, F)
+            images.record_stream(side)
+        else:
+            feat, rows_per_img, row0, g = self.visual_features_cl(images, F)
         clip_in = images_clip.index_select(0, plan.clip_index)                          # one CLIP image per sequence (LISA.py:271-303)
         ce, logits, hidden = self.llava_forward(clip_in.contiguous(), input_ids, plan, want_logits=return_aux or not inference)
+        if side is not None:
+            cur.wait_stream(side)
+            feat.record_stream(cur)
 
         # [SEG] rows: gather first, then the MLP (identical to the reference's MLP-on-everything + boolean gather, LISA.py:318-323)
         N, T, H = hidden.shape
