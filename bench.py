@@ -33,6 +33,19 @@ def cpu_baseline(threads=None, budget_s=45.0):
     return cb.run(threads=threads, budget_s=budget_s)
 
 
+def pmc_traffic(kernel, B):
+    """HBM bytes per launch of `kernel` from the fabric counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x 2 on
+    gfx950; tools/pmc_traffic.sh -> profiles/traffic.json, collected on an MI355X with this same bench command at the same batch).  The
+    counters cannot be read from inside this process: None when no record for this kernel and batch is committed."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"batch_{B}", {}).get("kernels", {})
+    except (OSError, ValueError):
+        return None
+    key = kernel.replace("<*", "<false")
+    hit = rec.get(key)
+    return None if hit is None else hit["hbm_bytes_per_launch"]
+
+
 def attention_flops(cfg, B, T):
     """Dense attention FLOPs per step (heads * 2*Nq*Nk*hd * 2), as SURVEY.md §8d counts them."""
     f = 0.0
@@ -51,22 +64,27 @@ def attention_flops(cfg, B, T):
     return f * B
 
 
+def _sync(dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+
+
 def timed(step, steps, warmup, dist, dev):
     """W untimed + exactly K timed calls of step(), bracketed by barrier + synchronize; max over ranks.  -> (seconds, last output)"""
     out = None
     for _ in range(warmup):
         out = step()
-    torch.cuda.synchronize()
+    _sync(dev)
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    _sync(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
-    torch.cuda.synchronize()
+    _sync(dev)
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    _sync(dev)
     dt = time.perf_counter() - t0
     if dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -128,7 +146,7 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
     ach_all = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     model_flops = gemm_flops / n_prof + attention_flops(cfg, B, T)
     res["roofline"] = {"bound": "mfma", "kernel": prof["dominant_kernel"], "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                       "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "launches_per_step": dom_launches / n_prof,
+                       "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(prof["dominant_kernel"], B), "launches_per_step": dom_launches / n_prof,
                        "avg_launch_us": dom_ms * 1e3 / max(1, dom_launches), "time_share_of_step": dom_ms / n_prof / res["ms_per_step"],
                        "timing": "HIP events around every GEMM launch, %d eager steps of the same micro-step after the timed region" % n_prof,
                        "all_gemm_kernels": {"achieved": ach_all, "launches_per_step": gemm_launches / n_prof,
@@ -166,7 +184,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="issue the frozen backbone on the main stream instead of its own HIP stream")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--ddp-wrapper", action="store_true", help="torch DDP wrapper + bf16 .grad instead of the fp32 gradient arena")
-    ap.add_argument("--force-ddp", action="store_true", help="with --ddp-wrapper: wrap in DDP even at world size 1")
+    ap.add_argument("--force-ddp", "--force-dist", dest="force_ddp", action="store_true",
+                    help="initialise the RCCL process group even at world size 1 (the gradient all-reduce / the DDP wrapper then run on one GPU)")
     ap.add_argument("--lora-dropout", type=float, default=0.05, help="peft lora_dropout (reference training.py:91)")
     ap.add_argument("--accum", type=int, default=10, help="gradient-accumulation micro-steps per optimizer step (reference: 10)")
     args = ap.parse_args()

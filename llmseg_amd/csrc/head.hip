@@ -80,6 +80,76 @@ __global__ __launch_bounds__(256) void mask_pullback_kernel(const bf16_t* __rest
   if (wsum_out && tid == 0) wsum_out[k] = wsum;
 }
 
+// The same pull-back for the shape the path really has (S = 256 proposals pixels, g = 64 cells, 4 pixels per cell) with COALESCED loads:
+// the mask is walked in chunks of 8 rows; thread t loads ONE 16-byte piece (row t / 32, pixels 8c .. 8c + 7, c = t % 32) -- a row is 32
+// lanes x 16 B = one 512-byte burst -- and computes in registers the horizontal partial sums of the four source columns its 8 pixels
+// touch (2c-1, 2c, 2c+1, 2c+2: a source column gathers from pixels 4 sx - 2 .. 4 sx + 5); the two outer partials go to the neighbour
+// lanes by shuffle.  The 8 x 64 row results pass through LDS once for the vertical taps (same stencil), accumulated in acc[64][64].
+// The previous kernel issued 16 scalar 2-byte loads per thread per row (0.47 TB/s); this one streams the masks (read once) with the
+// next chunk's load in flight behind the current chunk's arithmetic.
+__global__ __launch_bounds__(256) void mask_pullback_s256_kernel(const bf16_t* __restrict__ segs, bf16_t* __restrict__ wn, float* __restrict__ pb_out,
+                                                                float* __restrict__ wsum_out) {
+  constexpr int S = 256, G = 64;
+  __shared__ float tmp[2][8][G];                 // horizontal sums of the current 8-row chunk (double-buffered: one barrier per chunk)
+  __shared__ float acc[G * G];
+  __shared__ float red[16];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const int r = tid >> 5, c = tid & 31;          // this thread's row inside a chunk / 8-pixel piece inside the row
+  const float scale = 0.25f;
+  const bf16_t* m = segs + (long)k * S * S + r * S + c * 8;
+  // horizontal tap weights of this thread's 8 pixels onto its four source columns (exact bilinear adjoint incl. the clamped borders)
+  float wa[8], wb[8], wc[2], wd[2];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { wa[j] = bilin_w(8 * c + j, 2 * c, scale, G); wb[j] = bilin_w(8 * c + j, 2 * c + 1, scale, G); }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { wc[j] = c > 0 ? bilin_w(8 * c + j, 2 * c - 1, scale, G) : 0.f; wd[j] = c < 31 ? bilin_w(8 * c + 6 + j, 2 * c + 2, scale, G) : 0.f; }
+  // vertical pass: thread t owns (target slot q = t / 64 -> sy = 2C - 1 + q, column sx = t % 64) of every chunk C
+  const int q = tid >> 6, sx = tid & 63;
+  for (int i = tid; i < G * G; i += 256) acc[i] = 0.f;
+  uint4 cur = *reinterpret_cast<const uint4*>(m);
+  for (int C = 0; C < S / 8; ++C) {
+    uint4 nxt = cur;
+    if (C + 1 < S / 8) nxt = *reinterpret_cast<const uint4*>(m + (long)(C + 1) * 8 * S);
+    float e[8];
+    unpack8(cur, e);
+    float ha = 0.f, hb = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ha = fmaf(e[j], wa[j], ha); hb = fmaf(e[j], wb[j], hb); }
+    const float hc = e[0] * wc[0] + e[1] * wc[1];          // -> source column 2c - 1 (owned by lane c - 1 as its hb)
+    const float hd = e[6] * wd[0] + e[7] * wd[1];          // -> source column 2c + 2 (owned by lane c + 1 as its ha)
+    const float from_left = __shfl_up(hd, 1, 32), from_right = __shfl_down(hc, 1, 32);
+    if (c > 0) ha += from_left;
+    if (c < 31) hb += from_right;
+    float* tb = &tmp[C & 1][r][0];
+    *reinterpret_cast<float2*>(tb + 2 * c) = make_float2(ha, hb);
+    __syncthreads();
+    const int sy = 2 * C - 1 + q;
+    if (sy >= 0 && sy < G) {
+      float a = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) a = fmaf(tmp[C & 1][rr][sx], bilin_w(8 * C + rr, sy, scale, G), a);
+      acc[sy * G + sx] += a;                                // (sy, sx) is touched by exactly one thread per chunk
+    }
+    cur = nxt;
+  }
+  __syncthreads();
+  float part = 0.f;
+  for (int i = tid; i < G * G; i += 256) part += acc[i];
+  const float wsum = block_sum(part, red);
+  const float inv = 1.f / (wsum + 1e-8f);
+  for (int i = tid; i < G * G / 8; i += 256) {
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = acc[i * 8 + j] * inv;
+    *reinterpret_cast<uint4*>(wn + (long)k * G * G + i * 8) = pack8(o);
+    if (pb_out) {
+      *reinterpret_cast<float4*>(pb_out + (long)k * G * G + i * 8) = make_float4(acc[i * 8], acc[i * 8 + 1], acc[i * 8 + 2], acc[i * 8 + 3]);
+      *reinterpret_cast<float4*>(pb_out + (long)k * G * G + i * 8 + 4) = make_float4(acc[i * 8 + 4], acc[i * 8 + 5], acc[i * 8 + 6], acc[i * 8 + 7]);
+    }
+  }
+  if (wsum_out && tid == 0) wsum_out[k] = wsum;
+}
+
 // ---- cosine scores: one wave per proposal ------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cosine_kernel(const bf16_t* __restrict__ t, const bf16_t* __restrict__ e, float* __restrict__ sim, int K, int D) {
   const int lane = threadIdx.x & 63;
@@ -204,6 +274,11 @@ __global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logi
 extern "C" int llmseg_mask_pullback(const void* segs, void* ws, float* pulled_back, float* wsum, int32_t K, int32_t g, int32_t S, void* stream) {
   LL_CHECK(segs && ws && K > 0 && g > 0 && S >= g, "mask_pullback: bad arguments");
   LL_CHECK(256 % g == 0 && ((g * g) & 7) == 0, "mask_pullback: feature grid %d must divide 256", g);
+  if (S == 256 && g == 64 && ((((uintptr_t)segs) | ((uintptr_t)ws)) & 15) == 0 && (!pulled_back || (((uintptr_t)pulled_back) & 15) == 0)) {
+    hipLaunchKernelGGL(mask_pullback_s256_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)segs, (bf16_t*)ws, pulled_back, wsum);
+    LL_LAUNCH_CHECK("mask_pullback");
+    return LLMSEG_OK;
+  }
   const size_t lds = ((size_t)((S + 1) / 2) * g + (size_t)g * g + 16) * sizeof(float);
   LL_CHECK(lds <= 64 * 1024, "mask_pullback: S=%d g=%d need %zu bytes of LDS", S, g, lds);
   hipLaunchKernelGGL(mask_pullback_kernel, dim3(K), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)segs, (bf16_t*)ws, pulled_back, wsum, g, S);

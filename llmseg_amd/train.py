@@ -42,14 +42,19 @@ class GradArena:
     ALIGN = 64          # elements: every block starts 256-byte aligned (vector accesses of the GEMM epilogue)
 
     def __init__(self, model):
-        from .params import fused_groups
         self.model = model
-        flat = model.params.flat
-        groups = {g: [m for m in members if m in flat] for g, members in fused_groups(model.config) if g in flat}
+        if hasattr(model, "params") and hasattr(model.params, "flat"):           # LISAForCausalLM: ParamTree with fused weight groups
+            from .params import fused_groups
+            flat = model.params.flat
+            named = list(model.params.named_parameters())
+            groups = {g: [m for m in members if m in flat] for g, members in fused_groups(model.config) if g in flat}
+        else:                                                                     # any nn.Module whose Functions honour `_g32`
+            named = list(model.named_parameters())
+            flat, groups = dict(named), {}
         member_of = {m: g for g, ms in groups.items() for m in ms}
         blocks, seen, total = [], set(), 0
         self.params = []
-        for name, p in model.params.named_parameters():
+        for name, p in named:
             if not p.requires_grad:
                 continue
             self.params.append(p)
@@ -90,6 +95,7 @@ class GradArena:
                     self._attach(w2d, p._g32.view(p.shape[0], p.shape[1]), make_leaf=True)
                     views["model.lisa_dino_conv.weight2d"] = w2d
         model.__dict__["_arena_views"] = views
+
 
     def _attach(self, t, view, make_leaf=False):
         t._g32 = view
@@ -190,13 +196,18 @@ class Trainer:
     `LISAForCausalLM` (the gloo tests' toy modules), uses plain `.grad` tensors and torch DDP."""
 
     def __init__(self, module, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.0, clip=1.0, grad_accum=10, warmup=100, total_steps=5000,
-                 optimizer=None, device_ids=None, force_ddp=False, ddp_wrapper=False, use_graph=False, graph_warmup=2):
+                 optimizer=None, device_ids=None, force_ddp=False, ddp_wrapper=False, use_graph=False, graph_warmup=2, use_arena=None):
+        """optimizer: None = HipAdamW; or a factory `params -> optimizer` / an optimizer object (CPU tests).  use_arena: None = automatic
+        (the HIP model with the built-in optimizer), True = force the fp32 gradient arena (the module's autograd Functions must honour `_g32`)."""
         self.module = module
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.dist_on = dist.is_initialized()
         self.ddp = None
         self.arena = None
-        arena_ok = hasattr(module, "params") and hasattr(module, "make_plan") and optimizer is None and not ddp_wrapper
-        if arena_ok:
+        is_hip_model = hasattr(module, "params") and hasattr(module, "make_plan")
+        if use_arena is None:
+            use_arena = is_hip_model and optimizer is None and not ddp_wrapper
+        if use_arena:
             self.arena = GradArena(module)
             self.params = self.arena.params
         else:
@@ -204,13 +215,16 @@ class Trainer:
                 self.ddp = torch.nn.parallel.DistributedDataParallel(module, device_ids=device_ids, broadcast_buffers=False,
                                                                    gradient_as_bucket_view=False)
             self.params = [p for p in module.parameters() if p.requires_grad]
+        if callable(optimizer) and not hasattr(optimizer, "step"):
+            optimizer = optimizer(self.params)
         self.opt = optimizer if optimizer is not None else HipAdamW(self.params, betas, weight_decay=weight_decay)
         if hasattr(self.opt, "resync_master") and hasattr(module, "__dict__"):
             module.__dict__.setdefault("_weight_hooks", []).append(self.opt.resync_master)
         self.lr, self.clip, self.accum, self.warmup, self.total = lr, clip, grad_accum, warmup, total_steps
         self.micro = 0
         self.opt_steps = 0
-        self.use_graph = bool(use_graph) and self.arena is not None
+        self.is_hip_model = is_hip_model
+        self.use_graph = bool(use_graph) and self.arena is not None and is_hip_model
         self.graph_warmup = graph_warmup
         self._graphs = {}
         self.graph_error = None
@@ -229,12 +243,15 @@ class Trainer:
         """Forward + backward of one micro-batch; runs the optimizer on every `grad_accum`-th call.  Returns the loss dict.
         `plan` (HIP model only): the batch's `BatchPlan`; built here when absent (one device synchronisation)."""
         last = (self.micro + 1) % self.accum == 0
-        if self.arena is not None:
+        if self.arena is not None and self.is_hip_model:
             if getattr(self.module.config.llama, "lora_dropout", 0.0) > 0:
                 self.module.advance_dropout()
             if plan is None:
                 plan = self.module.make_plan(**batch)
             out = self._graph_step(batch, plan) if self.use_graph else self._eager_step(batch, plan)
+        elif self.arena is not None:
+            out = self.module(**batch)
+            out["loss"].backward()
         else:
             fwd = self.ddp if self.ddp is not None else self.module
             sync_ctx = contextlib.nullcontext() if (last or self.ddp is None) else self.ddp.no_sync()
@@ -287,11 +304,14 @@ class Trainer:
         lr = warmup_decay_lr(self.opt_steps, self.lr, self.warmup, self.total)
         scale = 1.0 / self.accum
         if self.arena is not None:
-            if self.world > 1:                           # the data-parallel exchange: one all-reduce of the flat fp32 gradient arena
-                dist.all_reduce(self.arena.flat)
+            if self.dist_on:                             # the data-parallel exchange: ONE all-reduce of the flat fp32 gradient arena
+                dist.all_reduce(self.arena.flat)         # (also issued at world size 1, where it is the identity)
                 scale /= self.world
-            ss = torch.zeros(1, device=self.arena.flat.device, dtype=torch.float32)
-            self.opt.ops.sumsq(self.arena.flat, ss)                                      # global gradient norm: ONE reduction over the arena
+            if hasattr(self.opt, "sumsq_flat"):
+                ss = self.opt.sumsq_flat(self.arena.flat)
+            else:
+                ss = torch.zeros(1, device=self.arena.flat.device, dtype=torch.float32)
+                self.opt.ops.sumsq(self.arena.flat, ss)                                  # global gradient norm: ONE reduction over the arena
         else:
             ss = self.opt.grad_sumsq()                  # gradients hold the SUM over `accum` micro-steps (DDP already averaged over ranks)
         norm = torch.sqrt(ss) * scale

@@ -357,6 +357,19 @@ def check_head():
     ref = ohead.mask_pooling(up, segs.float())
     got = ops.upsample_maskpool(feat[0].permute(1, 2, 0).reshape(g * g, Cc).contiguous().to(DEV), segs.to(DEV), g, S)
     out.append(("upsample_maskpool", err(got, ref), tol_bf16(ref)))
+    # BASELINE configs[4] size: K = 512 proposals; the raw pull-back (segs . U, fp32) and the mask areas against the exact adjoint of
+    # F.interpolate obtained by autograd, and the pooled features against the oracle
+    K5 = 512
+    segs5 = (torch.rand(K5, S, S, generator=gen) > 0.6).to(BF)
+    segs5[7] = torch.rand(S, S, generator=gen).to(BF)
+    x0 = torch.zeros(1, K5, g, g, requires_grad=True)
+    (F.interpolate(x0, size=(S, S), mode="bilinear", align_corners=False)[0] * segs5.float()).sum().backward()
+    featc = feat[0].permute(1, 2, 0).reshape(g * g, Cc).contiguous().to(DEV)
+    got5, pb5, ws5 = ops.upsample_maskpool(featc, segs5.to(DEV), g, S, want_aux=True)
+    out.append(("mask pull-back K=512 vs autograd adjoint", err(pb5.view(K5, g, g), x0.grad[0]), 2e-4 * x0.grad.abs().max().item()))
+    out.append(("mask areas K=512", err(ws5, segs5.float().flatten(1).sum(1)), 2e-2))
+    ref5 = ohead.mask_pooling(up, segs5.float())
+    out.append(("upsample_maskpool K=512", err(got5, ref5), tol_bf16(ref5)))
     Kp, D = 256, 256
     e, t = rnd(Kp, D, seed=3), rnd(D, seed=4)
     ref = ohead.cosine_scores(t.float()[None], e.float())[0]

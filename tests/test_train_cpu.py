@@ -33,6 +33,49 @@ class CpuAdamW:
             p.data.add_(-(lr * (mh / (vh.sqrt() + self.eps) + self.wd * p.data)))
 
 
+class ArenaLinearFn(torch.autograd.Function):
+    """y = x W^T + b whose weight / bias gradients are ACCUMULATED into the tensors' `_g32` arena views (what the HIP Functions do kernel-side)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.g = (w._g32, b._g32)
+        return x @ w.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        ctx.g[0].add_(dy.t() @ x)
+        ctx.g[1].add_(dy.sum(0))
+        return dy @ w, None, None
+
+
+class ArenaToy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.a = nn.Linear(6, 5)
+        self.b = nn.Linear(5, 1)
+
+    def forward(self, x, y):
+        h = torch.tanh(ArenaLinearFn.apply(x, self.a.weight, self.a.bias))
+        return {"loss": ((ArenaLinearFn.apply(h, self.b.weight, self.b.bias) - y) ** 2).mean()}
+
+
+class CpuArenaAdamW(CpuAdamW):
+    """reads the fp32 arena views instead of .grad"""
+
+    def sumsq_flat(self, flat):
+        return (flat.double() ** 2).sum().float().reshape(1)
+
+    def step(self, lr, grad_scale):
+        for p in self.params:
+            p.grad = p._g32.clone()
+        super().step(lr, grad_scale)
+        for p in self.params:
+            p.grad = None
+
+
 class Toy(nn.Module):
     def __init__(self):
         super().__init__()
@@ -59,6 +102,53 @@ def _worker(rank, world, port, ret):
         tr.micro_step(dict(x=x, y=y))
     ret[rank] = (tr.opt_steps, torch.cat([p.detach().flatten() for p in m.parameters()]))
     dist.destroy_process_group()
+
+
+def _arena_worker(rank, world, port, ret):
+    """The arena path of the trainer (one all-reduce of the flat fp32 gradient buffer per optimizer step) + bench.py's timing plumbing
+    (barrier, per-rank wall clock, all_reduce(MAX)) under gloo on the CPU."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = ArenaToy()
+    tr = Trainer(m, lr=1e-2, clip=1.0, grad_accum=3, warmup=2, total_steps=10, optimizer=lambda ps: CpuArenaAdamW(ps), use_arena=True)
+    assert tr.arena is not None and tr.ddp is None
+    import bench
+    step_no = [0]
+
+    def step():
+        x, y = _data(rank, step_no[0])
+        step_no[0] += 1
+        return tr.micro_step(dict(x=x, y=y))
+    dt, out = bench.timed(step, 5, 1, dist, torch.device("cpu"))
+    assert all(p.grad is None for p in m.parameters())
+    ret[rank] = (tr.opt_steps, torch.cat([p.detach().flatten() for p in m.parameters()]), dt, float(out["loss"]))
+    dist.destroy_process_group()
+
+
+def test_arena_gloo_matches_single_process_and_bench_plumbing():
+    world, port = 2, 29613
+    ret = mp.Manager().dict()
+    mp.spawn(_arena_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret[0][0] == 2 and ret[1][0] == 2                       # 1 warm-up + 5 timed micro-steps / accum 3
+    assert torch.equal(ret[0][1], ret[1][1])                        # replicas stay bit-identical
+    assert ret[0][2] == ret[1][2] and ret[0][2] > 0                 # bench.timed: MAX over ranks -> the same number on every rank
+    m = Toy()                                                       # same init (seed 0), plain autograd
+    opt = CpuAdamW(list(m.parameters()))
+    for o in range(2):
+        for p in m.parameters():
+            p.grad = None
+        for s in range(3 * o, 3 * o + 3):
+            for r in range(world):
+                x, y = _data(r, s)
+                (m(x, y)["loss"] / world).backward()
+        ss = opt.grad_sumsq()
+        norm = ss.sqrt() / 3
+        coef = torch.clamp(1.0 / (norm + 1e-6), max=1.0) / 3
+        opt.step(warmup_decay_lr(o, 1e-2, 2, 10), coef)
+    ref = torch.cat([p.detach().flatten() for p in m.parameters()])
+    assert torch.allclose(ret[0][1], ref, atol=1e-6), (ret[0][1] - ref).abs().max()
 
 
 def test_ddp_gloo_matches_single_process():
