@@ -195,6 +195,8 @@ int llmseg_align_reg_loss(const void* e, const void* t, const float* gt_iou, con
  * logits bf16/fp32-as-float [M][HW] given as fp32, targets fp32; out[0] = dice (scale 1000, eps 1e-6), out[1] = bce,
  * both summed over masks / (num_masks + 1e-8).  out must be zeroed by the caller. */
 int llmseg_dice_bce(const float* logits, const float* targets, float* out, int32_t M, int64_t HW, float num_masks, void* stream);
+/* gradient of g[0] * dice + g[1] * bce w.r.t. the logits (g: device fp32[2], the upstream gradients of the two losses) */
+int llmseg_dice_bce_bwd(const float* logits, const float* targets, const float* g, float* dlogits, int32_t M, int64_t HW, float num_masks, void* stream);
 
 /* Shifted cross-entropy over bf16 logits (llava_llama.py:108-118): rows = N*T positions, labels int64 [N][T] already in
  * spliced form; position (n,t) is scored against labels[n][t+1]; ignore_index -100.  acc fp32[2] += {sum nll, count}. */
@@ -207,10 +209,28 @@ int llmseg_ce_loss(const void* logits, const int64_t* labels, float* acc, int32_
 int llmseg_intersection_union(const uint8_t* pred, const uint8_t* target, int64_t n, int32_t ignore_index, int64_t* out, void* stream);
 
 /* validate_threshold's per-image body (training.py:712-766) in one pass: union of the proposals with select[k] != 0 (segs uint8
- * [H][W][K], the reader's layout), nearest-resize of that union and of gt (uint8 [Hg][Wg], 255 = ignore) to out_size^2, 2-class I/U.
+ * [H][W][K], the reader's layout), nearest-resize of that union and of gt (uint8 [Hg][Wg], 255 = ignore) to out_h x out_w, 2-class I/U.
+ * `validate` (arg-max of the similarity, training.py:605-687) is the same with a one-hot select and out = Hg x Wg.
  * out int64[6] += {I0, I1, U0, U1, T0, T1}. */
 int llmseg_union_resize_iou(const uint8_t* segs, const uint8_t* select, const uint8_t* gt, int32_t H, int32_t W, int32_t K, int32_t Hg, int32_t Wg,
-                            int32_t out_size, int32_t ignore_index, int64_t* out, void* stream);
+                            int32_t out_h, int32_t out_w, int32_t ignore_index, int64_t* out, void* stream);
+
+/* ---- proposal decode + training targets on the device (the reference does this per sample on CPU workers) -----
+ * rle_decode: COCO run-length proposals -> dense uint8 masks (pycocotools `mask_util.decode`, utils/sam_mask_reader.py:86-87).  run_ends =
+ *   inclusive prefix sums of every mask's run lengths, concatenated; offsets int64 [K+1] delimits mask k's slice; runs alternate 0 / 1 from 0
+ *   and walk the image column-major.  out uint8 [K][H][W] (hwk = 0) or [H][W][K] (hwk = 1, the reader's layout).
+ * mask_targets: `compute_all_iou` / `compute_all_iop` (utils/utils.py:234-272) for all K proposals: ground truth gt [Hg][Wg] resampled to the
+ *   proposals' H x W grid through the nearest-neighbour index maps gy [H], gx [W] (skimage.transform.resize(order=0) rule, built on the host
+ *   in float64), counts int64 [K][2] += {|seg & gt|, |seg|}, gt_area int64 [1] += |gt'| (caller zero-fills both), then
+ *   iou[k] = I / (S + G - I), iop[k] = I / S as IEEE doubles (0 / 0 = nan, as numpy gives the reference).  Integer parts are exact.
+ * resize_aa: proposal maps (utils/reason_seg_dataset.py:166-173): masks uint8 [K][H][W], zero-padded bottom / right to the square of side
+ *   max(H, W), resampled to out_size x out_size with torch's antialiased bilinear filter, written as bf16 [K][out][out].  Tap tables per
+ *   output index (first source index, tap count, float64 weights [out][taps]) come from the host (aten `_compute_indices_weights_aa`). */
+int llmseg_rle_decode(const uint32_t* run_ends, const int64_t* offsets, uint8_t* out, int32_t K, int32_t H, int32_t W, int32_t hwk, void* stream);
+int llmseg_mask_targets(const uint8_t* segs, const uint8_t* gt, const int32_t* gy, const int32_t* gx, int32_t K, int32_t H, int32_t W, int32_t Hg,
+                        int32_t Wg, int64_t* counts, int64_t* gt_area, double* iou, double* iop, void* stream);
+int llmseg_resize_aa(const uint8_t* segs, void* out, int32_t K, int32_t H, int32_t W, int32_t out_size, const int32_t* y0, const int32_t* ny,
+                     const double* wy, const int32_t* x0, const int32_t* nx, const double* wx, int32_t taps, void* stream);
 
 /* ---- backward pass + optimizer (trainable part: LoRA'd Llama stack, embed/lm_head, text_hidden_fcs, mask-selection head) -----
  * GEMM-shaped gradients use llmseg_gemm_bf16 with trans_a / trans_w (dX = dY W, dW = dY^T X); the kernels below are the

@@ -73,9 +73,13 @@ SIGNATURES = {
     "llmseg_cosine_scores": [_p, _p, _p, _i32, _i32, _p],
     "llmseg_align_reg_loss": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
     "llmseg_dice_bce": [_p, _p, _p, _i32, _i64, _f32, _p],
+    "llmseg_dice_bce_bwd": [_p, _p, _p, _p, _i32, _i64, _f32, _p],
     "llmseg_ce_loss": [_p, _p, _p, _i32, _i32, _i64, _i64, _p],
     "llmseg_intersection_union": [_p, _p, _i64, _i32, _p, _p],
-    "llmseg_union_resize_iou": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p],
+    "llmseg_union_resize_iou": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p],
+    "llmseg_rle_decode": [_p, _p, _p, _i32, _i32, _i32, _i32, _p],
+    "llmseg_mask_targets": [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p],
+    "llmseg_resize_aa": [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p],
     "llmseg_colsum": [_p, _p, _i64, _i64, _i64, _p],
     "llmseg_norm_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _f32, C.c_int, _p],
     "llmseg_swiglu_bwd": [_p, _p, _p, _i64, _i64, _p],

@@ -432,6 +432,23 @@ class AlignRegFn(Function):
         return (d_e * g[0]).to(BF16), (d_t * g[0]).to(BF16), (d_p * g[1]).to(BF16), None, None
 
 
+class DiceBceFn(Function):
+    """dice_loss + sigmoid_ce_loss on mask logits (reference model/loss.py:4-47; named by the north_star, no caller in the reference):
+    logits / targets fp32 [M, H, W] -> fp32[2] = (dice, bce), both already divided by (num_masks + 1e-8)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, num_masks):
+        logits, targets = logits.contiguous(), targets.contiguous()
+        ctx.num = float(num_masks)
+        ctx.save_for_backward(logits, targets)
+        return ops.dice_bce(logits, targets, num_masks)
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, targets = ctx.saved_tensors
+        return ops.dice_bce_bwd(logits, targets, g.float().contiguous(), ctx.num), None, None
+
+
 class MaskPoolFn(Function):
     @staticmethod
     def forward(ctx, feat_cl, segs, g, S):

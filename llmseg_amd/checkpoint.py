@@ -1,0 +1,118 @@
+"""Checkpoint interchange: read the reference's DeepSpeed checkpoints, save / resume this trainer in the same
+directory layout.
+
+The reference saves with `model_engine.save_checkpoint(log_dir/ckpt_model)` and resumes with `load_checkpoint` + the `latest` tag file
+(reference `training.py:404-421,460-477`; layout documented in its `README.md:118-130`):
+
+    <dir>/latest                                   text file holding the tag, e.g. "global_step5000"
+    <dir>/<tag>/mp_rank_00_model_states.pt         {"module": state_dict of the engine's module, "global_steps": ..., ...}
+    <dir>/<tag>/bf16_zero_pp_rank_<r>_mp_rank_00_optim_states.pt     ZeRO-2 optimizer partitions, one per data-parallel rank
+
+The module is `PeftModel(LISAForCausalLM)`: its keys carry the prefix `base_model.model.`; LoRA keys are `...q_proj.lora_A.default.weight`.
+Everything after the prefix is a key of this package's state dict (llmseg_amd/params.py keeps the reference's names), except buffers that
+are recomputed here (`rotary_emb.inv_freq`) and SAM's prompt encoder / mask decoder (not on the `model_forward` path).
+
+Written by this package: the same directory layout and the same `module` key names, so the reference's loader (and ours) can read the
+weights; the optimizer state is ONE file in this package's own format (`llmseg_optim_states.pt`: fp32 master weights, Adam moments, step
+counters) -- DeepSpeed's rank-partitioned flat buffers are not reproduced (PARITY UNPINNED: deepspeed==0.10.0 is absent).
+"""
+import os
+import re
+
+import torch
+
+PEFT_PREFIX = "base_model.model."
+_DROP = (re.compile(r"\.rotary_emb\.inv_freq$"), re.compile(r"^model\.visual_model\.(prompt_encoder|mask_decoder)\."), re.compile(r"^model\.visual_model\.pixel_(mean|std)$"))
+
+
+def reference_key(name):
+    """Key of a reference checkpoint (`module` dict of mp_rank_00_model_states.pt) -> key of this package's state dict, or None when
+    the entry is not used on the `model_forward` path."""
+    for pfx in ("module.", PEFT_PREFIX):
+        if name.startswith(pfx):
+            name = name[len(pfx):]
+    if any(p.search(name) for p in _DROP):
+        return None
+    return name
+
+
+def resolve(path):
+    """A checkpoint directory (with `latest`), a tag directory or the model-states file itself -> (model-states file, tag)."""
+    if os.path.isdir(path):
+        latest = os.path.join(path, "latest")
+        if os.path.exists(latest):
+            tag = open(latest).read().strip().splitlines()[0].strip()
+            return os.path.join(path, tag, "mp_rank_00_model_states.pt"), tag
+        return os.path.join(path, "mp_rank_00_model_states.pt"), os.path.basename(os.path.normpath(path))
+    return path, os.path.basename(os.path.dirname(path))
+
+
+def load_reference_checkpoint(model, path, strict=False):
+    """Load the weights of a DeepSpeed checkpoint of the reference (or one written by `save_checkpoint`) into `model`.
+    -> dict(missing=[...], ignored=[...], tag=..., global_steps=...)."""
+    f, tag = resolve(path)
+    try:
+        blob = torch.load(f, map_location="cpu", weights_only=True)
+    except Exception:                                   # DeepSpeed pickles config objects next to the tensors
+        blob = torch.load(f, map_location="cpu", weights_only=False)
+    sd_in = blob["module"] if "module" in blob else blob
+    sd, ignored = {}, []
+    for k, v in sd_in.items():
+        nk = reference_key(k)
+        if nk is None or not torch.is_tensor(v):
+            ignored.append(k)
+        else:
+            sd[nk] = v
+    own = {n for n, _ in model.params.named_parameters()}
+    ignored += [k for k in sd if k not in own]
+    sd = {k: v for k, v in sd.items() if k in own}
+    missing, _ = model.load_state_dict(sd, strict=False)
+    if strict and missing:
+        raise KeyError(f"checkpoint lacks {len(missing)} tensors, e.g. {missing[:5]}")
+    return {"missing": missing, "ignored": ignored, "tag": tag, "global_steps": blob.get("global_steps") if isinstance(blob, dict) else None}
+
+
+def save_checkpoint(save_dir, model, trainer=None, global_step=0, trainable_only=False, rank=0):
+    """Write <save_dir>/global_step<N>/{mp_rank_00_model_states.pt, llmseg_optim_states.pt} + <save_dir>/latest (rank 0 writes)."""
+    tag = f"global_step{int(global_step)}"
+    d = os.path.join(save_dir, tag)
+    if rank != 0:
+        return d
+    os.makedirs(d, exist_ok=True)
+    req = {n for n, p in model.params.named_parameters() if p.requires_grad}
+    module = {PEFT_PREFIX + k: v.detach().to("cpu") for k, v in model.state_dict().items() if (not trainable_only or k in req)}
+    torch.save({"module": module, "global_steps": int(global_step), "dp_world_size": getattr(trainer, "world", 1), "mp_world_size": 1,
+                "writer": "llmseg_amd"}, os.path.join(d, "mp_rank_00_model_states.pt"))
+    if trainer is not None:
+        st = trainer.state_dict()
+        st["param_names"] = [n for n, p in model.params.named_parameters() if p.requires_grad]
+        if hasattr(model, "dropout_state"):
+            st["dropout_state"] = model.dropout_state().cpu()
+        torch.save(st, os.path.join(d, "llmseg_optim_states.pt"))
+    with open(os.path.join(save_dir, "latest"), "w") as fh:
+        fh.write(tag)
+    return d
+
+
+def load_checkpoint(load_dir, model, trainer=None, steps_per_epoch=500):
+    """Resume (`--auto_resume`, training.py:404-421): weights, then -- when this package wrote the checkpoint -- the optimizer state.
+    -> dict(tag, global_steps, start_epoch, optimizer_restored)."""
+    info = load_reference_checkpoint(model, load_dir)
+    f, tag = resolve(load_dir)
+    opt_file = os.path.join(os.path.dirname(f), "llmseg_optim_states.pt")
+    restored = False
+    if trainer is not None:
+        if os.path.exists(opt_file):
+            st = torch.load(opt_file, map_location="cpu", weights_only=True)
+            names = [n for n, p in model.params.named_parameters() if p.requires_grad]
+            assert st.get("param_names") == names, "optimizer state belongs to a different trainable set"
+            trainer.load_state_dict(st)
+            if "dropout_state" in st and hasattr(model, "dropout_state"):
+                model.dropout_state().copy_(st["dropout_state"])
+            restored = True
+        elif hasattr(trainer.opt, "resync_master"):
+            trainer.opt.resync_master()                 # a reference checkpoint: fresh Adam moments on the loaded weights
+    m = re.search(r"(\d+)$", tag or "")
+    steps = int(m.group(1)) if m else (info.get("global_steps") or 0)
+    return {"tag": tag, "global_steps": steps, "start_epoch": steps // max(1, steps_per_epoch), "optimizer_restored": restored,
+            "missing": info["missing"], "ignored": info["ignored"]}

@@ -249,6 +249,30 @@ __global__ __launch_bounds__(256) void dice_bce_kernel(const float* __restrict__
   }
 }
 
+// Backward of the pair above in one launch: dx = g[0] * d(dice)/dx + g[1] * d(bce)/dx, one workgroup per mask (sums first, then the
+// per-pixel gradient).  dice_m = 1 - N / D with N = 2 sum(s t) / sc + eps, D = (sum s + sum t) / sc + eps, s = sigmoid(x):
+// d dice_m / dx_i = -(2 t_i D - N) / (sc D^2) * s_i (1 - s_i);  d bce / dx_i = (s_i - t_i) / HW; both / (num_masks + 1e-8).
+__global__ __launch_bounds__(256) void dice_bce_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ g,
+                                                          float* __restrict__ dx, long HW, float num_masks) {
+  __shared__ float red[16];
+  const long m = blockIdx.x;
+  float sxy = 0.f, sx = 0.f, sy = 0.f;
+  for (long i = threadIdx.x; i < HW; i += blockDim.x) {
+    const float l = x[m * HW + i], t = y[m * HW + i];
+    const float s = 1.f / (1.f + __expf(-l));
+    sxy += s * t; sx += s; sy += t;
+  }
+  sxy = block_sum(sxy, red); sx = block_sum(sx, red); sy = block_sum(sy, red);
+  const float sc = 1000.f, eps = 1e-6f;
+  const float Nn = 2.f * sxy / sc + eps, D = sx / sc + sy / sc + eps;
+  const float inv = 1.f / (num_masks + 1e-8f), gd = g[0] * inv / (sc * D * D), gb = g[1] * inv / (float)HW;
+  for (long i = threadIdx.x; i < HW; i += blockDim.x) {
+    const float l = x[m * HW + i], t = y[m * HW + i];
+    const float s = 1.f / (1.f + __expf(-l));
+    dx[m * HW + i] = -gd * (2.f * t * D - Nn) * s * (1.f - s) + gb * (s - t);
+  }
+}
+
 // ---- shifted CE: one workgroup per (n, t) with a valid label -------------------------------------------------------------
 __global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logits, const int64_t* __restrict__ labels, float* __restrict__ acc, int T,
                                                 long V, long ldl) {
@@ -325,6 +349,14 @@ extern "C" int llmseg_dice_bce(const float* logits, const float* targets, float*
   return LLMSEG_OK;
 }
 
+extern "C" int llmseg_dice_bce_bwd(const float* logits, const float* targets, const float* g, float* dlogits, int32_t M, int64_t HW, float num_masks,
+                                   void* stream) {
+  LL_CHECK(logits && targets && g && dlogits && M > 0 && HW > 0, "dice_bce_bwd: bad arguments");
+  hipLaunchKernelGGL(dice_bce_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, targets, g, dlogits, (long)HW, num_masks);
+  LL_LAUNCH_CHECK("dice_bce_bwd");
+  return LLMSEG_OK;
+}
+
 extern "C" int llmseg_ce_loss(const void* logits, const int64_t* labels, float* acc, int32_t N, int32_t T, int64_t V, int64_t ldl, void* stream) {
   LL_CHECK(logits && labels && acc && N > 0 && T > 1 && V > 0 && ldl >= V, "ce_loss: bad arguments");
   hipLaunchKernelGGL(ce_kernel, dim3((unsigned)(N * (T - 1))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, labels, acc, T, (long)V,
@@ -375,23 +407,25 @@ extern "C" int llmseg_intersection_union(const uint8_t* pred, const uint8_t* tar
 }
 
 // ---- validate_threshold inner loop (reference training.py:712-766) fused: union of the selected proposals at original
-// resolution -> nearest resize of prediction and ground truth to out x out -> 2-class I/U with ignore 255.
+// resolution -> nearest resize of prediction and ground truth to out_h x out_w -> 2-class I/U with ignore 255 (the arg-max variant,
+// training.py:605-687, selects ONE proposal and scores at the ground truth's own resolution: out = Hg x Wg).
 // segs uint8 [H][W][K] (the reader's (H, W, K) layout), select uint8 [K] (pred_iou > threshold), gt uint8 [Hg][Wg].
 namespace {
 __global__ __launch_bounds__(256) void union_resize_iou_kernel(const uint8_t* __restrict__ segs, const uint8_t* __restrict__ select, const uint8_t* __restrict__ gt,
-                                                              int H, int W, int K, int Hg, int Wg, int out, int ignore, unsigned long long* __restrict__ res) {
+                                                              int H, int W, int K, int Hg, int Wg, int outh, int outw, int ignore,
+                                                              unsigned long long* __restrict__ res) {
   __shared__ unsigned long long sh[6];
   extern __shared__ uint8_t sel[];
   if (threadIdx.x < 6) sh[threadIdx.x] = 0;
   for (int k = threadIdx.x; k < K; k += blockDim.x) sel[k] = select[k];
   __syncthreads();
   unsigned int c[6] = {0, 0, 0, 0, 0, 0};
-  const long n = (long)out * out;
+  const long n = (long)outh * outw;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const int y = (int)(i / out), x = (int)(i % out);
+    const int y = (int)(i / outw), x = (int)(i % outw);
     // F.interpolate(mode="nearest"): src = min(floor(dst * in / out), in - 1)
-    const int sy = min((int)floorf((float)y * ((float)H / (float)out)), H - 1), sx = min((int)floorf((float)x * ((float)W / (float)out)), W - 1);
-    const int gy = min((int)floorf((float)y * ((float)Hg / (float)out)), Hg - 1), gx = min((int)floorf((float)x * ((float)Wg / (float)out)), Wg - 1);
+    const int sy = min((int)floorf((float)y * ((float)H / (float)outh)), H - 1), sx = min((int)floorf((float)x * ((float)W / (float)outw)), W - 1);
+    const int gy = min((int)floorf((float)y * ((float)Hg / (float)outh)), Hg - 1), gx = min((int)floorf((float)x * ((float)Wg / (float)outw)), Wg - 1);
     const int t = gt[(long)gy * Wg + gx];
     if (t == ignore) continue;
     const uint8_t* px = segs + ((long)sy * W + sx) * K;
@@ -418,9 +452,9 @@ __global__ __launch_bounds__(256) void union_resize_iou_kernel(const uint8_t* __
 }  // namespace
 
 extern "C" int llmseg_union_resize_iou(const uint8_t* segs, const uint8_t* select, const uint8_t* gt, int32_t H, int32_t W, int32_t K, int32_t Hg,
-                                       int32_t Wg, int32_t out_size, int32_t ignore_index, int64_t* out, void* stream) {
-  LL_CHECK(segs && select && gt && out && H > 0 && W > 0 && K > 0 && Hg > 0 && Wg > 0 && out_size > 0, "union_resize_iou: bad arguments");
-  hipLaunchKernelGGL(union_resize_iou_kernel, dim3(1024), dim3(256), (size_t)K, (hipStream_t)stream, segs, select, gt, H, W, K, Hg, Wg, out_size,
+                                       int32_t Wg, int32_t out_h, int32_t out_w, int32_t ignore_index, int64_t* out, void* stream) {
+  LL_CHECK(segs && select && gt && out && H > 0 && W > 0 && K > 0 && Hg > 0 && Wg > 0 && out_h > 0 && out_w > 0, "union_resize_iou: bad arguments");
+  hipLaunchKernelGGL(union_resize_iou_kernel, dim3(1024), dim3(256), (size_t)K, (hipStream_t)stream, segs, select, gt, H, W, K, Hg, Wg, out_h, out_w,
                      ignore_index, (unsigned long long*)out);
   LL_LAUNCH_CHECK("union_resize_iou");
   return LLMSEG_OK;

@@ -276,6 +276,15 @@ def dice_bce(logits, targets, num_masks):
     return out
 
 
+def dice_bce_bwd(logits, targets, g, num_masks):
+    """g fp32[2] = upstream gradients of (dice, bce) -> d logits (fp32, same shape)."""
+    M = logits.shape[0]
+    HW = logits[0].numel()
+    dx = torch.empty_like(logits)
+    _lib.check(_lib.load().llmseg_dice_bce_bwd(_ptr(logits), _ptr(targets), _ptr(g), _ptr(dx), M, HW, float(num_masks), _stream()), "dice_bce_bwd")
+    return dx
+
+
 def ce_loss(logits, labels):
     """logits bf16 [N,T,V(ld)], labels int64 [N,T] (spliced) -> fp32[2] = (sum nll, count)."""
     N, T, V = logits.shape
@@ -295,13 +304,15 @@ def intersection_union(pred_u8, target_u8, ignore_index=255, out=None):
 
 
 def union_resize_iou(segs_hwk_u8, select_u8, gt_u8, out_size=1024, ignore_index=255, out=None):
-    """Union of selected proposals (segs [H,W,K] uint8) + nearest resize of it and of gt [Hg,Wg] to out_size^2 + I/U -> int64[6]."""
+    """Union of selected proposals (segs [H,W,K] uint8) + nearest resize of it and of gt [Hg,Wg] to out_size (an int: square; a (h, w)
+    pair; or None = the ground truth's own size) + I/U -> int64[6]."""
     H, W, K = segs_hwk_u8.shape
     Hg, Wg = gt_u8.shape
+    oh, ow = (Hg, Wg) if out_size is None else ((out_size, out_size) if isinstance(out_size, int) else out_size)
     if out is None:
         out = torch.zeros((6,), device=segs_hwk_u8.device, dtype=torch.int64)
     _lib.check(_lib.load().llmseg_union_resize_iou(_ptr(segs_hwk_u8.contiguous()), _ptr(select_u8.contiguous()), _ptr(gt_u8.contiguous()), H, W, K,
-                                                   Hg, Wg, out_size, ignore_index, _ptr(out), _stream()), "union_resize_iou")
+                                                   Hg, Wg, oh, ow, ignore_index, _ptr(out), _stream()), "union_resize_iou")
     return out
 
 

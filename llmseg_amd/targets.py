@@ -1,0 +1,146 @@
+"""Proposal decode + IoU / IoP targets + the 256 x 256 proposal maps on the device: the per-sample work the
+reference does on CPU data-loader workers, feeding `model_forward`'s `sam_segs_list` / `sam_ious_list` / `sam_iops_list`.
+
+Mirrors, with the same names and argument meaning where they exist in the reference:
+  * `SAM_Mask_Reader.extract_sam_segs` (utils/sam_mask_reader.py:69-113): proposals sorted by area, top 50, RLE -> dense, padded square;
+  * `compute_all_iou` / `compute_all_iop` (utils/utils.py:234-272): ground truth resampled to the proposals' grid with
+    `skimage.transform.resize(order=0)`, then |seg & gt| / |seg | gt| and |seg & gt| / |seg|;
+  * the dataset's proposal maps (utils/reason_seg_dataset.py:166-173): float64 zero-padded square -> `F.interpolate(size=(256, 256),
+    mode="bilinear", align_corners=False, antialias=True)` -> bf16.
+Host side: parsing the COCO run-length strings and building the (tiny) index / tap tables in float64; every per-pixel operation runs in
+libllmseg_hip.so (`llmseg_rle_decode`, `llmseg_mask_targets`, `llmseg_resize_aa`)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+
+
+def rle_counts(rle):
+    """COCO RLE dict {'size': [h, w], 'counts': str | bytes | list} -> run lengths (uint32).  The compressed string packs each count
+    in 5-bit groups, low group first, bit 5 = continuation, bit 4 of the last group = sign; counts from the fourth on are deltas against
+    the count two positions back (pycocotools maskApi rleFrString)."""
+    cnts = rle["counts"]
+    if isinstance(cnts, (list, tuple, np.ndarray)):
+        return np.asarray(cnts, dtype=np.uint32)
+    if isinstance(cnts, str):
+        cnts = cnts.encode("ascii")
+    b = np.frombuffer(cnts, dtype=np.uint8).astype(np.int64) - 48
+    last = (b & 0x20) == 0                                   # final group of each count
+    idx = np.cumsum(np.concatenate([[0], last[:-1]]))        # which count a group belongs to
+    start = np.concatenate([[0], np.nonzero(last)[0][:-1] + 1])
+    pos = np.arange(len(b)) - start[idx]                     # group position inside its count
+    vals = np.zeros(int(idx[-1]) + 1, dtype=np.int64)
+    np.add.at(vals, idx, (b & 0x1f) << (5 * pos))
+    ends = np.nonzero(last)[0]
+    neg = (b[ends] & 0x10) != 0
+    vals[neg] |= -1 << (5 * (pos[ends][neg] + 1))
+    for i in range(3, len(vals)):                            # delta coding (sequential by definition; masks have O(1e3) runs)
+        vals[i] += vals[i - 2]
+    return vals.astype(np.uint32)
+
+
+def nearest_index(out_n, in_n):
+    """Source index of every output index for skimage.transform.resize(order=0, anti_aliasing=False) == scipy.ndimage.zoom(order=0,
+    grid_mode=True): coordinate (i + 0.5) * (in / out) - 0.5 in float64, nearest = floor(c + 0.5)."""
+    zoom = np.float64(in_n) / np.float64(out_n)
+    c = (np.arange(out_n, dtype=np.float64) + 0.5) * zoom - 0.5
+    return np.clip(np.floor(c + 0.5), 0, in_n - 1).astype(np.int32)
+
+
+def aa_taps(in_size, out_size):
+    """Tap tables of torch's antialiased bilinear resampling (aten UpSampleKernel `_compute_indices_weights_aa`, triangle filter, float64):
+    -> (first [out] int32, count [out] int32, weights [out, taps] float64)."""
+    scale = np.float64(in_size) / np.float64(out_size)
+    support = scale if scale >= 1.0 else np.float64(1.0)
+    invscale = 1.0 / scale if scale >= 1.0 else np.float64(1.0)
+    taps = int(np.ceil(support)) * 2 + 1
+    first = np.zeros(out_size, np.int32)
+    count = np.zeros(out_size, np.int32)
+    w = np.zeros((out_size, taps), np.float64)
+    for i in range(out_size):
+        center = scale * (i + 0.5)
+        xmin = max(int(center - support + 0.5), 0)
+        xsize = min(int(center + support + 0.5), in_size) - xmin
+        ws = np.array([max(0.0, 1.0 - abs((j + xmin - center + 0.5) * invscale)) for j in range(xsize)], dtype=np.float64)
+        tot = ws.sum()
+        first[i], count[i] = xmin, xsize
+        w[i, :xsize] = ws / tot if tot != 0 else ws
+    return first, count, w
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def decode_rles(rles, device, hwk=False):
+    """list of COCO RLE dicts (same size) -> uint8 [K, H, W] (or [H, W, K], `mask_util.decode`'s layout) on the device."""
+    H, W = rles[0]["size"]
+    runs = [rle_counts(r) for r in rles]
+    assert all(tuple(r["size"]) == (H, W) for r in rles)
+    ends = np.concatenate([np.cumsum(r, dtype=np.uint64).astype(np.uint32) for r in runs])
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in runs])]).astype(np.int64)
+    K = len(rles)
+    d_ends = torch.from_numpy(ends.view(np.int32)).to(device)
+    d_offs = torch.from_numpy(offs).to(device)
+    out = torch.empty((H, W, K) if hwk else (K, H, W), device=device, dtype=torch.uint8)
+    _lib.check(_lib.load().llmseg_rle_decode(_p(d_ends), _p(d_offs), _p(out), K, H, W, 1 if hwk else 0, _stream()), "rle_decode")
+    return out
+
+
+def mask_targets(segs, gt):
+    """segs uint8 [K, H, W] (device), gt uint8 [Hg, Wg] (device, non-zero = object) -> (iou, iop) float64 [K] -- `compute_all_iou` /
+    `compute_all_iop` of the reference for all K proposals in one pass -- plus the exact integer counts [K, 2] = (|seg & gt|, |seg|)."""
+    K, H, W = segs.shape
+    Hg, Wg = gt.shape
+    dev = segs.device
+    gy = torch.from_numpy(nearest_index(H, Hg)).to(dev)
+    gx = torch.from_numpy(nearest_index(W, Wg)).to(dev)
+    cnt = torch.zeros((K, 2), device=dev, dtype=torch.int64)
+    garea = torch.zeros((1,), device=dev, dtype=torch.int64)
+    iou = torch.empty((K,), device=dev, dtype=torch.float64)
+    iop = torch.empty((K,), device=dev, dtype=torch.float64)
+    _lib.check(_lib.load().llmseg_mask_targets(_p(segs.contiguous()), _p(gt.contiguous()), _p(gy), _p(gx), K, H, W, Hg, Wg, _p(cnt), _p(garea), _p(iou), _p(iop),
+                                               _stream()), "mask_targets")
+    return iou, iop, cnt
+
+
+def resize_square_aa(segs, out_size=256):
+    """segs uint8 [K, H, W] -> bf16 [K, out, out]: zero-pad to the square of side max(H, W) (bottom / right, `preprocess_mask`) and
+    resample with the antialiased bilinear filter."""
+    K, H, W = segs.shape
+    side = max(H, W)
+    first, count, w = aa_taps(side, out_size)
+    dev = segs.device
+    d_first, d_count, d_w = torch.from_numpy(first).to(dev), torch.from_numpy(count).to(dev), torch.from_numpy(w).to(dev)
+    out = torch.empty((K, out_size, out_size), device=dev, dtype=BF16)
+    _lib.check(_lib.load().llmseg_resize_aa(_p(segs.contiguous()), _p(out), K, H, W, out_size, _p(d_first), _p(d_count), _p(d_w), _p(d_first), _p(d_count), _p(d_w),
+                                            w.shape[1], _stream()), "resize_aa")
+    return out
+
+
+def extract_sam_segs(masks, device, top=50):
+    """`SAM_Mask_Reader.extract_sam_segs` on the device: `masks` = the image's proposal records ({'segmentation': RLE, 'area', 'bbox'}).
+    -> {"segs_origin": uint8 [K, H, W], "bbox": [...]} (the zero-padded square is never materialised: `resize_square_aa` pads on the fly)."""
+    ms = sorted(masks, key=lambda m: m["area"], reverse=True)[:top]
+    return {"segs_origin": decode_rles([m["segmentation"] for m in ms], device), "bbox": [m["bbox"] for m in ms]}
+
+
+def proposals_and_targets(masks, gt_masks, device, top=50, out_size=256):
+    """Everything `model_forward` needs about one image's proposals: -> dict(sam_segs bf16 [K, 256, 256], sam_ious / sam_iops float64 [C, K]
+    for the C sampled ground-truth masks (uint8 [Hg, Wg] tensors or arrays), segs_origin uint8 [K, H, W])."""
+    d = extract_sam_segs(masks, device, top)
+    segs = d["segs_origin"]
+    ious, iops = [], []
+    for g in gt_masks:
+        g = torch.as_tensor(np.asarray(g) if not torch.is_tensor(g) else g).to(device=device, dtype=torch.uint8)
+        iou, iop, _ = mask_targets(segs, g)
+        ious.append(iou); iops.append(iop)
+    return {"sam_segs": resize_square_aa(segs, out_size), "sam_ious": torch.stack(ious), "sam_iops": torch.stack(iops), "segs_origin": segs, "bbox": d["bbox"]}

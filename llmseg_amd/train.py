@@ -82,16 +82,14 @@ class GradArena:
                 if key.endswith("cross_attn_image_to_token.qkv.weight") or key.endswith("cross_attn_image_to_token.qkv.bias"):
                     # the k|v half as one operand (rows D.. of the fused tensor): a leaf view that carries its arena block
                     D = buf.shape[0] // 3
-                    with torch.no_grad():
-                        kv = buf[D:]
+                    kv = buf[D:].detach()        # an alias without an autograd view relation to `buf` (which is itself a leaf that is updated in place)
                     self._attach(kv, gv[D:], make_leaf=True)
                     views[key.replace("qkv.", "kv.")] = kv
             else:
                 p = flat[key]
                 self._attach(p, self.flat[off:off + n].view(p.shape))
                 if key == "model.lisa_dino_conv.weight":
-                    with torch.no_grad():
-                        w2d = p.view(p.shape[0], p.shape[1])
+                    w2d = p.detach().view(p.shape[0], p.shape[1]).detach()
                     self._attach(w2d, p._g32.view(p.shape[0], p.shape[1]), make_leaf=True)
                     views["model.lisa_dino_conv.weight2d"] = w2d
         model.__dict__["_arena_views"] = views

@@ -11,13 +11,44 @@ import torch.distributed as dist
 from . import ops
 
 
+def _meters(dev):
+    return (torch.zeros(2, device=dev, dtype=torch.float64), torch.zeros(2, device=dev, dtype=torch.float64),
+            torch.zeros(2, device=dev, dtype=torch.float64), torch.zeros(1, device=dev, dtype=torch.float64))
+
+
+def _finish(inter, union, acc, count):
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        for t in (inter, union, acc, count):
+            dist.all_reduce(t)
+    giou = (acc / count.clamp(min=1))[1].item()
+    ciou = (inter / (union + 1e-10))[1].item()
+    return {"giou": giou, "ciou": ciou, "images": int(count.item())}
+
+
+@torch.no_grad()
+def validate(model, samples):
+    """The arg-max variant (reference `training.py:605-687` `validate`): the proposal with the highest cosine similarity to the [SEG]
+    embedding IS the prediction; it is nearest-resized to the ground truth's resolution and scored there."""
+    dev = next(model.parameters()).device
+    inter, union, acc, count = _meters(dev)
+    for s in samples:
+        kw = {k: v for k, v in s.items() if k not in ("origin_segs", "gt_mask")}
+        out = model.model_forward(**kw, inference=True)
+        sim = out["pred_similarity"][0][0]
+        select = torch.zeros_like(sim, dtype=torch.uint8)
+        select[torch.argmax(sim)] = 1                                                   # training.py:627-634
+        iu = ops.union_resize_iou(s["origin_segs"], select, s["gt_mask"], out_size=None).double()
+        i, u = iu[0:2], iu[2:4]
+        a = i / (u + 1e-8)
+        a = torch.where(u == 0, a + 1.0, a)                                             # no-object target (training.py:653)
+        inter += i; union += u; acc += a; count += 1
+    return _finish(inter, union, acc, count)
+
+
 @torch.no_grad()
 def validate_threshold(model, samples, threshold=0.5, out_size=1024):
     dev = next(model.parameters()).device
-    inter = torch.zeros(2, device=dev, dtype=torch.float64)
-    union = torch.zeros(2, device=dev, dtype=torch.float64)
-    acc = torch.zeros(2, device=dev, dtype=torch.float64)
-    count = torch.zeros(1, device=dev, dtype=torch.float64)
+    inter, union, acc, count = _meters(dev)
     for s in samples:
         kw = {k: v for k, v in s.items() if k not in ("origin_segs", "gt_mask")}
         out = model.model_forward(**kw, inference=True)
@@ -27,9 +58,4 @@ def validate_threshold(model, samples, threshold=0.5, out_size=1024):
         a = i / (u + 1e-8)
         a = torch.where(u == 0, a + 1.0, a)                                             # no-object target (training.py:768)
         inter += i; union += u; acc += a; count += 1
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        for t in (inter, union, acc, count):
-            dist.all_reduce(t)
-    giou = (acc / count.clamp(min=1))[1].item()
-    ciou = (inter / (union + 1e-10))[1].item()
-    return {"giou": giou, "ciou": ciou, "images": int(count.item())}
+    return _finish(inter, union, acc, count)

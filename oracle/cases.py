@@ -79,8 +79,9 @@ def loss_inputs():
 
 
 def head_case(C=2, K=256, D=256):
+    """K = 256: BASELINE configs[1]/[2]; K = 512: configs[4] (the weights are the same seeded head)."""
     sd = seeded.fill_state_dict(seeded.head_shapes(512, D), 51)
-    pooled = seeded.uniform((K, D), 52, -1, 1)
+    pooled = seeded.uniform((K, D), 52 if K == 256 else 52 + K, -1, 1)
     text = seeded.uniform((C, D), 53, -1, 1)
     return sd, pooled, text
 

@@ -88,16 +88,24 @@ def gold_head():
     for n, m in mods.items():
         m.load_state_dict({k[len("model." + n) + 1:]: v for k, v in sd.items() if k.startswith("model." + n + ".")},
                           strict=True)
-    with torch.no_grad():
-        C = text.shape[0]
-        s, t = pooled.unsqueeze(0).expand(C, -1, -1), text.unsqueeze(1)       # LISA.py:363-372
-        for l in layers:
-            s, t = l(queries=s, keys=t)
-        s = nrm(s + fin(q=s, k=t, v=t))
-        r_iou, r_emb = iou_h(s), emb_h(s)
-        m_iou, m_emb = mask_head.mask_head(sd, "model.", pooled, text)
-    _check("head.iou", r_iou, m_iou); _check("head.emb", r_emb, m_emb)
-    torch.save({"iou": r_iou, "emb": r_emb}, os.path.join(OUT, "mask_head.pt"))
+
+    def run(pooled, text):
+        with torch.no_grad():
+            C = text.shape[0]
+            s, t = pooled.unsqueeze(0).expand(C, -1, -1), text.unsqueeze(1)       # LISA.py:363-372
+            for l in layers:
+                s, t = l(queries=s, keys=t)
+            s = nrm(s + fin(q=s, k=t, v=t))
+            r_iou, r_emb = iou_h(s), emb_h(s)
+            m_iou, m_emb = mask_head.mask_head(sd, "model.", pooled, text)
+        _check(f"head.iou K={pooled.shape[0]}", r_iou, m_iou); _check(f"head.emb K={pooled.shape[0]}", r_emb, m_emb)
+        return r_iou, r_emb
+    r_iou, r_emb = run(pooled, text)
+    # BASELINE configs[4]: 512 candidate masks -- the embeddings as a strided sample (file size), the scores in full
+    _, pooled5, text5 = cases.head_case(K=512)
+    r_iou5, r_emb5 = run(pooled5, text5)
+    torch.save({"iou": r_iou, "emb": r_emb, "iou_k512": r_iou5, "emb_k512_cols8": r_emb5[:, :, ::8].clone(),
+                "emb_k512_rownorm": r_emb5.norm(dim=-1)}, os.path.join(OUT, "mask_head.pt"))
 
 
 def gold_lisa_tiny():

@@ -178,6 +178,28 @@ def check_gemm():
     return out
 
 
+def check_gemm_hot_shapes():
+    """The GEMMs the benchmark spends its time in, at their real sizes (24 and 2 images per step), checked on a strided sample of output
+    rows / columns against an fp32 reference computed on the device in fp64-free chunks (A sample rows x full W)."""
+    out = []
+    shapes = [(98304, 5120, 1280, ops.ACT_GELU, "sam lin1 B=24"), (7656, 22016, 4096, ops.ACT_NONE, "llama gate_up B=24"),
+              (638, 4096, 11008, ops.ACT_NONE, "llama down B=2 (split-K)"), (638, 12288, 4096, ops.ACT_NONE, "llama qkv B=2 (128x256 tiles)")]
+    g = torch.Generator(device=DEV).manual_seed(0)
+    for M, N, K, act, tag in shapes:
+        a = (torch.rand((M, K), device=DEV, generator=g) * 2 - 1).to(BF)
+        w = ((torch.rand((N, K), device=DEV, generator=g) * 2 - 1) * (3.0 / K) ** 0.5).to(BF)
+        b = torch.randn((N,), device=DEV, generator=g).to(BF)
+        got = ops.gemm(a, w, bias=b, act=act)
+        rows = torch.arange(0, M, max(1, M // 97), device=DEV)
+        rows = torch.cat([rows, torch.tensor([M - 1, max(0, M - 130)], device=DEV)])        # incl. the ragged last tile
+        ref = a[rows].float() @ w.float().t() + b.float()
+        if act == ops.ACT_GELU:
+            ref = F.gelu(ref)
+        e = (got[rows].float() - ref).abs().max().item()
+        out.append((f"gemm hot shape {tag} {M}x{N}x{K} (sampled rows)", e, tol_bf16(ref.cpu(), 1.5)))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------- attention
 def _attn_ref(q, k, v, scale, bias=None):
     s = (q.float() @ k.float().transpose(-1, -2)) * scale
@@ -444,6 +466,13 @@ def check_validate_body():
         i, u, t, _ = metric.union_resize_iou(segs, piou, gt)
         got = ops.union_resize_iou(segs.to(DEV), (piou > 0.5).to(torch.uint8).to(DEV), gt.to(DEV)).cpu()
         out.append((f"union+resize+I/U case {n}", float((got - torch.cat([i, u, t]).long()).abs().max()), 0.0))
+        # the arg-max variant (`validate`): one proposal, scored at the ground truth's own resolution
+        sim = torch.rand(K, generator=gen)
+        i, u, t, _ = metric.argmax_iou(segs, sim, gt)
+        sel = torch.zeros(K, dtype=torch.uint8)
+        sel[int(torch.argmax(sim))] = 1
+        got = ops.union_resize_iou(segs.to(DEV), sel.to(DEV), gt.to(DEV), out_size=None).cpu()
+        out.append((f"arg-max proposal + resize-to-gt + I/U case {n}", float((got - torch.cat([i, u, t]).long()).abs().max()), 0.0))
     return out
 
 

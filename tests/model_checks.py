@@ -2,7 +2,8 @@
 
 Weights and inputs are rounded to bf16 once and shared, so what is compared is arithmetic, not weight rounding.
 Three numbers per output: |hip - oracle_fp32|, and for scale |oracle_bf16(CPU) - oracle_fp32| -- the error the
-reference's own bf16 CPU path makes against fp32.  Tolerance = max(floor, 3 x that bf16-CPU error).
+reference's own bf16 CPU path makes against fp32.  Tolerance = max(floor, 1.5 x that bf16-CPU error): the HIP path must be
+about as close to fp32 as the reference's own arithmetic is (it accumulates in fp32, so it normally sits below 1 x).
 """
 import dataclasses
 
@@ -81,7 +82,7 @@ def check_tiny_inference(backbone="dinov2", with_bf16_cpu=True):
     def add(name, g_, r_, l_, floor):
         scale = max(1.0, r_.abs().max().item())
         lo_e = _e(l_, r_) if with_bf16_cpu else 0.0
-        res.append((f"{backbone} {name} (bf16-CPU err {lo_e:.2e})", _e(g_, r_), max(floor * scale, 3.0 * lo_e)))
+        res.append((f"{backbone} {name} (bf16-CPU err {lo_e:.2e})", _e(g_, r_), max(floor * scale, 1.5 * lo_e)))
 
     rows_per = got["feats"].shape[0] // B
     gf = got["feats"].view(B, rows_per, C)[:, rows_per - g * g:].reshape(B * g * g, C)
@@ -119,7 +120,7 @@ def check_tiny_train_losses(backbone="dinov2", ragged=False):
         res.append((f"{backbone}{' ragged-K' if ragged else ''} train {k} (ref {r:.4f}, bf16-CPU err {abs(float(lo[k]) - r):.2e})", abs(float(got[k]) - r),
                     # scalar losses carry the bf16 rounding of the whole network (eps = 3.9e-3): 0.5 % of the value, or three
                     # times what the SAME fp32 oracle run in bf16 on the CPU deviates, whichever is larger
-                    max(5e-3 * max(1.0, abs(r)), 3.0 * abs(float(lo[k]) - r))))
+                    max(5e-3 * max(1.0, abs(r)), 1.5 * abs(float(lo[k]) - r))))
     return res
 
 
@@ -184,5 +185,95 @@ def check_validate_loop(backbone="dinov2"):
         i, u, _, a = metric.union_resize_iou(segs, row, gt, threshold=thr)
         I += i.double(); U += u.double(); A += a.double()
     ref_g, ref_c = (A / 3)[1].item(), (I / (U + 1e-10))[1].item()
-    return [(f"{backbone} validate gIoU ({nsel} proposals selected)", abs(got["giou"] - ref_g), 1e-6),
-            (f"{backbone} validate cIoU", abs(got["ciou"] - ref_c), 1e-6)]
+    res = [(f"{backbone} validate gIoU ({nsel} proposals selected)", abs(got["giou"] - ref_g), 1e-6),
+           (f"{backbone} validate cIoU", abs(got["ciou"] - ref_c), 1e-6)]
+    # the arg-max variant (`validate`, training.py:605-687), fed with the model's own similarity rows
+    got2 = validate.validate(m, samples)
+    I = torch.zeros(2, dtype=torch.float64); U = torch.zeros(2, dtype=torch.float64); A = torch.zeros(2, dtype=torch.float64)
+    for s, segs, gt in zip(samples, segs_cpu, gts_cpu):
+        kw = {k: v for k, v in s.items() if k not in ("origin_segs", "gt_mask")}
+        with torch.no_grad():
+            row = m.model_forward(**kw, inference=True)["pred_similarity"][0][0].float().cpu()
+        i, u, _, a = metric.argmax_iou(segs, row, gt)
+        I += i.double(); U += u.double(); A += a.double()
+    res += [(f"{backbone} validate (arg-max) gIoU", abs(got2["giou"] - (A / 3)[1].item()), 1e-6),
+            (f"{backbone} validate (arg-max) cIoU", abs(got2["ciou"] - (I / (U + 1e-10))[1].item()), 1e-6)]
+    return res
+
+
+def check_head_golden(golden_loader):
+    """The mask-selection head at BASELINE sizes (K = 256 of configs[1]/[2], K = 512 of configs[4], C = 2 conversations) against the
+    fixture recorded from the imported reference modules (tests/golden/mask_head.pt)."""
+    from llmseg_amd.trainable import _Direct
+    g = golden_loader("mask_head.pt")
+    cfg = cases.tiny_lisa_cfg("sam")
+    m = hip_lisa.LISAForCausalLM(to_hip_cfg(cfg), device=DEV).init_random(seed=1)
+    res = []
+    for K, key_iou in ((256, "iou"), (512, "iou_k512")):
+        sd, pooled, text = cases.head_case(K=K)
+        head_sd = {k: v.to(BF).float() for k, v in sd.items() if ".lisa_" in k and "dino_conv" not in k}
+        missing, unexpected = m.load_state_dict(head_sd, strict=False)
+        from oracle import mask_head as ohead
+        with torch.no_grad():
+            ref_iou, ref_emb = ohead.mask_head(head_sd, "model.", pooled.to(BF).float(), text.to(BF).float())     # same bf16-rounded weights / inputs
+            iou, emb = m._mask_head(pooled.to(BF).to(DEV), text.to(BF).to(DEV), _Direct)
+        C = text.shape[0]
+        iou = iou.view(C, K, 1).float().cpu()
+        emb = emb.view(C, K, -1).float().cpu()
+        res.append((f"head K={K} pred_iou vs oracle (rounded weights)", (iou - ref_iou).abs().max().item(), 4e-3))
+        res.append((f"head K={K} embedding vs oracle (rounded weights)", (emb - ref_emb).abs().max().item(), 2e-2 * max(1.0, ref_emb.abs().max().item())))
+        # against the reference fixture itself (fp32, un-rounded weights): adds the bf16 rounding of the weights
+        res.append((f"head K={K} pred_iou vs reference fixture", (iou - g[key_iou]).abs().max().item(), 8e-3))
+        if K == 256:
+            res.append(("head K=256 embedding vs reference fixture", (emb - g["emb"]).abs().max().item(), 3e-2 * max(1.0, g["emb"].abs().max().item())))
+        else:
+            res.append(("head K=512 embedding (strided columns) vs reference fixture", (emb[:, :, ::8] - g["emb_k512_cols8"]).abs().max().item(),
+                        3e-2 * max(1.0, g["emb_k512_cols8"].abs().max().item())))
+    return res
+
+
+def check_full_width_llama_layer():
+    """ONE Llama-7B decoder layer at full width (H = 4096, 32 heads x 128, inter 11008) on N = 2 sequences of T = 319 tokens (the benchmark's
+    micro-batch: every GEMM at M = 638, split-K / 128 x 256 dispatch, causal attention with right padding) against the fp32 oracle."""
+    from llmseg_amd.trainable import _Direct
+    from oracle import llama as ol, seeded
+    lcfg = ol.LlamaCfg(layers=1, vocab=64)
+    cfg = cases.tiny_lisa_cfg("sam")
+    cfg.llama = lcfg
+    sd = {k: v.to(BF).float() for k, v in seeded.fill_state_dict(seeded.llama_shapes(lcfg), 7).items()}
+    m = hip_lisa.LISAForCausalLM(to_hip_cfg(cfg), device=DEV).init_random(seed=1)
+    m.load_state_dict(sd, strict=False)
+    N, T = 2, 319
+    x = (seeded.uniform((N, T, lcfg.hidden), 8, -1, 1) * 2).to(BF).float()
+    am = torch.ones(N, T, dtype=torch.bool)
+    am[1, 300:] = False
+    with torch.no_grad():
+        ref = ol.llama_model(sd, "model.", x, am, lcfg)[-1]
+        lo = ol.llama_model({k: v.to(BF) for k, v in sd.items()}, "model.", x.to(BF), am, lcfg)[-1].float()
+        got = m._llama(x.to(BF).to(DEV), am.to(torch.uint8).to(DEV).contiguous(), _Direct).float().cpu()
+    keep = am[:, :, None]                                      # padded positions carry no meaning
+    e, lo_e = ((got - ref) * keep).abs().max().item(), ((lo - ref) * keep).abs().max().item()
+    return [(f"full-width Llama layer (M = 638) final-norm output (bf16-CPU err {lo_e:.2e}, |ref| {ref.abs().max().item():.1f})", e,
+             max(2e-2 * ref.abs().max().item(), 1.5 * lo_e))]
+
+
+def check_full_width_sam_blocks():
+    """SAM ViT-H at full width (dim 1280, 16 heads x 80, 64 x 64 grid at 1024 x 1024) with ONE windowed and ONE global block: patch embed,
+    14 x 14 windows with zero padding, decomposed rel-pos on both paths, neck -- against the fp32 oracle."""
+    from oracle import sam_encoder as osam, seeded
+    scfg = osam.SamCfg(depth=2, global_idx=(1,))
+    cfg = cases.tiny_lisa_cfg("sam")
+    cfg.sam = scfg
+    full = seeded.fill_state_dict(seeded.lisa_shapes(cfg), 5)
+    sd = {k: v.to(BF).float() for k, v in full.items()}
+    m = hip_lisa.LISAForCausalLM(to_hip_cfg(cfg), device=DEV)
+    m.load_state_dict(sd, strict=False)
+    img = seeded.uniform((1, 3, 1024, 1024), 9, -2, 2).to(BF).float()
+    pfx = "model.visual_model.image_encoder."
+    with torch.no_grad():
+        ref = osam.sam_image_encoder(sd, pfx, img, scfg)
+        lo = osam.sam_image_encoder({k: v.to(BF) for k, v in sd.items()}, pfx, img.to(BF), scfg).float()
+        got = m.get_visual_embs(img.to(DEV)).float().cpu()
+    lo_e = (lo - ref).abs().max().item()
+    return [(f"full-width SAM-H windowed + global block + neck (bf16-CPU err {lo_e:.2e}, |ref| {ref.abs().max().item():.2f})", (got - ref).abs().max().item(),
+             max(2e-2 * max(1.0, ref.abs().max().item()), 1.5 * lo_e))]

@@ -47,3 +47,8 @@ def test_model_grads_lora_arena():
 def test_trainer_eager_and_graph():
     from tests import backward_checks as bc
     _assert(bc.check_trainer_graph_vs_eager())
+
+
+def test_checkpoint_save_resume_and_reference_layout(tmp_path):
+    from tests import backward_checks as bc
+    _assert(bc.check_checkpoint_resume(str(tmp_path)))

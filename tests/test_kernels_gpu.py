@@ -21,6 +21,11 @@ def test_gemm():
     _run(kc.check_gemm)
 
 
+def test_gemm_hot_shapes():
+    from tests import kernel_checks as kc
+    _run(kc.check_gemm_hot_shapes)
+
+
 def test_attention():
     from tests import kernel_checks as kc
     _run(kc.check_attention)

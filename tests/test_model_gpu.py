@@ -40,3 +40,18 @@ def test_reference_api():
 def test_validate_loop():
     from tests import model_checks as mc
     _assert(mc.check_validate_loop("dinov2"))
+
+
+def test_head_golden_k256_k512(golden):
+    from tests import model_checks as mc
+    _assert(mc.check_head_golden(golden))
+
+
+def test_full_width_llama_layer():
+    from tests import model_checks as mc
+    _assert(mc.check_full_width_llama_layer())
+
+
+def test_full_width_sam_blocks():
+    from tests import model_checks as mc
+    _assert(mc.check_full_width_sam_blocks())

@@ -43,6 +43,10 @@ def test_mask_head(golden):
     with torch.no_grad():
         iou, emb = mask_head.mask_head(sd, "model.", pooled, text)
     assert close(iou, g["iou"]) and close(emb, g["emb"])
+    sd, pooled, text = cases.head_case(K=512)                         # BASELINE configs[4]: 512 candidate masks
+    with torch.no_grad():
+        iou, emb = mask_head.mask_head(sd, "model.", pooled, text)
+    assert close(iou, g["iou_k512"]) and close(emb[:, :, ::8], g["emb_k512_cols8"]) and close(emb.norm(dim=-1), g["emb_k512_rownorm"])
 
 
 def test_lisa_tiny_train_and_inference(golden):

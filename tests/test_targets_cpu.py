@@ -1,0 +1,82 @@
+"""CPU: the oracle of the proposal-decode / target path (oracle/targets.py) pinned against what is installed here -- scipy.ndimage.zoom
+(what skimage.transform.resize(order=0) calls), torch's antialiased F.interpolate (what the reference itself calls) -- and the host-side
+tables of the product (llmseg_amd/targets.py: RLE string parser, nearest-index rule, resampling taps) against the oracle."""
+import numpy as np
+import scipy.ndimage as ndi
+import torch
+import torch.nn.functional as F
+
+from llmseg_amd import targets as ht
+from oracle import targets as ot
+
+
+def _masks(rng, h, w, k):
+    out = []
+    for i in range(k):
+        m = np.zeros((h, w), np.uint8)
+        y0, x0 = rng.integers(0, h - 4), rng.integers(0, w - 4)
+        m[y0:y0 + rng.integers(2, h - y0), x0:x0 + rng.integers(2, w - x0)] = 1
+        m &= (rng.random((h, w)) > 0.1).astype(np.uint8)
+        out.append(m)
+    out.append(np.zeros((h, w), np.uint8))            # an empty proposal (its IoP is 0 / 0)
+    out.append(np.ones((h, w), np.uint8))             # one run only
+    return out
+
+
+def test_rle_codec_round_trip_and_product_parser():
+    rng = np.random.default_rng(1)
+    for h, w in ((37, 53), (64, 64), (5, 300)):
+        for m in _masks(rng, h, w, 4):
+            r = ot.rle_encode(m)
+            assert (ot.rle_decode(r) == m).all()
+            cn = ht.rle_counts(r)
+            flat, pos, v = np.zeros(h * w, np.uint8), 0, 0
+            for n in cn:
+                flat[pos:pos + n] = v
+                pos += n
+                v ^= 1
+            assert pos == h * w and (flat.reshape(w, h).T == m).all()
+    # hand-built run lists: 2 x 3 image, column-major pixels 0 0 | 1 1 | 1 0  ->  counts [2, 3, 1]
+    m = np.array([[0, 1, 1], [0, 1, 0]], np.uint8)
+    assert (ot.rle_decode({"size": [2, 3], "counts": [2, 3, 1]}) == m).all()
+    assert list(ht.rle_counts(ot.rle_encode(m))) == [2, 3, 1]
+    # a count > 31 needs two 5-bit groups; a negative delta needs the sign bit
+    big = np.zeros((40, 3), np.uint8)
+    big[35:, 0] = 1
+    big[:2, 1] = 1
+    big[39, 2] = 1                         # runs: 35 zeros, 5 + 2 ones, 38 + 39 zeros, 1 one (4th count is stored as 1 - 7 = -6)
+    assert (ot.rle_decode(ot.rle_encode(big)) == big).all() and list(ht.rle_counts(ot.rle_encode(big))) == [35, 7, 77, 1]
+
+
+def test_nearest_rule_is_scipy_zoom():
+    rng = np.random.default_rng(2)
+    for hin, win, H, W in ((300, 420, 1024, 683), (97, 130, 1024, 1024), (1365, 2048, 682, 1024), (512, 512, 512, 512), (333, 500, 1000, 1501)):
+        gt = (rng.random((hin, win)) > 0.5).astype(np.uint8)
+        z = ndi.zoom(gt.astype(np.float64), (H / hin, W / win), order=0, mode="mirror", grid_mode=True)
+        mine = ot.resize_nearest(gt, H, W)
+        assert z.shape == mine.shape and (z == mine).all()
+        assert (gt[ht.nearest_index(H, hin)][:, ht.nearest_index(W, win)] == mine).all()
+
+
+def test_aa_taps_are_torch_antialias():
+    for S, O in ((1024, 256), (683, 256), (300, 256), (200, 256), (1365, 256)):
+        first, count, w = ht.aa_taps(S, O)
+        x = torch.rand(1, 1, S, S, dtype=torch.float64, generator=torch.Generator().manual_seed(S))
+        ref = F.interpolate(x, size=(O, O), mode="bilinear", align_corners=False, antialias=True)[0, 0]
+        Wm = np.zeros((O, S))
+        for i in range(O):
+            Wm[i, first[i]:first[i] + count[i]] = w[i, :count[i]]
+        mine = torch.from_numpy(Wm) @ x[0, 0] @ torch.from_numpy(Wm).T
+        assert (mine - ref).abs().max().item() < 1e-14
+
+
+def test_targets_known_answers():
+    seg = np.zeros((4, 4, 2), np.uint8)
+    seg[:2, :, 0] = 1                     # top half
+    seg[:, :2, 1] = 1                     # left half
+    gt = np.zeros((8, 8), np.uint8)
+    gt[:4, :4] = 1                        # top-left quadrant at twice the resolution
+    iou, iop = ot.compute_all_iou_iop(seg, gt)
+    assert np.allclose(iou, [4 / 8, 4 / 8]) and np.allclose(iop, [4 / 8, 4 / 8])
+    iou, iop = ot.compute_all_iou_iop(np.zeros((4, 4, 1), np.uint8), gt)
+    assert iou[0] == 0.0 and np.isnan(iop[0])

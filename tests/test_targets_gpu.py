@@ -1,0 +1,60 @@
+"""GPU: proposal decode + IoU / IoP targets + proposal maps (llmseg_rle_decode / llmseg_mask_targets / llmseg_resize_aa through the C ABI)
+against the oracle restatement of the reference's CPU data path.  Integer work must be bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _proposals(rng, h, w, k):
+    from oracle import targets as ot
+    recs = []
+    for i in range(k):
+        m = np.zeros((h, w), np.uint8)
+        y0, x0 = rng.integers(0, h - 8), rng.integers(0, w - 8)
+        m[y0:y0 + rng.integers(4, h - y0), x0:x0 + rng.integers(4, w - x0)] = 1
+        m &= (rng.random((h, w)) > 0.15).astype(np.uint8)
+        recs.append({"segmentation": ot.rle_encode(m), "area": int(m.sum()), "bbox": [int(x0), int(y0), 1, 1]})
+    z = np.zeros((h, w), np.uint8)
+    recs.append({"segmentation": ot.rle_encode(z), "area": 0, "bbox": [0, 0, 0, 0]})                 # empty proposal: IoP = 0 / 0
+    return recs
+
+
+@pytest.mark.parametrize("h,w,hg,wg,k", [(683, 1024, 1365, 2048, 60), (300, 420, 300, 420, 7), (1024, 1024, 512, 384, 12), (97, 130, 194, 260, 3)])
+def test_decode_targets_and_maps_vs_oracle(h, w, hg, wg, k):
+    from llmseg_amd import targets as ht
+    from oracle import targets as ot
+    rng = np.random.default_rng(h * 7 + k)
+    recs = _proposals(rng, h, w, k)
+    gts = [(rng.random((hg, wg)) > 0.6).astype(np.uint8), np.zeros((hg, wg), np.uint8)]            # the second: empty ground truth
+    ref = ot.extract_sam_segs(recs, top=50)
+    got = ht.proposals_and_targets(recs, gts, DEV, top=50)
+    K = min(50, len(recs))
+    assert got["segs_origin"].shape == (K, h, w)
+    # decode: bit-exact, both layouts
+    assert torch.equal(got["segs_origin"].cpu(), torch.from_numpy(ref["segs_origin"]).permute(2, 0, 1))
+    ms = sorted(recs, key=lambda m: m["area"], reverse=True)[:50]
+    hwk = ht.decode_rles([m["segmentation"] for m in ms], DEV, hwk=True)
+    assert torch.equal(hwk.cpu(), torch.from_numpy(ref["segs_origin"]))
+    # targets: IEEE-double identical (nan == nan for the empty proposal / empty union)
+    for c, gt in enumerate(gts):
+        iou, iop = ot.compute_all_iou_iop(ref["segs_origin"], gt)
+        assert np.array_equal(got["sam_ious"][c].cpu().numpy(), iou, equal_nan=True), (got["sam_ious"][c].cpu().numpy() - iou)
+        assert np.array_equal(got["sam_iops"][c].cpu().numpy(), iop, equal_nan=True)
+    # proposal maps: the float64 antialiased resize rounded to bf16 -- identical up to (rare) double-rounding ties: <= 1 bf16 ulp, < 0.01 % of pixels
+    maps = ot.proposal_maps(ref["segs_square"]).float()
+    d = (got["sam_segs"].float().cpu() - maps).abs()
+    assert d.max().item() <= 2.0 ** -8, d.max().item()
+    assert (d > 0).float().mean().item() < 1e-4, (d > 0).float().mean().item()
+
+
+def test_targets_feed_model_forward_contract():
+    """dtype / shape contract of `collate_fn_new` (utils/dataset.py:33-170): segs bf16 [K, 256, 256], ious / iops float64 [C, K]."""
+    from llmseg_amd import targets as ht
+    rng = np.random.default_rng(3)
+    recs = _proposals(rng, 120, 90, 5)
+    out = ht.proposals_and_targets(recs, [(rng.random((120, 90)) > 0.5).astype(np.uint8)], DEV)
+    assert out["sam_segs"].dtype == torch.bfloat16 and out["sam_segs"].shape == (6, 256, 256)
+    assert out["sam_ious"].dtype == torch.float64 and out["sam_ious"].shape == (1, 6) and out["sam_iops"].shape == (1, 6)
