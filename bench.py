@@ -116,6 +116,7 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
         # per-kernel timing: events cannot be recorded inside a replayed hipGraph, so the same micro-step runs eagerly (identical launches)
         # for a few steps right after the timed region, with an event pair around every GEMM launch on its stream
         trainer.use_graph = False
+        overlap, model.overlap_towers = model.overlap_towers, False      # one stream: a launch's duration must not include another stream's kernels
         trainer.micro_step(batch, plan)
         torch.cuda.synchronize()
         ops.prof_enable(True)
@@ -125,6 +126,7 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
         torch.cuda.synchronize()
         ops.prof_enable(False)
         prof = ops.prof_collect()
+        model.overlap_towers = overlap
         trainer.close()
         del trainer
     else:
@@ -133,6 +135,7 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
                 return model.model_forward(**batch, inference=False, plan=plan)
         dt, out = timed(fstep, args.steps, args.warmup, dist, dev)
         res.update(value=B * world * args.steps / dt, ms_per_step=dt / args.steps * 1e3, loss=float(out["loss"]), graph=False)
+        overlap, model.overlap_towers = model.overlap_towers, False
         ops.prof_enable(True)
         n_prof = min(args.steps, 3)
         for _ in range(n_prof):
@@ -140,21 +143,23 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
         torch.cuda.synchronize()
         ops.prof_enable(False)
         prof = ops.prof_collect()
+        model.overlap_towers = overlap
     gemm_ms, gemm_flops, gemm_launches = prof["all"]
     dom_ms, dom_flops, dom_launches = prof["dominant"]
     ach = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     ach_all = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     model_flops = gemm_flops / n_prof + attention_flops(cfg, B, T)
     res["roofline"] = {"bound": "mfma", "kernel": prof["dominant_kernel"], "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                       "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(prof["dominant_kernel"], B), "launches_per_step": dom_launches / n_prof,
+                       "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(prof["dominant_kernel"], B),
+                       "algorithmic_bytes_per_launch": prof["dominant_alg_bytes"] / max(1, dom_launches), "launches_per_step": dom_launches / n_prof,
                        "avg_launch_us": dom_ms * 1e3 / max(1, dom_launches), "time_share_of_step": dom_ms / n_prof / res["ms_per_step"],
-                       "timing": "HIP events around every GEMM launch, %d eager steps of the same micro-step after the timed region" % n_prof,
+                       "timing": "HIP events around every GEMM launch, %d eager single-stream steps of the same micro-step after the timed region" % n_prof,
                        "all_gemm_kernels": {"achieved": ach_all, "launches_per_step": gemm_launches / n_prof,
                                             "avg_launch_us": gemm_ms * 1e3 / max(1, gemm_launches),
                                             "time_share_of_step": gemm_ms / n_prof / res["ms_per_step"]}}
     res["model_tflop_per_image"] = model_flops / B / 1e12
     res["model_mfma_frac"] = model_flops / (res["ms_per_step"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS
-    if args.mode == "train":                    # BASELINE configs[1]: the same batch, forward only (no grad)
+    if args.mode == "train" and not args.no_fwd_only:       # BASELINE configs[1]: the same batch, forward only (no grad)
         def fstep():
             with torch.no_grad():
                 return model.model_forward(**batch, inference=False, plan=plan)
@@ -181,6 +186,7 @@ def main():
     ap.add_argument("--mode", default="train", choices=["fwd", "train"],
                     help="train (default; BASELINE metric 'fwd+bwd'): fwd+bwd with LoRA r=8, optimizer step every --accum steps, and a "
                          "forward-only pass (BASELINE configs[1]) reported under 'fwd_only'; fwd: forward only")
+    ap.add_argument("--no-fwd-only", action="store_true", help="skip the forward-only measurement (profiling runs)")
     ap.add_argument("--no-overlap", action="store_true", help="issue the frozen backbone on the main stream instead of its own HIP stream")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--ddp-wrapper", action="store_true", help="torch DDP wrapper + bf16 .grad instead of the fp32 gradient arena")

@@ -298,6 +298,8 @@ int llmseg_prof_enable(int on);                 /* 1 = record events around GEMM
  * (gemm_bf16_tn_glds_kernel<false, 2, 1>: bf16-out 128x128 LDS-DMA variant) so that it can be compared with rocprofv3's per-kernel row */
 /* name of the GEMM kernel class that took the most time in the last collected window (its totals are dom_*) */
 const char* llmseg_prof_dominant_kernel(void);
+/* algorithmic bytes (A + W + C read / written once, bf16) summed over that class's launches in the last collected window */
+double llmseg_prof_dominant_bytes(void);
 int llmseg_prof_collect(double* total_ms, double* total_flops, int64_t* launches, double* dom_ms, double* dom_flops, int64_t* dom_launches);
 
 #ifdef __cplusplus

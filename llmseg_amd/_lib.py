@@ -97,6 +97,7 @@ SIGNATURES = {
     "llmseg_adamw": [_p, _p, _p, C.c_int, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _p, _p],
     "llmseg_prof_enable": [C.c_int],
     "llmseg_prof_dominant_kernel": [],
+    "llmseg_prof_dominant_bytes": [],
     "llmseg_prof_collect": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double),
                             C.POINTER(C.c_int64)],
 }
@@ -116,7 +117,8 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)            # AttributeError if the symbol is missing
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name in ("llmseg_last_error", "llmseg_prof_dominant_kernel") else C.c_int
+        fn.restype = (C.c_char_p if name in ("llmseg_last_error", "llmseg_prof_dominant_kernel") else
+                      C.c_double if name == "llmseg_prof_dominant_bytes" else C.c_int)
     _lib = lib
     return lib
 

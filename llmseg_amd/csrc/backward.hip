@@ -114,15 +114,24 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16_t* __restri
 #undef LL_FOR_CHUNKS
   }
   if constexpr (ACC) {
+    // fold the workgroup's 4 waves in LDS, then ONE atomic per column per workgroup (512 rows onto 256 columns used to issue 512 atomics
+    // per address: 100 us of serialised L2 atomics for a 260 KB tensor)
+    __shared__ float red[2][4][NR * 64 * 8];
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int c = lane + 64 * i;
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[0][wv][(i * 64 + lane) * 8 + e] = aw[i][e];
+        red[1][wv][(i * 64 + lane) * 8 + e] = ab[i][e];
+      }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NR * 64 * 8; idx += blockDim.x) {
+      const int i = idx / (64 * 8), ln = (idx / 8) % 64, e = idx % 8;
+      const int c = ln + 64 * i;
       if (c < nch) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          if (dw) atomicAdd(&dw[c * 8 + e], aw[i][e]);
-          if (db) atomicAdd(&db[c * 8 + e], ab[i][e]);
-        }
+        if (dw) atomicAdd(&dw[c * 8 + e], red[0][0][idx] + red[0][1][idx] + red[0][2][idx] + red[0][3][idx]);
+        if (db) atomicAdd(&db[c * 8 + e], red[1][0][idx] + red[1][1][idx] + red[1][2][idx] + red[1][3][idx]);
       }
     }
   }
@@ -283,7 +292,7 @@ extern "C" int llmseg_norm_bwd(const void* dy, const void* x, const void* w, voi
   const int cpl = (int)(((cols >> 3) + 63) / 64);
   const bool acc = (dw || db) && cpl <= 2;
   const long wgs = (rows + 3) / 4;
-  const dim3 grid((unsigned)(acc ? std::min<long>(wgs, 256) : wgs));
+  const dim3 grid((unsigned)(acc ? std::min<long>(std::max<long>(1, (rows + 31) / 32), 256) : wgs));     // ACC: every wave walks >= 8 rows
 #define LL_NORMB(C, A)                                                                                                                       \
   hipLaunchKernelGGL((norm_bwd_kernel<C, A>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, \
                      (bf16_t*)dx, dw, db, (long)rows, (int)cols, eps, rms)
@@ -443,11 +452,13 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict
 // gradient arena).  out_rn = 0: out [N][8]; 1: out [8][N].  b has row pitch ldb.  blockIdx.z selects one of up to two independent
 // products that share the shapes (the q and v branches of one layer: dAq / dAv read the same activation with their own dropout streams,
 // dBq / dBv two column blocks of dY).
-// Workgroup = 256 columns x one slice of rows: lane = (row-lane 0..7, column chunk 0..7), a wave reads 8 rows x 128 contiguous
-// bytes per step (16 B per lane, three steps in flight); the 8 row-lanes are folded with shuffles, so one set of atomics per
-// column per wave (the same atomic count as a column-per-thread layout, 20x the loads in flight).
+// Workgroup = 64 columns x one slice of rows, split again over its 4 waves: lane = (row-lane 0..7, column chunk 0..7), a wave reads 8
+// rows x 128 contiguous bytes per step (16 B per lane, three steps in flight); the 8 row-lanes are folded with shuffles, the 4 waves in
+// LDS, so ONE atomic per output cell per workgroup (the first version issued one per WAVE over 9 row slices: 590 K atomics per call
+// at M = 638, which was the whole 30 us).
 struct OuterP { const bf16_t* a[2]; const bf16_t* b[2]; float* out[2]; };
 __global__ __launch_bounds__(256) void lora_outer_kernel(OuterP q, long lda, long ldb, long M, long N, int out_rn, float alpha, DropP dp) {
+  __shared__ float red[4][8][8 * LR];                  // [wave][column chunk][8 columns x 8 ranks]
   const int z = blockIdx.z;
   const bf16_t* __restrict__ a = q.a[z];
   const bf16_t* __restrict__ b = q.b[z];
@@ -455,9 +466,9 @@ __global__ __launch_bounds__(256) void lora_outer_kernel(OuterP q, long lda, lon
   const uint32_t dstream = dp.stream + z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cl = lane & 7, rl = lane >> 3;
-  const long n = ((long)blockIdx.x * 32 + wave * 8 + cl) * 8;
-  const long per = (M + gridDim.y - 1) / gridDim.y;
-  const long m0 = (long)blockIdx.y * per, m1 = min(M, m0 + per);
+  const long n = ((long)blockIdx.x * 8 + cl) * 8;      // the workgroup's 4 waves cover the SAME 64 columns, each its own quarter of the row slice
+  const long per = (M + gridDim.y * 4 - 1) / (gridDim.y * 4);
+  const long m0 = ((long)blockIdx.y * 4 + wave) * per, m1 = min(M, m0 + per);
   const bool on = n < N;
   float acc[8][LR];
 #pragma unroll
@@ -503,14 +514,22 @@ __global__ __launch_bounds__(256) void lora_outer_kernel(OuterP q, long lda, lon
       v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
       acc[j][r] = v * alpha;
     }
-  if (on && rl == 0) {
+  if (rl == 0) {
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
-      for (int r = 0; r < LR; ++r) {
-        if (out_rn) atomicAdd(&out[(long)r * N + n + j], acc[j][r]);
-        else atomicAdd(&out[(n + j) * LR + r], acc[j][r]);
-      }
+      for (int r = 0; r < LR; ++r) red[wave][cl][j * LR + r] = acc[j][r];
+  }
+  __syncthreads();
+  // 512 outputs (64 columns x 8 ranks) per workgroup: two per thread, ONE atomic each (row slices of other workgroups add to the same cell)
+  for (int idx = threadIdx.x; idx < 8 * 8 * LR; idx += blockDim.x) {
+    const int c = idx / (8 * LR), jr = idx % (8 * LR), j = jr / LR, r = jr % LR;
+    const long nn = ((long)blockIdx.x * 8 + c) * 8 + j;
+    if (nn < N) {
+      const float v = red[0][c][jr] + red[1][c][jr] + red[2][c][jr] + red[3][c][jr];
+      if (out_rn) atomicAdd(&out[(long)r * N + nn], v);
+      else atomicAdd(&out[nn * LR + r], v);
+    }
   }
 }
 
@@ -647,10 +666,12 @@ extern "C" int llmseg_lora_outer(const void* a0, const void* a1, int64_t lda, co
   const int nz = (a1 && b1 && out1) ? 2 : 1;
   LL_CHECK(a0 && b0 && out0 && ((!a1) == (!b1)) && ((!a1) == (!out1)) && M > 0 && N > 0 && (N & 7) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && AL16(a0) &&
                AL16(a1) && AL16(b0) && AL16(b1) && LL_DROP_OK(drop), "lora_outer: bad arguments (N, lda, ldb multiples of 8)");
-  const unsigned gy = (unsigned)max((long)1, min((long)32, M / 64));
+  // 64 columns per workgroup (its 4 waves split the rows): enough row slices to put >= 2 workgroups on every CU, each wave >= 24 rows
+  const long colwg = (N + 63) / 64;
+  const unsigned gy = (unsigned)max(max((long)1, 256 / (colwg * nz)), min((long)32, M / 512));
   OuterP q;
   q.a[0] = (const bf16_t*)a0; q.a[1] = (const bf16_t*)a1; q.b[0] = (const bf16_t*)b0; q.b[1] = (const bf16_t*)b1; q.out[0] = out0; q.out[1] = out1;
-  hipLaunchKernelGGL(lora_outer_kernel, dim3((unsigned)((N + 255) / 256), gy, nz), dim3(256), 0, (hipStream_t)stream, q, (long)lda, (long)ldb, (long)M, (long)N,
+  hipLaunchKernelGGL(lora_outer_kernel, dim3((unsigned)colwg, gy, nz), dim3(256), 0, (hipStream_t)stream, q, (long)lda, (long)ldb, (long)M, (long)N,
                      out_rn, alpha, make_drop(drop));
   LL_LAUNCH_CHECK("lora_outer");
   return LLMSEG_OK;
