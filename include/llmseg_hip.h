@@ -101,6 +101,9 @@ typedef struct {
   float* lse;
 } llmseg_attn_args;
 int llmseg_attn_fwd(const llmseg_attn_args* args, void* stream);
+/* tuning knob (identical results up to fp32 summation order): bit 0 = 1 [default]: SAM 14x14 windows on the resident-window kernel
+ * (one workgroup per window and head, no key tiling); 0: the general tiled kernel */
+int llmseg_attn_set_variant(int variant);
 
 /* ---- fused attention backward ----------------------------------------------------------------
  * Gradients of O = softmax(scale * Q.K^T + mask) V w.r.t. Q, K, V (plain / causal / key_mask forms; no relative position:

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libllmseg_hip.so")
+LIB_PATH = os.environ.get("LLMSEG_LIB") or os.path.join(_HERE, "libllmseg_hip.so")     # LLMSEG_LIB: side builds of the same ABI (tools/ experiments)
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SILU, ACT_SIGMOID = range(6)
 
@@ -59,6 +59,7 @@ SIGNATURES = {
     "llmseg_gemm_bf16": [C.POINTER(GemmArgs), _p],
     "llmseg_gemm_set_variant": [C.c_int],
     "llmseg_attn_fwd": [C.POINTER(AttnArgs), _p],
+    "llmseg_attn_set_variant": [C.c_int],
     "llmseg_attn_bwd": [C.POINTER(AttnBwdArgs), _p],
     "llmseg_norm": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _f32, C.c_int, _p, _p],
     "llmseg_rope": [_p, _p, _p, _i64, _i64, _i32, _i32, _i64, _p],

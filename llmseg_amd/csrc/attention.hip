@@ -369,13 +369,262 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnP p) {
   }
 }
 
+// ---- SAM 14 x 14 window attention (head_dim 80, 196 tokens, decomposed rel-pos from the tables): ONE workgroup per (window, head) ----
+// 8 waves x 32 queries = 256 query slots (196 used); all 196 keys (padded to 7 blocks of 32) and V^T stay resident in LDS, so there is
+// no tile loop, no online-softmax rescale and one barrier: every lane holds the complete score row of its query (7 x 16 fp32 registers
+// per half-lane), takes the exact max / sum, and feeds P to the P.V MFMAs in accumulator order.  K / V are fetched ONCE per workgroup
+// (global -> registers, issued first so they fly behind the rel-pos MFMAs; V transposed 4 x 8 in registers on the way into LDS).
+// The general kernel above walked 64-key tiles with two barriers each, gave half of its workgroups 68 of 128 query rows and a
+// 4-of-64-key last tile: 177 TF/s on this shape.
+__global__ __launch_bounds__(512, 2) void attn_win14_kernel(AttnP p) {
+  constexpr int HD = 80, KS = HD / 16, DT = 3, NKB = 7, NKP = NKB * 32, NKEY = 196, NT = 512;
+  constexpr int CH = HD / 8;                  // 16-byte chunks per K row
+  constexpr int PK = (HD + 8) * 2;            // K row pitch (bytes): 11 chunks -> conflict-free ds_read_b128
+  constexpr int PV = (NKP + 4) * 2;           // V^T row pitch (bytes) = 8 * 57
+  constexpr int G_SLAB = 32 * 33;
+  __shared__ __attribute__((aligned(16))) char smem[NKP * PK + DT * 32 * PV + 8 * 2 * G_SLAB * 4];
+  char* Ks = smem;
+  char* Vt = smem + NKP * PK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, half = lane >> 5;
+  const int q = wave * 32 + ql;
+  const int qc = min(q, NKEY - 1);
+  const int qh = qc / 14, qw = qc - qh * 14;
+  // persistent workgroups: item = (window, head), heads fastest.  Workgroup w sits on XCD w % 8; give each XCD runs of 32 consecutive
+  // items (two windows x 16 heads: the heads of a token row share cache lines) per sweep of 256.
+  const int nitems = p.batch * p.heads;
+  const int wg = (int)blockIdx.x, nwg = (int)gridDim.x;
+  const int vwg = (nwg % 8 == 0) ? (wg % 8) * (nwg / 8) + wg / 8 : wg;
+  int item = vwg;
+  if (item >= nitems) return;
+  int b = item / p.heads, h = item - b * p.heads;
+  const bf16_t* Qg = p.Q + (long)b * p.qsb + (long)h * p.qsh;
+  const bf16_t* Kg = p.K + (long)b * p.ksb + (long)h * p.ksh;
+  const bf16_t* Vg = p.V + (long)b * p.vsb + (long)h * p.vsh;
+
+  // per-lane offsets are 32-bit element offsets from the (uniform) item base: one VGPR each, SGPR-base addressing
+  const int ksr = (int)p.ksr, vsr = (int)p.vsr, qoff = qc * (int)p.qsr + half * 8;
+  // ---- K / V global loads into registers (explicit scalars: arrays indexed by the staging loops end up in scratch) ----
+  uint4 kr0, kr1, kr2, kr3, kr4, va0, va1, va2, va3, vb0, vb1, vb2, vb3;
+  kr0 = kr1 = kr2 = kr3 = kr4 = va0 = va1 = va2 = va3 = vb0 = vb1 = vb2 = vb3 = make_uint4(0, 0, 0, 0);
+#define WIN_K_LOAD(IT, REG)                                                                        \
+  {                                                                                                \
+    const int idx = tid + IT * NT;                                                                 \
+    if (idx < NKP * CH) {                                                                          \
+      const int key = idx / CH, c = idx - key * CH;                                                \
+      REG = *reinterpret_cast<const uint4*>(Kg + (min(key, NKEY - 1) * ksr + c * 8));              \
+    }                                                                                              \
+  }
+#define WIN_K_STORE(IT, REG)                                                                       \
+  {                                                                                                \
+    const int idx = tid + IT * NT;                                                                 \
+    if (idx < NKP * CH) {                                                                          \
+      const int key = idx / CH, c = idx - key * CH;                                                \
+      *reinterpret_cast<uint4*>(Ks + key * PK + c * 16) = REG;                                     \
+    }                                                                                              \
+  }
+  // V: item = (key quad kq of 56, column chunk c of 10): 4 keys x 8 d
+#define WIN_V_LOAD(IT, R0, R1, R2, R3)                                                             \
+  {                                                                                                \
+    const int idx = tid + IT * NT;                                                                 \
+    if (idx < (NKP / 4) * CH) {                                                                    \
+      const int kq = idx / CH, c = idx - kq * CH;                                                  \
+      R0 = *reinterpret_cast<const uint4*>(Vg + (min(4 * kq + 0, NKEY - 1) * vsr + c * 8));        \
+      R1 = *reinterpret_cast<const uint4*>(Vg + (min(4 * kq + 1, NKEY - 1) * vsr + c * 8));        \
+      R2 = *reinterpret_cast<const uint4*>(Vg + (min(4 * kq + 2, NKEY - 1) * vsr + c * 8));        \
+      R3 = *reinterpret_cast<const uint4*>(Vg + (min(4 * kq + 3, NKEY - 1) * vsr + c * 8));        \
+    }                                                                                              \
+  }
+#define WIN_V_STORE(IT, R0, R1, R2, R3)                                                            \
+  {                                                                                                \
+    const int idx = tid + IT * NT;                                                                 \
+    if (idx < (NKP / 4) * CH) {                                                                    \
+      const int kq = idx / CH, c = idx - kq * CH;                                                  \
+      char* dst = Vt + (8 * c) * PV + 8 * kq;                                                      \
+      *reinterpret_cast<uint2*>(dst + 0 * PV) = make_uint2(perm_lo(R0.x, R1.x), perm_lo(R2.x, R3.x)); \
+      *reinterpret_cast<uint2*>(dst + 1 * PV) = make_uint2(perm_hi(R0.x, R1.x), perm_hi(R2.x, R3.x)); \
+      *reinterpret_cast<uint2*>(dst + 2 * PV) = make_uint2(perm_lo(R0.y, R1.y), perm_lo(R2.y, R3.y)); \
+      *reinterpret_cast<uint2*>(dst + 3 * PV) = make_uint2(perm_hi(R0.y, R1.y), perm_hi(R2.y, R3.y)); \
+      *reinterpret_cast<uint2*>(dst + 4 * PV) = make_uint2(perm_lo(R0.z, R1.z), perm_lo(R2.z, R3.z)); \
+      *reinterpret_cast<uint2*>(dst + 5 * PV) = make_uint2(perm_hi(R0.z, R1.z), perm_hi(R2.z, R3.z)); \
+      *reinterpret_cast<uint2*>(dst + 6 * PV) = make_uint2(perm_lo(R0.w, R1.w), perm_lo(R2.w, R3.w)); \
+      *reinterpret_cast<uint2*>(dst + 7 * PV) = make_uint2(perm_hi(R0.w, R1.w), perm_hi(R2.w, R3.w)); \
+    }                                                                                              \
+  }
+  // Q fragments (B operand of S^T = K . Q^T): col = query, k-slots = 8 consecutive d
+  bf16x8_t qn[KS];
+#define WIN_LOAD_ALL()                                                                             \
+  WIN_K_LOAD(0, kr0) WIN_K_LOAD(1, kr1) WIN_K_LOAD(2, kr2) WIN_K_LOAD(3, kr3) WIN_K_LOAD(4, kr4)   \
+  WIN_V_LOAD(0, va0, va1, va2, va3) WIN_V_LOAD(1, vb0, vb1, vb2, vb3)                              \
+  _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) qn[ks] = *reinterpret_cast<const bf16x8_t*>(Qg + (qoff + ks * 16));
+  WIN_LOAD_ALL()
+
+  while (true) {
+  // ---- this item's K -> LDS row-major (padded pitch), V -> LDS transposed, Q -> fragments; then the NEXT item's loads are issued and
+  //      fly behind this item's MFMAs (one workgroup per CU: without the prefetch HBM idles during compute and the CU during loads) ----
+  WIN_K_STORE(0, kr0) WIN_K_STORE(1, kr1) WIN_K_STORE(2, kr2) WIN_K_STORE(3, kr3) WIN_K_STORE(4, kr4)
+  WIN_V_STORE(0, va0, va1, va2, va3) WIN_V_STORE(1, vb0, vb1, vb2, vb3)
+  bf16x8_t qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
+  const int cb = b, chd = h;
+  __syncthreads();
+  item += nwg;
+  const bool more = item < nitems;
+  if (more) {
+    b = item / p.heads; h = item - b * p.heads;
+    Qg = p.Q + (long)b * p.qsb + (long)h * p.qsh;
+    Kg = p.K + (long)b * p.ksb + (long)h * p.ksh;
+    Vg = p.V + (long)b * p.vsb + (long)h * p.vsh;
+    WIN_LOAD_ALL()
+  }
+
+  // ---- scores of the whole key range: s[kb][r] = S^T[key = 32 kb + (r&3) + 8 (r>>2) + 4 half][query], rel-pos bias added after (keeps the bias registers off the MFMA phase's peak) ----
+  f32x16_t s[NKB];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {                               // 7 independent accumulators between dependent MFMAs
+      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (kb * 32 + ql) * PK + (2 * ks + half) * 16);
+      s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+    }
+  // ---- decomposed rel-pos (image_encoder.py:354-392): G^T = R . Q^T on the matrix cores, bounced through a per-wave slab so that each
+  //      lane can pick the entries at its own (qh - kh + 13) / (qw - kw + 13); the lane-half (key or key + 4) is folded into the LOAD ----
+  {
+  float bh_s[14], bh_x[13], bw_y[14];
+  {
+    float* gs = reinterpret_cast<float*>(smem + NKP * PK + DT * 32 * PV) + wave * (2 * G_SLAB);
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+      const bf16_t* tab = tb == 0 ? p.rtab_h : p.rtab_w;
+      f32x16_t g;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) g[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t rf = *reinterpret_cast<const bf16x8_t*>(tab + ql * HD + ks * 16 + half * 8);
+        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rf, qf[ks], g, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) gs[tb * G_SLAB + ql * 33 + (e & 3) + 8 * (e >> 2) + 4 * half] = g[e];
+    }
+    const float* gh = gs + ql * 33;
+    const float* gw = gs + G_SLAB + ql * 33;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+      bh_s[j] = gh[qh - j + 13] * p.inv_scale;
+      bw_y[j] = gw[qw - ((j + 4 * half) % 14) + 13] * p.inv_scale;
+    }
+#pragma unroll
+    for (int j = 0; j < 13; ++j) bh_x[j] = gh[qh - (j + half) + 13] * p.inv_scale;
+  }
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key0 = kb * 32 + (r & 3) + 8 * (r >> 2);            // this register's key for half 0; half 1: + 4
+      const int kh0 = key0 / 14 > 13 ? 13 : key0 / 14, kw0 = key0 % 14;
+      const bool cross = kw0 >= 10 && kh0 < 13;                    // key0 + 4 falls into the next key row
+      s[kb][r] += (cross ? bh_x[kh0 > 12 ? 12 : kh0] : bh_s[kh0]) + bw_y[kw0];
+    }
+  }
+  // keys >= 196 live in block 6 only: key = 192 + (r&3) + 8 (r>>2) + 4 half is valid for half 0, r < 4
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if (half != 0 || r >= 4) s[NKB - 1][r] = NEG;
+  float mx = NEG;
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float nmc = -mx * p.scale_log2;
+  float lsum = 0.f;
+  uint32_t pk[NKB][8];                                               // P in bf16 pairs, accumulator order (halves the live registers of the P.V phase)
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float p0 = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2, nmc));
+      const float p1 = __builtin_amdgcn_exp2f(fmaf(s[kb][r + 1], p.scale_log2, nmc));
+      lsum += p0 + p1;
+      pk[kb][r >> 1] = pack2bf(p0, p1);
+    }
+
+  // ---- O^T = V^T . P^T: k-steps of 16 keys; the P fragment of step (kb, u) = accumulator regs 8u .. 8u+7 of block kb ----
+  f32x16_t o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (kb == NKB - 1 && u == 1) continue;                         // keys 208..223: all padding
+      const int rb = 8 * u, ss = 2 * kb + u;
+      const uint4 pu = make_uint4(pk[kb][rb / 2 + 0], pk[kb][rb / 2 + 1], pk[kb][rb / 2 + 2], pk[kb][rb / 2 + 3]);
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const char* vrow = Vt + (d * 32 + ql) * PV + (16 * ss + 4 * half) * 2;
+        const uint2 va = *reinterpret_cast<const uint2*>(vrow);
+        const uint2 vb = *reinterpret_cast<const uint2*>(vrow + 16);
+        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(va.x, va.y, vb.x, vb.y));
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+      }
+    }
+
+  // ---- normalise and store through the window un-partition map ----
+  const float l_tot = lsum + __shfl_xor(lsum, 32, 64);
+  const float inv = 1.f / l_tot;
+  if (q < NKEY) {
+    bf16_t* orow;
+    bool skip = false;
+    if (p.o_row_map) {
+      const int row = p.o_row_map[(long)cb * p.Nq + q];
+      skip = row < 0;
+      orow = p.O + (long)chd * p.osh + (long)(skip ? 0 : row) * p.osr;
+    } else {
+      orow = p.O + (long)cb * p.osb + (long)chd * p.osh + (long)q * p.osr;
+    }
+    if (!skip) {
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dd = d * 32 + 8 * g + 4 * half;
+          if (dd < HD)
+            *reinterpret_cast<uint2*>(orow + dd) =
+                make_uint2(pack2bf(o[d][4 * g] * inv, o[d][4 * g + 1] * inv), pack2bf(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv));
+        }
+    }
+  }
+  if (!more) break;
+  __syncthreads();                              // every wave is done with this item's K / V^T before the next item overwrites them
+  }
+#undef WIN_LOAD_ALL
+#undef WIN_K_LOAD
+#undef WIN_K_STORE
+#undef WIN_V_LOAD
+#undef WIN_V_STORE
+}
+
+static int g_attn_win_new = 1;
+static int g_attn_win_wgs = 256;    // persistent workgroups of the window kernel: one per CU      // tuning knob (tools): 0 = the general tiled kernel on the window shape
+
 template <int HD>
 int launch_hd(const AttnP& p, hipStream_t s) {
   const bool wide = p.Nq >= 1024 && !p.causal;                       // long non-causal sequences: 256 queries per workgroup
   const int bq = wide ? 256 : 128;
   dim3 grid((p.Nq + bq - 1) / bq, p.heads, p.batch);
   constexpr int NT4 = 256, NT8 = 512;
-  if (p.rtab_h != nullptr) hipLaunchKernelGGL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 4 : 0>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
+  if (p.rtab_h != nullptr && HD == 80 && g_attn_win_new && p.lse == nullptr) hipLaunchKernelGGL(attn_win14_kernel, dim3((unsigned)std::min(p.batch * p.heads, g_attn_win_wgs)), dim3(NT8), 0, s, p);
+  else if (p.rtab_h != nullptr) hipLaunchKernelGGL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 4 : 0>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
   else if (p.rel_h == nullptr) {
     if (wide) hipLaunchKernelGGL((attn_fwd_kernel<HD, 0, 8>), grid, dim3(NT8), 0, s, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<HD, 0>), grid, dim3(NT4), 0, s, p);
@@ -389,6 +638,12 @@ int launch_hd(const AttnP& p, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int llmseg_attn_set_variant(int v) {
+  g_attn_win_new = v & 1;
+  g_attn_win_wgs = (v >> 4) > 0 ? (v >> 4) : 256;
+  return LLMSEG_OK;
+}
 
 extern "C" int llmseg_attn_fwd(const llmseg_attn_args* a, void* stream) {
   LL_CHECK(a && a->Q && a->K && a->V && a->O, "attn: null pointer");

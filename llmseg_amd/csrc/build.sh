@@ -3,7 +3,7 @@
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
-OUT="$ROOT/llmseg_amd/libllmseg_hip.so"
+OUT="${LLMSEG_OUT:-$ROOT/llmseg_amd/libllmseg_hip.so}"      # LLMSEG_OUT: side builds for experiments (tools/)
 SRCS="$HERE/gemm.hip $HERE/attention.hip $HERE/attention_bwd.hip $HERE/pointwise.hip $HERE/head.hip $HERE/backward.hip $HERE/targets.hip $HERE/capi.cpp"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I"$ROOT/include" -I"$HERE" $SRCS -o "$OUT" "$@"
 echo "built $OUT"
