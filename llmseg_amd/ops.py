@@ -33,11 +33,12 @@ _WS = {}
 
 
 def _workspace(dev, stream):
-    """Per-(device, stream) scratch of the split-K GEMM path (fp32 partial tiles), allocated on first use and kept."""
+    """Per-(device, stream) scratch of the split-K / stream-K GEMM paths (fp32 partial tiles + the stream-K arrival counters in the
+    last 64 KiB, which must start out zero), allocated on first use and kept."""
     key = (dev.index, stream)
     ws = _WS.get(key)
     if ws is None:
-        ws = _WS[key] = torch.empty(WS_BYTES, device=dev, dtype=torch.uint8)
+        ws = _WS[key] = torch.zeros(WS_BYTES, device=dev, dtype=torch.uint8)
     return ws
 
 
