@@ -33,8 +33,7 @@ _WS = {}
 
 
 def _workspace(dev, stream):
-    """Per-(device, stream) scratch of the split-K / stream-K GEMM paths (fp32 partial tiles + the stream-K arrival counters in the
-    last 64 KiB, which must start out zero), allocated on first use and kept."""
+    """Per-(device, stream) scratch of the split-K GEMM path (fp32 partial tiles), allocated on first use and kept."""
     key = (dev.index, stream)
     ws = _WS.get(key)
     if ws is None:

@@ -458,9 +458,10 @@ def check_model_grads_lora(backbone="sam"):
         assert prm[n].grad is None, n
         got, r = prm[n]._g32 / 2, sd[n].grad
         lo_e = (sd_lo[n].grad.float() - r).abs().max().item()
-        # floor 1e-4: a tensor whose true gradient vanishes (k-projections: softmax is shift-invariant) holds rounding noise only
+        # floor 3e-4 (other gradients here are 1e-2 .. 2): a tensor whose true gradient vanishes (k-projections: softmax is
+        # shift-invariant, |ref| ~ 1e-6) holds rounding noise only, and that noise moves with every change of summation order upstream
         res.append((f"arena grad {n} (bf16-CPU err {lo_e:.2e}, |ref| {r.abs().max().item():.2e})", err(got.reshape(r.shape), r),
-                    max(0.06 * r.abs().max().item(), 3.0 * lo_e, 1e-4)))
+                    max(0.06 * r.abs().max().item(), 3.0 * lo_e, 3e-4)))
     arena.detach()
     return res
 

@@ -6,7 +6,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_${TAG}_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_${TAG}_$c -o p -- "$@" > $OUT/pmc_${TAG}_$c.log 2>&1
+  # PMC_REGEX (optional): collect counters only for matching kernels (the unfiltered FETCH_SIZE pass segfaults inside rocprofv3 on the 24-image step)
+  rocprofv3 --kernel-trace --pmc $c ${PMC_REGEX:+--kernel-include-regex "$PMC_REGEX"} --output-format csv -d /tmp/pmc_${TAG}_$c -o p -- "$@" > $OUT/pmc_${TAG}_$c.log 2>&1
   echo "pmc $c rc=$?"
 done
 python - "$TAG" "$OUT" <<'PY'
