@@ -249,7 +249,7 @@ class TrainableMixin:
         return plan
 
     # ------------------------------------------------------------------------------------------------ language
-    def _llama(self, embeds, key_mask_u8, F):
+    def _llama(self, embeds, key_mask_u8, F, kv_out=None):
         """32 x [RMSNorm -> q|k|v GEMM (+LoRA) -> RoPE -> causal attention -> o_proj(+res) -> RMSNorm -> gate|up GEMM ->
         SwiGLU -> down(+res)], final RMSNorm (HF LlamaModel, transformers 4.29; call site llava_llama.py:93-102).
         Activations of every layer are kept for the backward pass (288 GB HBM: no recompute, unlike the reference's
@@ -274,6 +274,8 @@ class TrainableMixin:
                 mem = [p + f"self_attn.{n}_proj.weight" for n in "qkv"]
                 qkv = F.linear(h, self._wcat(p + "qkv", mem, F), None, ops.ACT_NONE, None, self._wT(p + "qkv", F) if self._frozen(mem) else None)
             a = F.rope_attn(qkv, rope, N, T, c.heads, c.head_dim, True, key_mask_u8)
+            if kv_out is not None:                     # generation prefill (no-grad path): qkv now holds the rotated K and V
+                kv_out(i, qkv)
             x = F.linear(a, self._w(p + "self_attn.o_proj.weight", F), None, ops.ACT_NONE, x, self._wT(p + "self_attn.o_proj.weight", F))
             h = F.norm(x, self._w(p + "post_attention_layernorm.weight", F), None, c.eps, True)
             mem = [p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"]

@@ -108,6 +108,72 @@ def gold_head():
                 "emb_k512_rownorm": r_emb5.norm(dim=-1)}, os.path.join(OUT, "mask_head.pt"))
 
 
+def _tiny_ref():
+    """The imported reference model at the tiny configuration, loaded with the seeded tiny state."""
+    cfg = cases.tiny_lisa_cfg()
+    rh.setup(clip_cfg_kwargs=dict(hidden_size=cfg.clip.dim, intermediate_size=cfg.clip.mlp,
+                                  num_hidden_layers=cfg.clip.layers, num_attention_heads=cfg.clip.heads),
+             dino_cfg_kwargs=dict(num_hidden_layers=cfg.dino.layers))
+    m = rh.build_lisa(dict(hidden_size=cfg.llama.hidden, intermediate_size=cfg.llama.inter,
+                           num_hidden_layers=cfg.llama.layers, num_attention_heads=cfg.llama.heads,
+                           num_key_value_heads=cfg.llama.heads, vocab_size=cfg.llama.vocab,
+                           max_position_embeddings=2048, rms_norm_eps=cfg.llama.eps), seg_token_idx=cfg.seg_token_idx)
+    sd = cases.tiny_lisa_state(cfg)
+    ref_sd = {}
+    for k, v in sd.items():
+        if k.startswith("model.visual_model_dinov2.") or k.startswith("model.visual_model."):
+            continue
+        ref_sd[k.replace("vision_tower.vision_tower.vision_model.", "vision_tower.vision_tower.hf.")] = v
+    ref_sd.update(rh.hub_to_hf_dino_names(sd, "model.visual_model_dinov2.", "model.visual_model_dinov2.m.", cfg.dino.layers))
+    res = m.load_state_dict(ref_sd, strict=False)
+    assert not res.unexpected_keys and all(k.startswith("model.visual_model.") for k in res.missing_keys), res
+    return cfg, sd, m
+
+
+def gold_generate():
+    """evaluate()'s generation (LISA.py:487-521): greedy loop over the IMPORTED reference forward vs the restatement."""
+    from oracle import generate as gen
+    cfg, sd, m = _tiny_ref()
+    m.eval()
+    batch = cases.tiny_lisa_batch()
+    clip, ids0 = batch["images_clip"][:2], batch["input_ids"][:2]
+
+    def ref_forward(ids):
+        with torch.no_grad():
+            o = super(type(m), m).forward(images=clip, attention_mask=torch.ones_like(ids, dtype=torch.bool), input_ids=ids,
+                                          output_hidden_states=True)
+        return o.logits, o.hidden_states
+    out = {}
+    with torch.no_grad():
+        seq_r, hid_r = gen.greedy_generate(None, cfg, clip, ids0, max_new_tokens=6, eos_token_id=None, forward=ref_forward)
+        seq_m, hid_m = gen.greedy_generate(sd, cfg, clip, ids0, max_new_tokens=6, eos_token_id=None)
+        assert torch.equal(seq_r, seq_m), (seq_r, seq_m)
+        _check("generate.hidden", hid_r, hid_m, 1e-4)
+        eos = int(seq_r[0, ids0.shape[1] + 2])          # make sequence 0 finish at its third new token
+        seq_re, hid_re = gen.greedy_generate(None, cfg, clip, ids0, max_new_tokens=6, eos_token_id=eos, pad_token_id=0, forward=ref_forward)
+        seq_me, hid_me = gen.greedy_generate(sd, cfg, clip, ids0, max_new_tokens=6, eos_token_id=eos, pad_token_id=0)
+        assert torch.equal(seq_re, seq_me), (seq_re, seq_me)
+        _check("generate.hidden(eos)", hid_re, hid_me, 1e-4)
+        # margins of the greedy choices (top-1 minus top-2 logit) so that a bf16 run knows which steps are decidable
+        lg, _ = ref_forward(seq_r[:, :-1])
+        L = ids0.shape[1]
+        top2 = lg[:, -6:, :].float().topk(2, -1).values
+        out.update(sequences=seq_r, hidden=hid_r, eos=eos, sequences_eos=seq_re, hidden_eos_sum=hid_re.double().sum(),
+                   margins=(top2[..., 0] - top2[..., 1]), prompt_len=L)
+        print("   generated", seq_r[:, L:].tolist(), "eos-run", seq_re[:, L:].tolist(), "min margin", float(out["margins"].min()))
+        # HF's own driver on the installed transformers (5.x, not the pinned 4.29): informative only
+        try:
+            g = m.generate(images=clip, input_ids=ids0, max_new_tokens=6, num_beams=1, do_sample=False, use_cache=False)
+            ge = m.generate(images=clip, input_ids=ids0, max_new_tokens=6, num_beams=1, do_sample=False, use_cache=False, eos_token_id=eos,
+                            pad_token_id=0)
+            seq = lambda x: x if torch.is_tensor(x) else x.sequences
+            print("   HF generate agrees:", torch.equal(seq(g), seq_r), "with eos/pad:", torch.equal(seq(ge), seq_re))
+            out["hf_generate_agrees"] = bool(torch.equal(seq(g), seq_r) and torch.equal(seq(ge), seq_re))
+        except Exception as e:      # noqa: BLE001
+            print("   HF generate on transformers", __import__("transformers").__version__, "not usable with the reference model:", type(e).__name__, str(e)[:120])
+    torch.save(out, os.path.join(OUT, "generate_tiny.pt"))
+
+
 def gold_lisa_tiny():
     cfg = cases.tiny_lisa_cfg()
     rh.setup(clip_cfg_kwargs=dict(hidden_size=cfg.clip.dim, intermediate_size=cfg.clip.mlp,
@@ -169,7 +235,7 @@ def main():
     rh.setup(clip_cfg_kwargs=dict(hidden_size=cfg.clip.dim, intermediate_size=cfg.clip.mlp,
                                   num_hidden_layers=cfg.clip.layers, num_attention_heads=cfg.clip.heads),
              dino_cfg_kwargs=dict(num_hidden_layers=cfg.dino.layers))
-    for f in (gold_losses, gold_iou_metric, gold_sam_small, gold_head, gold_lisa_tiny):
+    for f in (gold_losses, gold_iou_metric, gold_sam_small, gold_head, gold_lisa_tiny, gold_generate):
         print(f.__name__)
         f()
     print("wrote", sorted(os.listdir(OUT)))

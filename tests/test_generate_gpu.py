@@ -1,0 +1,14 @@
+"""GPU: the generation path of evaluate()."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert(res):
+    bad = [(n, e, t) for n, e, t in res if not (e <= t)]
+    assert not bad, "; ".join(f"{n}: err {e:.3e} > tol {t:.3e}" for n, e, t in bad)
+
+
+def test_kv_cache_greedy_generation_matches_oracle():
+    from tests import generate_checks as gc
+    _assert(gc.check_generate())
