@@ -99,6 +99,9 @@ typedef struct {
   const void* rel_tab_h; const void* rel_tab_w;
   /* optional fp32 [batch][heads][Nq]: log2-sum-exp of every score row (max*scale*log2e + log2 sum), what llmseg_attn_bwd needs */
   float* lse;
+  /* optional device int32: the number of keys present NOW (<= Nk, which is then the capacity of K / V); read by the kernel, so that a
+   * decode step captured in a hipGraph can be replayed while the KV cache grows (llava_llama.py:137-163 prepare_inputs_for_generation) */
+  const int32_t* nk_dev;
 } llmseg_attn_args;
 int llmseg_attn_fwd(const llmseg_attn_args* args, void* stream);
 /* tuning knob (identical results up to fp32 summation order): bit 0 = 1 [default]: SAM 14x14 windows on the resident-window kernel
@@ -145,6 +148,13 @@ int llmseg_norm(const void* x, const void* w, const void* b, void* y, int64_t ro
  * positions = row % T (HF LlamaRotaryEmbedding, position_ids = arange(T)); cos/sin fp32 [T][head_dim/2]. */
 int llmseg_rope(void* x, const float* cos, const float* sin, int64_t rows, int64_t T, int32_t heads, int32_t head_dim,
                 int64_t ld, void* stream);
+/* Decode step of generation (HF LlamaAttention with past_key_values; call site llava_llama.py:93-102,137-163): qkv bf16 [N][3 * heads *
+ * head_dim] (row stride ld) holds one new token per sequence.  With pos = *pos_dev: q is rotated in place at position pos, k is
+ * rotated and written to kcache[n][pos], v is copied to vcache[n][pos] (caches bf16 [N][capacity][heads * head_dim], sequence stride
+ * cache_stride_n elements).  cos/sin fp32 [capacity][head_dim/2].  The position lives in device memory so that the step can be
+ * replayed from a hipGraph. */
+int llmseg_rope_kv_append(void* qkv, int64_t ld, const float* cos, const float* sin, void* kcache, void* vcache, int64_t cache_stride_n,
+                          const int32_t* pos_dev, int64_t N, int32_t heads, int32_t head_dim, void* stream);
 
 /* out[r][c] = silu(gu[r][c]) * gu[r][I + c]   (HF LlamaMLP: down(silu(gate(x)) * up(x)); gu = x.[Wgate;Wup]^T) */
 int llmseg_swiglu(const void* gu, void* out, int64_t rows, int64_t I, int64_t ldgu, int64_t ldo, void* stream);

@@ -35,7 +35,7 @@ class AttnArgs(C.Structure):
                 ("scale", C.c_float), ("causal", C.c_int32),
                 ("key_mask", C.c_void_p), ("rel_h", C.c_void_p), ("rel_w", C.c_void_p),
                 ("rel_ld", C.c_int32), ("grid_h", C.c_int32), ("grid_w", C.c_int32),
-                ("o_row_map", C.c_void_p), ("rel_tab_h", C.c_void_p), ("rel_tab_w", C.c_void_p), ("lse", C.c_void_p)]
+                ("o_row_map", C.c_void_p), ("rel_tab_h", C.c_void_p), ("rel_tab_w", C.c_void_p), ("lse", C.c_void_p), ("nk_dev", C.c_void_p)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -63,6 +63,7 @@ SIGNATURES = {
     "llmseg_attn_bwd": [C.POINTER(AttnBwdArgs), _p],
     "llmseg_norm": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _f32, C.c_int, _p, _p],
     "llmseg_rope": [_p, _p, _p, _i64, _i64, _i32, _i32, _i64, _p],
+    "llmseg_rope_kv_append": [_p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _p],
     "llmseg_swiglu": [_p, _p, _i64, _i64, _i64, _i64, _p],
     "llmseg_add_rows": [_p, _p, _p, _i64, _i64, _i64, _p],
     "llmseg_patchify": [_p, _p, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _p],

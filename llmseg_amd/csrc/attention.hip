@@ -35,6 +35,7 @@ struct AttnP {
   const int32_t* o_row_map;
   float* lse;                                   // optional [batch][heads][Nq]: row log2-sum-exp for llmseg_attn_bwd
   const bf16_t* rtab_h; const bf16_t* rtab_w;   // REL == 4: bf16 [32][head_dim] relative-position tables (rows >= 2*14-1 are zero)
+  const int32_t* nk_dev;                        // optional: the key count is read from device memory (decode steps replayed from a hipGraph)
 };
 
 __device__ __forceinline__ uint32_t perm_lo(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }
@@ -46,6 +47,7 @@ __device__ __forceinline__ uint32_t perm_hi(uint32_t a, uint32_t b) { return (a 
 // queries per workgroup halve the L2 -> LDS traffic and the staging work per query; the K/V tile and LDS footprint are the same).
 template <int HD, int REL, int NW = 4>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnP p) {
+  if (p.nk_dev) p.Nk = min(p.Nk, *p.nk_dev);   // Nk (host) = capacity, *nk_dev = keys present now
   constexpr int NT = NW * 64, BQ = NW * 32;
   constexpr int KS = HD / 16;                 // k-steps of QK^T
   constexpr int DT = (HD + 31) / 32;          // 32-row blocks of O^T
@@ -677,6 +679,8 @@ extern "C" int llmseg_attn_fwd(const llmseg_attn_args* a, void* stream) {
   p.o_row_map = a->o_row_map;
   p.lse = a->lse;
   p.rtab_h = (const bf16_t*)a->rel_tab_h; p.rtab_w = (const bf16_t*)a->rel_tab_w;
+  p.nk_dev = a->nk_dev;
+  LL_CHECK(!a->nk_dev || (!a->rel_tab_h && !a->rel_h && !a->causal), "attn: nk_dev is for plain (decode-step) attention");
   hipStream_t s = (hipStream_t)stream;
   switch (a->head_dim) {
     case 32: launch_hd<32>(p, s); break;

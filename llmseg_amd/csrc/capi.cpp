@@ -105,7 +105,7 @@ extern "C" int llmseg_prof_collect(double* total_ms, double* total_flops, int64_
   // dominant kernel = the GEMM kernel class with the largest total time in this window
   long dom = -1;
   for (auto& kv : by_class) if (dom < 0 || kv.second[0] > by_class[dom][0]) dom = kv.first;
-  static const char* names[] = {"gemm_bf16_tn_kernel<*, ...> (register staging, 128x128)", "?", "gemm_bf16_tn_glds_kernel<*, 2, 1>", "?", "?", "?", "?", "?",
+  static const char* names[] = {"gemm_bf16_tn_kernel<*, ...> (register staging, 128x128)", "?", "gemm_bf16_tn_glds_kernel<*, 2, 1>", "gemm_skinny_kernel<M>", "?", "?", "?", "?",
                                 "gemm_bf16_tn_pp_kernel<*, false, 4>", "gemm_bf16_tn_pp_kernel<*, false, 2>"};
   if (dom >= 0) {
     const long v = dom / 2;

@@ -712,6 +712,82 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
   epilogue_lds<OUT_F32, MI>(p, Acc16<MI>{acc}, smem, wave, m0, n0, wm, wn, lane, bz);
 }
 
+// ---- variant V: skinny GEMM, M <= 8 rows (the decode step of generation: one token per sequence) ---------------------------------
+// C[m][n] = epi(alpha * sum_k A[m][k] W[n][k]) is a WEIGHT STREAM: every W row is read once (13.2 GB per Llama-7B token), the few A
+// rows come from L1 / L2.  HBM-bound, so no MFMA and no LDS: one wave owns 4 consecutive W rows, its 64 lanes walk K in 16-byte
+// chunks (1 KiB per row per instruction, fully coalesced), two K-steps in flight per lane (8 W loads + 2 MT A loads), fp32 FMA
+// accumulators acc[4][MT], a 6-step butterfly at the end, lane (r, m) applies the epilogue and stores.  Workgroup = 4 waves = 16 W rows:
+// N = 4096 gives 256 workgroups (one per CU, 40 KiB of loads in flight each).  K % 8 == 0, K-contiguous A and W, batch == 1.
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int out_f32) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = (blockIdx.x * 4 + wave) * 4;
+  if (n0 >= p.N) return;
+  const bf16_t* wr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) wr[r] = p.W + (long)min(n0 + r, p.N - 1) * p.ldw;
+  float acc[4][MT];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[r][m] = 0.f;
+  auto fma8 = [&](const uint4& w, const uint4& x, float& a) {
+    a = fmaf(__uint_as_float(w.x << 16), __uint_as_float(x.x << 16), a); a = fmaf(__uint_as_float(w.x & 0xffff0000u), __uint_as_float(x.x & 0xffff0000u), a);
+    a = fmaf(__uint_as_float(w.y << 16), __uint_as_float(x.y << 16), a); a = fmaf(__uint_as_float(w.y & 0xffff0000u), __uint_as_float(x.y & 0xffff0000u), a);
+    a = fmaf(__uint_as_float(w.z << 16), __uint_as_float(x.z << 16), a); a = fmaf(__uint_as_float(w.z & 0xffff0000u), __uint_as_float(x.z & 0xffff0000u), a);
+    a = fmaf(__uint_as_float(w.w << 16), __uint_as_float(x.w << 16), a); a = fmaf(__uint_as_float(w.w & 0xffff0000u), __uint_as_float(x.w & 0xffff0000u), a);
+  };
+  const int K = p.K;
+  int k = lane * 8;
+  for (; k + 512 < K; k += 1024) {                   // two K-steps per trip: all loads issued before the first FMA
+    uint4 w0[4], w1[4], x0[MT], x1[MT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { w0[r] = *reinterpret_cast<const uint4*>(wr[r] + k); w1[r] = *reinterpret_cast<const uint4*>(wr[r] + k + 512); }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const bf16_t* ar = p.A + (long)min(m, p.M - 1) * p.lda;
+      x0[m] = *reinterpret_cast<const uint4*>(ar + k); x1[m] = *reinterpret_cast<const uint4*>(ar + k + 512);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { fma8(w0[r], x0[m], acc[r][m]); fma8(w1[r], x1[m], acc[r][m]); }
+  }
+  if (k < K) {
+    uint4 w0[4], x0[MT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w0[r] = *reinterpret_cast<const uint4*>(wr[r] + k);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) x0[m] = *reinterpret_cast<const uint4*>(p.A + (long)min(m, p.M - 1) * p.lda + k);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) fma8(w0[r], x0[m], acc[r][m]);
+  }
+  float mine = 0.f;                                  // lane r * MT + m keeps C[m][n0 + r]
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float t = wave_sum(acc[r][m]);
+      if (lane == r * MT + m) mine = t;
+    }
+  if (lane < 4 * MT) {
+    const int r = lane / MT, m = lane - r * MT, n = n0 + r;
+    if (n < p.N && m < p.M) {
+      float v = mine * p.alpha;
+      if (p.bias) v += bf2f(p.bias[n]);
+      v = apply_act(v, p.act);
+      if (p.gamma) v *= bf2f(p.gamma[n]);
+      if (p.res) v += bf2f(p.res[(long)m * p.ldr + n]);
+      if (out_f32) {
+        float* cp = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+        *cp = p.accum ? *cp + v : v;
+      } else reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n] = f2bf(v);
+    }
+  }
+}
+
 // Split-K tail: C = epi(alpha * sum_s slab[s]) with the GEMM's epilogue (bias, activation, LayerScale, residual, bf16 or fp32 out,
 // optional += into an fp32 C).  slab: fp32 [S][M][N] (dense), one thread per 4 consecutive columns (N % 4 == 0).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float* __restrict__ slab, int S, int out_f32) {
@@ -898,6 +974,21 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
       g2.A2 = g2.W2 = nullptr;
       return llmseg_gemm_bf16(&g2, stream);
     }
+  }
+  if (p.M <= 8 && !ta && !tw && batch == 1 && !p.A2 && (p.K & 7) == 0 && g_gemm_variant == 5) {
+    // skinny GEMM (decode steps, single-row head GEMMs): a weight stream, HBM-bound
+    hipStream_t s = (hipStream_t)stream;
+    llmseg_prof_begin(s);
+    llmseg_prof_tag(p.M, p.N, p.K, 3000 + (p.res ? 20 : 0) + p.act * 2 + (a->out_f32 ? 1 : 0));
+    const dim3 grid((unsigned)((p.N + 15) / 16));
+    const int of = a->out_f32 ? 1 : 0;
+    if (p.M == 1) hipLaunchKernelGGL(gemm_skinny_kernel<1>, grid, dim3(256), 0, s, p, of);
+    else if (p.M == 2) hipLaunchKernelGGL(gemm_skinny_kernel<2>, grid, dim3(256), 0, s, p, of);
+    else if (p.M <= 4) hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, dim3(256), 0, s, p, of);
+    else hipLaunchKernelGGL(gemm_skinny_kernel<8>, grid, dim3(256), 0, s, p, of);
+    llmseg_prof_end(s, 2.0 * (double)a->M * (double)a->N * (double)a->K);
+    LL_LAUNCH_CHECK("gemm_skinny");
+    return LLMSEG_OK;
   }
   const bool pp = variant == 8 || variant == 9;
   const int bm = variant == 8 ? 256 : 128, bn = pp ? 256 : BN;

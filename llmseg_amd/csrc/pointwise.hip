@@ -121,6 +121,42 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ x, const
   }
 }
 
+// decode step: RoPE of the new token's q (in place) and k (into the cache) at the device-side position, v copied into the cache
+__global__ __launch_bounds__(256) void rope_kv_append_kernel(bf16_t* __restrict__ qkv, long ld, const float* __restrict__ cs, const float* __restrict__ sn,
+                                                            bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, long cstride, const int32_t* __restrict__ pos_dev,
+                                                            long N, int heads, int hd) {
+  const int hc = hd >> 4;
+  const long D = (long)heads * hd, per = (long)heads * hc, total = N * 3 * per;
+  const long pos = *pos_dev;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % hc);
+    const int h = (int)((i / hc) % heads);
+    const int sec = (int)((i / per) % 3);                 // 0 = q, 1 = k, 2 = v
+    const long n = i / (3 * per);
+    bf16_t* p1 = qkv + n * ld + sec * D + (long)h * hd + c * 8;
+    bf16_t* p2 = p1 + (hd >> 1);
+    const uint4 u1 = *reinterpret_cast<const uint4*>(p1), u2 = *reinterpret_cast<const uint4*>(p2);
+    bf16_t* d1 = (sec == 1 ? kc : vc) + n * cstride + pos * D + (long)h * hd + c * 8;
+    if (sec == 2) {
+      *reinterpret_cast<uint4*>(d1) = u1;
+      *reinterpret_cast<uint4*>(d1 + (hd >> 1)) = u2;
+      continue;
+    }
+    float a[8], b[8], o1[8], o2[8];
+    unpack8(u1, a);
+    unpack8(u2, b);
+    const float* cp = cs + pos * (hd >> 1) + c * 8;
+    const float* sp = sn + pos * (hd >> 1) + c * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      o1[e] = a[e] * cp[e] - b[e] * sp[e];
+      o2[e] = b[e] * cp[e] + a[e] * sp[e];
+    }
+    if (sec == 0) { *reinterpret_cast<uint4*>(p1) = pack8(o1); *reinterpret_cast<uint4*>(p2) = pack8(o2); }
+    else { *reinterpret_cast<uint4*>(d1) = pack8(o1); *reinterpret_cast<uint4*>(d1 + (hd >> 1)) = pack8(o2); }
+  }
+}
+
 __global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, long rows, long I,
                                                     long ldgu, long ldo) {
   const long ich = I >> 3, total = rows * ich;
@@ -259,6 +295,18 @@ extern "C" int llmseg_rope(void* x, const float* cos, const float* sin, int64_t 
   hipLaunchKernelGGL(rope_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, cos, sin, (long)rows, (long)T, heads,
                      head_dim, (long)ld);
   LL_LAUNCH_CHECK("rope");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_rope_kv_append(void* qkv, int64_t ld, const float* cos, const float* sin, void* kcache, void* vcache, int64_t cache_stride_n,
+                                     const int32_t* pos_dev, int64_t N, int32_t heads, int32_t head_dim, void* stream) {
+  LL_CHECK(qkv && cos && sin && kcache && vcache && pos_dev && N > 0 && heads > 0, "rope_kv_append: bad arguments");
+  LL_CHECK((head_dim & 15) == 0 && (ld & 7) == 0 && (cache_stride_n & 7) == 0 && AL16(qkv) && AL16(kcache) && AL16(vcache),
+           "rope_kv_append: head_dim %% 16 and 16-byte alignment required");
+  const long total = N * 3 * heads * (head_dim >> 4);
+  hipLaunchKernelGGL(rope_kv_append_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv, (long)ld, cos, sin, (bf16_t*)kcache,
+                     (bf16_t*)vcache, (long)cache_stride_n, pos_dev, (long)N, heads, head_dim);
+  LL_LAUNCH_CHECK("rope_kv_append");
   return LLMSEG_OK;
 }
 

@@ -22,55 +22,78 @@ from .trainable import _Direct
 BF16 = torch.bfloat16
 
 
-class KVCache:
-    """K / V of every decoder layer, [layers][N, Tmax, H] bf16 each; `len` = tokens stored."""
+class DecodeState:
+    """Everything a decode step touches, at fixed addresses (so the step can be captured once and replayed): the KV cache
+    [layers][N, capacity, H] bf16 x 2, the device-side position {pos, pos + 1}, the step's input embeddings and its outputs."""
 
-    def __init__(self, layers, N, Tmax, H, device):
-        self.k = torch.empty((layers, N, Tmax, H), device=device, dtype=BF16)
-        self.v = torch.empty((layers, N, Tmax, H), device=device, dtype=BF16)
-        self.N, self.Tmax, self.H, self.len = N, Tmax, H, 0
+    def __init__(self, layers, N, cap, H, V, device):
+        self.k = torch.empty((layers, N, cap, H), device=device, dtype=BF16)
+        self.v = torch.empty((layers, N, cap, H), device=device, dtype=BF16)
+        self.pos = torch.zeros((2,), device=device, dtype=torch.int32)       # [0] = position of the token being fed, [1] = keys present after it
+        self.x = torch.empty((N, H), device=device, dtype=BF16)
+        self.hidden = torch.empty((N, H), device=device, dtype=BF16)
+        self.logits = torch.empty((N, V), device=device, dtype=BF16)
+        self.N, self.cap, self.H = N, cap, H
+        self.graph = None
 
 
 class GenerateMixin:
-    def _decode_step(self, x, cache, logits_out=True):
-        """One token per sequence through the decoder stack.  x bf16 [N, H] (token embeddings) at position `cache.len`.
-        -> (final-norm hidden [N, H], logits [N, V] | None); the cache grows by one."""
+    def _decode_body(self, st):
+        """One token per sequence through the decoder stack: st.x (embeddings of the token at position st.pos[0]) -> st.hidden, st.logits;
+        K / V of the token are appended to the cache and the position advances.  No host-visible state: the step is a pure kernel
+        sequence over fixed buffers, replayable from a hipGraph."""
         c = self.config.llama
         F = _Direct
-        N, H = x.shape
-        pos = cache.len
-        assert pos < cache.Tmax
-        cos, sin, _ = self._rope(cache.Tmax)
+        N, H = st.x.shape
+        cos, sin, _ = self._rope(st.cap)
         s = c.lora_alpha / c.lora_r if c.lora_r > 0 else 0.0
         hd, heads = c.head_dim, c.heads
+        x = st.x
         att = torch.empty((N, H), device=x.device, dtype=BF16)
         for i in range(c.layers):
             p = f"model.layers.{i}."
             h = F.norm(x, self._w(p + "input_layernorm.weight", F), None, c.eps, True)
+            qkv = ops.gemm(h, self._wcat(p + "qkv", [p + f"self_attn.{n}_proj.weight" for n in "qkv"], F))      # skinny GEMM: a weight stream
             if c.lora_r > 0:
                 lp = p + "self_attn."
-                qkv = F.lora_qkv(h, self._w(p + "qkv", F), self._w(lp + "q_proj.lora_A.default.weight", F),
-                                 self._w(lp + "q_proj.lora_B.default.weight", F), self._w(lp + "v_proj.lora_A.default.weight", F),
-                                 self._w(lp + "v_proj.lora_B.default.weight", F), s)
-            else:
-                qkv = ops.gemm(h, self._wcat(p + "qkv", [p + f"self_attn.{n}_proj.weight" for n in "qkv"], F))
+                aq, bq = self._w(lp + "q_proj.lora_A.default.weight", F), self._w(lp + "q_proj.lora_B.default.weight", F)
+                av, bv = self._w(lp + "v_proj.lora_A.default.weight", F), self._w(lp + "v_proj.lora_B.default.weight", F)
+                if c.lora_r == 8:                              # rank-8 kernels: [h Aq^T | h Av^T] in one pass, then the two rank-8 updates
+                    xa = ops.lora_down(h, aq, x2=h, w2=av)
+                    ops.lora_apply_(qkv[:, :H], xa, bq, alpha=s)
+                    ops.lora_apply_(qkv[:, 2 * H:], xa[:, 8:], bv, alpha=s)
+                else:
+                    ops.gemm(ops.gemm(h, aq), bq, residual=qkv[:, :H], out=qkv[:, :H], alpha=s)
+                    ops.gemm(ops.gemm(h, av), bv, residual=qkv[:, 2 * H:], out=qkv[:, 2 * H:], alpha=s)
             ld = qkv.stride(0)
-            ops.rope_(qkv, cos[pos:pos + 1], sin[pos:pos + 1], N, 1, 2 * heads, hd, ld)       # q and k of every row at position `pos`
-            kc, vc = cache.k[i], cache.v[i]
-            kc[:, pos].copy_(qkv[:, H:2 * H])
-            vc[:, pos].copy_(qkv[:, 2 * H:3 * H])
-            ops.attention(qkv, kc, vc, att, batch=N, heads=heads, Nq=1, Nk=pos + 1, head_dim=hd, q_strides=(ld, hd, ld),
-                          k_strides=(cache.Tmax * H, hd, H), v_strides=(cache.Tmax * H, hd, H), o_strides=(H, hd, H))
+            ops.rope_kv_append_(qkv, cos, sin, st.k[i], st.v[i], st.pos, heads, hd)       # q, k rotated at the device-side position; k, v -> cache
+            ops.attention(qkv, st.k[i], st.v[i], att, batch=N, heads=heads, Nq=1, Nk=st.cap, head_dim=hd, q_strides=(ld, hd, ld),
+                          k_strides=(st.cap * H, hd, H), v_strides=(st.cap * H, hd, H), o_strides=(H, hd, H), nk_dev=st.pos[1:])
             x = ops.gemm(att, self._w(p + "self_attn.o_proj.weight", F), residual=x)
             h = F.norm(x, self._w(p + "post_attention_layernorm.weight", F), None, c.eps, True)
             gu = ops.gemm(h, self._wcat(p + "gate_up", [p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"], F))
             x = ops.gemm(ops.swiglu(gu, c.inter), self._w(p + "mlp.down_proj.weight", F), residual=x)
-        cache.len = pos + 1
-        hidden = F.norm(x, self._w("model.norm.weight", F), None, c.eps, True)
-        return hidden, (ops.gemm(hidden, self._w("lm_head.weight", F)) if logits_out else None)
+        ops.norm(x, self._w("model.norm.weight", F), None, eps=c.eps, rms=True, out=st.hidden)
+        ops.gemm(st.hidden, self._w("lm_head.weight", F), out=st.logits)
+        st.pos.add_(1)
+
+    def _decode_step(self, st, use_graph=True):
+        """Run one decode step; from the second step of a state on, replay it from a hipGraph (captured once per (N, capacity): a step is
+        ~420 launches of 5-20 us kernels, the host cannot issue them as fast as the GPU finishes them)."""
+        if not use_graph:
+            return self._decode_body(st)
+        if st.graph is None:
+            if not getattr(st, "warm", False):
+                st.warm = True
+                return self._decode_body(st)                    # first step of this state: eager (also warms every allocation)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._decode_body(st)
+            st.graph = g                                        # capture records, it does not execute: fall through to the replay
+        st.graph.replay()
 
     @torch.no_grad()
-    def generate(self, images_clip, input_ids, max_new_tokens=32, eos_token_id=2, pad_token_id=0):
+    def generate(self, images_clip, input_ids, max_new_tokens=32, eos_token_id=2, pad_token_id=0, use_graph=True):
         """Greedy generation.  images_clip bf16 [N, 3, 224, 224] (one image per sequence), input_ids int64 [N, L] holding exactly one
         IMAGE_TOKEN_INDEX each, no padding (evaluate() passes no attention mask).
         -> (sequences int64 [N, L + n_new], hidden bf16 [N, T + n_new - 1, H]: final-norm hidden state of every token but the last)."""
@@ -86,13 +109,17 @@ class GenerateMixin:
         F = _Direct
         proj = self.encode_images(images_clip.to(dev, BF16))
         embeds = F.embed_splice(input_ids.to(dev).contiguous(), self._w("model.embed_tokens.weight", F), proj[1:], Pn, (Pn + 1) * H, plan.tok_index)
-        cache = KVCache(cl.layers, N, T + max_new_tokens, H, dev)
+        cap = (T + max_new_tokens + 63) // 64 * 64
+        states = self.__dict__.setdefault("_decode_states", {})
+        st = states.get((N, cap))
+        if st is None:
+            st = states[(N, cap)] = DecodeState(cl.layers, N, cap, H, cl.vocab, dev)
 
         def keep_kv(i, qkv):                                   # qkv [N*T, 3H] after the in-place RoPE of q and k
-            cache.k[i, :, :T].copy_(qkv[:, H:2 * H].view(N, T, H))
-            cache.v[i, :, :T].copy_(qkv[:, 2 * H:3 * H].view(N, T, H))
+            st.k[i, :, :T].copy_(qkv[:, H:2 * H].view(N, T, H))
+            st.v[i, :, :T].copy_(qkv[:, 2 * H:3 * H].view(N, T, H))
         hidden_p = self._llama(embeds, plan.key_mask, F, kv_out=keep_kv)          # [N, T, H]
-        cache.len = T
+        st.pos.copy_(torch.tensor([T, T + 1], dtype=torch.int32))
         hidden = torch.empty((N, T + max_new_tokens - 1, H), device=dev, dtype=BF16)
         hidden[:, :T] = hidden_p
         emb_w = self._w("model.embed_tokens.weight", F)
@@ -112,8 +139,10 @@ class GenerateMixin:
                     break
             if n_new == max_new_tokens:
                 break
-            h1, logits = self._decode_step(ops.gather_rows(emb_w, nxt), cache)
-            hidden[:, T + n_new - 1] = h1
+            st.x.copy_(ops.gather_rows(emb_w, nxt))
+            self._decode_step(st, use_graph)
+            hidden[:, T + n_new - 1] = st.hidden
+            logits = st.logits
         return torch.cat(seqs, 1), hidden[:, :T + n_new - 1]
 
     @torch.no_grad()

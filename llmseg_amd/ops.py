@@ -92,7 +92,8 @@ def gemm_batched(a, w, out, M, N, K, lda, ldw, ldc, batch, sA, sW, sC, out_f32=T
 
 
 def attention(q, k, v, out, *, batch, heads, Nq, Nk, head_dim, q_strides, k_strides, v_strides, o_strides, scale=None,
-              causal=False, key_mask=None, rel_h=None, rel_w=None, rel_ld=0, grid_hw=(0, 0), o_row_map=None, rel_tab_h=None, rel_tab_w=None, lse=None):
+              causal=False, key_mask=None, rel_h=None, rel_w=None, rel_ld=0, grid_hw=(0, 0), o_row_map=None, rel_tab_h=None, rel_tab_w=None, lse=None,
+              nk_dev=None):
     """Strided fused attention.  *_strides = (batch, head, row) in elements relative to the given tensors' data_ptr."""
     a = AttnArgs(Q=q.data_ptr(), K=k.data_ptr(), V=v.data_ptr(), O=out.data_ptr(),
                  q_stride_b=q_strides[0], q_stride_h=q_strides[1], q_stride_row=q_strides[2],
@@ -106,7 +107,7 @@ def attention(q, k, v, out, *, batch, heads, Nq, Nk, head_dim, q_strides, k_stri
                  rel_ld=rel_ld, grid_h=grid_hw[0], grid_w=grid_hw[1],
                  o_row_map=None if o_row_map is None else o_row_map.data_ptr(),
                  rel_tab_h=None if rel_tab_h is None else rel_tab_h.data_ptr(), rel_tab_w=None if rel_tab_w is None else rel_tab_w.data_ptr(),
-                 lse=None if lse is None else lse.data_ptr())
+                 lse=None if lse is None else lse.data_ptr(), nk_dev=None if nk_dev is None else nk_dev.data_ptr())
     _lib.check(_lib.load().llmseg_attn_fwd(C.byref(a), _stream()), "attn_fwd")
     return out
 
@@ -153,6 +154,15 @@ def norm(x, w, b=None, eps=1e-5, rms=False, out=None, row_map=None, out_rows=Non
 def rope_(x, cos, sin, rows, T, heads, head_dim, ld):
     _lib.check(_lib.load().llmseg_rope(_ptr(x), _ptr(cos), _ptr(sin), rows, T, heads, head_dim, ld, _stream()), "rope")
     return x
+
+
+def rope_kv_append_(qkv, cos, sin, kcache, vcache, pos_dev, heads, head_dim):
+    """Decode step: rotate q (in place) and k at position *pos_dev, write k / v into the caches [N, capacity, heads*head_dim]."""
+    N = qkv.shape[0]
+    assert kcache.shape == vcache.shape and kcache.shape[0] == N and kcache.stride(1) == heads * head_dim and pos_dev.dtype == torch.int32
+    _lib.check(_lib.load().llmseg_rope_kv_append(_ptr(qkv), qkv.stride(0), _ptr(cos), _ptr(sin), _ptr(kcache), _ptr(vcache), kcache.stride(0), _ptr(pos_dev),
+                                                 N, heads, head_dim, _stream()), "rope_kv_append")
+    return qkv
 
 
 def swiglu(gu, inter, out=None):

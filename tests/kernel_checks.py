@@ -46,6 +46,23 @@ def check_gemm():
         ref = r.float() + g.float() * fn(a.float() @ w.float().t() + b.float())
         got = ops.gemm(a.to(DEV), w.to(DEV), bias=b.to(DEV), act=act, residual=r.to(DEV), gamma=g.to(DEV))
         out.append((f"gemm epilogue act={act}", err(got, ref), tol_bf16(ref, 1.5)))
+    # skinny GEMM (M <= 8: the decode step of generation, single-row head GEMMs): every row count, ragged N, K below / across /
+    # far above one 512-element K-step, the full epilogue, fp32 output with accumulate, strided A
+    for i, (M, N, K) in enumerate([(1, 4096, 4096), (2, 12288, 4096), (3, 37, 24), (4, 4096, 11008), (5, 250, 520), (7, 16, 1024), (8, 1000, 1544)]):
+        a, w = rnd(M, K, seed=110 + i), rnd(N, K, seed=120 + i, scale=1 / math.sqrt(K))
+        ref = a.float() @ w.float().t()
+        out.append((f"gemm skinny {M}x{N}x{K}", err(ops.gemm(a.to(DEV), w.to(DEV)), ref), tol_bf16(ref)))
+    M, N, K = 2, 530, 1032
+    a, w, b, g, r = rnd(M, K, seed=131), rnd(N, K, seed=132, scale=1 / 32), rnd(N, seed=133), rnd(N, seed=134), rnd(M, N, seed=135)
+    ref = r.float() + g.float() * F.silu(0.5 * (a.float() @ w.float().t()) + b.float())
+    got = ops.gemm(a.to(DEV), w.to(DEV), bias=b.to(DEV), act=ops.ACT_SILU, residual=r.to(DEV), gamma=g.to(DEV), alpha=0.5)
+    out.append(("gemm skinny epilogue (alpha, bias, silu, gamma, residual)", err(got, ref), tol_bf16(ref, 1.5)))
+    big = rnd(3, 3 * 256, seed=136)
+    w = rnd(45, 256, seed=137)
+    acc0 = torch.randn(3, 45, generator=torch.Generator().manual_seed(138))
+    o = acc0.clone().to(DEV)
+    ops.gemm(big.to(DEV)[:, 256:512], w.to(DEV), out=o, out_f32=True, accumulate=True)
+    out.append(("gemm skinny f32-out accumulate strided-A", err(o, acc0 + big[:, 256:512].float() @ w.float().t()), 1e-3))
     # fp32 output, odd ldc, alpha, strided A (a view into a wider buffer)
     M, N, K = 200, 27, 80
     big = rnd(M, 3 * K, seed=6)

@@ -20,6 +20,9 @@ if os.environ.get("GEMM_SET") == "b2":   # BASELINE configs[2]: 2 images per mic
               (638, 4096, 12288, "llama dx(qkv)"), (638, 4096, 22016, "llama dx(gate_up)"), (638, 11008, 4096, "llama dx(down)"),
               (638, 32004, 4096, "lm_head"), (638, 4096, 32064, "lm_head dx"), (32064, 4096, 640, "lm_head dw"), (514, 3072, 1024, "clip qkv"),
               (514, 4096, 1024, "clip fc1")]
+if os.environ.get("GEMM_SET") == "dec":  # decode steps of generation (one token per sequence): weight streams
+    SHAPES = [(m, n, k, f"dec {t}") for m in (1, 4) for n, k, t in ((12288, 4096, "qkv"), (4096, 4096, "o"), (22016, 4096, "gate_up"), (4096, 11008, "down"),
+                                                                     (32004, 4096, "lm_head"))]
 RACE_REPEATS = int(os.environ.get("RACE_REPEATS", "0"))
 if os.environ.get("GEMM_SHAPES"):
     SHAPES = [SHAPES[int(i)] for i in os.environ["GEMM_SHAPES"].split(",")]
@@ -83,5 +86,7 @@ for M, N, K, tag in SHAPES:
         e1.record()
         torch.cuda.synchronize()
         extra = f"   torch.addmm {2.0 * M * N * K / (e0.elapsed_time(e1) / 10) / 1e9:6.0f}"
+    if os.environ.get("GEMM_SET") == "dec":
+        extra += "   GB/s " + " ".join(f"{r * 1e12 / (2.0 * M * N * K) * (N * K * 2) / 1e9:7.0f}" for r in res)      # weight bytes / time
     print(f"{tag + f' {M}x{N}x{K}':32s} " + " ".join(f"{r:9.0f}" for r in res) + "   check " + " ".join(f"{c:.1e}" for c in chk) + extra, flush=True)
 lib.llmseg_gemm_set_variant(5)
