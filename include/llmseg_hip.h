@@ -156,6 +156,14 @@ int llmseg_rope(void* x, const float* cos, const float* sin, int64_t rows, int64
 int llmseg_rope_kv_append(void* qkv, int64_t ld, const float* cos, const float* sin, void* kcache, void* vcache, int64_t cache_stride_n,
                           const int32_t* pos_dev, int64_t N, int32_t heads, int32_t head_dim, void* stream);
 
+/* y[i] = act(x[i]), bf16, n % 8 == 0, in place allowed (the GELU between LayerNorm2d and the second transposed convolution of SAM's
+ * mask decoder, mask_decoder.py:53-63: every other activation on the path rides in a GEMM epilogue) */
+int llmseg_act(const void* x, void* y, int64_t n, int32_t act, void* stream);
+/* Sam.postprocess_masks (model/segment_anything/modeling/sam.py:137-172), fused: low fp32 [n_masks][256*256] mask logits ->
+ * F.interpolate(bilinear, align_corners=False) to img_size^2 -> crop [:in_h, :in_w] -> F.interpolate to (out_h, out_w); out fp32
+ * [n_masks][out_h][out_w].  nested = 1: `low` is in the row order the GEMM-form transposed convolutions emit (see head.hip). */
+int llmseg_sam_postprocess(const float* low, float* out, int32_t n_masks, int32_t img_size, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
+                           int32_t nested, void* stream);
 /* out[r][c] = silu(gu[r][c]) * gu[r][I + c]   (HF LlamaMLP: down(silu(gate(x)) * up(x)); gu = x.[Wgate;Wup]^T) */
 int llmseg_swiglu(const void* gu, void* out, int64_t rows, int64_t I, int64_t ldgu, int64_t ldo, void* stream);
 

@@ -65,6 +65,8 @@ SIGNATURES = {
     "llmseg_rope": [_p, _p, _p, _i64, _i64, _i32, _i32, _i64, _p],
     "llmseg_rope_kv_append": [_p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _p],
     "llmseg_swiglu": [_p, _p, _i64, _i64, _i64, _i64, _p],
+    "llmseg_act": [_p, _p, _i64, _i32, _p],
+    "llmseg_sam_postprocess": [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     "llmseg_add_rows": [_p, _p, _p, _i64, _i64, _i64, _p],
     "llmseg_patchify": [_p, _p, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _p],
     "llmseg_im2col3x3": [_p, _p, _i32, _i32, _i32, _i32, _p],

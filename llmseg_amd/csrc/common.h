@@ -1,5 +1,6 @@
 // Shared device helpers for the gfx950 kernels (wave64, bf16 storage as uint16).
 #pragma once
+#include "llmseg_hip.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,6 +34,24 @@ __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
 }
 __device__ __forceinline__ uint4 pack8(const float* f) {
   return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+}
+
+// epilogue / pointwise activations (LLMSEG_ACT_* of llmseg_hip.h)
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case LLMSEG_ACT_RELU: return fmaxf(v, 0.f);
+    case LLMSEG_ACT_GELU: {   // exact (erf) GELU; erf via Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7 (far below bf16 resolution)
+      const float z = fabsf(v) * 0.70710678118654752f;
+      const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+      const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+      const float erfa = 1.f - poly * __expf(-z * z);
+      return 0.5f * v * (1.f + copysignf(erfa, v));
+    }
+    case LLMSEG_ACT_QUICKGELU: return v * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v));
+    case LLMSEG_ACT_SILU: return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
+    case LLMSEG_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.f + __expf(-v));
+    default: return v;
+  }
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -45,23 +45,6 @@ struct GemmP {
   int accum;                 // fp32 output only: C += result (gradient accumulation into an fp32 arena)
 };
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-  switch (act) {
-    case LLMSEG_ACT_RELU: return fmaxf(v, 0.f);
-    case LLMSEG_ACT_GELU: {   // exact (erf) GELU; erf via Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7 (far below bf16 resolution)
-      const float z = fabsf(v) * 0.70710678118654752f;
-      const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
-      const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-      const float erfa = 1.f - poly * __expf(-z * z);
-      return 0.5f * v * (1.f + copysignf(erfa, v));
-    }
-    case LLMSEG_ACT_QUICKGELU: return v * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v));
-    case LLMSEG_ACT_SILU: return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
-    case LLMSEG_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.f + __expf(-v));
-    default: return v;
-  }
-}
-
 // exact-erf GELU on a pair (packed fp32 VALU: v_pk_fma / v_pk_mul).  Same Abramowitz-Stegun 7.1.26 erf as apply_act, rearranged:
 // 0.5 v (1 + erf(v/sqrt2)) = max(v, 0) - 0.5|v| * t*poly(t) * exp(-v^2/2),  t = 1 / (1 + p|v|/sqrt2);  exp via exp2.
 __device__ __forceinline__ f32x2_t gelu2(f32x2_t v) {

@@ -295,6 +295,58 @@ __global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logi
 
 }  // namespace
 
+// SAM mask post-processing (sam.py:137-172): low-res logits 256 x 256 -> bilinear (align_corners = False) to img x img, crop to the
+// input size, bilinear to the original size, all in fp32 -- fused: every output pixel evaluates its four stage-1 samples on the fly
+// (16 reads of a 256 KiB mask that lives in L2).  torch's upsample_bilinear2d arithmetic: src = max(0, scale (o + 0.5) - 0.5),
+// i0 = floor(src), i1 = i0 + (i0 < in - 1), weights (1 - frac, frac), value = w_y0 (w_x0 v00 + w_x1 v01) + w_y1 (w_x0 v10 + w_x1 v11).
+// `nested` = the layout the two stride-2 transposed convolutions of the mask decoder leave when run as GEMMs on token-major rows:
+// pixel (Y, X) sits at ((y 64 + x) 4 + dy1 2 + dx1) 4 + dy2 2 + dx2 with Y = 4 y + 2 dy1 + dy2 (no pixel-shuffle pass is needed).
+__device__ __forceinline__ float sam_low(const float* __restrict__ m, int Y, int X, int nested) {
+  if (!nested) return m[Y * 256 + X];
+  const int tok = (Y >> 2) * 64 + (X >> 2);
+  return m[(tok * 4 + ((Y >> 1) & 1) * 2 + ((X >> 1) & 1)) * 4 + (Y & 1) * 2 + (X & 1)];
+}
+__device__ __forceinline__ void bil_coord(int o, float scale, int in, int& i0, int& i1, float& w0, float& w1) {
+  const float src = fmaxf(0.f, __fmul_rn(scale, (float)o + 0.5f) - 0.5f);
+  i0 = (int)src;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  w1 = src - (float)i0;
+  w0 = 1.f - w1;
+}
+__global__ __launch_bounds__(256) void sam_postprocess_kernel(const float* __restrict__ low, float* __restrict__ out, int img, int in_h, int in_w, int oh, int ow,
+                                                             int nested) {
+  const int b = blockIdx.z, oy = blockIdx.y;
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ox >= ow) return;
+  const float* m = low + (long)b * 65536;
+  const float s1 = 256.f / (float)img, s2y = (float)in_h / (float)oh, s2x = (float)in_w / (float)ow;
+  int y0, y1, x0, x1;
+  float wy0, wy1, wx0, wx1;
+  bil_coord(oy, s2y, in_h, y0, y1, wy0, wy1);
+  bil_coord(ox, s2x, in_w, x0, x1, wx0, wx1);
+  auto stage1 = [&](int Y, int X) {                        // value of the img x img intermediate at (Y, X)
+    int a0, a1, c0, c1;
+    float u0, u1, v0, v1;
+    bil_coord(Y, s1, 256, a0, a1, u0, u1);
+    bil_coord(X, s1, 256, c0, c1, v0, v1);
+    return __fadd_rn(__fmul_rn(u0, __fadd_rn(__fmul_rn(v0, sam_low(m, a0, c0, nested)), __fmul_rn(v1, sam_low(m, a0, c1, nested)))),
+                     __fmul_rn(u1, __fadd_rn(__fmul_rn(v0, sam_low(m, a1, c0, nested)), __fmul_rn(v1, sam_low(m, a1, c1, nested)))));
+  };
+  const float r = __fadd_rn(__fmul_rn(wy0, __fadd_rn(__fmul_rn(wx0, stage1(y0, x0)), __fmul_rn(wx1, stage1(y0, x1)))),
+                            __fmul_rn(wy1, __fadd_rn(__fmul_rn(wx0, stage1(y1, x0)), __fmul_rn(wx1, stage1(y1, x1)))));
+  out[((long)b * oh + oy) * ow + ox] = r;
+}
+
+extern "C" int llmseg_sam_postprocess(const float* low, float* out, int32_t n_masks, int32_t img_size, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
+                                      int32_t nested, void* stream) {
+  LL_CHECK(low && out && n_masks > 0 && img_size > 0 && in_h > 0 && in_w > 0 && in_h <= img_size && in_w <= img_size && out_h > 0 && out_w > 0,
+           "sam_postprocess: bad arguments");
+  hipLaunchKernelGGL(sam_postprocess_kernel, dim3((unsigned)((out_w + 255) / 256), (unsigned)out_h, (unsigned)n_masks), dim3(256), 0, (hipStream_t)stream, low, out,
+                     img_size, in_h, in_w, out_h, out_w, nested);
+  LL_LAUNCH_CHECK("sam_postprocess");
+  return LLMSEG_OK;
+}
+
 extern "C" int llmseg_mask_pullback(const void* segs, void* ws, float* pulled_back, float* wsum, int32_t K, int32_t g, int32_t S, void* stream) {
   LL_CHECK(segs && ws && K > 0 && g > 0 && S >= g, "mask_pullback: bad arguments");
   LL_CHECK(256 % g == 0 && ((g * g) & 7) == 0, "mask_pullback: feature grid %d must divide 256", g);

@@ -157,6 +157,17 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(bf16_t* __restrict_
   }
 }
 
+// elementwise activation, in place or not (rows of 8-element chunks)
+__global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n8, int act) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float v[8];
+    unpack8(reinterpret_cast<const uint4*>(x)[i], v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], act);
+    reinterpret_cast<uint4*>(y)[i] = pack8(v);
+  }
+}
+
 __global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, long rows, long I,
                                                     long ldgu, long ldo) {
   const long ich = I >> 3, total = rows * ich;
@@ -307,6 +318,13 @@ extern "C" int llmseg_rope_kv_append(void* qkv, int64_t ld, const float* cos, co
   hipLaunchKernelGGL(rope_kv_append_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv, (long)ld, cos, sin, (bf16_t*)kcache,
                      (bf16_t*)vcache, (long)cache_stride_n, pos_dev, (long)N, heads, head_dim);
   LL_LAUNCH_CHECK("rope_kv_append");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_act(const void* x, void* y, int64_t n, int32_t act, void* stream) {
+  LL_CHECK(x && y && n > 0 && (n & 7) == 0 && AL16(x) && AL16(y), "act: n %% 8 and 16-byte alignment required");
+  hipLaunchKernelGGL(act_kernel, dim3(grid_for(n >> 3)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (long)(n >> 3), act);
+  LL_LAUNCH_CHECK("act");
   return LLMSEG_OK;
 }
 

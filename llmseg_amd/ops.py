@@ -165,6 +165,24 @@ def rope_kv_append_(qkv, cos, sin, kcache, vcache, pos_dev, heads, head_dim):
     return qkv
 
 
+def act_(x, act):
+    """In-place elementwise activation (bf16, contiguous)."""
+    assert x.is_contiguous() and x.numel() % 8 == 0
+    _lib.check(_lib.load().llmseg_act(_ptr(x), _ptr(x), x.numel(), act, _stream()), "act")
+    return x
+
+
+def sam_postprocess(low, input_size, original_size, img_size=1024, nested=True):
+    """low fp32 [n, 65536] mask logits -> fp32 [n, H, W] (Sam.postprocess_masks)."""
+    assert low.dtype == torch.float32 and low.is_contiguous() and low.shape[1] == 65536
+    n = low.shape[0]
+    out = torch.empty((n, int(original_size[0]), int(original_size[1])), device=low.device, dtype=torch.float32)
+    if n:
+        _lib.check(_lib.load().llmseg_sam_postprocess(_ptr(low), _ptr(out), n, img_size, int(input_size[0]), int(input_size[1]), int(original_size[0]),
+                                                      int(original_size[1]), 1 if nested else 0, _stream()), "sam_postprocess")
+    return out
+
+
 def swiglu(gu, inter, out=None):
     rows = gu.shape[0]
     if out is None:

@@ -72,6 +72,7 @@ class LisaConfig:
     align_loss_weight: float = 1.0
     regression_loss_weight: float = 1.0
     build_unused_towers: bool = True   # keep both vision backbones' parameters, as the reference does
+    sam_decoder: bool = False          # SAM prompt encoder (text path) + mask decoder: only `evaluate()` reaches them (LISA.py:523-557)
 
     @property
     def n_img_tokens(self):
@@ -181,6 +182,41 @@ def head_shapes(hidden, out_dim=256, dino_dim=1024, pfx="model."):
     return s
 
 
+def sam_decoder_shapes(pfx="model.visual_model.", D=256, mlp=2048):
+    """Prompt encoder (the tensors the text-prompt path reads) + mask decoder under the reference's names
+    (model/segment_anything/modeling/{prompt_encoder,mask_decoder,transformer}.py; sizes from build_sam.py:56-102)."""
+    s = {pfx + "prompt_encoder.pe_layer.positional_encoding_gaussian_matrix": (2, D // 2),
+         pfx + "prompt_encoder.no_mask_embed.weight": (1, D),
+         pfx + "mask_decoder.iou_token.weight": (1, D), pfx + "mask_decoder.mask_tokens.weight": (4, D)}
+
+    def attn(p, inner):
+        for n in ("q_proj", "k_proj", "v_proj"):
+            s[p + n + ".weight"], s[p + n + ".bias"] = (inner, D), (inner,)
+        s[p + "out_proj.weight"], s[p + "out_proj.bias"] = (D, inner), (D,)
+    t = pfx + "mask_decoder.transformer."
+    for i in range(2):
+        p = f"{t}layers.{i}."
+        attn(p + "self_attn.", D)
+        attn(p + "cross_attn_token_to_image.", D // 2)
+        attn(p + "cross_attn_image_to_token.", D // 2)
+        for n in ("norm1", "norm2", "norm3", "norm4"):
+            s[p + n + ".weight"], s[p + n + ".bias"] = (D,), (D,)
+        s[p + "mlp.lin1.weight"], s[p + "mlp.lin1.bias"] = (mlp, D), (mlp,)
+        s[p + "mlp.lin2.weight"], s[p + "mlp.lin2.bias"] = (D, mlp), (D,)
+    attn(t + "final_attn_token_to_image.", D // 2)
+    s[t + "norm_final_attn.weight"], s[t + "norm_final_attn.bias"] = (D,), (D,)
+    m = pfx + "mask_decoder."
+    s[m + "output_upscaling.0.weight"], s[m + "output_upscaling.0.bias"] = (D, D // 4, 2, 2), (D // 4,)
+    s[m + "output_upscaling.1.weight"], s[m + "output_upscaling.1.bias"] = (D // 4,), (D // 4,)
+    s[m + "output_upscaling.3.weight"], s[m + "output_upscaling.3.bias"] = (D // 4, D // 8, 2, 2), (D // 8,)
+    for i in range(4):
+        for j, (o, k) in enumerate(((D, D), (D, D), (D // 8, D))):
+            s[f"{m}output_hypernetworks_mlps.{i}.layers.{j}.weight"], s[f"{m}output_hypernetworks_mlps.{i}.layers.{j}.bias"] = (o, k), (o,)
+    for j, (o, k) in enumerate(((D, D), (D, D), (4, D))):
+        s[f"{m}iou_prediction_head.layers.{j}.weight"], s[f"{m}iou_prediction_head.layers.{j}.bias"] = (o, k), (o,)
+    return s
+
+
 def lisa_shapes(c: LisaConfig):
     s = {}
     s.update(llama_shapes(c.llama))
@@ -191,6 +227,8 @@ def lisa_shapes(c: LisaConfig):
     if c.backbone == "sam" or c.build_unused_towers:
         s.update(sam_shapes(c.sam))
     s.update(head_shapes(c.llama.hidden, c.out_dim, c.dino.dim))
+    if c.sam_decoder:
+        s.update(sam_decoder_shapes())
     return s
 
 

@@ -96,3 +96,17 @@ def iou_metric_cases():
         out.append((pred, tgt))
     out.append((torch.zeros(64, 64, dtype=torch.long), torch.zeros(64, 64, dtype=torch.long)))   # empty union
     return out
+
+
+def sam_decoder_state(seed=11):
+    """Seeded weights of SAM's prompt encoder (text path) + mask decoder under the reference's state-dict names."""
+    from . import sam_decoder as sdec
+    sd = seeded.fill_state_dict(sdec.decoder_shapes(), seed)
+    k = sdec.PFX + "prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"
+    sd[k] = seeded.uniform((2, 128), 1234, -1.5, 1.5)                 # the reference draws it from randn (scale 1)
+    return sd
+
+
+def sam_decoder_case(b=2):
+    """image embedding [1, 256, 64, 64] (what the SAM encoder's neck emits) and b [SEG] text embeddings [b, 256]."""
+    return seeded.uniform((1, 256, 64, 64), 51, -1.0, 1.0), seeded.uniform((b, 256), 52, -1.0, 1.0)

@@ -61,3 +61,21 @@ def seg_embeddings(sd, cfg, output_ids, hidden):
     off = [0] + cnt.cumsum(0).tolist()
     pe = h[m]
     return [pe[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+
+
+def evaluate(sd, cfg, images_clip, images, input_ids, resize_list, original_size_list, max_new_tokens=32, eos_token_id=2, pad_token_id=0):
+    """`LISAForCausalLM.evaluate` (LISA.py:477-559) from the restated pieces: generation, [SEG] embeddings, SAM image embedding
+    (oracle/lisa.py::visual_features), prompt encoder + mask decoder + post-processing (oracle/sam_decoder.py).
+    -> (output_ids, [fp32 [n_seg, H, W]], aux)"""
+    from . import sam_decoder as sdec
+    ids, hidden = greedy_generate(sd, cfg, images_clip, input_ids, max_new_tokens, eos_token_id, pad_token_id)
+    pe = seg_embeddings(sd, cfg, ids, hidden)
+    feats = _lisa.visual_features(sd, cfg, images)                      # [B, 256, 64, 64]
+    masks = []
+    for i in range(len(pe)):
+        if pe[i].shape[0] == 0:
+            masks.append(torch.empty((0,) + tuple(original_size_list[i])))
+            continue
+        low, _ = sdec.decode_masks(sd, feats[i:i + 1], pe[i])
+        masks.append(sdec.postprocess_masks(low, resize_list[i], original_size_list[i], cfg.sam.img)[:, 0])
+    return ids, masks, dict(hidden=hidden, pred_embeddings=pe, feats=feats)

@@ -174,6 +174,39 @@ def gold_generate():
     torch.save(out, os.path.join(OUT, "generate_tiny.pt"))
 
 
+def gold_sam_decoder():
+    """evaluate()'s mask path (LISA.py:523-557): the imported reference PromptEncoder / MaskDecoder / postprocess vs the restatement."""
+    from oracle import sam_decoder as sdec, seeded
+    cfg = cases.tiny_lisa_cfg()
+    rh.setup(clip_cfg_kwargs=dict(hidden_size=cfg.clip.dim, intermediate_size=cfg.clip.mlp,
+                                  num_hidden_layers=cfg.clip.layers, num_attention_heads=cfg.clip.heads),
+             dino_cfg_kwargs=dict(num_hidden_layers=cfg.dino.layers))
+    from model.segment_anything.modeling import MaskDecoder, PromptEncoder, TwoWayTransformer
+    from model.segment_anything.modeling.sam import Sam
+    pe = PromptEncoder(embed_dim=256, image_embedding_size=(64, 64), input_image_size=(1024, 1024), mask_in_chans=16)
+    md = MaskDecoder(num_multimask_outputs=3, transformer=TwoWayTransformer(depth=2, embedding_dim=256, mlp_dim=2048, num_heads=8),
+                     transformer_dim=256, iou_head_depth=3, iou_head_hidden_dim=256)
+    sd = cases.sam_decoder_state()
+    r1 = pe.load_state_dict({k[len(sdec.PFX + "prompt_encoder."):]: v for k, v in sd.items() if ".prompt_encoder." in k}, strict=False)
+    r2 = md.load_state_dict({k[len(sdec.PFX + "mask_decoder."):]: v for k, v in sd.items() if ".mask_decoder." in k}, strict=True)
+    assert not r1.unexpected_keys, r1
+    emb, text = cases.sam_decoder_case()
+    with torch.no_grad():
+        sparse, dense = pe(points=None, boxes=None, masks=None, text_embeds=text[:, None, :])
+        low, iou = md(image_embeddings=emb, image_pe=pe.get_dense_pe(), sparse_prompt_embeddings=sparse, dense_prompt_embeddings=dense,
+                      multimask_output=False)
+        holder = type("S", (), {"image_encoder": type("E", (), {"img_size": 1024})()})()
+        post = Sam.postprocess_masks(holder, low, input_size=(683, 1024), original_size=(427, 640))
+        m_low, m_iou = sdec.decode_masks(sd, emb, text)
+        m_post = sdec.postprocess_masks(m_low, (683, 1024), (427, 640))
+    _check("sam_decoder.dense_pe", pe.get_dense_pe()[0], sdec.dense_pe(sd), 1e-5)
+    _check("sam_decoder.low_res_masks", low, m_low, 1e-4)
+    _check("sam_decoder.iou", iou, m_iou, 1e-4)
+    _check("sam_decoder.postprocess", post, m_post, 1e-4)
+    torch.save({"low_res_sub": low[:, 0, ::4, ::4].clone(), "low_res_sum": low.double().sum(), "iou": iou, "post_sub": post[:, 0, ::7, ::9].clone(),
+                "post_sum": post.double().sum(), "input_size": (683, 1024), "original_size": (427, 640)}, os.path.join(OUT, "sam_decoder.pt"))
+
+
 def gold_lisa_tiny():
     cfg = cases.tiny_lisa_cfg()
     rh.setup(clip_cfg_kwargs=dict(hidden_size=cfg.clip.dim, intermediate_size=cfg.clip.mlp,
@@ -235,7 +268,7 @@ def main():
     rh.setup(clip_cfg_kwargs=dict(hidden_size=cfg.clip.dim, intermediate_size=cfg.clip.mlp,
                                   num_hidden_layers=cfg.clip.layers, num_attention_heads=cfg.clip.heads),
              dino_cfg_kwargs=dict(num_hidden_layers=cfg.dino.layers))
-    for f in (gold_losses, gold_iou_metric, gold_sam_small, gold_head, gold_lisa_tiny, gold_generate):
+    for f in (gold_losses, gold_iou_metric, gold_sam_small, gold_head, gold_lisa_tiny, gold_generate, gold_sam_decoder):
         print(f.__name__)
         f()
     print("wrote", sorted(os.listdir(OUT)))

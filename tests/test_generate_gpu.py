@@ -12,3 +12,13 @@ def _assert(res):
 def test_kv_cache_greedy_generation_matches_oracle():
     from tests import generate_checks as gc
     _assert(gc.check_generate())
+
+
+def test_sam_mask_decoder_and_postprocess_match_oracle():
+    from tests import sam_decoder_checks as sc
+    _assert(sc.check_sam_decoder())
+
+
+def test_evaluate_end_to_end_matches_oracle():
+    from tests import sam_decoder_checks as sc
+    _assert(sc.check_evaluate())

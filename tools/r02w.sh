@@ -1,3 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-GEMM_SET=dec WITH_TORCH=1 python tools/gemm_bench.py 5,0 2>&1 | grep -v amdgpu | cut -c1-220 > gpurun_out/r02w.txt; cat gpurun_out/r02w.txt
+timeout 900 python -m pytest tests/test_generate_gpu.py -q -x > gpurun_out/r02w.txt 2>&1; tail -25 gpurun_out/r02w.txt | cut -c1-600
