@@ -164,6 +164,19 @@ int llmseg_act(const void* x, void* y, int64_t n, int32_t act, void* stream);
  * [n_masks][out_h][out_w].  nested = 1: `low` is in the row order the GEMM-form transposed convolutions emit (see head.hip). */
 int llmseg_sam_postprocess(const float* low, float* out, int32_t n_masks, int32_t img_size, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
                            int32_t nested, void* stream);
+/* SAM "everything" mode (model/segment_anything/automatic_mask_generator.py:264-324, utils/amg.py:78-88,156-176,303-346), per candidate
+ * mask at the ORIGINAL resolution without materialising the logits there.  low fp32 [n][256*256] (nested as above):
+ *   llmseg_sam_mask_stats: stats int32 [n][7] += { |m > thr + off|, |m > thr - off|, |m > thr|, min x, min y, max x, max y } of the
+ *     post-processed mask m; the caller initialises rows to {0, 0, 0, INT_MAX, INT_MAX, -1, -1}.  iou (optional, fp32 [n]): candidates
+ *     with !(iou > iou_thresh) are skipped (pred_iou_thresh filter).  stability score = stats[0] / stats[1]; box = stats[3..6].
+ *   llmseg_sam_binarize: out uint8 [n_sel][out_h][out_w] = m[sel[k]] > thr for the surviving candidates.
+ *   llmseg_nms: greedy box NMS with torchvision.ops.nms semantics (one category): boxes fp32 [*][4] XYXY, order int32 [n] = candidate
+ *     indices by decreasing score, keep uint8 [n] (position in `order`). */
+int llmseg_sam_mask_stats(const float* low, const float* iou, float iou_thresh, int32_t* stats, int32_t n_masks, int32_t img_size, int32_t in_h,
+                          int32_t in_w, int32_t out_h, int32_t out_w, int32_t nested, float mask_threshold, float offset, void* stream);
+int llmseg_sam_binarize(const float* low, const int32_t* sel, uint8_t* out, int32_t n_sel, int32_t img_size, int32_t in_h, int32_t in_w, int32_t out_h,
+                        int32_t out_w, int32_t nested, float mask_threshold, void* stream);
+int llmseg_nms(const float* boxes, const int32_t* order, int32_t n, float iou_threshold, uint8_t* keep, void* stream);
 /* out[r][c] = silu(gu[r][c]) * gu[r][I + c]   (HF LlamaMLP: down(silu(gate(x)) * up(x)); gu = x.[Wgate;Wup]^T) */
 int llmseg_swiglu(const void* gu, void* out, int64_t rows, int64_t I, int64_t ldgu, int64_t ldo, void* stream);
 

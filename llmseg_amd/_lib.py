@@ -67,6 +67,9 @@ SIGNATURES = {
     "llmseg_swiglu": [_p, _p, _i64, _i64, _i64, _i64, _p],
     "llmseg_act": [_p, _p, _i64, _i32, _p],
     "llmseg_sam_postprocess": [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    "llmseg_sam_mask_stats": [_p, _p, _f32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _p],
+    "llmseg_sam_binarize": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _p],
+    "llmseg_nms": [_p, _p, _i32, _f32, _p, _p],
     "llmseg_add_rows": [_p, _p, _p, _i64, _i64, _i64, _p],
     "llmseg_patchify": [_p, _p, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _p],
     "llmseg_im2col3x3": [_p, _p, _i32, _i32, _i32, _i32, _p],

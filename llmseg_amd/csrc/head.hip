@@ -1,6 +1,7 @@
 // Mask-selection head kernels (HBM-bound): fused upsample+mask-pooling, cosine scoring, the two live losses
 // (softmax-KL align + weighted-MSE IoP regression), the north_star-named dice/BCE losses, and the shifted
 // cross-entropy over the LM logits.  See include/llmseg_hip.h for the reference lines each one replaces.
+#include <algorithm>
 #include "common.h"
 #include "llmseg_hip.h"
 
@@ -344,6 +345,119 @@ extern "C" int llmseg_sam_postprocess(const float* low, float* out, int32_t n_ma
   hipLaunchKernelGGL(sam_postprocess_kernel, dim3((unsigned)((out_w + 255) / 256), (unsigned)out_h, (unsigned)n_masks), dim3(256), 0, (hipStream_t)stream, low, out,
                      img_size, in_h, in_w, out_h, out_w, nested);
   LL_LAUNCH_CHECK("sam_postprocess");
+  return LLMSEG_OK;
+}
+
+// ---- SAM "everything" mode (automatic_mask_generator.py:264-324), the per-candidate work at the ORIGINAL resolution without ever
+// materialising the logits there: one pass that evaluates the fused post-processing per pixel and reduces it to
+//   st[c] = { |m > thr + off|, |m > thr - off|, |m > thr|, min x, min y, max x, max y of m > thr }      (int32 x 7)
+// (stability score = st0 / st1, amg.py:156-176; box = amg.py:303-346), skipping candidates whose predicted IoU already fails; and a
+// second pass that writes the binary masks of the survivors only.
+__device__ __forceinline__ float sam_post_value(const float* __restrict__ m, int oy, int ox, float s1, float s2y, float s2x, int in_h, int in_w, int nested) {
+  int y0, y1, x0, x1;
+  float wy0, wy1, wx0, wx1;
+  bil_coord(oy, s2y, in_h, y0, y1, wy0, wy1);
+  bil_coord(ox, s2x, in_w, x0, x1, wx0, wx1);
+  auto stage1 = [&](int Y, int X) {
+    int a0, a1, c0, c1;
+    float u0, u1, v0, v1;
+    bil_coord(Y, s1, 256, a0, a1, u0, u1);
+    bil_coord(X, s1, 256, c0, c1, v0, v1);
+    return __fadd_rn(__fmul_rn(u0, __fadd_rn(__fmul_rn(v0, sam_low(m, a0, c0, nested)), __fmul_rn(v1, sam_low(m, a0, c1, nested)))),
+                     __fmul_rn(u1, __fadd_rn(__fmul_rn(v0, sam_low(m, a1, c0, nested)), __fmul_rn(v1, sam_low(m, a1, c1, nested)))));
+  };
+  return __fadd_rn(__fmul_rn(wy0, __fadd_rn(__fmul_rn(wx0, stage1(y0, x0)), __fmul_rn(wx1, stage1(y0, x1)))),
+                   __fmul_rn(wy1, __fadd_rn(__fmul_rn(wx0, stage1(y1, x0)), __fmul_rn(wx1, stage1(y1, x1)))));
+}
+
+__global__ __launch_bounds__(256) void sam_mask_stats_kernel(const float* __restrict__ low, const float* __restrict__ iou, float iou_thr, int32_t* __restrict__ st,
+                                                            int img, int in_h, int in_w, int oh, int ow, int nested, float thr, float off) {
+  const int c = blockIdx.y;
+  if (iou && !(iou[c] > iou_thr)) return;                  // predicted-IoU filter first (automatic_mask_generator.py:290-292)
+  const float* m = low + (long)c * 65536;
+  const float s1 = 256.f / (float)img, s2y = (float)in_h / (float)oh, s2x = (float)in_w / (float)ow;
+  int hi = 0, lo = 0, ar = 0, mnx = 1 << 30, mny = 1 << 30, mxx = -1, mxy = -1;
+  const long n = (long)oh * ow;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int oy = (int)(i / ow), ox = (int)(i - (long)oy * ow);
+    const float v = sam_post_value(m, oy, ox, s1, s2y, s2x, in_h, in_w, nested);
+    hi += v > thr + off;
+    lo += v > thr - off;
+    if (v > thr) { ++ar; mnx = min(mnx, ox); mny = min(mny, oy); mxx = max(mxx, ox); mxy = max(mxy, oy); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    hi += __shfl_xor(hi, o, 64); lo += __shfl_xor(lo, o, 64); ar += __shfl_xor(ar, o, 64);
+    mnx = min(mnx, __shfl_xor(mnx, o, 64)); mny = min(mny, __shfl_xor(mny, o, 64));
+    mxx = max(mxx, __shfl_xor(mxx, o, 64)); mxy = max(mxy, __shfl_xor(mxy, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    int32_t* s = st + (long)c * 7;
+    if (hi) atomicAdd(s + 0, hi);
+    if (lo) atomicAdd(s + 1, lo);
+    if (ar) { atomicAdd(s + 2, ar); atomicMin(s + 3, mnx); atomicMin(s + 4, mny); atomicMax(s + 5, mxx); atomicMax(s + 6, mxy); }
+  }
+}
+
+// binary masks (uint8 0 / 1) of the selected candidates at the original resolution
+__global__ __launch_bounds__(256) void sam_binarize_kernel(const float* __restrict__ low, const int32_t* __restrict__ sel, uint8_t* __restrict__ out, int img, int in_h,
+                                                          int in_w, int oh, int ow, int nested, float thr) {
+  const int k = blockIdx.z, oy = blockIdx.y;
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ox >= ow) return;
+  const float* m = low + (long)sel[k] * 65536;
+  const float v = sam_post_value(m, oy, ox, 256.f / (float)img, (float)in_h / (float)oh, (float)in_w / (float)ow, in_h, in_w, nested);
+  out[((long)k * oh + oy) * ow + ox] = v > thr ? 1 : 0;
+}
+
+// Greedy box NMS (torchvision.ops.nms semantics, one category): `order` = candidate indices by decreasing score; keep[i] = 1 if box
+// order[i] survives: a kept box suppresses every later box with IoU > thr, areas (x2 - x1)(y2 - y1).  One workgroup; n <= 8192.
+__global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ boxes, const int32_t* __restrict__ order, int n, float thr, uint8_t* __restrict__ keep) {
+  extern __shared__ uint8_t dead[];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dead[i] = 0;
+  __syncthreads();
+  for (int i = 0; i < n; ++i) {
+    if (!dead[i]) {                                        // uniform: read after the barrier of the previous iteration
+      const float* a = boxes + 4 * order[i];
+      const float ax1 = a[0], ay1 = a[1], ax2 = a[2], ay2 = a[3], aa = (ax2 - ax1) * (ay2 - ay1);
+      for (int j = i + 1 + threadIdx.x; j < n; j += blockDim.x) {
+        if (dead[j]) continue;
+        const float* b = boxes + 4 * order[j];
+        const float iw = fmaxf(fminf(ax2, b[2]) - fmaxf(ax1, b[0]), 0.f), ih = fmaxf(fminf(ay2, b[3]) - fmaxf(ay1, b[1]), 0.f);
+        const float inter = iw * ih;
+        if (inter / (aa + (b[2] - b[0]) * (b[3] - b[1]) - inter) > thr) dead[j] = 1;
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) keep[i] = dead[i] ? 0 : 1;
+}
+
+extern "C" int llmseg_sam_mask_stats(const float* low, const float* iou, float iou_thresh, int32_t* stats, int32_t n_masks, int32_t img_size, int32_t in_h,
+                                     int32_t in_w, int32_t out_h, int32_t out_w, int32_t nested, float mask_threshold, float offset, void* stream) {
+  LL_CHECK(low && stats && n_masks > 0 && img_size > 0 && in_h > 0 && in_w > 0 && in_h <= img_size && in_w <= img_size && out_h > 0 && out_w > 0,
+           "sam_mask_stats: bad arguments");
+  const long n = (long)out_h * out_w;
+  const unsigned bx = (unsigned)std::min<long>((n + 256 * 8 - 1) / (256 * 8), 64);
+  hipLaunchKernelGGL(sam_mask_stats_kernel, dim3(bx, (unsigned)n_masks), dim3(256), 0, (hipStream_t)stream, low, iou, iou_thresh, stats, img_size, in_h, in_w, out_h,
+                     out_w, nested, mask_threshold, offset);
+  LL_LAUNCH_CHECK("sam_mask_stats");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_sam_binarize(const float* low, const int32_t* sel, uint8_t* out, int32_t n_sel, int32_t img_size, int32_t in_h, int32_t in_w, int32_t out_h,
+                                   int32_t out_w, int32_t nested, float mask_threshold, void* stream) {
+  LL_CHECK(low && sel && out && n_sel > 0 && img_size > 0 && in_h > 0 && in_w > 0 && out_h > 0 && out_w > 0, "sam_binarize: bad arguments");
+  hipLaunchKernelGGL(sam_binarize_kernel, dim3((unsigned)((out_w + 255) / 256), (unsigned)out_h, (unsigned)n_sel), dim3(256), 0, (hipStream_t)stream, low, sel, out,
+                     img_size, in_h, in_w, out_h, out_w, nested, mask_threshold);
+  LL_LAUNCH_CHECK("sam_binarize");
+  return LLMSEG_OK;
+}
+
+extern "C" int llmseg_nms(const float* boxes, const int32_t* order, int32_t n, float iou_threshold, uint8_t* keep, void* stream) {
+  LL_CHECK(boxes && order && keep && n > 0 && n <= 8192, "nms: 1 <= n <= 8192 boxes");
+  hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), (size_t)n, (hipStream_t)stream, boxes, order, n, iou_threshold, keep);
+  LL_LAUNCH_CHECK("nms");
   return LLMSEG_OK;
 }
 

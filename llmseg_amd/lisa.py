@@ -24,6 +24,7 @@ import torch.nn.functional as F  # only F.interpolate for the one-time DINOv2 po
 
 from . import ops
 from .params import LisaConfig, ParamTree, fused_groups, init_random_, lisa_shapes
+from .amg import AmgMixin
 from .generate import GenerateMixin
 from .sam_decoder import SamDecoderMixin
 from .trainable import TrainableMixin
@@ -39,7 +40,7 @@ def _pad_rows(t, rows):
     return out
 
 
-class LISAForCausalLM(TrainableMixin, GenerateMixin, SamDecoderMixin, nn.Module):
+class LISAForCausalLM(TrainableMixin, GenerateMixin, SamDecoderMixin, AmgMixin, nn.Module):
     def __init__(self, config: LisaConfig, device="cuda", **kwargs):
         super().__init__()
         # reference kwargs (model/LISA.py:150-161, training.py:140-150)

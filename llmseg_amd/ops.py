@@ -183,6 +183,38 @@ def sam_postprocess(low, input_size, original_size, img_size=1024, nested=True):
     return out
 
 
+def sam_mask_stats(low, iou, iou_thresh, input_size, original_size, img_size=1024, mask_threshold=0.0, offset=1.0, nested=True):
+    """low fp32 [n, 65536], iou fp32 [n] -> int32 [n, 7] = {|m > thr+off|, |m > thr-off|, |m > thr|, min x, min y, max x, max y} of every candidate
+    whose predicted IoU passes (rows of the others keep their initial value)."""
+    n = low.shape[0]
+    assert low.dtype == torch.float32 and low.is_contiguous() and low.shape[1] == 65536 and iou.dtype == torch.float32 and iou.numel() == n
+    st = torch.tensor([0, 0, 0, 2 ** 31 - 1, 2 ** 31 - 1, -1, -1], device=low.device, dtype=torch.int32).repeat(n, 1)
+    _lib.check(_lib.load().llmseg_sam_mask_stats(_ptr(low), _ptr(iou), float(iou_thresh), _ptr(st), n, img_size, int(input_size[0]), int(input_size[1]),
+                                                 int(original_size[0]), int(original_size[1]), 1 if nested else 0, float(mask_threshold), float(offset),
+                                                 _stream()), "sam_mask_stats")
+    return st
+
+
+def sam_binarize(low, sel, input_size, original_size, img_size=1024, mask_threshold=0.0, nested=True):
+    """uint8 [len(sel), H, W] binary masks of the selected candidates (rows `sel` of low)."""
+    k = sel.shape[0]
+    out = torch.empty((k, int(original_size[0]), int(original_size[1])), device=low.device, dtype=torch.uint8)
+    if k:
+        _lib.check(_lib.load().llmseg_sam_binarize(_ptr(low), _ptr(sel.to(torch.int32).contiguous()), _ptr(out), k, img_size, int(input_size[0]), int(input_size[1]),
+                                                   int(original_size[0]), int(original_size[1]), 1 if nested else 0, float(mask_threshold), _stream()), "sam_binarize")
+    return out
+
+
+def nms(boxes, order, iou_threshold):
+    """boxes fp32 [*, 4] XYXY, order int32 [n] (candidate indices by decreasing score) -> uint8 [n] keep flags (torchvision.ops.nms semantics)."""
+    n = order.shape[0]
+    keep = torch.empty((n,), device=boxes.device, dtype=torch.uint8)
+    if n:
+        assert boxes.dtype == torch.float32 and boxes.is_contiguous() and order.dtype == torch.int32 and order.is_contiguous()
+        _lib.check(_lib.load().llmseg_nms(_ptr(boxes), _ptr(order), n, float(iou_threshold), _ptr(keep), _stream()), "nms")
+    return keep
+
+
 def swiglu(gu, inter, out=None):
     rows = gu.shape[0]
     if out is None:

@@ -187,6 +187,9 @@ def sam_decoder_shapes(pfx="model.visual_model.", D=256, mlp=2048):
     (model/segment_anything/modeling/{prompt_encoder,mask_decoder,transformer}.py; sizes from build_sam.py:56-102)."""
     s = {pfx + "prompt_encoder.pe_layer.positional_encoding_gaussian_matrix": (2, D // 2),
          pfx + "prompt_encoder.no_mask_embed.weight": (1, D),
+         pfx + "prompt_encoder.not_a_point_embed.weight": (1, D),
+         pfx + "prompt_encoder.point_embeddings.0.weight": (1, D), pfx + "prompt_encoder.point_embeddings.1.weight": (1, D),
+         pfx + "prompt_encoder.point_embeddings.2.weight": (1, D), pfx + "prompt_encoder.point_embeddings.3.weight": (1, D),
          pfx + "mask_decoder.iou_token.weight": (1, D), pfx + "mask_decoder.mask_tokens.weight": (4, D)}
 
     def attn(p, inner):

@@ -69,6 +69,7 @@ class SamDecoderMixin:
             s[key + ".w"] = w.permute(2, 3, 1, 0).reshape(4 * w.shape[1], w.shape[0]).contiguous()      # rows (dy, dx, co)
             s[key + ".b"] = P[f"{m}output_upscaling.{k}.bias"].repeat(4).contiguous()
         s["out_tokens"] = torch.cat([P[m + "iou_token.weight"], P[m + "mask_tokens.weight"]], 0).contiguous()     # [5, 256]
+        s["G"] = G
         d["samdec"] = s
         return s
 
@@ -93,16 +94,20 @@ class SamDecoderMixin:
         return o, wo, P[p + "out_proj.bias"]
 
     @torch.no_grad()
-    def sam_decode(self, feats_cl, text_embeds):
-        """feats_cl bf16 [4096, 256]: one image's SAM embedding, channels-last rows; text_embeds bf16 [b, 256]: its [SEG] embeddings.
-        -> (low_res fp32 [b, 65536] mask logits in nested row order, iou bf16 [b, 1])."""
+    def sam_decode(self, feats_cl, text_embeds, sparse=None, multimask_output=False):
+        """feats_cl bf16 [4096, 256]: one image's SAM embedding, channels-last rows; text_embeds bf16 [b, 256]: its [SEG] embeddings
+        (or `sparse` bf16 [b, n, 256]: any sparse prompt tokens, e.g. `embed_points`).
+        -> (low_res fp32 [b, 65536] mask logits in nested row order, iou bf16 [b, 1]); with multimask_output (mask tokens 1..3,
+        mask_decoder.py:97-104): low_res [b, 3, 65536], iou [b, 3]."""
         P, S = self.params, self._samdec()
-        b = text_embeds.shape[0]
-        D, NT, NI = 256, 6, 4096
+        if sparse is None:
+            sparse = text_embeds.to(BF16)[:, None, :]
+        b = sparse.shape[0]
+        D, NT, NI = 256, 5 + sparse.shape[1], 4096
         m = PFX + "mask_decoder."
         t = m + "transformer."
         ln = lambda x, name, eps=1e-5: ops.norm(x, P[name + ".weight"], P[name + ".bias"], eps=eps, rms=False)
-        pe_q = torch.cat([S["out_tokens"][None].expand(b, -1, -1), text_embeds.to(BF16)[:, None, :]], 1).reshape(b * NT, D).contiguous()   # point_embedding
+        pe_q = torch.cat([S["out_tokens"][None].expand(b, -1, -1), sparse.to(BF16)], 1).reshape(b * NT, D).contiguous()   # point_embedding
         keys = ops.add_rows(feats_cl.repeat(b, 1) if b > 1 else feats_cl.contiguous(), P[PFX + "prompt_encoder.no_mask_embed.weight"])   # + dense prompt
         queries = pe_q
         for i in range(2):
@@ -137,12 +142,19 @@ class SamDecoderMixin:
             for j in range(3):
                 x = ops.gemm(x, P[f"{pfx}layers.{j}.weight"], bias=P[f"{pfx}layers.{j}.bias"], act=ops.ACT_RELU if j < 2 else ops.ACT_NONE)
             return x
-        hyper = mlp(hs[:, 1].contiguous(), m + "output_hypernetworks_mlps.0.")           # [b, 32]: mask token 0 (multimask_output = False)
-        low = torch.empty((b, NI * 16), device=keys.device, dtype=torch.float32)
-        for bi in range(b):
-            ops.gemm(u[bi], hyper[bi:bi + 1], out=low[bi].view(NI * 16, 1), out_f32=True)
-        iou = mlp(hs[:, 0].contiguous(), m + "iou_prediction_head.")[:, 0:1]
-        return low, iou
+        iou = mlp(hs[:, 0].contiguous(), m + "iou_prediction_head.")
+        if not multimask_output:
+            hyper = mlp(hs[:, 1].contiguous(), m + "output_hypernetworks_mlps.0.")       # [b, 32]: mask token 0
+            low = torch.empty((b, NI * 16), device=keys.device, dtype=torch.float32)
+            for bi in range(b):
+                ops.gemm(u[bi], hyper[bi:bi + 1], out=low[bi].view(NI * 16, 1), out_f32=True)
+            return low, iou[:, 0:1]
+        hyper = torch.stack([mlp(hs[:, 1 + i].contiguous(), f"{m}output_hypernetworks_mlps.{i}.") for i in (1, 2, 3)], 1).contiguous()   # [b, 3, 32]
+        low = torch.empty((b, 3, NI * 16), device=keys.device, dtype=torch.float32)
+        # masks[b] = hyper[b] (3 x 32) . up[b]^T (32 x 65536): one strided-batched launch over the prompts
+        ops.gemm_batched(hyper, u, low, M=3, N=NI * 16, K=D // 8, lda=D // 8, ldw=D // 8, ldc=NI * 16, batch=b, sA=3 * (D // 8), sW=NI * 16 * (D // 8),
+                         sC=3 * NI * 16)
+        return low, iou[:, 1:4].contiguous()
 
     @torch.no_grad()
     def evaluate(self, images_clip, images, input_ids, resize_list, original_size_list, max_new_tokens=32, tokenizer=None,

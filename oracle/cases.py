@@ -110,3 +110,20 @@ def sam_decoder_state(seed=11):
 def sam_decoder_case(b=2):
     """image embedding [1, 256, 64, 64] (what the SAM encoder's neck emits) and b [SEG] text embeddings [b, 256]."""
     return seeded.uniform((1, 256, 64, 64), 51, -1.0, 1.0), seeded.uniform((b, 256), 52, -1.0, 1.0)
+
+
+def amg_thresholds():
+    """Everything-mode thresholds for the SEEDED decoder (random weights give small logits and arbitrary IoU predictions: the
+    reference's defaults 0.88 / 0.95 / offset 1.0 would keep nothing; on `amg_embedding_case` these keep 112 of 192 candidates and 8 records after NMS; the stability filter itself is exercised with 0.08 in the tests)."""
+    return dict(pred_iou_thresh=0.1, stability_score_thresh=0.0, stability_score_offset=0.05, box_nms_thresh=0.7)
+
+
+def amg_embedding_case():
+    """A spatially STRUCTURED image embedding [1, 256, 64, 64] (a few Gaussian bumps with per-channel coefficients over a constant background vector):
+    with i.i.d. noise every seeded mask covers the whole image and box NMS degenerates to one survivor."""
+    ys, xs = torch.meshgrid(torch.arange(64.0), torch.arange(64.0), indexing="ij")
+    cen = [(12, 14, 7.0), (20, 48, 9.0), (44, 20, 8.0), (50, 50, 6.0), (32, 32, 14.0), (8, 56, 5.0)]
+    bumps = torch.stack([torch.exp(-((ys - cy) ** 2 + (xs - cx) ** 2) / (2 * sg * sg)) for cy, cx, sg in cen], 0)       # [6, 64, 64]
+    coef = seeded.uniform((256, len(cen)), 61, -2.0, 2.0)
+    emb = torch.einsum("ck,kyx->cyx", coef, bumps) + seeded.uniform((256, 1, 1), 62, -1.0, 1.0)       # + a constant background vector
+    return emb[None]

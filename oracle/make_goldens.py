@@ -207,6 +207,70 @@ def gold_sam_decoder():
                 "post_sum": post.double().sum(), "input_size": (683, 1024), "original_size": (427, 640)}, os.path.join(OUT, "sam_decoder.pt"))
 
 
+def gold_amg():
+    """SAM everything mode (automatic_mask_generator.py:127-324) from the image embedding on: the imported reference generator (with
+    the image embedding set on its predictor) vs the restatement.  torchvision's batched_nms is absent -> the restated nms is shimmed
+    into the reference for the last step (that step is therefore NOT pinned)."""
+    from oracle import amg as oamg, sam_decoder as sdec
+    import numpy as np
+    cfg = cases.tiny_lisa_cfg()
+    rh.setup(clip_cfg_kwargs=dict(hidden_size=cfg.clip.dim, intermediate_size=cfg.clip.mlp,
+                                  num_hidden_layers=cfg.clip.layers, num_attention_heads=cfg.clip.heads),
+             dino_cfg_kwargs=dict(num_hidden_layers=cfg.dino.layers))
+    import model.segment_anything.automatic_mask_generator as ramg
+    from model.segment_anything.modeling import MaskDecoder, PromptEncoder, TwoWayTransformer
+    from model.segment_anything.modeling.sam import Sam
+    ramg.batched_nms = lambda boxes, scores, idxs, iou_threshold: oamg.nms(boxes, scores, iou_threshold)
+    pe = PromptEncoder(embed_dim=256, image_embedding_size=(64, 64), input_image_size=(1024, 1024), mask_in_chans=16)
+    md = MaskDecoder(num_multimask_outputs=3, transformer=TwoWayTransformer(depth=2, embedding_dim=256, mlp_dim=2048, num_heads=8),
+                     transformer_dim=256, iou_head_depth=3, iou_head_hidden_dim=256)
+    sd = cases.sam_decoder_state()
+    pe.load_state_dict({k[len(sdec.PFX + "prompt_encoder."):]: v for k, v in sd.items() if ".prompt_encoder." in k}, strict=False)
+    md.load_state_dict({k[len(sdec.PFX + "mask_decoder."):]: v for k, v in sd.items() if ".mask_decoder." in k}, strict=True)
+    enc = torch.nn.Module()
+    enc.img_size = 1024
+    sam = Sam(image_encoder=enc, prompt_encoder=pe, mask_decoder=md)
+    # the vendored predictor (predictor.py:233) still calls the prompt encoder without the `text_embeds` argument LISA added to it
+    # (prompt_encoder.py:140-146): the generator cannot run in the reference tree as it stands (the authors used the pip package
+    # offline); pass text_embeds=None, which is what the upstream signature means
+    fwd = pe.forward
+    pe.forward = lambda points, boxes, masks, text_embeds=None: fwd(points, boxes, masks, text_embeds)
+    thr = cases.amg_thresholds()
+    gen = ramg.SamAutomaticMaskGenerator(sam, points_per_side=8, points_per_batch=16, pred_iou_thresh=thr["pred_iou_thresh"],
+                                         stability_score_thresh=thr["stability_score_thresh"], stability_score_offset=thr["stability_score_offset"],
+                                         box_nms_thresh=thr["box_nms_thresh"])
+    emb = cases.amg_embedding_case()
+    orig, inp = (427, 640), (683, 1024)
+    pr = gen.predictor
+    pr.features, pr.original_size, pr.input_size, pr.is_image_set = emb, orig, inp, True
+    grid = gen.point_grids[0] * np.array([[orig[1], orig[0]]])
+    assert np.array_equal(gen.point_grids[0], oamg.build_point_grid(8))
+    with torch.no_grad():
+        gen.stability_score_thresh = 0.08                         # first batch: with an active stability filter
+        rb = gen._process_batch(grid[:16], orig, [0, 0, orig[1], orig[0]], orig)
+        gen.stability_score_thresh = thr["stability_score_thresh"]
+        mb = oamg.process_batch(sd, emb, grid[:16], inp, orig, thr["pred_iou_thresh"], 0.08, thr["stability_score_offset"])
+    assert len(rb["rles"]) == mb["masks"].shape[0] and len(rb["rles"]) > 4, (len(rb["rles"]), mb["masks"].shape)
+    assert rb["rles"] == oamg.mask_to_rle(mb["masks"])
+    assert torch.equal(rb["boxes"].long(), mb["boxes"].long())
+    _check("amg.iou_preds", rb["iou_preds"], mb["iou_preds"], 1e-5)
+    _check("amg.stability", rb["stability_score"], mb["stability_score"], 1e-6)
+    assert torch.equal(rb["points"], mb["points"])
+    # whole pipeline (NMS step shimmed, see the docstring)
+    with torch.no_grad():
+        data = ramg.MaskData()
+        for i in range(0, len(grid), 16):
+            data.cat(gen._process_batch(grid[i:i + 16], orig, [0, 0, orig[1], orig[0]], orig))
+        keep = oamg.nms(data["boxes"].float(), data["iou_preds"], thr["box_nms_thresh"])
+        data.filter(keep)
+        mine = oamg.generate(sd, emb, inp, orig, points_per_side=8, points_per_batch=16, **thr)
+    assert data["rles"] == mine["rles"] and len(mine["rles"]) >= 3
+    print("   kept", mb["masks"].shape[0], "of 48 in the first batch;", len(mine["rles"]), "records after NMS of", sum(1 for _ in data["rles"]))
+    torch.save({"n_first_batch": mb["masks"].shape[0], "boxes": mine["boxes"], "iou_preds": mine["iou_preds"], "stability_score": mine["stability_score"],
+                "points": mine["points"], "rle_counts": [r["counts"] for r in mine["rles"]], "areas": mine["masks"].flatten(1).sum(1),
+                "original_size": orig, "input_size": inp}, os.path.join(OUT, "amg.pt"))
+
+
 def gold_lisa_tiny():
     cfg = cases.tiny_lisa_cfg()
     rh.setup(clip_cfg_kwargs=dict(hidden_size=cfg.clip.dim, intermediate_size=cfg.clip.mlp,
@@ -268,7 +332,7 @@ def main():
     rh.setup(clip_cfg_kwargs=dict(hidden_size=cfg.clip.dim, intermediate_size=cfg.clip.mlp,
                                   num_hidden_layers=cfg.clip.layers, num_attention_heads=cfg.clip.heads),
              dino_cfg_kwargs=dict(num_hidden_layers=cfg.dino.layers))
-    for f in (gold_losses, gold_iou_metric, gold_sam_small, gold_head, gold_lisa_tiny, gold_generate, gold_sam_decoder):
+    for f in (gold_losses, gold_iou_metric, gold_sam_small, gold_head, gold_lisa_tiny, gold_generate, gold_sam_decoder, gold_amg):
         print(f.__name__)
         f()
     print("wrote", sorted(os.listdir(OUT)))

@@ -22,6 +22,9 @@ PFX = "model.visual_model."
 def decoder_shapes(pfx=PFX, D=256, mlp=2048):
     s = {pfx + "prompt_encoder.pe_layer.positional_encoding_gaussian_matrix": (2, D // 2),
          pfx + "prompt_encoder.no_mask_embed.weight": (1, D),
+         pfx + "prompt_encoder.not_a_point_embed.weight": (1, D),
+         pfx + "prompt_encoder.point_embeddings.0.weight": (1, D), pfx + "prompt_encoder.point_embeddings.1.weight": (1, D),
+         pfx + "prompt_encoder.point_embeddings.2.weight": (1, D), pfx + "prompt_encoder.point_embeddings.3.weight": (1, D),
          pfx + "mask_decoder.iou_token.weight": (1, D), pfx + "mask_decoder.mask_tokens.weight": (4, D)}
 
     def attn(p, inner):
@@ -109,12 +112,31 @@ def _mlp(sd, p, x, n=3):
     return x
 
 
-def decode_masks(sd, image_embedding, text_embeds, pfx=PFX):
+def embed_points(sd, points, labels, pfx=PFX, input_image_size=(1024, 1024)):
+    """prompt_encoder.py:77-97 with pad = True (no boxes): points [b, n, 2] (x, y) in the 1024-frame, labels [b, n] -> [b, n + 1, 256]."""
+    G = sd[pfx + "prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"].float()
+    pts = torch.cat([points.float() + 0.5, torch.zeros((points.shape[0], 1, 2))], 1)
+    lab = torch.cat([labels.float(), -torch.ones((labels.shape[0], 1))], 1)
+    c = pts.clone()
+    c[:, :, 0] = c[:, :, 0] / input_image_size[1]
+    c[:, :, 1] = c[:, :, 1] / input_image_size[0]
+    c = 2 * math.pi * ((2 * c - 1) @ G)
+    e = torch.cat([c.sin(), c.cos()], -1)
+    e[lab == -1] = 0.0
+    e[lab == -1] += sd[pfx + "prompt_encoder.not_a_point_embed.weight"]
+    e[lab == 0] += sd[pfx + "prompt_encoder.point_embeddings.0.weight"]
+    e[lab == 1] += sd[pfx + "prompt_encoder.point_embeddings.1.weight"]
+    return e
+
+
+def decode_masks(sd, image_embedding, text_embeds, pfx=PFX, sparse=None, multimask_output=False):
     """LISA.py:531-547 for ONE image: image_embedding [1, 256, 64, 64], text_embeds [b, 256] (the [SEG] embeddings of that image).
-    -> (low_res_masks [b, 1, 256, 256], iou_predictions [b, 1]) with multimask_output = False."""
-    b = text_embeds.shape[0]
+    -> (low_res_masks [b, 1, 256, 256], iou_predictions [b, 1]) with multimask_output = False.
+    sparse [b, n, 256] (e.g. `embed_points`) replaces the text prompt; multimask_output = True -> mask tokens 1..3 (mask_decoder.py:97-104)."""
     m = pfx + "mask_decoder."
-    sparse = text_embeds[:, None, :]
+    if sparse is None:
+        sparse = text_embeds[:, None, :]
+    b = sparse.shape[0]
     dense = sd[pfx + "prompt_encoder.no_mask_embed.weight"].reshape(1, -1, 1, 1).expand(b, -1, 64, 64)
     pe = dense_pe(sd, pfx)[None].to(image_embedding.dtype)
     out_tokens = torch.cat([sd[m + "iou_token.weight"], sd[m + "mask_tokens.weight"]], 0)[None].expand(b, -1, -1)
@@ -132,7 +154,8 @@ def decode_masks(sd, image_embedding, text_embeds, pfx=PFX):
     hyper = torch.stack([_mlp(sd, f"{m}output_hypernetworks_mlps.{i}.", hs[:, 1 + i, :]) for i in range(4)], 1)
     masks = (hyper @ u.reshape(b, 32, 256 * 256)).reshape(b, 4, 256, 256)
     iou = _mlp(sd, m + "iou_prediction_head.", hs[:, 0, :])
-    return masks[:, 0:1], iou[:, 0:1]
+    sl = slice(1, None) if multimask_output else slice(0, 1)
+    return masks[:, sl], iou[:, sl]
 
 
 def postprocess_masks(masks, input_size, original_size, img_size=1024):

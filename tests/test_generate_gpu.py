@@ -22,3 +22,8 @@ def test_sam_mask_decoder_and_postprocess_match_oracle():
 def test_evaluate_end_to_end_matches_oracle():
     from tests import sam_decoder_checks as sc
     _assert(sc.check_evaluate())
+
+
+def test_everything_mode_proposals_match_oracle():
+    from tests import amg_checks as ac
+    _assert(ac.check_amg())
