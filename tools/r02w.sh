@@ -1,3 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_generate_gpu.py -q -x > gpurun_out/r02w.txt 2>&1; tail -25 gpurun_out/r02w.txt | cut -c1-600
+timeout 900 python tools/amg_bench.py 64 > gpurun_out/r02w.txt 2>&1; timeout 900 python tools/amg_bench.py 256 >> gpurun_out/r02w.txt 2>&1; timeout 900 python tools/amg_bench.py 1024 >> gpurun_out/r02w.txt 2>&1
+grep -v amdgpu gpurun_out/r02w.txt | tail -14 | cut -c1-300
