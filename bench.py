@@ -69,11 +69,14 @@ def _sync(dev):
         torch.cuda.synchronize()
 
 
-def timed(step, steps, warmup, dist, dev):
-    """W untimed + exactly K timed calls of step(), bracketed by barrier + synchronize; max over ranks.  -> (seconds, last output)"""
+def timed(step, steps, warmup, dist, dev, after_warmup=None):
+    """W untimed + exactly K timed calls of step(), bracketed by barrier + synchronize; max over ranks.  -> (seconds, last output)
+    after_warmup: untimed hook between the warm-up and the first barrier (first execution of code the warm-up steps do not reach)."""
     out = None
     for _ in range(warmup):
         out = step()
+    if after_warmup is not None:
+        after_warmup()
     _sync(dev)
     if dist:
         dist.barrier()
@@ -106,7 +109,13 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
         trainer = trainer_cls(model, lr=3e-4, grad_accum=args.accum, device_ids=[local], use_graph=use_graph, ddp_wrapper=args.ddp_wrapper,
                               force_ddp=args.force_ddp)
         # warm-up covers the eager warm-up calls of the graph path + the capture itself
-        dt, out = timed(lambda: trainer.micro_step(batch, plan), args.steps, args.warmup + (3 if use_graph else 0), dist, dev)
+        def first_optimizer_step():
+            # the warm-up micro-steps never reach the optimizer (one step per --accum micro-steps): run it once untimed -- on a cold box its
+            # first execution (kernel code pages, lazy AdamW state) cost 50 ms, 10 % of a 10-step timed region -- and restart the
+            # accumulation window so that the timed region contains exactly steps / accum optimizer steps
+            trainer.optimizer_step()
+            trainer.micro = 0
+        dt, out = timed(lambda: trainer.micro_step(batch, plan), args.steps, args.warmup + (3 if use_graph else 0), dist, dev, first_optimizer_step)
         loss = float(out["loss"].detach())
         assert loss == loss, "NaN loss"
         res.update(value=B * world * args.steps / dt, ms_per_step=dt / args.steps * 1e3, loss=loss,
@@ -169,6 +178,48 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
     return res
 
 
+def neighbours(model, cfg, dev, prompt_len):
+    """Side measurements of the rows next to the path, same model, outside the timed region: N3 = `evaluate()`'s generation
+    (KV-cache decode, ms per token vs the 13.2 GB weight stream), N1 = SAM everything mode from the image embedding (32 x 32 point grid).
+    Never fatal for the benchmark line."""
+    import time
+    out = {}
+    try:
+        model.eval()
+        g = torch.Generator().manual_seed(7)
+        ids = torch.randint(3, 31999, (1, prompt_len), generator=g)
+        ids[:, 0], ids[:, 1], ids[:, 2], ids[:, 3] = 1, 32001, -200, 32002
+        clip = torch.randn(1, 3, 224, 224, generator=g).to(dev, torch.bfloat16)
+        c = cfg.llama
+        wbytes = 2.0 * (c.layers * (4 * c.hidden * c.hidden + 3 * c.hidden * c.inter) + c.vocab * c.hidden)
+
+        def run(n):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            model.generate(clip, ids, max_new_tokens=n, eos_token_id=None)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        run(3)                                                   # warm-up + graph capture
+        t_a, t_b = min(run(2), run(2)), min(run(18), run(18))
+        per = (t_b - t_a) / 16
+        out["generation"] = {"ms_per_token": per * 1e3, "tokens_per_s": 1.0 / per, "prefill_plus_first_token_ms": t_a * 1e3 - per * 1e3, "sequences": 1,
+                              "weight_stream_gb_per_token": wbytes / 1e9, "hbm_tb_per_s": wbytes / per / 1e12, "frac_of_8tbps": wbytes / per / 8e12,
+                              "what": "LISAForCausalLM.generate (evaluate()'s greedy decode, KV cache, LoRA r=8): (18-token run - 2-token run) / 16"}
+        img = torch.randn(1, 3, 1024, 1024, generator=g).to(dev, torch.bfloat16)
+        feats = model._sam_encoder_cl(img)
+        kw = dict(points_per_side=32, pred_iou_thresh=-1e9, stability_score_thresh=0.0, stability_score_offset=0.02)
+        model.generate_proposals(feats, (1024, 1024), (1024, 1024), **kw)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        rec = model.generate_proposals(feats, (1024, 1024), (1024, 1024), **kw)
+        torch.cuda.synchronize()
+        out["everything_mode"] = {"ms_per_image": (time.perf_counter() - t0) * 1e3, "points": 1024, "candidates": 3072, "records": int(rec["masks"].shape[0]),
+                                   "what": "generate_proposals from the image embedding, 1024x1024 original: 1024 point prompts through the multimask "
+                                           "decoder, statistics pass over all 3072 candidates (filters opened), NMS, binarisation of the survivors; random "
+                                           "decoder weights, so the survivor count is not representative (profiles/r02_amg.md: 75-83 ms with ~1000 records)"}
+    except Exception as e:      # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"[:300]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,6 +244,7 @@ def main():
     ap.add_argument("--force-ddp", "--force-dist", dest="force_ddp", action="store_true",
                     help="initialise the RCCL process group even at world size 1 (the gradient all-reduce / the DDP wrapper then run on one GPU)")
     ap.add_argument("--lora-dropout", type=float, default=0.05, help="peft lora_dropout (reference training.py:91)")
+    ap.add_argument("--no-neighbours", action="store_true", help="skip the generation / everything-mode side measurements (SURVEY.md 8f N3, N1)")
     ap.add_argument("--accum", type=int, default=10, help="gradient-accumulation micro-steps per optimizer step (reference: 10)")
     args = ap.parse_args()
 
@@ -215,7 +267,7 @@ def main():
     from llmseg_amd.params import LisaConfig, LlamaConfig, SamConfig, VitConfig
     from llmseg_amd.train import Trainer
 
-    cfg = LisaConfig(backbone=args.backbone, build_unused_towers=False)
+    cfg = LisaConfig(backbone=args.backbone, build_unused_towers=False, sam_decoder=(args.backbone == "sam"))
     train = args.mode == "train"
     if train:
         cfg.llama = LlamaConfig(lora_r=8, lora_dropout=args.lora_dropout)
@@ -265,6 +317,8 @@ def main():
             res["fwd_only"] = main_res["fwd_only"]
         if extra is not None:
             res[f"batch_{args.extra_batch}"] = extra
+        if world == 1 and not args.no_neighbours and not args.small and args.backbone == "sam":
+            res["neighbours"] = neighbours(model, cfg, dev, args.prompt_len)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
     else:
