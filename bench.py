@@ -278,6 +278,8 @@ def main():
     model = LISAForCausalLM(cfg, device=dev).init_random(seed=0)
     model.prepare()
     model.overlap_towers = not args.no_overlap
+    if os.environ.get("LLMSEG_CE_FULL"):
+        model.ce_gather_first = False
     if train:
         model.set_trainable()
     use_graph = train and not args.no_graph and not args.ddp_wrapper

@@ -22,6 +22,7 @@ BF16 = torch.bfloat16
 
 
 BIG_LINEAR = 1 << 34          # M*N*K above which LinearFn.backward transposes/pads its operands for the LDS-DMA GEMM kernels
+BIG_WEIGHT = 1 << 26          # N * K of a Linear whose dX / dW always take the transposed-operand route below (lm_head: 131 M)
 
 
 def g32_of(t):
@@ -64,7 +65,8 @@ class LinearFn(Function):
         dx = dw = db = None
         gw = ctx.gw
         need_w = gw is not None or ctx.needs_input_grad[1]
-        if M * N * Kin >= BIG_LINEAR and Kin % 8 == 0 and (need_w or ctx.wt is None or N % 8 != 0):
+        big = M * N * Kin >= BIG_LINEAR or (N * Kin >= BIG_WEIGHT and M >= 16)      # the weight itself is big: also with few rows (lm_head on the label rows only)
+        if big and Kin % 8 == 0 and (need_w or ctx.wt is None or N % 8 != 0):
             # wide trainable Linear (lm_head, [32004, 4096]): pad the contraction dims to multiples of 64 and transpose the
             # operands once, so that both gradient GEMMs run on the K-contiguous LDS-DMA kernels instead of the
             # transposed-operand register-staged one (3-4x slower at this size)

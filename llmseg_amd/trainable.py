@@ -220,6 +220,15 @@ class TrainableMixin:
             src = torch.where(ar < pos[:, None], ar, (ar - Pn + 1).clamp(min=0))
             new_labels = torch.gather(lab, 1, src.clamp(max=L - 1))
             new_labels = torch.where((ar >= pos[:, None]) & (ar < pos[:, None] + Pn), torch.full_like(new_labels, IGNORE_INDEX), new_labels)
+        # CE rows: only hidden rows whose NEXT token carries a label reach the loss (shifted CE, llava_llama.py:108-118), so lm_head and the
+        # CE run on those rows only -- same loss, same gradients (the other rows' dlogits are zero), ~10 x fewer lm_head rows in training
+        ce_rows = ce_labels = None
+        if new_labels is not None:
+            valid = new_labels[:, 1:] != IGNORE_INDEX                                    # [N, T-1]: row t predicts label t + 1
+            flat = (torch.arange(N)[:, None] * T + torch.arange(T - 1)[None, :])[valid]
+            if flat.numel() > 0:
+                ce_rows = torch.cat([flat, flat[:1]])                                    # + one trailing row: the shifted CE never uses the last position as a predictor
+                ce_labels = torch.cat([torch.tensor([IGNORE_INDEX]), new_labels[:, 1:][valid]])[None, :]     # [1, R + 1]
         tok = ag.embed_token_index(ids, Pn)
         # [SEG] rows: mask shifted by one and by the P-1 extra image tokens (LISA.py:254-266)
         segm = torch.zeros((N, T), dtype=torch.bool)
@@ -230,7 +239,7 @@ class TrainableMixin:
         rounds = [seg_off[b + 1] - seg_off[b] for b in range(B)]
         plan = BatchPlan()
         segs_shapes = tuple(tuple(s.shape) for s in sam_segs_list) if sam_segs_list is not None else None
-        plan.sig = (N, L, T, B, tuple(off), tuple(seg_off), bool(inference), labels is not None, segs_shapes)
+        plan.sig = (N, L, T, B, tuple(off), tuple(seg_off), bool(inference), labels is not None, segs_shapes, None if ce_rows is None else int(ce_rows.numel()))
         plan.N, plan.L, plan.T, plan.B, plan.off, plan.seg_off, plan.rounds = N, L, T, B, off, seg_off, rounds
         # groups of images with the same proposal count (the head runs once per group), and the loss weights 1 / (R + 1e-8) of
         # every (image, round) item in group order (LISA.py:452-455)
@@ -243,7 +252,8 @@ class TrainableMixin:
             for K, members in plan.groups.items():
                 loss_w[K] = torch.tensor([1.0 / (rounds[b] + 1e-8) for b in members for _ in range(rounds[b])], dtype=torch.float32)
         plan.tensors = dict(key_mask=key_mask.contiguous().to(dev), clip_index=clip_index.to(dev), tok_index=tok.reshape(-1).to(dev),
-                            seg_idx=seg_idx.to(dev), new_labels=None if new_labels is None else new_labels.contiguous().to(dev))
+                            seg_idx=seg_idx.to(dev), new_labels=None if new_labels is None else new_labels.contiguous().to(dev),
+                            ce_rows=None if ce_rows is None else ce_rows.to(dev), ce_labels=None if ce_labels is None else ce_labels.contiguous().to(dev))
         for K, w in loss_w.items():
             plan.tensors[f"loss_w{K}"] = w.to(dev)
         return plan
@@ -296,9 +306,13 @@ class TrainableMixin:
         embeds = F.embed_splice(input_ids.contiguous(), self._w("model.embed_tokens.weight", F), proj[1:], Pn, (Pn + 1) * H, plan.tok_index)
         hidden = self._llama(embeds, plan.key_mask, F)
         logits, loss = None, None
-        if want_logits or plan.new_labels is not None:
+        gathered = plan.new_labels is not None and not want_logits and plan.ce_rows is not None and self.ce_gather_first
+        if want_logits or (plan.new_labels is not None and not gathered):
             logits = F.linear(hidden.view(N * T, H), self._w("lm_head.weight", F)).view(N, T, -1)
-        if plan.new_labels is not None:
+        if gathered:                                                       # lm_head + CE on the label-carrying rows only (see make_plan)
+            rows = F.gather_rows(hidden.view(N * T, H), plan.ce_rows)
+            loss = F.ce(F.linear(rows, self._w("lm_head.weight", F)).view(1, rows.shape[0], -1), plan.ce_labels)
+        elif plan.new_labels is not None:
             loss = F.ce(logits, plan.new_labels)
         return loss, logits, hidden
 
@@ -345,6 +359,7 @@ class TrainableMixin:
         return iou.view(Cn * K), emb
 
     # ------------------------------------------------------------------------------------------------ model_forward
+    ce_gather_first = True         # lm_head + CE on the label-carrying rows only (class default; False = all N*T rows, as the reference computes them)
     overlap_towers = True          # issue the frozen segmentation backbone on its own HIP stream (class default; set False to serialise)
 
     def _tower_stream(self):
@@ -408,7 +423,7 @@ class TrainableMixin:
         else:
             feat, rows_per_img, row0, g = self.visual_features_cl(images, F)
         clip_in = images_clip.index_select(0, plan.clip_index)                          # one CLIP image per sequence (LISA.py:271-303)
-        ce, logits, hidden = self.llava_forward(clip_in.contiguous(), input_ids, plan, want_logits=return_aux or not inference)
+        ce, logits, hidden = self.llava_forward(clip_in.contiguous(), input_ids, plan, want_logits=return_aux or (not inference and plan.new_labels is None))
         if side is not None:
             cur.wait_stream(side)
             feat.record_stream(cur)

@@ -217,10 +217,12 @@ def check_head_golden(golden_loader):
         with torch.no_grad():
             ref_iou, ref_emb = ohead.mask_head(head_sd, "model.", pooled.to(BF).float(), text.to(BF).float())     # same bf16-rounded weights / inputs
             iou, emb = m._mask_head(pooled.to(BF).to(DEV), text.to(BF).to(DEV), _Direct)
+            lo_iou, _ = ohead.mask_head({k: v.to(BF) for k, v in head_sd.items()}, "model.", pooled.to(BF), text.to(BF))     # the reference's own bf16 arithmetic
+        e_cpu = (lo_iou.float() - ref_iou).abs().max().item()
         C = text.shape[0]
         iou = iou.view(C, K, 1).float().cpu()
         emb = emb.view(C, K, -1).float().cpu()
-        res.append((f"head K={K} pred_iou vs oracle (rounded weights)", (iou - ref_iou).abs().max().item(), 4e-3))
+        res.append((f"head K={K} pred_iou vs oracle (rounded weights; bf16-CPU err {e_cpu:.2e})", (iou - ref_iou).abs().max().item(), max(4e-3, 1.5 * e_cpu)))
         res.append((f"head K={K} embedding vs oracle (rounded weights)", (emb - ref_emb).abs().max().item(), 2e-2 * max(1.0, ref_emb.abs().max().item())))
         # against the reference fixture itself (fp32, un-rounded weights): adds the bf16 rounding of the weights
         res.append((f"head K={K} pred_iou vs reference fixture", (iou - g[key_iou]).abs().max().item(), 8e-3))
