@@ -274,6 +274,10 @@ int llmseg_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ld, v
 /* LayerNorm / RMSNorm backward (contiguous rows): dx bf16; dw/db fp32 accumulated (NULL = frozen weight) */
 int llmseg_norm_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw, float* db, int64_t rows, int64_t cols,
                     float eps, int rms, void* stream);
+/* same, dx = norm backward + dres (bf16 [rows][cols] or NULL): x of a pre-norm block also feeds the residual connection, and the
+ * gradient arriving that way is added here instead of in a separate pass (HF LlamaDecoderLayer: hidden = residual + sublayer(norm(hidden))) */
+int llmseg_norm_bwd_add(const void* dy, const void* x, const void* w, const void* dres, void* dx, float* dw, float* db, int64_t rows, int64_t cols,
+                        float eps, int rms, void* stream);
 /* SwiGLU backward: gu [rows][2I] (gate|up), dout [rows][I] -> dgu [rows][2I] */
 int llmseg_swiglu_bwd(const void* gu, const void* dout, void* dgu, int64_t rows, int64_t I, void* stream);
 /* out = dy * f'(y) computed from the OUTPUT y of a fused GEMM epilogue (act = RELU or SIGMOID) */

@@ -89,6 +89,7 @@ SIGNATURES = {
     "llmseg_resize_aa": [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p],
     "llmseg_colsum": [_p, _p, _i64, _i64, _i64, _p],
     "llmseg_norm_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _f32, C.c_int, _p],
+    "llmseg_norm_bwd_add": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f32, C.c_int, _p],
     "llmseg_swiglu_bwd": [_p, _p, _p, _i64, _i64, _p],
     "llmseg_act_bwd": [_p, _p, _p, _i64, C.c_int, _p],
     "llmseg_softmax_rows": [_p, _p, _i64, _i32, _i32, _i32, _f32, _i32, _p, _i32, _p],

@@ -223,6 +223,39 @@ def norm(x, w, b=None, eps=1e-5, rms=False):
     return NormFn.apply(x, w, b, eps, rms)
 
 
+class NormPassFn(Function):
+    """(norm(x), x): the pre-norm block's input with its pass-through to the residual connection as ONE node, so that the two gradients
+    of x (through the norm, through the residual) are summed inside the norm-backward kernel instead of by an autograd add pass
+    (64 of them per Llama micro-step)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, rms):
+        x = x.contiguous()
+        ctx.eps, ctx.rms, ctx.has_b = eps, rms, b is not None
+        ctx.gw, ctx.gb = g32_of(w), (g32_of(b) if b is not None else None)
+        ctx.save_for_backward(x, w)
+        ctx.set_materialize_grads(False)
+        return ops.norm(x, w, b, eps=eps, rms=rms), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dpass):
+        x, w = ctx.saved_tensors
+        if dy is None:
+            return dpass, None, None, None, None
+        dres = None if dpass is None else dpass.contiguous()
+        if ctx.gw is not None:
+            return ops.norm_bwd(dy.contiguous(), x, w, ctx.eps, ctx.rms, ctx.gw, ctx.gb, dres=dres), None, None, None, None
+        need_w = ctx.needs_input_grad[1]
+        dw = torch.zeros(w.shape, device=w.device, dtype=torch.float32) if need_w else None
+        db = torch.zeros(w.shape, device=w.device, dtype=torch.float32) if (need_w and ctx.has_b) else None
+        dx = ops.norm_bwd(dy.contiguous(), x, w, ctx.eps, ctx.rms, dw, db, dres=dres)
+        return dx, (dw.to(BF16) if need_w else None), (db.to(BF16) if db is not None else None), None, None
+
+
+def norm_pass(x, w, b=None, eps=1e-5, rms=False):
+    return NormPassFn.apply(x, w, b, eps, rms)
+
+
 def attention_backward(q, k, v, do, dq, dk, dv, *, batch, heads, Nq, Nk, hd, qs, ks, vs, dos, dqs, dks, dvs, scale, causal=False,
                        key_mask=None):
     """Materialised attention backward.  q/k/v/do and the outputs dq/dk/dv are tensors whose data_ptr is the (b=0,h=0,row=0)

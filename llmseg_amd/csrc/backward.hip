@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 template <int CPL, bool ACC>
 __global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                          bf16_t* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, long rows, int cols,
-                                                         float eps, int rms) {
+                                                         float eps, int rms, const bf16_t* __restrict__ dres) {
   const int lane = threadIdx.x & 63;
   const int nch = cols >> 3;
   constexpr int NR = CPL > 0 ? CPL : 1;
@@ -108,6 +108,11 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16_t* __restri
           if (dw) atomicAdd(&dw[c * 8 + e], g[e] * xh);
           if (db) atomicAdd(&db[c * 8 + e], g[e]);
         }
+      }
+      if (dres) {                                            // + the gradient that reaches x through the residual connection
+        float rr[8];
+        unpack8(*reinterpret_cast<const uint4*>(dres + row * cols + c * 8), rr);
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) o[e] += rr[e];
       }
       *reinterpret_cast<uint4*>(dx + row * cols + c * 8) = pack8(o);
     })
@@ -288,14 +293,19 @@ extern "C" int llmseg_colsum(const void* x, float* out, int64_t M, int64_t N, in
 
 extern "C" int llmseg_norm_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw, float* db, int64_t rows, int64_t cols, float eps,
                                int rms, void* stream) {
-  LL_CHECK(dy && x && w && dx && rows > 0 && cols > 0 && (cols & 7) == 0 && AL16(dy) && AL16(x) && AL16(w) && AL16(dx), "norm_bwd: bad arguments");
+  return llmseg_norm_bwd_add(dy, x, w, nullptr, dx, dw, db, rows, cols, eps, rms, stream);
+}
+
+extern "C" int llmseg_norm_bwd_add(const void* dy, const void* x, const void* w, const void* dres, void* dx, float* dw, float* db, int64_t rows, int64_t cols,
+                                   float eps, int rms, void* stream) {
+  LL_CHECK(dy && x && w && dx && rows > 0 && cols > 0 && (cols & 7) == 0 && AL16(dy) && AL16(x) && AL16(w) && AL16(dx) && AL16(dres), "norm_bwd: bad arguments");
   const int cpl = (int)(((cols >> 3) + 63) / 64);
   const bool acc = (dw || db) && cpl <= 2;
   const long wgs = (rows + 3) / 4;
   const dim3 grid((unsigned)(acc ? std::min<long>(std::max<long>(1, (rows + 31) / 32), 256) : wgs));     // ACC: every wave walks >= 8 rows
 #define LL_NORMB(C, A)                                                                                                                       \
   hipLaunchKernelGGL((norm_bwd_kernel<C, A>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, \
-                     (bf16_t*)dx, dw, db, (long)rows, (int)cols, eps, rms)
+                     (bf16_t*)dx, dw, db, (long)rows, (int)cols, eps, rms, (const bf16_t*)dres)
   if (acc) { if (cpl <= 1) LL_NORMB(1, true); else LL_NORMB(2, true); }
   else if (cpl <= 1) LL_NORMB(1, false); else if (cpl <= 2) LL_NORMB(2, false); else if (cpl <= 4) LL_NORMB(4, false);
   else if (cpl <= 8) LL_NORMB(8, false); else LL_NORMB(0, false);

@@ -385,12 +385,13 @@ def colsum(x, out=None):
     return out
 
 
-def norm_bwd(dy, x, w, eps, rms, dw=None, db=None):
+def norm_bwd(dy, x, w, eps, rms, dw=None, db=None, dres=None):
+    """dres: gradient reaching x through a residual connection, added to dx in the same pass."""
     rows, cols = x.shape
-    assert dy.is_contiguous() and x.is_contiguous()
+    assert dy.is_contiguous() and x.is_contiguous() and (dres is None or (dres.is_contiguous() and dres.shape == x.shape))
     dx = torch.empty_like(x)
-    _lib.check(_lib.load().llmseg_norm_bwd(_ptr(dy), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), rows, cols, eps, 1 if rms else 0,
-                                           _stream()), "norm_bwd")
+    _lib.check(_lib.load().llmseg_norm_bwd_add(_ptr(dy), _ptr(x), _ptr(w), _ptr(dres), _ptr(dx), _ptr(dw), _ptr(db), rows, cols, eps, 1 if rms else 0,
+                                               _stream()), "norm_bwd")
     return dx
 
 

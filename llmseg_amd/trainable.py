@@ -25,6 +25,7 @@ class _Direct:
     grad = False
     linear = staticmethod(lambda x, w, b=None, act=ops.ACT_NONE, residual=None, wt=None: ops.gemm(x, w, bias=b, act=act, residual=residual))
     norm = staticmethod(lambda x, w, b=None, eps=1e-5, rms=False: ops.norm(x, w, b, eps=eps, rms=rms))
+    norm_pass = staticmethod(lambda x, w, b=None, eps=1e-5, rms=False: (ops.norm(x, w, b, eps=eps, rms=rms), x))
     attn_packed = staticmethod(lambda qkv, batch, n, heads, hd, causal=False, key_mask=None:
                                ops.attention_packed(qkv, batch, n, heads, hd, causal=causal, key_mask=key_mask))
     swiglu = staticmethod(lambda gu, inter: ops.swiglu(gu, inter))
@@ -76,6 +77,7 @@ class _Auto:
     grad = True
     linear = staticmethod(ag.linear)
     norm = staticmethod(ag.norm)
+    norm_pass = staticmethod(ag.norm_pass)
     attn_packed = staticmethod(lambda qkv, batch, n, heads, hd, causal=False, key_mask=None:
                                ag.PackedAttnFn.apply(qkv, batch, n, heads, hd, causal, key_mask, None))
     rope_attn = staticmethod(ag.rope_attention)
@@ -273,7 +275,7 @@ class TrainableMixin:
         rng = self.dropout_state() if p_drop > 0 else None
         for i in range(c.layers):
             p = f"model.layers.{i}."
-            h = F.norm(x, self._w(p + "input_layernorm.weight", F), None, c.eps, True)
+            h, x = F.norm_pass(x, self._w(p + "input_layernorm.weight", F), None, c.eps, True)      # x: the residual branch of the same node
             if c.lora_r > 0:
                 lp = p + "self_attn."
                 qkv = F.lora_qkv(h, self._w(p + "qkv", F), self._w(lp + "q_proj.lora_A.default.weight", F),
@@ -287,7 +289,7 @@ class TrainableMixin:
             if kv_out is not None:                     # generation prefill (no-grad path): qkv now holds the rotated K and V
                 kv_out(i, qkv)
             x = F.linear(a, self._w(p + "self_attn.o_proj.weight", F), None, ops.ACT_NONE, x, self._wT(p + "self_attn.o_proj.weight", F))
-            h = F.norm(x, self._w(p + "post_attention_layernorm.weight", F), None, c.eps, True)
+            h, x = F.norm_pass(x, self._w(p + "post_attention_layernorm.weight", F), None, c.eps, True)
             mem = [p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"]
             gu = F.linear(h, self._wcat(p + "gate_up", mem, F), None, ops.ACT_NONE, None, self._wT(p + "gate_up", F) if self._frozen(mem) else None)
             x = F.linear(F.swiglu(gu, c.inter), self._w(p + "mlp.down_proj.weight", F), None, ops.ACT_NONE, x, self._wT(p + "mlp.down_proj.weight", F))
