@@ -302,7 +302,9 @@ int llmseg_scatter_add_rows(const void* src, const int64_t* idx, float* dst, int
  *   lora_outer: out_b(n,r) += alpha * sum_m drop_b(a_b)[m][n] b_b[m][r]  (fp32 [N][8], or [8][N] when out_rn; accumulates)   dB, dA
  *   lora_apply: y[M][N] += alpha * sum_b mask_b * (xa[M][8b..8b+7] . W_b^T)  (W stored [N][8], or [8][N] when w_rn)   bwd dx of the LoRA branches
  *   lora_pack:  the two [*][64] extension operands of llmseg_gemm_args (A2 / W2) for a LoRA'd q|k|v projection, from the current
- *               LoRA matrices: w2b [3H][64] = rows [s Bq | 0], 0, [0 | s Bv | 0];  w2a [H][64] = rows [Aq[:,h] | Av[:,h] | 0]
+ *               LoRA matrices: w2b [3H][64] = rows [s Bq | 0], 0, [0 | s Bv | 0];  w2a [H][64] = rows [Aq[:,h] | Av[:,h] | 0];
+ *               bt [16][H] = Bq^T | Bv^T (K-contiguous rows: the backward's dq.Bq | dv.Bv then runs on the MFMA form of lora_down);
+ *               every output is optional (NULL)
  * Dropout (NULL = none, as in eval mode) is counter-based, nothing is stored: Philox4x32-10 with key = rng_state[0] (seed), counter
  * = (element index / 8, stream, rng_state[1] (offset)); the 16-bit field j of the 128-bit output decides element 8 idx + j, kept
  * when field >= drop_thr (= round(p * 65536)) and scaled by 65536 / (65536 - drop_thr); element index = row * width + column of
@@ -314,11 +316,15 @@ typedef struct {
 } llmseg_dropout;
 int llmseg_lora_down(const void* x0, const void* x1, int64_t ldx, const void* w0, const void* w1, void* y, int64_t ldy, int64_t M, int64_t K,
                      int32_t w_kr, float alpha, int32_t zero_cols, const llmseg_dropout* drop, void* stream);
+/* lora_down with caller-owned scratch (fp32, >= 2 * 32 * M * 16 * 4 bytes lets every split be taken): short activations (M = 2 x 319) are
+ * split along K over several workgroups per 16-row tile so that the whole chip fetches the operand, a second launch adds the slices */
+int llmseg_lora_down_ws(const void* x0, const void* x1, int64_t ldx, const void* w0, const void* w1, void* y, int64_t ldy, int64_t M, int64_t K,
+                        int32_t w_kr, float alpha, int32_t zero_cols, const llmseg_dropout* drop, void* scratch, int64_t scratch_bytes, void* stream);
 int llmseg_lora_outer(const void* a0, const void* a1, int64_t lda, const void* b0, const void* b1, int64_t ldb, float* out0, float* out1, int64_t M,
                       int64_t N, int32_t out_rn, float alpha, const llmseg_dropout* drop, void* stream);
 int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, int64_t ldxa, const void* w0, const void* w1, int64_t M, int64_t N, int32_t w_rn,
                       float alpha, const llmseg_dropout* drop, void* stream);
-int llmseg_lora_pack(const void* aq, const void* bq, const void* av, const void* bv, void* w2b, void* w2a, int64_t H, float s, void* stream);
+int llmseg_lora_pack(const void* aq, const void* bq, const void* av, const void* bv, void* w2b, void* w2a, void* bt, int64_t H, float s, void* stream);
 /* out[c][r] = in[r][c] (bf16; in [rows][cols] with leading dimension ld_in, out [cols][ld_out]); rows r in [rows, rows_pad) of the
  * source are taken as zero.  Lets the weight / input gradients of a wide trainable Linear (lm_head: dX = dY.W, dW = dY^T.X) run on
  * the K-contiguous LDS-DMA GEMM kernels with the contraction dimension padded to a multiple of 64. */

@@ -111,19 +111,20 @@ def linear(x, w, b=None, act=ops.ACT_NONE, residual=None, wt=None):
     return LinearFn.apply(x, w, b, act, residual, wt)
 
 
-def lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, drop=None):
+def lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, drop=None, want_bt=False):
     """qkv = x Wqkv^T + s (drop_q(x) Aq^T) Bq^T on the q block + s (drop_v(x) Av^T) Bv^T on the v block, rank 8.  The two updates
     ride in the qkv GEMM as one extra 64-wide K-tile: A2 = [x Aq^T | x Av^T | 0], W2 rows of the q block = [s Bq | 0], rows of the
     v block = [0 | s Bv | 0] (no read-modify-write pass over q and v).  Both operands are rebuilt from the current LoRA matrices
     on every call (two small kernels): nothing is cached, so an in-place optimizer update or a load_state_dict cannot leave a
-    stale operand behind.  drop = (rng_state, layer, p) or None.  -> (qkv, A2)"""
+    stale operand behind.  drop = (rng_state, layer, p) or None.  -> (qkv, A2, B^T | None)"""
     H = wqkv.shape[1]
     M = x.shape[0]
     a2 = torch.empty((M, 64), device=x.device, dtype=BF16)
     ops.lora_down(x, aq, out=a2, zero_cols=48, drop=_drops(drop)[0], x2=x, w2=av)      # [x Aq^T | x Av^T | 0], x read once
     w2b = torch.empty((3 * H, 64), device=x.device, dtype=BF16)
-    ops.lora_pack(aq, bq, av, bv, s, w2b=w2b)
-    return ops.gemm(x, wqkv, a2=a2, w2=w2b), a2
+    bt = torch.empty((16, H), device=x.device, dtype=BF16) if want_bt else None      # Bq^T | Bv^T for the backward's down projection
+    ops.lora_pack(aq, bq, av, bv, s, w2b=w2b, bt=bt)
+    return ops.gemm(x, wqkv, a2=a2, w2=w2b), a2, bt
 
 
 def _drops(drop):
@@ -146,7 +147,7 @@ class LoraQKVFn(Function):
         ctx.drop = drop if (drop is not None and drop[2] > 0.0) else None
         ctx.g = tuple(g32_of(t) for t in (aq, bq, av, bv))
         if ctx.fast:
-            qkv, a2 = lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, ctx.drop)
+            qkv, a2, ctx.bt = lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, ctx.drop, want_bt=True)
             xaq, xav = a2[:, :8], a2[:, 8:16]
         else:
             assert ctx.drop is None, "LoRA dropout is implemented for rank 8"
@@ -169,7 +170,7 @@ class LoraQKVFn(Function):
         if ctx.fast:
             drq = _drops(ctx.drop)[0]                                        # stream of the q branch; the v branch is stream + 1
             t2 = torch.empty((M, 64), device=d.device, dtype=BF16)       # [s dq Bq | s dv Bv | 0]
-            ops.lora_down(dq, bq, w_kr=True, alpha=s, out=t2, zero_cols=48, x2=dv, w2=bv)
+            ops.lora_down(dq, ctx.bt[:8], alpha=s, out=t2, zero_cols=48, x2=dv, w2=ctx.bt[8:])      # B^T packed in the forward: K-contiguous rows
             tq, tv = t2[:, :8], t2[:, 8:16]
             if ctx.wqkv_t is not None and ctx.drop is None:               # dx = d Wqkv + tq Aq + tv Av in ONE GEMM
                 w2a = torch.empty((H, 64), device=d.device, dtype=BF16)

@@ -2,6 +2,7 @@
 // text_hidden_fcs, mask-selection head).  All HBM-bound streaming kernels; GEMM-shaped gradients go through
 // llmseg_gemm_bf16 with trans_a / trans_w.  See include/llmseg_hip.h for the reference ops each one differentiates.
 #include <algorithm>
+#include <cstdlib>
 #include "common.h"
 #include "llmseg_hip.h"
 
@@ -458,6 +459,102 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict
   }
 }
 
+// The same product on the matrix cores (W stored [8][K]).  What bounds this product at M = 638 is the operand fetch rate of a CU
+// (~16 B/clk): the per-row kernel above spreads over 160 CUs but re-reads both 8 x K weight blocks for every row (82 MB through L2:
+// 20 us), a 16-row MFMA tile per workgroup reads every byte once but keeps only 40 CUs busy (20 us again).  So the 16-row tile is
+// ALSO split along K over gridDim.y workgroups (320 workgroups at M = 638, K = 4096): a wave's v_mfma_f32_16x16x32_bf16 computes
+// D[rank][m] += W[rank][k..k+32] . X[m][k..k+32]^T for the 16 rows (rows 8..15 of the W operand are zero), the 4 waves of a workgroup
+// are folded through LDS, and a K-slice's fp32 partial goes to the caller's scratch [slice][M][16]; lora_down_finish_kernel adds the
+// slices in order (deterministic), scales and writes the bf16 rows.  With gridDim.y == 1 (tall activations: enough row tiles to fill
+// the chip) the first kernel writes the bf16 rows itself.  Dropout: the Philox mask zeroes elements of the bf16 X fragment (exact), the
+// 1 / (1 - p) scale is folded into alpha -- no extra rounding.  Branches with different dropout streams need their own MFMA (X differs).
+__global__ __launch_bounds__(256) void lora_down_mfma_kernel(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1, long ldx, const bf16_t* __restrict__ w0,
+                                                            const bf16_t* __restrict__ w1, bf16_t* __restrict__ y, long ldy, long M, int K, float alpha,
+                                                            int zero_cols, int nb, DropP dp, float* __restrict__ part) {
+  __shared__ float red[4][2][8][16];                   // [wave][branch][rank][row]
+  __shared__ float fin[16][16];                        // [row][branch * 8 + rank]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, kc = lane >> 4;
+  const long m0 = (long)blockIdx.x * 16;
+  const long m = min(m0 + r, M - 1);
+  const int kq = K / (4 * (int)gridDim.y);             // K-range of one wave (a multiple of 32)
+  const int kbeg = ((int)blockIdx.y * 4 + wave) * kq;
+  const bool same = x0 == x1;
+  f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  auto masked = [&](uint4 v, unsigned long idx, uint32_t stream) {
+    const unsigned long seed = dp.rng[0], off = dp.rng[1];
+    const Philox8 ph = philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), stream, (uint32_t)off, (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint32_t* u = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t lo = (ph.w[j] & 0xffffu) >= dp.thr ? 0x0000ffffu : 0u, hi = (ph.w[j] >> 16) >= dp.thr ? 0xffff0000u : 0u;
+      u[j] &= lo | hi;
+    }
+    return v;
+  };
+#pragma unroll 4
+  for (int k = kbeg + kc * 8; k < kbeg + kq; k += 32) {
+    uint4 xa = *reinterpret_cast<const uint4*>(x0 + m * ldx + k);
+    uint4 xb = (nb > 1 && !same) ? *reinterpret_cast<const uint4*>(x1 + m * ldx + k) : xa;
+    const uint4 wa = r < LR ? *reinterpret_cast<const uint4*>(w0 + (long)r * K + k) : make_uint4(0, 0, 0, 0);
+    const uint4 wb = (nb > 1 && r < LR) ? *reinterpret_cast<const uint4*>(w1 + (long)r * K + k) : make_uint4(0, 0, 0, 0);
+    if (dp.thr) {
+      const unsigned long idx = ((unsigned long)m * (unsigned long)K + (unsigned long)k) >> 3;
+      xa = masked(xa, idx, dp.stream);
+      if (nb > 1) xb = masked(xb, idx, dp.stream + 1);
+    }
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, xa), acc0, 0, 0, 0);
+    if (nb > 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wb), __builtin_bit_cast(bf16x8_t, xb), acc1, 0, 0, 0);
+  }
+  if (kc < 2) {                                        // acc[e] = D[rank 4 kc + e][row r]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[wave][0][4 * kc + e][r] = acc0[e]; red[wave][1][4 * kc + e][r] = acc1[e]; }
+  }
+  __syncthreads();
+  {
+    const int b = threadIdx.x >> 7, rank = (threadIdx.x >> 4) & 7, mm = threadIdx.x & 15;
+    const float sum = (red[0][b][rank][mm] + red[1][b][rank][mm]) + (red[2][b][rank][mm] + red[3][b][rank][mm]);
+    if (part) {                                        // K-slice partial: [slice][M][16]
+      if (m0 + mm < M) part[((long)blockIdx.y * M + m0 + mm) * 16 + b * 8 + rank] = sum;
+    } else fin[mm][b * 8 + rank] = sum * alpha * (dp.thr ? dp.scale : 1.f);
+  }
+  if (part) return;
+  __syncthreads();
+  const int nch = nb + zero_cols / 8;                  // 16-byte chunks per output row
+  for (int t = threadIdx.x; t < 16 * nch; t += blockDim.x) {
+    const int mm = t / nch, ch = t - mm * nch;
+    if (m0 + mm >= M) continue;
+    uint4 o = make_uint4(0, 0, 0, 0);
+    if (ch < nb) o = pack8(&fin[mm][ch * 8]);
+    *reinterpret_cast<uint4*>(y + (m0 + mm) * ldy + ch * 8) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void lora_down_finish_kernel(const float* __restrict__ part, int S, bf16_t* __restrict__ y, long ldy, long M, float scale,
+                                                              int zero_cols, int nb) {
+  const int nch = nb + zero_cols / 8;
+  const long total = M * nch;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long mm = t / nch;
+    const int ch = (int)(t - mm * nch);
+    uint4 o = make_uint4(0, 0, 0, 0);
+    if (ch < nb) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      for (int s2 = 0; s2 < S; ++s2) {
+        const float* pp = part + ((long)s2 * M + mm) * 16 + ch * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += pp[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= scale;
+      o = pack8(v);
+    }
+    *reinterpret_cast<uint4*>(y + mm * ldy + ch * 8) = o;
+  }
+}
+
 // out(n,r) += alpha * sum_m drop(a)[m][n] * b[m][r]  (fp32 atomics onto `out`: the caller zero-fills it or accumulates into a
 // gradient arena).  out_rn = 0: out [N][8]; 1: out [8][N].  b has row pitch ldb.  blockIdx.z selects one of up to two independent
 // products that share the shapes (the q and v branches of one layer: dAq / dAv read the same activation with their own dropout streams,
@@ -590,9 +687,21 @@ __global__ __launch_bounds__(256) void lora_apply_kernel(bf16_t* __restrict__ y,
 //   w2b [3H][64]: rows of the q block = [s Bq | 0], k block = 0, v block = [0 | s Bv | 0]     (forward: qkv += [xAq | xAv | 0] . w2b^T)
 //   w2a [H][64]:  row h = [Aq[:, h] | Av[:, h] | 0]                                             (backward: dx += [tq | tv | 0] . w2a^T)
 __global__ __launch_bounds__(256) void lora_pack_kernel(const bf16_t* __restrict__ aq, const bf16_t* __restrict__ bq, const bf16_t* __restrict__ av,
-                                                       const bf16_t* __restrict__ bv, bf16_t* __restrict__ w2b, bf16_t* __restrict__ w2a, long H, float s) {
-  const long total = 4 * H * 8;                                      // (3H + H) rows x 8 chunks of 8 columns
+                                                       const bf16_t* __restrict__ bv, bf16_t* __restrict__ w2b, bf16_t* __restrict__ w2a, bf16_t* __restrict__ bt,
+                                                       long H, float s) {
+  const long total = 4 * H * 8 + (bt ? 2 * H : 0);                   // (3H + H) rows x 8 chunks of 8 columns (+ the B^T copies: 16 rows x H / 8 chunks)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    if (i >= 4 * H * 8) {                                            // bt [16][H]: rows 0..7 = Bq^T, 8..15 = Bv^T (the backward's rank-8 down projection wants K-contiguous rows)
+      const long j = i - 4 * H * 8;
+      const int row16 = (int)(j / (H >> 3));
+      const long h0 = (j - (long)row16 * (H >> 3)) * 8;
+      const bf16_t* src = row16 < 8 ? bq : bv;
+      uint32_t o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (uint32_t)src[(h0 + 2 * e) * LR + (row16 & 7)] | ((uint32_t)src[(h0 + 2 * e + 1) * LR + (row16 & 7)] << 16);
+      *reinterpret_cast<uint4*>(bt + (long)row16 * H + h0) = make_uint4(o[0], o[1], o[2], o[3]);
+      continue;
+    }
     const long row = i >> 3;
     const int ch = (int)(i & 7);
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -656,17 +765,36 @@ static DropP make_drop(const llmseg_dropout* d) {
 
 extern "C" int llmseg_lora_down(const void* x0, const void* x1, int64_t ldx, const void* w0, const void* w1, void* y, int64_t ldy, int64_t M, int64_t K,
                                 int32_t w_kr, float alpha, int32_t zero_cols, const llmseg_dropout* drop, void* stream) {
+  return llmseg_lora_down_ws(x0, x1, ldx, w0, w1, y, ldy, M, K, w_kr, alpha, zero_cols, drop, nullptr, 0, stream);
+}
+
+extern "C" int llmseg_lora_down_ws(const void* x0, const void* x1, int64_t ldx, const void* w0, const void* w1, void* y, int64_t ldy, int64_t M, int64_t K,
+                                   int32_t w_kr, float alpha, int32_t zero_cols, const llmseg_dropout* drop, void* scratch, int64_t scratch_bytes, void* stream) {
   const int nb = (x1 && w1) ? 2 : 1;
   LL_CHECK(x0 && w0 && y && (!x1) == (!w1) && M > 0 && K > 0 && (K & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0 && ldy >= 8 * nb + zero_cols &&
                zero_cols >= 0 && (zero_cols & 7) == 0 && zero_cols <= 480 && AL16(x0) && AL16(x1) && AL16(w0) && AL16(w1) && AL16(y) && LL_DROP_OK(drop),
            "lora_down: bad arguments");
   const DropP dp = make_drop(drop);
-  if (M <= 2048)
-    hipLaunchKernelGGL(lora_down_kernel<1>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x0, (const bf16_t*)(x1 ? x1 : x0),
-                       (long)ldx, (const bf16_t*)w0, (const bf16_t*)(w1 ? w1 : w0), (bf16_t*)y, (long)ldy, (long)M, (int)K, w_kr, alpha, zero_cols, nb, dp);
+  const bf16_t *X0 = (const bf16_t*)x0, *X1 = (const bf16_t*)(x1 ? x1 : x0), *W0 = (const bf16_t*)w0, *W1 = (const bf16_t*)(w1 ? w1 : w0);
+  static const int force = getenv("LLMSEG_LORA_DOWN") ? atoi(getenv("LLMSEG_LORA_DOWN")) : 0;      // tuning / bisecting: 1 = per-row kernel, 2 = MFMA without K slices
+  if (!w_kr && (K & 127) == 0 && force != 1) {
+    if (force == 2) scratch = nullptr;
+    // MFMA form: 16-row tiles; K slices so that the launch has >= ~256 workgroups (each slice a multiple of 4 waves x 32 columns)
+    const long tiles = (M + 15) / 16;
+    int S = 1;
+    while (tiles * S < 256 && (K % (4 * 32 * S * 2)) == 0 && scratch && (int64_t)S * 2 * M * 16 * 4 <= scratch_bytes && S < 32) S *= 2;
+    float* part = S > 1 ? (float*)scratch : nullptr;
+    hipLaunchKernelGGL(lora_down_mfma_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, (hipStream_t)stream, X0, X1, (long)ldx, W0, W1, (bf16_t*)y, (long)ldy,
+                       (long)M, (int)K, alpha, zero_cols, nb, dp, part);
+    if (S > 1)
+      hipLaunchKernelGGL(lora_down_finish_kernel, dim3(grid_for(M * (nb + zero_cols / 8))), dim3(256), 0, (hipStream_t)stream, (const float*)part, S, (bf16_t*)y,
+                         (long)ldy, (long)M, alpha * (dp.thr ? dp.scale : 1.f), zero_cols, nb);
+  } else if (M <= 2048)
+    hipLaunchKernelGGL(lora_down_kernel<1>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X0, X1, (long)ldx, W0, W1, (bf16_t*)y, (long)ldy, (long)M,
+                       (int)K, w_kr, alpha, zero_cols, nb, dp);
   else
-    hipLaunchKernelGGL(lora_down_kernel<4>, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x0, (const bf16_t*)(x1 ? x1 : x0),
-                       (long)ldx, (const bf16_t*)w0, (const bf16_t*)(w1 ? w1 : w0), (bf16_t*)y, (long)ldy, (long)M, (int)K, w_kr, alpha, zero_cols, nb, dp);
+    hipLaunchKernelGGL(lora_down_kernel<4>, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, X0, X1, (long)ldx, W0, W1, (bf16_t*)y, (long)ldy, (long)M,
+                       (int)K, w_kr, alpha, zero_cols, nb, dp);
   LL_LAUNCH_CHECK("lora_down");
   return LLMSEG_OK;
 }
@@ -698,11 +826,11 @@ extern "C" int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, int64_t l
   return LLMSEG_OK;
 }
 
-extern "C" int llmseg_lora_pack(const void* aq, const void* bq, const void* av, const void* bv, void* w2b, void* w2a, int64_t H, float s, void* stream) {
-  LL_CHECK(aq && bq && av && bv && (w2b || w2a) && H > 0 && (H & 7) == 0 && AL16(aq) && AL16(bq) && AL16(av) && AL16(bv) && AL16(w2b) && AL16(w2a),
+extern "C" int llmseg_lora_pack(const void* aq, const void* bq, const void* av, const void* bv, void* w2b, void* w2a, void* bt, int64_t H, float s, void* stream) {
+  LL_CHECK(aq && bq && av && bv && (w2b || w2a || bt) && H > 0 && (H & 7) == 0 && AL16(aq) && AL16(bq) && AL16(av) && AL16(bv) && AL16(w2b) && AL16(w2a) && AL16(bt),
            "lora_pack: bad arguments");
-  hipLaunchKernelGGL(lora_pack_kernel, dim3(grid_for(4 * H * 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)aq, (const bf16_t*)bq, (const bf16_t*)av,
-                     (const bf16_t*)bv, (bf16_t*)w2b, (bf16_t*)w2a, (long)H, s);
+  hipLaunchKernelGGL(lora_pack_kernel, dim3(grid_for(4 * H * 8 + 2 * H)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)aq, (const bf16_t*)bq, (const bf16_t*)av,
+                     (const bf16_t*)bv, (bf16_t*)w2b, (bf16_t*)w2a, (bf16_t*)bt, (long)H, s);
   LL_LAUNCH_CHECK("lora_pack");
   return LLMSEG_OK;
 }

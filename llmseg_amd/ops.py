@@ -451,9 +451,12 @@ def lora_down(x, w, w_kr=False, alpha=1.0, out=None, zero_cols=0, drop=None, x2=
     nb = 1 if w2 is None else 2
     y = torch.empty((M, 8 * nb), device=x.device, dtype=BF16) if out is None else out
     assert y.shape[0] == M and y.stride(1) == 1 and (x2 is None or (x2.shape == x.shape and x2.stride(0) == x.stride(0)))
-    _lib.check(_lib.load().llmseg_lora_down(_ptr(x), _ptr(x2 if w2 is not None and x2 is not None else (x if w2 is not None else None)), x.stride(0),
-                                            _ptr(w), _ptr(w2), _ptr(y), y.stride(0), M, K, 1 if w_kr else 0, alpha, zero_cols, _drop(drop), _stream()),
-               "lora_down")
+    scratch = None
+    if not w_kr and (M + 15) // 16 < 256 and K % 256 == 0:       # short activations: K-sliced over several workgroups per row tile (fp32 partials)
+        scratch = torch.empty((32 * 2 * M * 16,), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().llmseg_lora_down_ws(_ptr(x), _ptr(x2 if w2 is not None and x2 is not None else (x if w2 is not None else None)), x.stride(0),
+                                               _ptr(w), _ptr(w2), _ptr(y), y.stride(0), M, K, 1 if w_kr else 0, alpha, zero_cols, _drop(drop),
+                                               _ptr(scratch), 0 if scratch is None else scratch.numel() * 4, _stream()), "lora_down")
     return y
 
 
@@ -484,13 +487,13 @@ def lora_apply_(y, xa, w, w_rn=False, alpha=1.0, drop=None, w2=None):
     return y
 
 
-def lora_pack(aq, bq, av, bv, s, w2b=None, w2a=None):
+def lora_pack(aq, bq, av, bv, s, w2b=None, w2a=None, bt=None):
     """Extension operands of the LoRA'd qkv GEMMs from the current LoRA matrices (aq/av [8, H], bq/bv [H, 8]):
-    w2b [3H, 64] (forward) and/or w2a [H, 64] (backward dX); written in place."""
+    w2b [3H, 64] (forward) and/or w2a [H, 64] (backward dX) and/or bt [16, H] = Bq^T | Bv^T; written in place."""
     H = aq.shape[1]
     for t in (aq, bq, av, bv):
         assert t.is_contiguous()
-    _lib.check(_lib.load().llmseg_lora_pack(_ptr(aq), _ptr(bq), _ptr(av), _ptr(bv), _ptr(w2b), _ptr(w2a), H, s, _stream()), "lora_pack")
+    _lib.check(_lib.load().llmseg_lora_pack(_ptr(aq), _ptr(bq), _ptr(av), _ptr(bv), _ptr(w2b), _ptr(w2a), _ptr(bt), H, s, _stream()), "lora_pack")
 
 
 def sumsq(x, out):

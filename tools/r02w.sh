@@ -1,6 +1,3 @@
 #!/bin/bash
-# final-state artefacts: kernel stats (B=2), default bench line
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-bash tools/gpu_prof.sh r02_final_b2 --batch 2 --extra-batch 0 --no-neighbours --steps 10 --warmup 3 > /dev/null 2>&1
-( time timeout 900 python bench.py ) > gpurun_out/r02_final_bench.txt 2>&1
-tail -4 gpurun_out/r02_final_bench.txt | cut -c1-300
+cd $GRAFT_REPO_ROOT
+LLMSEG_LORA_DOWN=$1 timeout 600 python -m pytest tests/test_backward_gpu.py -q -k checkpoint 2>&1 | grep -E "passed|failed|AssertionError:" | cut -c1-300

@@ -34,6 +34,9 @@ t("lora_down fwd (2 branches, no dropout)", lambda: ops.lora_down(x, aq, out=a2,
 d = r(M, 3 * H); bq, bv = r(H, 8), r(H, 8)
 t2 = torch.empty(M, 64, device=dev, dtype=BF)
 t("lora_down bwd (dq.Bq | dv.Bv)", lambda: ops.lora_down(d[:, :H], bq, w_kr=True, alpha=2.0, out=t2, zero_cols=48, x2=d[:, 2 * H:], w2=bv))
+bt = torch.empty(16, H, device=dev, dtype=BF)
+ops.lora_pack(aq, bq, av, bv, 2.0, bt=bt)
+t("lora_down bwd via B^T (MFMA form)", lambda: ops.lora_down(d[:, :H], bt[:8], alpha=2.0, out=t2, zero_cols=48, x2=d[:, 2 * H:], w2=bt[8:]))
 g1, g2 = torch.zeros(H, 8, device=dev), torch.zeros(H, 8, device=dev)
 t("lora_outer dB (2 products)", lambda: ops.lora_outer(d[:, :H], a2[:, :8], alpha=2.0, out=g1, a2=d[:, 2 * H:], b2=a2[:, 8:16], out2=g2))
 g3, g4 = torch.zeros(8, H, device=dev), torch.zeros(8, H, device=dev)
