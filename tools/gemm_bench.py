@@ -28,16 +28,14 @@ if os.environ.get("GEMM_SHAPES"):
     SHAPES = [SHAPES[int(i)] for i in os.environ["GEMM_SHAPES"].split(",")]
 def _variant(spec):          # "8" | "9:3" (kernel 9, 3 K-slices) | "5" (auto)
     v, _, sp = spec.partition(":")
-    legacy = "q" in v                       # "8q": the two-buffer ping-pong kernel instead of the half-tile ring
-    v, _, rot = v.replace("q", "").partition("r")       # "8qr3": 2^3 K-loop rotations
-    return int(v) | (int(sp) << 8 if sp else 0) | ((1 << 13) if legacy else 0) | ((int(rot) << 14) if rot else 0)
+    return int(v) | (int(sp) << 8 if sp else 0)
 
 
 variants = [_variant(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "2", "8"])]
 lib = _lib.load()
 torch.manual_seed(0)
 print("variants: v & 15 = kernel variant, (v >> 4) - 1 = XCD skew (none = default 13)")
-print(f"{'shape':32s} " + " ".join(f"{'v%d%s%s:%d' % (v & 15, 'q' if v >> 13 & 1 else '', 'r%d' % (v >> 14 & 7) if v >> 14 & 7 else '', v >> 8 & 31):>9s}" for v in variants) + "   (TFLOP/s; check = max|v - v0|)")
+print(f"{'shape':32s} " + " ".join(f"{'v%d:%d' % (v & 15, v >> 8 & 31):>9s}" for v in variants) + "   (TFLOP/s; check = max|v - v0|)")
 for M, N, K, tag in SHAPES:
     a = (torch.rand(M, K, device="cuda") * 2 - 1).to(torch.bfloat16)
     w = (torch.rand(N, K, device="cuda") * 2 - 1).to(torch.bfloat16)
