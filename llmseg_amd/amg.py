@@ -86,3 +86,21 @@ class AmgMixin:
         if return_aux:                                       # tests: every candidate's low-resolution logits / predicted IoU / statistics
             out.update(low=low, iou_all=iou, stats=st, selected=sel)
         return out
+
+
+def to_records(out, original_size, output_mode="coco_rle"):
+    """`SamAutomaticMaskGenerator.generate`'s return value (automatic_mask_generator.py:160-197) from `generate_proposals`' tensors: a list of
+    dicts {segmentation, area, bbox (XYWH), predicted_iou, point_coords, stability_score, crop_box}; segmentation = the COCO RLE the
+    reference's preparation scripts store (prepare_datasets/prepare_ReasonSeg.py:90-97) or the binary mask."""
+    from .targets import rle_encode_masks
+    H, W = int(original_size[0]), int(original_size[1])
+    masks = out["masks"].cpu()
+    boxes = out["boxes"].cpu().tolist()
+    seg = rle_encode_masks(masks) if output_mode == "coco_rle" else [m.numpy().astype(bool) for m in masks]
+    recs = []
+    for k in range(masks.shape[0]):
+        x0, y0, x1, y1 = boxes[k]
+        recs.append({"segmentation": seg[k], "area": int(out["areas"][k]), "bbox": [x0, y0, x1 - x0, y1 - y0],
+                     "predicted_iou": float(out["iou_preds"][k]), "point_coords": [out["points"][k].tolist()],
+                     "stability_score": float(out["stability_score"][k]), "crop_box": [0, 0, W, H]})
+    return recs

@@ -43,6 +43,37 @@ def rle_counts(rle):
     return vals.astype(np.uint32)
 
 
+def rle_encode_masks(masks):
+    """uint8 / bool [K, H, W] (tensor or array) -> [{'size': [H, W], 'counts': str}]: pycocotools `mask.encode` output (maskApi rleEncode +
+    rleToString: column-major runs starting with zeros; counts from the fourth on as deltas against the count two back; 5-bit groups, low
+    first, bit 5 = continuation, bit 4 of the last group = sign).  Host-side: this is the reference's FILE format (prepare_datasets/*),
+    the path itself consumes the dense masks."""
+    m = masks.detach().cpu().numpy() if torch.is_tensor(masks) else np.asarray(masks)
+    K, H, W = m.shape
+    out = []
+    for k in range(K):
+        flat = np.ascontiguousarray(m[k].astype(bool).T).reshape(-1)
+        ch = np.flatnonzero(flat[1:] != flat[:-1]) + 1
+        idx = np.concatenate([[0], ch, [H * W]])
+        cnts = np.diff(idx).astype(np.int64)
+        if flat[0]:
+            cnts = np.concatenate([[0], cnts])
+        d = cnts.copy()
+        d[3:] -= cnts[1:-2]
+        chars = []
+        for x in d.tolist():
+            more = True
+            while more:
+                c = x & 0x1f
+                x >>= 5
+                more = (x != -1) if (c & 0x10) else (x != 0)
+                if more:
+                    c |= 0x20
+                chars.append(c + 48)
+        out.append({"size": [int(H), int(W)], "counts": bytes(chars).decode("ascii")})
+    return out
+
+
 def nearest_index(out_n, in_n):
     """Source index of every output index for skimage.transform.resize(order=0, anti_aliasing=False) == scipy.ndimage.zoom(order=0,
     grid_mode=True): coordinate (i + 0.5) * (in / out) - 0.5 in float64, nearest = floor(c + 0.5)."""
@@ -144,3 +175,16 @@ def proposals_and_targets(masks, gt_masks, device, top=50, out_size=256):
         iou, iop, _ = mask_targets(segs, g)
         ious.append(iou); iops.append(iop)
     return {"sam_segs": resize_square_aa(segs, out_size), "sam_ious": torch.stack(ious), "sam_iops": torch.stack(iops), "segs_origin": segs, "bbox": d["bbox"]}
+
+
+def proposals_and_targets_dense(masks, areas, gt_masks, top=50, out_size=256):
+    """The same for proposals that are already dense masks on the device (uint8 [K, H, W] + their areas, e.g. the output of
+    `LISAForCausalLM.generate_proposals`): largest `top` by area (sam_mask_reader.py:69-75), no RLE round trip."""
+    order = torch.argsort(areas, descending=True, stable=True)[:top]
+    segs = masks[order].contiguous()
+    ious, iops = [], []
+    for g in gt_masks:
+        g = torch.as_tensor(np.asarray(g) if not torch.is_tensor(g) else g).to(device=segs.device, dtype=torch.uint8)
+        iou, iop, _ = mask_targets(segs, g)
+        ious.append(iou); iops.append(iop)
+    return {"sam_segs": resize_square_aa(segs, out_size), "sam_ious": torch.stack(ious), "sam_iops": torch.stack(iops), "segs_origin": segs, "order": order}

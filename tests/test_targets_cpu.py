@@ -80,3 +80,40 @@ def test_targets_known_answers():
     assert np.allclose(iou, [4 / 8, 4 / 8]) and np.allclose(iop, [4 / 8, 4 / 8])
     iou, iop = ot.compute_all_iou_iop(np.zeros((4, 4, 1), np.uint8), gt)
     assert iou[0] == 0.0 and np.isnan(iop[0])
+
+
+def test_rle_encode_masks_matches_the_restated_pycocotools_codec():
+    """llmseg_amd.targets.rle_encode_masks (vectorised run extraction) against oracle.targets.rle_encode (maskApi restated loop), incl. a mask
+    that starts with ones, an empty and a full mask, long runs (delta coding with negative deltas), and decode(encode(m)) == m."""
+    import numpy as np
+    import torch
+    from llmseg_amd import targets as ht
+    from oracle import targets as ot
+    g = torch.Generator().manual_seed(3)
+    H, W = 37, 53
+    m = (torch.rand(6, H, W, generator=g) > 0.6).to(torch.uint8)
+    m[1] = 0
+    m[2] = 1
+    m[3, 0, 0] = 1
+    m[4, :, :20] = 1; m[4, :, 20:] = 0
+    m[5] = (torch.rand(H, W, generator=g) > 0.97).to(torch.uint8)
+    got = ht.rle_encode_masks(m)
+    for k in range(6):
+        ref = ot.rle_encode(m[k].numpy())
+        assert got[k] == ref, (k, got[k], ref)
+        assert np.array_equal(ot.rle_decode(got[k]), m[k].numpy())
+        assert np.array_equal(ht.rle_counts(got[k]), ht.rle_counts({"size": [H, W], "counts": ref["counts"]}))
+
+
+def test_amg_records_have_the_reference_fields():
+    import torch
+    from llmseg_amd import amg
+    masks = torch.zeros((2, 8, 10), dtype=torch.uint8)
+    masks[0, 2:5, 3:7] = 1
+    masks[1, 0, 0] = 1
+    out = dict(masks=masks, boxes=torch.tensor([[3, 2, 6, 4], [0, 0, 0, 0]]), iou_preds=torch.tensor([0.93, 0.9]), stability_score=torch.tensor([0.97, 0.96]),
+               points=torch.tensor([[4.5, 3.5], [0.5, 0.5]], dtype=torch.float64), areas=torch.tensor([12, 1]))
+    recs = amg.to_records(out, (8, 10))
+    assert set(recs[0]) == {"segmentation", "area", "bbox", "predicted_iou", "point_coords", "stability_score", "crop_box"}
+    assert recs[0]["bbox"] == [3, 2, 3, 2] and recs[0]["area"] == 12 and recs[0]["crop_box"] == [0, 0, 10, 8] and recs[0]["segmentation"]["size"] == [8, 10]
+    assert recs[1]["point_coords"] == [[0.5, 0.5]]

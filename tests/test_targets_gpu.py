@@ -58,3 +58,31 @@ def test_targets_feed_model_forward_contract():
     out = ht.proposals_and_targets(recs, [(rng.random((120, 90)) > 0.5).astype(np.uint8)], DEV)
     assert out["sam_segs"].dtype == torch.bfloat16 and out["sam_segs"].shape == (6, 256, 256)
     assert out["sam_ious"].dtype == torch.float64 and out["sam_ious"].shape == (1, 6) and out["sam_iops"].shape == (1, 6)
+
+
+def test_dense_proposals_equal_the_rle_route():
+    """Everything-mode output feeds the target computation directly: dense uint8 masks + areas (llmseg_amd/amg.py) must give exactly what the
+    reference's file route gives (masks -> COCO RLE records -> sort by area / top 50 -> decode -> targets -> 256 x 256 maps)."""
+    from llmseg_amd import amg, targets as ht
+    rng = np.random.default_rng(11)
+    h, w, k = 240, 320, 60
+    m = np.zeros((k, h, w), np.uint8)
+    for i in range(k):
+        y0, x0 = rng.integers(0, h - 8), rng.integers(0, w - 8)
+        m[i, y0:y0 + rng.integers(4, h - y0), x0:x0 + rng.integers(4, w - x0)] = 1
+    masks = torch.from_numpy(m).to(DEV)
+    areas = masks.flatten(1).sum(1)
+    out = dict(masks=masks, boxes=torch.zeros((k, 4), dtype=torch.long), iou_preds=torch.ones(k), stability_score=torch.ones(k),
+               points=torch.zeros((k, 2), dtype=torch.float64), areas=areas)
+    recs = amg.to_records(out, (h, w))
+    gts = [(rng.random((h, w)) > 0.5).astype(np.uint8)]
+    a = ht.proposals_and_targets(recs, gts, DEV, top=50)
+    b = ht.proposals_and_targets_dense(masks, areas, gts, top=50)
+    # equal areas may be ordered differently by the two sorts: compare as sets of (mask, iou, iop, map) keyed by the mask bytes
+    key = lambda segs: [bytes(s.cpu().numpy().tobytes()) for s in segs]
+    ka, kb = key(a["segs_origin"]), key(b["segs_origin"])
+    assert sorted(ka) == sorted(kb)
+    perm = [kb.index(x) for x in ka]
+    assert np.array_equal(a["sam_ious"].cpu().numpy(), b["sam_ious"][:, perm].cpu().numpy(), equal_nan=True)
+    assert np.array_equal(a["sam_iops"].cpu().numpy(), b["sam_iops"][:, perm].cpu().numpy(), equal_nan=True)
+    assert torch.equal(a["sam_segs"], b["sam_segs"][perm])
