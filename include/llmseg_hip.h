@@ -63,6 +63,11 @@ typedef struct {
   /* out_f32 only: C += result instead of C = result (weight gradients accumulate over micro-steps in an fp32 arena, as the
    * reference's DeepSpeed engine accumulates them: training.py:79-82 gradient_accumulation_steps, :292-332 bf16 config) */
   int accumulate;
+  /* decode-step fusions, M <= 8 only (one token per sequence: every kernel launch saved is ~8 us of a ~100 us layer):
+   *   a_norm_w (bf16 [K]) : A := RMSNorm(A) * a_norm_w on load (HF LlamaRMSNorm arithmetic, eps = a_norm_eps);
+   *   a_swiglu            : A rows are [gate | up] of width 2K (lda >= 2K), A := silu(gate) * up on load (HF LlamaMLP).
+   * Same bits as llmseg_norm / llmseg_swiglu followed by the GEMM. */
+  const void* a_norm_w; float a_norm_eps; int a_swiglu;
 } llmseg_gemm_args;
 int llmseg_gemm_bf16(const llmseg_gemm_args* args, void* stream);
 /* tuning knob (results are identical up to fp32 summation order of split-K; only speed differs):

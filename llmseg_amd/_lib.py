@@ -22,7 +22,8 @@ class GemmArgs(C.Structure):
                 ("alpha", C.c_float), ("act", C.c_int), ("out_f32", C.c_int), ("trans_a", C.c_int), ("trans_w", C.c_int),
                 ("batch2", C.c_int64), ("strideA2", C.c_int64), ("strideW2", C.c_int64), ("strideC2", C.c_int64),
                 ("A2", C.c_void_p), ("W2", C.c_void_p), ("lda2", C.c_int64), ("ldw2", C.c_int64),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("accumulate", C.c_int)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("accumulate", C.c_int),
+                ("a_norm_w", C.c_void_p), ("a_norm_eps", C.c_float), ("a_swiglu", C.c_int)]
 
 
 class AttnArgs(C.Structure):

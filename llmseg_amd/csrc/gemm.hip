@@ -43,6 +43,7 @@ struct GemmP {
   int skew;                  // per-XCD rotation of the tile walk (de-phases the 8 XCDs' HBM/MALL channel access)
   int kt_total;              // split-K (ping-pong kernel): total K-tiles of the product; 0 = blockIdx.y is a batch index, K = whole contraction
   int accum;                 // fp32 output only: C += result (gradient accumulation into an fp32 arena)
+  const bf16_t* a_norm_w; float a_norm_eps; int a_swiglu;     // skinny route: transform of the A rows while they are loaded (decode-step fusions)
 };
 
 // exact-erf GELU on a pair (packed fp32 VALU: v_pk_fma / v_pk_mul).  Same Abramowitz-Stegun 7.1.26 erf as apply_act, rearranged:
@@ -701,7 +702,12 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
 // chunks (1 KiB per row per instruction, fully coalesced), two K-steps in flight per lane (8 W loads + 2 MT A loads), fp32 FMA
 // accumulators acc[4][MT], a 6-step butterfly at the end, lane (r, m) applies the epilogue and stores.  Workgroup = 4 waves = 16 W rows:
 // N = 4096 gives 256 workgroups (one per CU, 40 KiB of loads in flight each).  K % 8 == 0, K-contiguous A and W, batch == 1.
-template <int MT>
+// AT: transform applied to the A rows on load, so that a decode step needs no separate launch for it (each wave walks ALL of K, so it
+// sees whole rows):  1 = A := RMSNorm(A) * a_norm_w with llmseg_norm's arithmetic (fp32 sum of squares, bf16 rounding before AND
+// after the weight multiply, as the stored bf16 output of the norm kernel has);  2 = A := silu(g) * u of rows [g | u] of width 2K
+// (llmseg_swiglu's arithmetic, rounded to bf16).  Both reproduce the two-launch result bit for bit up to the order of the fp32 dot
+// product, which is this kernel's own either way.
+template <int MT, int AT>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int out_f32) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = (blockIdx.x * 4 + wave) * 4;
@@ -714,23 +720,53 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int out_f32) 
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[r][m] = 0.f;
+  const int K = p.K;
+  float rstd[MT];
+  if constexpr (AT == 1) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const bf16_t* ar = p.A + (long)min(m, p.M - 1) * p.lda;
+      float ss = 0.f, f[8];
+      for (int k = lane * 8; k < K; k += 512) {
+        unpack8(*reinterpret_cast<const uint4*>(ar + k), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+      }
+      rstd[m] = rsqrtf(wave_sum(ss) / (float)K + p.a_norm_eps);
+    }
+  }
+  // the (transformed) 8 A values of row m at column k, as bf16 pairs
+  auto load_a = [&](int m, int k) -> uint4 {
+    const bf16_t* ar = p.A + (long)min(m, p.M - 1) * p.lda;
+    if constexpr (AT == 0) return *reinterpret_cast<const uint4*>(ar + k);
+    float f[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(ar + k), f);
+    if constexpr (AT == 1) {
+      float g[8];
+      unpack8(*reinterpret_cast<const uint4*>(p.a_norm_w + k), g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = g[e] * bf2f(f2bf(f[e] * rstd[m]));
+    } else {
+      float u[8];
+      unpack8(*reinterpret_cast<const uint4*>(ar + K + k), u);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f[e] / (1.f + __expf(-f[e])) * u[e];
+    }
+    return pack8(o);
+  };
   auto fma8 = [&](const uint4& w, const uint4& x, float& a) {
     a = fmaf(__uint_as_float(w.x << 16), __uint_as_float(x.x << 16), a); a = fmaf(__uint_as_float(w.x & 0xffff0000u), __uint_as_float(x.x & 0xffff0000u), a);
     a = fmaf(__uint_as_float(w.y << 16), __uint_as_float(x.y << 16), a); a = fmaf(__uint_as_float(w.y & 0xffff0000u), __uint_as_float(x.y & 0xffff0000u), a);
     a = fmaf(__uint_as_float(w.z << 16), __uint_as_float(x.z << 16), a); a = fmaf(__uint_as_float(w.z & 0xffff0000u), __uint_as_float(x.z & 0xffff0000u), a);
     a = fmaf(__uint_as_float(w.w << 16), __uint_as_float(x.w << 16), a); a = fmaf(__uint_as_float(w.w & 0xffff0000u), __uint_as_float(x.w & 0xffff0000u), a);
   };
-  const int K = p.K;
   int k = lane * 8;
   for (; k + 512 < K; k += 1024) {                   // two K-steps per trip: all loads issued before the first FMA
     uint4 w0[4], w1[4], x0[MT], x1[MT];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { w0[r] = *reinterpret_cast<const uint4*>(wr[r] + k); w1[r] = *reinterpret_cast<const uint4*>(wr[r] + k + 512); }
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const bf16_t* ar = p.A + (long)min(m, p.M - 1) * p.lda;
-      x0[m] = *reinterpret_cast<const uint4*>(ar + k); x1[m] = *reinterpret_cast<const uint4*>(ar + k + 512);
-    }
+    for (int m = 0; m < MT; ++m) { x0[m] = load_a(m, k); x1[m] = load_a(m, k + 512); }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -741,7 +777,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int out_f32) 
 #pragma unroll
     for (int r = 0; r < 4; ++r) w0[r] = *reinterpret_cast<const uint4*>(wr[r] + k);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) x0[m] = *reinterpret_cast<const uint4*>(p.A + (long)min(m, p.M - 1) * p.lda + k);
+    for (int m = 0; m < MT; ++m) x0[m] = load_a(m, k);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -958,17 +994,27 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
       return llmseg_gemm_bf16(&g2, stream);
     }
   }
-  if (p.M <= 8 && !ta && !tw && batch == 1 && !p.A2 && (p.K & 7) == 0 && g_gemm_variant == 5) {
+  p.a_norm_w = (const bf16_t*)a->a_norm_w; p.a_norm_eps = a->a_norm_eps; p.a_swiglu = a->a_swiglu;
+  const bool a_xform = p.a_norm_w || p.a_swiglu;
+  LL_CHECK(!a_xform || (p.M <= 8 && !ta && !tw && batch == 1 && !p.A2 && (p.K & 7) == 0 && !(p.a_norm_w && p.a_swiglu) &&
+                        (!p.a_norm_w || (((uintptr_t)p.a_norm_w) & 15) == 0) && (!p.a_swiglu || p.lda >= 2 * p.K)),
+           "gemm: A-row transforms (a_norm_w / a_swiglu) are decode-step fusions of the M <= 8 route");
+  if (p.M <= 8 && !ta && !tw && batch == 1 && !p.A2 && (p.K & 7) == 0 && (g_gemm_variant == 5 || a_xform)) {
     // skinny GEMM (decode steps, single-row head GEMMs): a weight stream, HBM-bound
     hipStream_t s = (hipStream_t)stream;
     llmseg_prof_begin(s);
     llmseg_prof_tag(p.M, p.N, p.K, 3000 + (p.res ? 20 : 0) + p.act * 2 + (a->out_f32 ? 1 : 0));
     const dim3 grid((unsigned)((p.N + 15) / 16));
     const int of = a->out_f32 ? 1 : 0;
-    if (p.M == 1) hipLaunchKernelGGL(gemm_skinny_kernel<1>, grid, dim3(256), 0, s, p, of);
-    else if (p.M == 2) hipLaunchKernelGGL(gemm_skinny_kernel<2>, grid, dim3(256), 0, s, p, of);
-    else if (p.M <= 4) hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, dim3(256), 0, s, p, of);
-    else hipLaunchKernelGGL(gemm_skinny_kernel<8>, grid, dim3(256), 0, s, p, of);
+#define LL_SKINNY(AT)                                                                                   \
+    do {                                                                                                \
+      if (p.M == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1, AT>), grid, dim3(256), 0, s, p, of);      \
+      else if (p.M == 2) hipLaunchKernelGGL((gemm_skinny_kernel<2, AT>), grid, dim3(256), 0, s, p, of); \
+      else if (p.M <= 4) hipLaunchKernelGGL((gemm_skinny_kernel<4, AT>), grid, dim3(256), 0, s, p, of); \
+      else hipLaunchKernelGGL((gemm_skinny_kernel<8, AT>), grid, dim3(256), 0, s, p, of);               \
+    } while (0)
+    if (p.a_norm_w) LL_SKINNY(1); else if (p.a_swiglu) LL_SKINNY(2); else LL_SKINNY(0);
+#undef LL_SKINNY
     llmseg_prof_end(s, 2.0 * (double)a->M * (double)a->N * (double)a->K);
     LL_LAUNCH_CHECK("gemm_skinny");
     return LLMSEG_OK;

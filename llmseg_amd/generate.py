@@ -14,6 +14,7 @@ MI355X-first shape of the loop:
 HF greedy-search rules restated from `transformers==4.29.0 generation/utils.py::greedy_search` (third party): finished rows emit
 `pad_token_id`, a row finishes on `eos_token_id`, the loop stops when all rows are finished or `max_new_tokens` tokens were added.
 """
+import os
 import torch
 
 from . import ops
@@ -35,16 +36,78 @@ class DecodeState:
         self.logits = torch.empty((N, V), device=device, dtype=BF16)
         self.N, self.cap, self.H = N, cap, H
         self.graph = None
+        self.fused = False           # decode step on merged-LoRA weights (+ norm / SwiGLU on the GEMM's A load for a single sequence)
+        self.qkv_w = None            # per-layer q|k|v weights with the LoRA deltas merged in (fused steps)
 
 
 class GenerateMixin:
+    def _merge_lora(self):
+        """q|k|v weights with the LoRA deltas folded in (W + (alpha / r) B A on the q and v blocks, peft `merge_and_unload` -- what the
+        reference's released checkpoints are, merge_lora_weights_and_save_hf_model.py), rebuilt from the CURRENT LoRA matrices at every
+        `generate()` call into persistent buffers (3.2 GB at Llama-7B; ~2 ms): a decode step then needs no LoRA launches.  The rounding of
+        W + delta to bf16 differs from the training forward's x W^T + (x A^T) B^T by one bf16 ulp of W."""
+        c = self.config.llama
+        F = _Direct
+        H = c.hidden
+        bufs = self.__dict__.setdefault("_merged_qkv", [None] * c.layers)
+        s = c.lora_alpha / c.lora_r
+        for i in range(c.layers):
+            p = f"model.layers.{i}."
+            w = self._wcat(p + "qkv", [p + f"self_attn.{n}_proj.weight" for n in "qkv"], F)
+            if bufs[i] is None:
+                bufs[i] = torch.empty_like(w)
+            bufs[i].copy_(w)
+            lp = p + "self_attn."
+            for blk, n in ((0, "q_proj"), (2, "v_proj")):
+                a_, b_ = self._w(lp + n + ".lora_A.default.weight", F), self._w(lp + n + ".lora_B.default.weight", F)
+                r = a_.shape[0]
+                if r % 8:                                     # the GEMM contracts in 16-byte chunks: pad the rank with zeros
+                    rp = (r + 7) // 8 * 8
+                    a_ = torch.cat([a_, torch.zeros((rp - r, H), device=a_.device, dtype=a_.dtype)], 0)
+                    b_ = torch.cat([b_, torch.zeros((H, rp - r), device=b_.device, dtype=b_.dtype)], 1).contiguous()
+                view = bufs[i][blk * H:(blk + 1) * H]
+                ops.gemm(b_, a_, trans_w=True, alpha=s, residual=view, out=view)           # [H, r] @ [r, H] + W block
+        return bufs
+
     def _decode_body(self, st):
         """One token per sequence through the decoder stack: st.x (embeddings of the token at position st.pos[0]) -> st.hidden, st.logits;
         K / V of the token are appended to the cache and the position advances.  No host-visible state: the step is a pure kernel
-        sequence over fixed buffers, replayable from a hipGraph."""
+        sequence over fixed buffers, replayable from a hipGraph.  Six launches per layer for a single sequence (LoRA
+        merged): q|k|v GEMM with the input RMSNorm on its A load, RoPE + KV append, attention, o_proj (+ residual), gate|up GEMM with the
+        post-attention RMSNorm on its A load, down_proj (+ residual) with SwiGLU on its A load."""
         c = self.config.llama
         F = _Direct
         N, H = st.x.shape
+        if st.fused:
+            onload = N == 1      # RMSNorm / SwiGLU on the skinny GEMM's A load: every wave redoes the transform, a small win for one row (4.40 -> 4.32 ms
+            #                      per token), VALU-bound from two rows on (measured 6.0 ms at N = 2): those keep the separate launches
+            cos, sin, _ = self._rope(st.cap)
+            hd, heads = c.head_dim, c.heads
+            x = st.x
+            att = torch.empty((N, H), device=x.device, dtype=BF16)
+            for i in range(c.layers):
+                p = f"model.layers.{i}."
+                wq = st.qkv_w[i] if st.qkv_w is not None else self._wcat(p + "qkv", [p + f"self_attn.{n}_proj.weight" for n in "qkv"], F)
+                if onload:
+                    qkv = ops.gemm(x, wq, a_norm_w=self._w(p + "input_layernorm.weight", F), a_norm_eps=c.eps)
+                else:
+                    qkv = ops.gemm(F.norm(x, self._w(p + "input_layernorm.weight", F), None, c.eps, True), wq)
+                ld = qkv.stride(0)
+                ops.rope_kv_append_(qkv, cos, sin, st.k[i], st.v[i], st.pos, heads, hd)
+                ops.attention(qkv, st.k[i], st.v[i], att, batch=N, heads=heads, Nq=1, Nk=st.cap, head_dim=hd, q_strides=(ld, hd, ld),
+                              k_strides=(st.cap * H, hd, H), v_strides=(st.cap * H, hd, H), o_strides=(H, hd, H), nk_dev=st.pos[1:])
+                x = ops.gemm(att, self._w(p + "self_attn.o_proj.weight", F), residual=x)
+                wgu = self._wcat(p + "gate_up", [p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"], F)
+                if onload:
+                    gu = ops.gemm(x, wgu, a_norm_w=self._w(p + "post_attention_layernorm.weight", F), a_norm_eps=c.eps)
+                    x = ops.gemm(gu, self._w(p + "mlp.down_proj.weight", F), residual=x, a_swiglu=True)
+                else:
+                    gu = ops.gemm(F.norm(x, self._w(p + "post_attention_layernorm.weight", F), None, c.eps, True), wgu)
+                    x = ops.gemm(ops.swiglu(gu, c.inter), self._w(p + "mlp.down_proj.weight", F), residual=x)
+            ops.norm(x, self._w("model.norm.weight", F), None, eps=c.eps, rms=True, out=st.hidden)
+            ops.gemm(st.hidden, self._w("lm_head.weight", F), out=st.logits)
+            st.pos.add_(1)
+            return
         cos, sin, _ = self._rope(st.cap)
         s = c.lora_alpha / c.lora_r if c.lora_r > 0 else 0.0
         hd, heads = c.head_dim, c.heads
@@ -93,7 +156,7 @@ class GenerateMixin:
         st.graph.replay()
 
     @torch.no_grad()
-    def generate(self, images_clip, input_ids, max_new_tokens=32, eos_token_id=2, pad_token_id=0, use_graph=True):
+    def generate(self, images_clip, input_ids, max_new_tokens=32, eos_token_id=2, pad_token_id=0, use_graph=True, fuse_decode=True):
         """Greedy generation.  images_clip bf16 [N, 3, 224, 224] (one image per sequence), input_ids int64 [N, L] holding exactly one
         IMAGE_TOKEN_INDEX each, no padding (evaluate() passes no attention mask).
         -> (sequences int64 [N, L + n_new], hidden bf16 [N, T + n_new - 1, H]: final-norm hidden state of every token but the last)."""
@@ -119,6 +182,10 @@ class GenerateMixin:
             st.k[i, :, :T].copy_(qkv[:, H:2 * H].view(N, T, H))
             st.v[i, :, :T].copy_(qkv[:, 2 * H:3 * H].view(N, T, H))
         hidden_p = self._llama(embeds, plan.key_mask, F, kv_out=keep_kv)          # [N, T, H]
+        fused = bool(fuse_decode)
+        if fused != st.fused:
+            st.fused, st.graph, st.warm = fused, None, False                      # a different kernel sequence: capture again
+        st.qkv_w = self._merge_lora() if (fused and cl.lora_r > 0) else None
         st.pos.copy_(torch.tensor([T, T + 1], dtype=torch.int32))
         hidden = torch.empty((N, T + max_new_tokens - 1, H), device=dev, dtype=BF16)
         hidden[:, :T] = hidden_p

@@ -42,14 +42,17 @@ def _workspace(dev, stream):
 
 
 def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alpha=1.0, out_f32=False, trans_a=False, trans_w=False,
-         a2=None, w2=None, accumulate=False):
+         a2=None, w2=None, accumulate=False, a_norm_w=None, a_norm_eps=1e-6, a_swiglu=False):
     """out[M,N] = residual + gamma * act(alpha * A @ W^T + bias) with A = a [M,K] (or a^T when trans_a: a stored [K,M]) and
     W = w [N,K] (or w^T when trans_w: w stored [K,N]).  2-D bf16 operands, last dim contiguous.  a2 [M,64] / w2 [N,64]: optional
     extension of the contraction (A @ W^T + a2 @ w2^T), e.g. zero-padded low-rank updates.  accumulate (fp32 `out` only):
-    out += result (gradient accumulation)."""
+    out += result (gradient accumulation).  M <= 8 only (decode steps): a_norm_w -> A := RMSNorm(A) * a_norm_w on load; a_swiglu ->
+    a holds [gate | up] rows of width 2K and A := silu(gate) * up on load."""
     _req(a); _req(w)
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    if a_swiglu:
+        K //= 2
     N, Kw = (w.shape[1], w.shape[0]) if trans_w else w.shape
     assert K == Kw, (a.shape, w.shape, trans_a, trans_w)
     if out is None:
@@ -67,6 +70,10 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alp
                  ldr=0 if residual is None else residual.stride(0),
                  batch=1, strideA=0, strideW=0, strideC=0, alpha=alpha, act=act, out_f32=1 if out_f32 else 0,
                  trans_a=1 if trans_a else 0, trans_w=1 if trans_w else 0, accumulate=1 if accumulate else 0)
+    if a_norm_w is not None:
+        g.a_norm_w, g.a_norm_eps = _req(a_norm_w).data_ptr(), a_norm_eps
+    if a_swiglu:
+        g.a_swiglu = 1
     if a2 is not None:
         _req(a2); _req(w2)
         assert a2.shape == (M, 64) and w2.shape == (N, 64) and a2.stride(1) == 1 and w2.stride(1) == 1

@@ -10,8 +10,9 @@ DEV = "cuda"
 MARGIN = 0.08          # logits of the tiny model are O(1); the bf16 path moves them by ~1e-2
 
 
-def check_generate(max_new=6):
-    cfg = cases.tiny_lisa_cfg()
+def check_generate(max_new=6, lora_r=0):
+    """lora_r = 8: the decode steps run on q|k|v weights with the LoRA deltas merged in (prefill: the unmerged training forward)."""
+    cfg = cases.tiny_lisa_cfg(lora_r=lora_r)
     m, sd = mc.build_pair(cfg)
     batch = mc._round_batch(cases.tiny_lisa_batch())
     clip, ids0 = batch["images_clip"][:2], batch["input_ids"][:2]
@@ -40,6 +41,18 @@ def check_generate(max_new=6):
             k = min(same_upto[n], max_new - 1)                         # decode step j is fed token j: valid while tokens 0..j agree
             if k > 0:
                 res.append((f"generate: decode hidden seq {n} ({k} cached steps)", (hid_g[n, Tp:Tp + k] - hid_r[n, Tp:Tp + k]).abs().max().item(), 3e-2 * scale))
+        # one sequence alone: the decode step with RMSNorm / SwiGLU on the skinny GEMM's A load (N = 1 only) against the same oracle run
+        seq_1, hid_1 = m.generate(clip[:1].to(DEV), ids0[:1].to(DEV), max_new_tokens=max_new, eos_token_id=None)
+        seq_1, hid_1 = seq_1.cpu(), hid_1.float().cpu()
+        k = 0
+        while k < max_new and seq_1[0, L + k] == seq_r[0, L + k]:
+            k += 1
+        if k < max_new:
+            res.append((f"generate: single sequence first differing step {k} has margin {float(mg[0, k]):.3f} (must be undecidable)", float(mg[0, k]), MARGIN))
+        res.append(("generate: single sequence steps compared (need >= 3)", 3.0 - k, 0.0))
+        k = min(k, max_new - 1)
+        if k > 0:
+            res.append((f"generate: single-sequence decode hidden ({k} cached steps)", (hid_1[0, Tp:Tp + k] - hid_r[0, Tp:Tp + k]).abs().max().item(), 3e-2 * scale))
         # eos / pad rule: sequence 0 finishes at its third new token
         if min(same_upto) >= 3:
             eos = int(seq_r[0, L + 2])

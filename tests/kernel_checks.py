@@ -63,6 +63,17 @@ def check_gemm():
     o = acc0.clone().to(DEV)
     ops.gemm(big.to(DEV)[:, 256:512], w.to(DEV), out=o, out_f32=True, accumulate=True)
     out.append(("gemm skinny f32-out accumulate strided-A", err(o, acc0 + big[:, 256:512].float() @ w.float().t()), 1e-3))
+    # decode-step fusions of the skinny route: RMSNorm / SwiGLU applied to the A rows on load == norm / swiglu launch followed by the GEMM
+    for M, N, K in ((1, 4096, 4096), (4, 530, 1032), (7, 256, 24)):
+        x, nw, w, r = rnd(M, K, seed=151, scale=2.0), rnd(K, seed=152), rnd(N, K, seed=153, scale=1 / math.sqrt(K)), rnd(M, N, seed=154)
+        xd, nwd, wd, rd = x.to(DEV), nw.to(DEV), w.to(DEV), r.to(DEV)
+        two = ops.gemm(ops.norm(xd, nwd, None, eps=1e-6, rms=True), wd, residual=rd)
+        one = ops.gemm(xd, wd, residual=rd, a_norm_w=nwd, a_norm_eps=1e-6)
+        out.append((f"gemm skinny + RMSNorm on load {M}x{N}x{K} == norm then gemm", 0.0 if torch.equal(one, two) else 1.0, 0.0))
+        gu = rnd(M, 2 * K, seed=155, scale=1.5).to(DEV)
+        two = ops.gemm(ops.swiglu(gu, K), wd, residual=rd)
+        one = ops.gemm(gu, wd, residual=rd, a_swiglu=True)
+        out.append((f"gemm skinny + SwiGLU on load {M}x{N}x{K} == swiglu then gemm", 0.0 if torch.equal(one, two) else 1.0, 0.0))
     # fp32 output, odd ldc, alpha, strided A (a view into a wider buffer)
     M, N, K = 200, 27, 80
     big = rnd(M, 3 * K, seed=6)

@@ -14,6 +14,11 @@ def test_kv_cache_greedy_generation_matches_oracle():
     _assert(gc.check_generate())
 
 
+def test_kv_cache_generation_with_merged_lora_matches_oracle():
+    from tests import generate_checks as gc
+    _assert(gc.check_generate(lora_r=8))
+
+
 def test_sam_mask_decoder_and_postprocess_match_oracle():
     from tests import sam_decoder_checks as sc
     _assert(sc.check_sam_decoder())
