@@ -161,6 +161,15 @@ int llmseg_rope(void* x, const float* cos, const float* sin, int64_t rows, int64
 int llmseg_rope_kv_append(void* qkv, int64_t ld, const float* cos, const float* sin, void* kcache, void* vcache, int64_t cache_stride_n,
                           const int32_t* pos_dev, int64_t N, int32_t heads, int32_t head_dim, void* stream);
 
+/* The same decode step with the attention in the launch (head_dim 128): with pos = *pos_dev, k is rotated and written to kcache[n][pos], v
+ * copied to vcache[n][pos], and out[n][h*128 ..] = softmax(rot(q_h) K_h^T * scale) V_h over the pos + 1 cached keys (HF LlamaAttention
+ * with past_key_values and a one-token query: no mask).  qkv is not modified.  scratch (optional, fp32, >= N * heads * splits * 130 * 4
+ * bytes for splits = min(16, 256 / (N * heads))): the keys of a head are split over workgroups until the launch covers the chip and a
+ * second launch merges the partial softmaxes; without scratch one workgroup walks all keys of a head. */
+int llmseg_decode_attn(const void* qkv, int64_t ld, const float* cos, const float* sin, void* kcache, void* vcache, int64_t cache_stride_n,
+                       const int32_t* pos_dev, int64_t N, int32_t heads, int32_t head_dim, float scale, void* out, int64_t ldo,
+                       void* scratch, int64_t scratch_bytes, void* stream);
+
 /* y[i] = act(x[i]), bf16, n % 8 == 0, in place allowed (the GELU between LayerNorm2d and the second transposed convolution of SAM's
  * mask decoder, mask_decoder.py:53-63: every other activation on the path rides in a GEMM epilogue) */
 int llmseg_act(const void* x, void* y, int64_t n, int32_t act, void* stream);

@@ -65,6 +65,7 @@ SIGNATURES = {
     "llmseg_norm": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _f32, C.c_int, _p, _p],
     "llmseg_rope": [_p, _p, _p, _i64, _i64, _i32, _i32, _i64, _p],
     "llmseg_rope_kv_append": [_p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _p],
+    "llmseg_decode_attn": [_p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _f32, _p, _i64, _p, _i64, _p],
     "llmseg_swiglu": [_p, _p, _i64, _i64, _i64, _i64, _p],
     "llmseg_act": [_p, _p, _i64, _i32, _p],
     "llmseg_sam_postprocess": [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],

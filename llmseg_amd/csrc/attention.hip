@@ -16,6 +16,8 @@
 // (conflict-free ds_read_b128 on gfx950's 16-lane service groups).
 #include "common.h"
 #include "llmseg_hip.h"
+#include <algorithm>
+#define AL16(p) ((((uintptr_t)(p)) & 15) == 0)
 
 namespace {
 
@@ -640,6 +642,150 @@ int launch_hd(const AttnP& p, hipStream_t s) {
 }
 
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Decode step (one new token per sequence): RoPE of q and k at the device-side position, k / v appended to the cache, and
+// softmax(q K^T * scale) V over the pos + 1 cached keys, in one launch (+ a merge when the keys of a head are split over workgroups).
+// A CU takes only ~16 B/clk of missing lines, so the ~170 KB of K and V rows of one head (330 keys) are spread over `splits` workgroups
+// until the launch covers the chip.  16 lanes own one key (8 dims each, one 16-byte load per K and V row); every 16-lane group runs an
+// online softmax over its keys with all of a trip's K and V rows requested together (one HBM round trip per 64 keys per workgroup).
+struct DecP {
+  const bf16_t* qkv; long ld;
+  const float *cs, *sn;
+  bf16_t *kc, *vc; long cstride;
+  const int32_t* pos_dev;
+  int heads, splits;
+  float scale;
+  bf16_t* out; long ldo;
+  float* part;                                         // [N][heads][splits][130]: 128 unnormalised outputs, running max, running sum
+};
+
+__global__ __launch_bounds__(256) void decode_attn_kernel(DecP p) {
+  constexpr int HD = 128, UN = 4;
+  __shared__ float qs[HD];
+  __shared__ __align__(16) bf16_t knew[HD], vnew[HD];
+  __shared__ float red[4][HD], rm[4], rl[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = tid >> 4, c = tid & 15;
+  const int h = blockIdx.x / p.splits, sp = blockIdx.x - h * p.splits, n = blockIdx.y;
+  const long D = (long)p.heads * HD;
+  const int pos = *p.pos_dev, nk = pos + 1;
+  const int per = ((nk + p.splits - 1) / p.splits + 15) & ~15;
+  const int j0 = sp * per, j1 = min(nk, j0 + per);
+  const bool owner = pos >= j0 && pos < j1;              // the workgroup whose key range holds the new token appends it
+  const bf16_t* row = p.qkv + (long)n * p.ld + (long)h * HD;
+  bf16_t* kb = p.kc + (long)n * p.cstride + (long)h * HD;
+  bf16_t* vb = p.vc + (long)n * p.cstride + (long)h * HD;
+  if (tid < 128) {
+    const int i = tid & 63;
+    if (tid < 64 || owner) {
+      const bf16_t* src = row + (tid < 64 ? 0 : D);
+      const float a = bf2f(src[i]), b = bf2f(src[i + 64]);
+      const float cv = p.cs[(long)pos * 64 + i], sv = p.sn[(long)pos * 64 + i];
+      const bf16_t o1 = f2bf(a * cv - b * sv), o2 = f2bf(b * cv + a * sv);
+      if (tid < 64) { qs[i] = bf2f(o1); qs[i + 64] = bf2f(o2); }
+      else {
+        knew[i] = o1; knew[i + 64] = o2;
+        kb[(long)pos * D + i] = o1; kb[(long)pos * D + i + 64] = o2;
+      }
+    }
+  } else if (tid < 192 && owner) {
+    const int i = tid - 128;
+    const bf16_t v1 = row[2 * D + i], v2 = row[2 * D + i + 64];
+    vnew[i] = v1; vnew[i + 64] = v2;
+    vb[(long)pos * D + i] = v1; vb[(long)pos * D + i + 64] = v2;
+  }
+  __syncthreads();
+  float q[8], acc[8], m = -1e30f, l = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { q[e] = qs[c * 8 + e]; acc[e] = 0.f; }
+  for (int jb = j0; jb < j1; jb += 16 * UN) {
+    uint4 kk[UN], vv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int j = jb + u * 16 + g;
+      kk[u] = make_uint4(0, 0, 0, 0); vv[u] = kk[u];
+      if (j < j1) {
+        if (j == pos) { kk[u] = *reinterpret_cast<const uint4*>(knew + c * 8); vv[u] = *reinterpret_cast<const uint4*>(vnew + c * 8); }
+        else { kk[u] = *reinterpret_cast<const uint4*>(kb + (long)j * D + c * 8); vv[u] = *reinterpret_cast<const uint4*>(vb + (long)j * D + c * 8); }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int j = jb + u * 16 + g;
+      float kf[8], vf[8], s = 0.f;
+      unpack8(kk[u], kf);
+      unpack8(vv[u], vf);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s = fmaf(q[e], kf[e], s);
+      s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+      const bool valid = j < j1;
+      s = valid ? s * p.scale : -1e30f;
+      const float mn = fmaxf(m, s), corr = __expf(m - mn), pj = valid ? __expf(s - mn) : 0.f;
+      l = l * corr + pj;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = acc[e] * corr + pj * vf[e];
+      m = mn;
+    }
+  }
+  // the four key groups of a wave, then the four waves
+  float mw = fmaxf(m, __shfl_xor(m, 16));
+  mw = fmaxf(mw, __shfl_xor(mw, 32));
+  const float f = __expf(m - mw);
+  l *= f; l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { float a = acc[e] * f; a += __shfl_xor(a, 16); a += __shfl_xor(a, 32); acc[e] = a; }
+  if (lane < 16) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave][c * 8 + e] = acc[e];
+    if (lane == 0) { rm[wave] = mw; rl[wave] = l; }
+  }
+  __syncthreads();
+  if (tid < HD) {
+    const float M = fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3]));
+    float L = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const float e = __expf(rm[w] - M); L += e * rl[w]; o += e * red[w][tid]; }
+    if (p.splits == 1) p.out[(long)n * p.ldo + (long)h * HD + tid] = f2bf(o / L);
+    else {
+      float* pp = p.part + (((long)n * p.heads + h) * p.splits + sp) * 130;
+      pp[tid] = o;
+      if (tid == 0) { pp[128] = M; pp[129] = L; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(128) void decode_attn_merge_kernel(const float* __restrict__ part, int heads, int splits, bf16_t* __restrict__ out, long ldo) {
+  const int h = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const float* pp = part + ((long)n * heads + h) * splits * 130;
+  float M = -1e30f;
+  for (int s = 0; s < splits; ++s) M = fmaxf(M, pp[s * 130 + 128]);
+  float L = 0.f, o = 0.f;
+  for (int s = 0; s < splits; ++s) { const float e = __expf(pp[s * 130 + 128] - M); L += e * pp[s * 130 + 129]; o += e * pp[s * 130 + tid]; }
+  out[(long)n * ldo + (long)h * 128 + tid] = f2bf(o / L);
+}
+
+extern "C" int llmseg_decode_attn(const void* qkv, int64_t ld, const float* cos, const float* sin, void* kcache, void* vcache, int64_t cache_stride_n,
+                                  const int32_t* pos_dev, int64_t N, int32_t heads, int32_t head_dim, float scale, void* out, int64_t ldo,
+                                  void* scratch, int64_t scratch_bytes, void* stream) {
+  LL_CHECK(qkv && cos && sin && kcache && vcache && pos_dev && out && N > 0 && N < 65536 && heads > 0, "decode_attn: bad arguments");
+  LL_CHECK(head_dim == 128, "decode_attn: head_dim 128 only (use llmseg_rope_kv_append + llmseg_attn_fwd otherwise)");
+  LL_CHECK((ld & 7) == 0 && (cache_stride_n & 7) == 0 && AL16(qkv) && AL16(kcache) && AL16(vcache), "decode_attn: 16-byte alignment required");
+  int splits = 1;
+  if (scratch) {
+    splits = (int)std::min<int64_t>(16, std::max<int64_t>(1, 256 / (N * heads)));
+    while (splits > 1 && (int64_t)N * heads * splits * 130 * 4 > scratch_bytes) --splits;
+  }
+  DecP p{(const bf16_t*)qkv, (long)ld, cos, sin, (bf16_t*)kcache, (bf16_t*)vcache, (long)cache_stride_n, pos_dev, heads, splits, scale,
+         (bf16_t*)out, (long)ldo, (float*)scratch};
+  hipLaunchKernelGGL(decode_attn_kernel, dim3(heads * splits, (unsigned)N), dim3(256), 0, (hipStream_t)stream, p);
+  LL_LAUNCH_CHECK("decode_attn");
+  if (splits > 1) {
+    hipLaunchKernelGGL(decode_attn_merge_kernel, dim3(heads, (unsigned)N), dim3(128), 0, (hipStream_t)stream, (const float*)scratch, heads, splits,
+                       (bf16_t*)out, (long)ldo);
+    LL_LAUNCH_CHECK("decode_attn_merge");
+  }
+  return LLMSEG_OK;
+}
 
 extern "C" int llmseg_attn_set_variant(int v) {
   g_attn_win_new = v & 1;

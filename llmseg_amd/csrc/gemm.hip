@@ -709,6 +709,9 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
 // product, which is this kernel's own either way.
 template <int MT, int AT>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int out_f32) {
+  constexpr int KS = MT >= 4 ? 1 : 2;                // K-steps (512 columns) per trip
+  constexpr int STEP = KS * 512;
+  constexpr int XB = AT == 2 ? MT : 1;               // second operand of the A transform: the norm gain (one row) or the up half (per row)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = (blockIdx.x * 4 + wave) * 4;
   if (n0 >= p.N) return;
@@ -721,36 +724,38 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int out_f32) 
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[r][m] = 0.f;
   const int K = p.K;
-  float rstd[MT];
-  if constexpr (AT == 1) {
+  auto loadw = [&](uint4 (&w)[KS][4], int k) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const bf16_t* ar = p.A + (long)min(m, p.M - 1) * p.lda;
-      float ss = 0.f, f[8];
-      for (int k = lane * 8; k < K; k += 512) {
-        unpack8(*reinterpret_cast<const uint4*>(ar + k), f);
+    for (int t = 0; t < KS; ++t)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+      for (int r = 0; r < 4; ++r) w[t][r] = *reinterpret_cast<const uint4*>(wr[r] + min(k + t * 512, K - 8));   // branch-free: past the end a
+  };                                                                                                            // valid chunk is re-read, its A chunk is zero
+  // raw A chunks of a trip (the transform runs at FMA time): xa = the 8 A values, xb = the norm gain / the up half
+  auto loadx = [&](uint4 (&xa)[KS][MT], uint4 (&xb)[KS][XB], int k) {
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+      const int kk = k + t * 512, kc = min(kk, K - 8);
+      const bool ok = kk < K;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const bf16_t* ar = p.A + (long)min(m, p.M - 1) * p.lda;
+        const uint4 v = *reinterpret_cast<const uint4*>(ar + kc);
+        xa[t][m] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+        if constexpr (AT == 2) xb[t][m] = *reinterpret_cast<const uint4*>(ar + K + kc);
       }
-      rstd[m] = rsqrtf(wave_sum(ss) / (float)K + p.a_norm_eps);
+      if constexpr (AT == 1) xb[t][0] = *reinterpret_cast<const uint4*>(p.a_norm_w + kc);
     }
-  }
-  // the (transformed) 8 A values of row m at column k, as bf16 pairs
-  auto load_a = [&](int m, int k) -> uint4 {
-    const bf16_t* ar = p.A + (long)min(m, p.M - 1) * p.lda;
-    if constexpr (AT == 0) return *reinterpret_cast<const uint4*>(ar + k);
-    float f[8], o[8];
-    unpack8(*reinterpret_cast<const uint4*>(ar + k), f);
-    if constexpr (AT == 1) {
-      float g[8];
-      unpack8(*reinterpret_cast<const uint4*>(p.a_norm_w + k), g);
+  };
+  float rstd[MT];
+  auto xform = [&](const uint4& a, const uint4& b, int m) -> uint4 {
+    if constexpr (AT == 0) return a;
+    float f[8], g[8], o[8];
+    unpack8(a, f);
+    unpack8(b, g);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = g[e] * bf2f(f2bf(f[e] * rstd[m]));
-    } else {
-      float u[8];
-      unpack8(*reinterpret_cast<const uint4*>(ar + K + k), u);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = f[e] / (1.f + __expf(-f[e])) * u[e];
+    for (int e = 0; e < 8; ++e) {
+      if constexpr (AT == 1) o[e] = g[e] * bf2f(f2bf(f[e] * rstd[m]));
+      else o[e] = f[e] / (1.f + __expf(-f[e])) * g[e];
     }
     return pack8(o);
   };
@@ -760,28 +765,60 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int out_f32) 
     a = fmaf(__uint_as_float(w.z << 16), __uint_as_float(x.z << 16), a); a = fmaf(__uint_as_float(w.z & 0xffff0000u), __uint_as_float(x.z & 0xffff0000u), a);
     a = fmaf(__uint_as_float(w.w << 16), __uint_as_float(x.w << 16), a); a = fmaf(__uint_as_float(w.w & 0xffff0000u), __uint_as_float(x.w & 0xffff0000u), a);
   };
+  auto compute = [&](const uint4 (&w)[KS][4], const uint4 (&xa)[KS][MT], const uint4 (&xb)[KS][XB]) {
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const uint4 x = xform(xa[t][m], xb[t][AT == 2 ? m : 0], m);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fma8(w[t][r], x, acc[r][m]);
+      }
+  };
+  // two trips in flight: the loads of trip i + 1 are issued before the FMAs of trip i; the first W rows are requested before the
+  // RMSNorm prologue, so that a cold A (written by the previous kernel on another XCD) does not delay the weight stream
+  uint4 wA[KS][4], wB[KS][4], xA[KS][MT], xB[KS][MT <= 2 ? MT : 1], gA[KS][XB], gB[KS][MT <= 2 ? XB : 1];
   int k = lane * 8;
-  for (; k + 512 < K; k += 1024) {                   // two K-steps per trip: all loads issued before the first FMA
-    uint4 w0[4], w1[4], x0[MT], x1[MT];
+  loadw(wA, k);
+  if constexpr (AT == 1) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { w0[r] = *reinterpret_cast<const uint4*>(wr[r] + k); w1[r] = *reinterpret_cast<const uint4*>(wr[r] + k + 512); }
+    for (int m = 0; m < MT; ++m) {
+      const bf16_t* ar = p.A + (long)min(m, p.M - 1) * p.lda;
+      float ss = 0.f, f[8];
+      for (int kk = lane * 8; kk < K; kk += 512) {
+        unpack8(*reinterpret_cast<const uint4*>(ar + kk), f);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) { x0[m] = load_a(m, k); x1[m] = load_a(m, k + 512); }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) { fma8(w0[r], x0[m], acc[r][m]); fma8(w1[r], x1[m], acc[r][m]); }
+        for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+      }
+      rstd[m] = rsqrtf(wave_sum(ss) / (float)K + p.a_norm_eps);
+    }
   }
-  if (k < K) {
-    uint4 w0[4], x0[MT];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) w0[r] = *reinterpret_cast<const uint4*>(wr[r] + k);
-#pragma unroll
-    for (int m = 0; m < MT; ++m) x0[m] = load_a(m, k);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) fma8(w0[r], x0[m], acc[r][m]);
+  const int trips = (K + STEP - 1) / STEP;
+  if constexpr (MT <= 2) {
+    loadx(xA, gA, k);
+    for (int t = 0; t < trips; t += 2) {
+      loadw(wB, k + STEP);
+      loadx(xB, gB, k + STEP);
+      compute(wA, xA, gA);
+      k += STEP;
+      if (t + 1 >= trips) break;
+      loadw(wA, k + STEP);
+      loadx(xA, gA, k + STEP);
+      compute(wB, xB, gB);
+      k += STEP;
+    }
+  } else {                                           // 4-8 rows: A chunks (cache hits) single-buffered, requested ahead of the next W rows
+    for (int t = 0; t < trips; t += 2) {             // (loads return in order: a later request would wait for the prefetch)
+      loadx(xA, gA, k);
+      loadw(wB, k + STEP);
+      compute(wA, xA, gA);
+      k += STEP;
+      if (t + 1 >= trips) break;
+      loadx(xA, gA, k);
+      loadw(wA, k + STEP);
+      compute(wB, xA, gA);
+      k += STEP;
+    }
   }
   float mine = 0.f;                                  // lane r * MT + m keeps C[m][n0 + r]
 #pragma unroll

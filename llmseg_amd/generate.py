@@ -85,6 +85,7 @@ class GenerateMixin:
             hd, heads = c.head_dim, c.heads
             x = st.x
             att = torch.empty((N, H), device=x.device, dtype=BF16)
+            scratch = ops.decode_attn_scratch(N, heads, x.device) if hd == 128 else None
             for i in range(c.layers):
                 p = f"model.layers.{i}."
                 wq = st.qkv_w[i] if st.qkv_w is not None else self._wcat(p + "qkv", [p + f"self_attn.{n}_proj.weight" for n in "qkv"], F)
@@ -92,10 +93,13 @@ class GenerateMixin:
                     qkv = ops.gemm(x, wq, a_norm_w=self._w(p + "input_layernorm.weight", F), a_norm_eps=c.eps)
                 else:
                     qkv = ops.gemm(F.norm(x, self._w(p + "input_layernorm.weight", F), None, c.eps, True), wq)
-                ld = qkv.stride(0)
-                ops.rope_kv_append_(qkv, cos, sin, st.k[i], st.v[i], st.pos, heads, hd)
-                ops.attention(qkv, st.k[i], st.v[i], att, batch=N, heads=heads, Nq=1, Nk=st.cap, head_dim=hd, q_strides=(ld, hd, ld),
-                              k_strides=(st.cap * H, hd, H), v_strides=(st.cap * H, hd, H), o_strides=(H, hd, H), nk_dev=st.pos[1:])
+                if hd == 128:                                  # RoPE + KV append + attention over the cache: one launch (+ the split's merge)
+                    ops.decode_attn(qkv, cos, sin, st.k[i], st.v[i], st.pos, heads, hd, out=att, scratch=scratch)
+                else:
+                    ld = qkv.stride(0)
+                    ops.rope_kv_append_(qkv, cos, sin, st.k[i], st.v[i], st.pos, heads, hd)
+                    ops.attention(qkv, st.k[i], st.v[i], att, batch=N, heads=heads, Nq=1, Nk=st.cap, head_dim=hd, q_strides=(ld, hd, ld),
+                                  k_strides=(st.cap * H, hd, H), v_strides=(st.cap * H, hd, H), o_strides=(H, hd, H), nk_dev=st.pos[1:])
                 x = ops.gemm(att, self._w(p + "self_attn.o_proj.weight", F), residual=x)
                 wgu = self._wcat(p + "gate_up", [p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"], F)
                 if onload:

@@ -172,6 +172,26 @@ def rope_kv_append_(qkv, cos, sin, kcache, vcache, pos_dev, heads, head_dim):
     return qkv
 
 
+def decode_attn(qkv, cos, sin, kcache, vcache, pos_dev, heads, head_dim, out=None, scale=None, scratch=None):
+    """Decode step in one launch (+ merge): k rotated / v copied into the caches at position *pos_dev, out[n] = attention of the rotated q
+    over the pos + 1 cached keys.  head_dim 128.  scratch: fp32 buffer from decode_attn_scratch (None = one workgroup per head)."""
+    N = qkv.shape[0]
+    assert kcache.shape == vcache.shape and kcache.shape[0] == N and kcache.stride(1) == heads * head_dim and pos_dev.dtype == torch.int32
+    if out is None:
+        out = torch.empty((N, heads * head_dim), device=qkv.device, dtype=torch.bfloat16)
+    _lib.check(_lib.load().llmseg_decode_attn(_ptr(qkv), qkv.stride(0), _ptr(cos), _ptr(sin), _ptr(kcache), _ptr(vcache), kcache.stride(0), _ptr(pos_dev),
+                                              N, heads, head_dim, float(scale if scale is not None else head_dim ** -0.5), _ptr(out), out.stride(0),
+                                              _ptr(scratch) if scratch is not None else None, scratch.numel() * 4 if scratch is not None else 0,
+                                              _stream()), "decode_attn")
+    return out
+
+
+def decode_attn_scratch(N, heads, device):
+    """fp32 scratch of decode_attn's key split: [N][heads][splits][130]."""
+    splits = min(16, max(1, 256 // (N * heads)))
+    return torch.empty((N * heads * splits * 130,), device=device, dtype=torch.float32) if splits > 1 else None
+
+
 def act_(x, act):
     """In-place elementwise activation (bf16, contiguous)."""
     assert x.is_contiguous() and x.numel() % 8 == 0

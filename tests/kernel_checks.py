@@ -321,6 +321,44 @@ def check_attention():
     return out
 
 
+def check_decode_attn():
+    """Decode step in one launch: RoPE + KV append + one-query attention over the cache, with and without the key split."""
+    out = []
+    hd, cap = 128, 700
+    g = torch.Generator().manual_seed(3)
+    ang = torch.rand(cap, hd // 2, generator=g) * 6.28
+    cos, sin = ang.cos().float(), ang.sin().float()
+    for N, H, pos, split in [(1, 32, 329, True), (1, 32, 329, False), (2, 4, 0, True), (3, 2, 15, True), (2, 8, 16, True), (4, 32, 640, True), (1, 2, 77, True)]:
+        D = H * hd
+        qkv = rnd(N, 3 * D, seed=pos + N)
+        kc, vc = rnd(N, cap, D, seed=pos + 11), rnd(N, cap, D, seed=pos + 12)
+        posd = torch.tensor([pos, pos + 1], dtype=torch.int32, device=DEV)
+        kd, vd = kc.to(DEV), vc.to(DEV)
+        scratch = ops.decode_attn_scratch(N, H, DEV) if split else None
+        o = ops.decode_attn(qkv.to(DEV), cos.to(DEV), sin.to(DEV), kd, vd, posd, H, hd, scratch=scratch)
+        x = qkv.float().view(N, 3, H, hd)
+
+        def rot(t):
+            a, b = t[..., :hd // 2], t[..., hd // 2:]
+            return torch.cat([a * cos[pos] - b * sin[pos], b * cos[pos] + a * sin[pos]], -1).to(BF).float()
+        q, kn, vn = rot(x[:, 0]), rot(x[:, 1]), x[:, 2]
+        kr, vr = kc.clone(), vc.clone()
+        kr[:, pos] = kn.reshape(N, D).to(BF)
+        vr[:, pos] = vn.reshape(N, D).to(BF)
+        K = kr[:, :pos + 1].float().view(N, pos + 1, H, hd).transpose(1, 2)
+        V = vr[:, :pos + 1].float().view(N, pos + 1, H, hd).transpose(1, 2)
+        ref = _attn_ref(q[:, :, None, :], K, V, hd ** -0.5).reshape(N, D)
+        tag = f"N={N} heads={H} pos={pos}" + ("" if split else " one workgroup per head")
+        out.append((f"decode_attn out {tag}", err(o, ref), tol_bf16(ref, 2.0)))
+        out.append((f"decode_attn k cache {tag}", err(kd, kr), tol_bf16(kr, 1.0)))
+        out.append((f"decode_attn v cache {tag}", err(vd, vr), 0.0))
+        # the two-launch route (rope_kv_append + attn_fwd with a device-side key count)
+        k2, v2, q2 = kc.to(DEV), vc.to(DEV), qkv.to(DEV)
+        ops.rope_kv_append_(q2, cos.to(DEV), sin.to(DEV), k2, v2, posd, H, hd)
+        out.append((f"decode_attn k cache == rope_kv_append {tag}", err(kd, k2.cpu()), 0.0))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------- pointwise
 def check_pointwise():
     out = []

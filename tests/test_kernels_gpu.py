@@ -31,6 +31,11 @@ def test_attention():
     _run(kc.check_attention)
 
 
+def test_decode_attn():
+    from tests import kernel_checks as kc
+    _run(kc.check_decode_attn)
+
+
 def test_pointwise():
     from tests import kernel_checks as kc
     _run(kc.check_pointwise)
