@@ -757,10 +757,20 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecP p) {
 __global__ __launch_bounds__(128) void decode_attn_merge_kernel(const float* __restrict__ part, int heads, int splits, bf16_t* __restrict__ out, long ldo) {
   const int h = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   const float* pp = part + ((long)n * heads + h) * splits * 130;
-  float M = -1e30f;
-  for (int s = 0; s < splits; ++s) M = fmaxf(M, pp[s * 130 + 128]);
+  float mv[16], lv[16], ov[16], M = -1e30f;            // every partial requested before the first use: one memory round trip
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int sc = min(s, splits - 1);
+    mv[s] = pp[sc * 130 + 128]; lv[s] = pp[sc * 130 + 129]; ov[s] = pp[sc * 130 + tid];
+  }
+#pragma unroll
+  for (int s = 0; s < 16; ++s) M = fmaxf(M, mv[s]);
   float L = 0.f, o = 0.f;
-  for (int s = 0; s < splits; ++s) { const float e = __expf(pp[s * 130 + 128] - M); L += e * pp[s * 130 + 129]; o += e * pp[s * 130 + tid]; }
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const float e = s < splits ? __expf(mv[s] - M) : 0.f;
+    L += e * lv[s]; o += e * ov[s];
+  }
   out[(long)n * ldo + (long)h * 128 + tid] = f2bf(o / L);
 }
 

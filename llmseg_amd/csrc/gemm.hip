@@ -707,13 +707,14 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
 // after the weight multiply, as the stored bf16 output of the norm kernel has);  2 = A := silu(g) * u of rows [g | u] of width 2K
 // (llmseg_swiglu's arithmetic, rounded to bf16).  Both reproduce the two-launch result bit for bit up to the order of the fp32 dot
 // product, which is this kernel's own either way.
-template <int MT, int AT>
+template <int MT, int AT, bool SK = false>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int out_f32) {
   constexpr int KS = MT >= 4 ? 1 : 2;                // K-steps (512 columns) per trip
   constexpr int STEP = KS * 512;
+  constexpr int ADV = SK ? 4 * STEP : STEP;          // SK (few W rows: N <= 8192): the 4 waves of a workgroup share 4 rows and interleave the trips
   constexpr int XB = AT == 2 ? MT : 1;               // second operand of the A transform: the norm gain (one row) or the up half (per row)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n0 = (blockIdx.x * 4 + wave) * 4;
+  const int n0 = SK ? blockIdx.x * 4 : (blockIdx.x * 4 + wave) * 4;
   if (n0 >= p.N) return;
   const bf16_t* wr[4];
 #pragma unroll
@@ -778,46 +779,59 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int out_f32) 
   // two trips in flight: the loads of trip i + 1 are issued before the FMAs of trip i; the first W rows are requested before the
   // RMSNorm prologue, so that a cold A (written by the previous kernel on another XCD) does not delay the weight stream
   uint4 wA[KS][4], wB[KS][4], xA[KS][MT], xB[KS][MT <= 2 ? MT : 1], gA[KS][XB], gB[KS][MT <= 2 ? XB : 1];
-  int k = lane * 8;
+  int k = lane * 8 + (SK ? wave * STEP : 0);
   loadw(wA, k);
   if constexpr (AT == 1) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const bf16_t* ar = p.A + (long)min(m, p.M - 1) * p.lda;
       float ss = 0.f, f[8];
-      for (int kk = lane * 8; kk < K; kk += 512) {
+      for (int kk = lane * 8 + (SK ? wave * 512 : 0); kk < K; kk += SK ? 2048 : 512) {
         unpack8(*reinterpret_cast<const uint4*>(ar + kk), f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
       }
-      rstd[m] = rsqrtf(wave_sum(ss) / (float)K + p.a_norm_eps);
+      rstd[m] = wave_sum(ss);
     }
+    if constexpr (SK) {                              // the workgroup's waves share the rows: each sums a quarter of the columns
+      __shared__ float ssq[4][MT];
+      if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) ssq[wave][m] = rstd[m];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < MT; ++m) rstd[m] = (ssq[0][m] + ssq[1][m]) + (ssq[2][m] + ssq[3][m]);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) rstd[m] = rsqrtf(rstd[m] / (float)K + p.a_norm_eps);
   }
-  const int trips = (K + STEP - 1) / STEP;
+  const int trips_all = (K + STEP - 1) / STEP;
+  const int trips = SK ? (trips_all - wave + 3) / 4 : trips_all;          // wave-uniform
   if constexpr (MT <= 2) {
     loadx(xA, gA, k);
     for (int t = 0; t < trips; t += 2) {
-      loadw(wB, k + STEP);
-      loadx(xB, gB, k + STEP);
+      loadw(wB, k + ADV);
+      loadx(xB, gB, k + ADV);
       compute(wA, xA, gA);
-      k += STEP;
+      k += ADV;
       if (t + 1 >= trips) break;
-      loadw(wA, k + STEP);
-      loadx(xA, gA, k + STEP);
+      loadw(wA, k + ADV);
+      loadx(xA, gA, k + ADV);
       compute(wB, xB, gB);
-      k += STEP;
+      k += ADV;
     }
   } else {                                           // 4-8 rows: A chunks (cache hits) single-buffered, requested ahead of the next W rows
     for (int t = 0; t < trips; t += 2) {             // (loads return in order: a later request would wait for the prefetch)
       loadx(xA, gA, k);
-      loadw(wB, k + STEP);
+      loadw(wB, k + ADV);
       compute(wA, xA, gA);
-      k += STEP;
+      k += ADV;
       if (t + 1 >= trips) break;
       loadx(xA, gA, k);
-      loadw(wA, k + STEP);
+      loadw(wA, k + ADV);
       compute(wB, xA, gA);
-      k += STEP;
+      k += ADV;
     }
   }
   float mine = 0.f;                                  // lane r * MT + m keeps C[m][n0 + r]
@@ -828,6 +842,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int out_f32) 
       const float t = wave_sum(acc[r][m]);
       if (lane == r * MT + m) mine = t;
     }
+  if constexpr (SK) {
+    __shared__ float red[4][4 * MT];
+    if (lane < 4 * MT) red[wave][lane] = mine;
+    __syncthreads();
+    if (wave != 0) return;
+    if (lane < 4 * MT) mine = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  }
   if (lane < 4 * MT) {
     const int r = lane / MT, m = lane - r * MT, n = n0 + r;
     if (n < p.N && m < p.M) {
@@ -1041,16 +1062,20 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     llmseg_prof_begin(s);
     llmseg_prof_tag(p.M, p.N, p.K, 3000 + (p.res ? 20 : 0) + p.act * 2 + (a->out_f32 ? 1 : 0));
-    const dim3 grid((unsigned)((p.N + 15) / 16));
+    static const int sk_env = getenv("LLMSEG_SKINNY_SK") ? atoi(getenv("LLMSEG_SKINNY_SK")) : 1;
+    const bool sk = sk_env == 2 ? p.K >= 2048 : (sk_env && p.N <= 8192 && p.K >= 2048);      // fewer than 2 waves per SIMD otherwise: the workgroup's waves split K instead
+    const dim3 grid((unsigned)(sk ? (p.N + 3) / 4 : (p.N + 15) / 16));
     const int of = a->out_f32 ? 1 : 0;
-#define LL_SKINNY(AT)                                                                                   \
-    do {                                                                                                \
-      if (p.M == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1, AT>), grid, dim3(256), 0, s, p, of);      \
-      else if (p.M == 2) hipLaunchKernelGGL((gemm_skinny_kernel<2, AT>), grid, dim3(256), 0, s, p, of); \
-      else if (p.M <= 4) hipLaunchKernelGGL((gemm_skinny_kernel<4, AT>), grid, dim3(256), 0, s, p, of); \
-      else hipLaunchKernelGGL((gemm_skinny_kernel<8, AT>), grid, dim3(256), 0, s, p, of);               \
+#define LL_SKINNY_(AT, SKV)                                                                                   \
+    do {                                                                                                      \
+      if (p.M == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1, AT, SKV>), grid, dim3(256), 0, s, p, of);      \
+      else if (p.M == 2) hipLaunchKernelGGL((gemm_skinny_kernel<2, AT, SKV>), grid, dim3(256), 0, s, p, of); \
+      else if (p.M <= 4) hipLaunchKernelGGL((gemm_skinny_kernel<4, AT, SKV>), grid, dim3(256), 0, s, p, of); \
+      else hipLaunchKernelGGL((gemm_skinny_kernel<8, AT, SKV>), grid, dim3(256), 0, s, p, of);               \
     } while (0)
+#define LL_SKINNY(AT) do { if (sk) LL_SKINNY_(AT, true); else LL_SKINNY_(AT, false); } while (0)
     if (p.a_norm_w) LL_SKINNY(1); else if (p.a_swiglu) LL_SKINNY(2); else LL_SKINNY(0);
+#undef LL_SKINNY_
 #undef LL_SKINNY
     llmseg_prof_end(s, 2.0 * (double)a->M * (double)a->N * (double)a->K);
     LL_LAUNCH_CHECK("gemm_skinny");
