@@ -753,10 +753,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int out_f32) 
     float f[8], g[8], o[8];
     unpack8(a, f);
     unpack8(b, g);
+    if constexpr (AT == 1) {                           // gain * bf16(x * rstd), both roundings by v_cvt_pk_bf16_f32 (RNE, as f2bf)
+      const float r = rstd[m];
+      const uint4 xn = make_uint4(pack2bf(f[0] * r, f[1] * r), pack2bf(f[2] * r, f[3] * r), pack2bf(f[4] * r, f[5] * r), pack2bf(f[6] * r, f[7] * r));
+      unpack8(xn, f);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if constexpr (AT == 1) o[e] = g[e] * bf2f(f2bf(f[e] * rstd[m]));
-      else o[e] = f[e] / (1.f + __expf(-f[e])) * g[e];
+      for (int e = 0; e < 8; ++e) o[e] = g[e] * f[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f[e] / (1.f + __expf(-f[e])) * g[e];
     }
     return pack8(o);
   };

@@ -14,7 +14,6 @@ MI355X-first shape of the loop:
 HF greedy-search rules restated from `transformers==4.29.0 generation/utils.py::greedy_search` (third party): finished rows emit
 `pad_token_id`, a row finishes on `eos_token_id`, the loop stops when all rows are finished or `max_new_tokens` tokens were added.
 """
-import os
 import torch
 
 from . import ops
@@ -79,8 +78,8 @@ class GenerateMixin:
         F = _Direct
         N, H = st.x.shape
         if st.fused:
-            onload = N == 1      # RMSNorm / SwiGLU on the skinny GEMM's A load: every wave redoes the transform, a small win for one row (4.40 -> 4.32 ms
-            #                      per token), VALU-bound from two rows on (measured 6.0 ms at N = 2): those keep the separate launches
+            onload = N == 1      # RMSNorm / SwiGLU on the skinny GEMM's A load: every wave redoes the transform, a win for one row only (two rows: 4.02 vs
+            #                      3.90 ms per token with the norm on load, 5.97 vs 4.34 with both): more rows keep the separate launches
             cos, sin, _ = self._rope(st.cap)
             hd, heads = c.head_dim, c.heads
             x = st.x
@@ -104,9 +103,11 @@ class GenerateMixin:
                 wgu = self._wcat(p + "gate_up", [p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"], F)
                 if onload:
                     gu = ops.gemm(x, wgu, a_norm_w=self._w(p + "post_attention_layernorm.weight", F), a_norm_eps=c.eps)
-                    x = ops.gemm(gu, self._w(p + "mlp.down_proj.weight", F), residual=x, a_swiglu=True)
                 else:
                     gu = ops.gemm(F.norm(x, self._w(p + "post_attention_layernorm.weight", F), None, c.eps, True), wgu)
+                if onload:
+                    x = ops.gemm(gu, self._w(p + "mlp.down_proj.weight", F), residual=x, a_swiglu=True)
+                else:
                     x = ops.gemm(ops.swiglu(gu, c.inter), self._w(p + "mlp.down_proj.weight", F), residual=x)
             ops.norm(x, self._w("model.norm.weight", F), None, eps=c.eps, rms=True, out=st.hidden)
             ops.gemm(st.hidden, self._w("lm_head.weight", F), out=st.logits)
