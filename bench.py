@@ -214,7 +214,7 @@ def neighbours(model, cfg, dev, prompt_len):
         out["everything_mode"] = {"ms_per_image": (time.perf_counter() - t0) * 1e3, "points": 1024, "candidates": 3072, "records": int(rec["masks"].shape[0]),
                                    "what": "generate_proposals from the image embedding, 1024x1024 original: 1024 point prompts through the multimask "
                                            "decoder, statistics pass over all 3072 candidates (filters opened), NMS, binarisation of the survivors; random "
-                                           "decoder weights, so the survivor count is not representative (profiles/r02_amg.md: 75-83 ms with ~1000 records)"}
+                                           "decoder weights, so the survivor count is not representative (profiles/r02_amg.md: 52 ms with ~1000 records)"}
     except Exception as e:      # noqa: BLE001
         out["error"] = f"{type(e).__name__}: {e}"[:300]
     return out

@@ -42,7 +42,8 @@ class AmgMixin:
         P, S = self.params, self._samdec()
         b = points_1024.shape[0]
         c = (points_1024.to(self.device_, torch.float32) + 0.5) / 1024.0                       # input_image_size = (1024, 1024)
-        c = 2 * math.pi * ((2 * c - 1) @ S["G"])
+        c = 2 * c - 1
+        c = 2 * math.pi * (c[:, :1] * S["G"][0] + c[:, 1:] * S["G"][1])          # the 2-term contraction spelled out: no BLAS call on the path
         e = torch.cat([c.sin(), c.cos()], -1) + P[PFX + "prompt_encoder.point_embeddings.1.weight"].float()
         pad = P[PFX + "prompt_encoder.not_a_point_embed.weight"].float().expand(b, -1)
         return torch.stack([e, pad], 1).to(BF16)

@@ -353,38 +353,96 @@ extern "C" int llmseg_sam_postprocess(const float* low, float* out, int32_t n_ma
 //   st[c] = { |m > thr + off|, |m > thr - off|, |m > thr|, min x, min y, max x, max y of m > thr }      (int32 x 7)
 // (stability score = st0 / st1, amg.py:156-176; box = amg.py:303-346), skipping candidates whose predicted IoU already fails; and a
 // second pass that writes the binary masks of the survivors only.
-__device__ __forceinline__ float sam_post_value(const float* __restrict__ m, int oy, int ox, float s1, float s2y, float s2x, int in_h, int in_w, int nested) {
-  int y0, y1, x0, x1;
-  float wy0, wy1, wx0, wx1;
-  bil_coord(oy, s2y, in_h, y0, y1, wy0, wy1);
-  bil_coord(ox, s2x, in_w, x0, x1, wx0, wx1);
-  auto stage1 = [&](int Y, int X) {
-    int a0, a1, c0, c1;
-    float u0, u1, v0, v1;
-    bil_coord(Y, s1, 256, a0, a1, u0, u1);
-    bil_coord(X, s1, 256, c0, c1, v0, v1);
-    return __fadd_rn(__fmul_rn(u0, __fadd_rn(__fmul_rn(v0, sam_low(m, a0, c0, nested)), __fmul_rn(v1, sam_low(m, a0, c1, nested)))),
-                     __fmul_rn(u1, __fadd_rn(__fmul_rn(v0, sam_low(m, a1, c0, nested)), __fmul_rn(v1, sam_low(m, a1, c1, nested)))));
-  };
-  return __fadd_rn(__fmul_rn(wy0, __fadd_rn(__fmul_rn(wx0, stage1(y0, x0)), __fmul_rn(wx1, stage1(y0, x1)))),
-                   __fmul_rn(wy1, __fadd_rn(__fmul_rn(wx0, stage1(y1, x0)), __fmul_rn(wx1, stage1(y1, x1)))));
+// The fused value is separable in its index arithmetic: every low-resolution address is rowpart(Y) + colpart(X), every weight belongs to a
+// row or to a column.  A workgroup owns 256 columns x 64 rows of one candidate: a thread computes its column's coordinates once, the 64
+// row records are built by the first 64 threads into LDS and read as broadcasts, so that a pixel costs 16 loads, 16 adds and the 28
+// fp32 operations of the two bilinear stages (same operations in the same order as sam_postprocess_kernel: bit-identical values).
+struct PostRow { int f[2][2]; float u[2][2]; float w[2]; };      // [y0 / y1][a0 / a1]: row offsets + stage-1 weights; stage-2 weights
+struct PostCol { int g[2][2]; float v[2][2]; float w[2]; };      // [x0 / x1][c0 / c1]
+__device__ __forceinline__ int low_rowpart(int Y, int nested) { return nested ? (Y >> 2) * 1024 + ((Y >> 1) & 1) * 8 + (Y & 1) * 2 : Y * 256; }
+__device__ __forceinline__ int low_colpart(int X, int nested) { return nested ? (X >> 2) * 16 + ((X >> 1) & 1) * 4 + (X & 1) : X; }
+__device__ __forceinline__ PostRow post_row(int oy, float s1, float s2y, int in_h, int nested) {
+  PostRow r;
+  int y[2];
+  bil_coord(oy, s2y, in_h, y[0], y[1], r.w[0], r.w[1]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int a0, a1;
+    bil_coord(y[i], s1, 256, a0, a1, r.u[i][0], r.u[i][1]);
+    r.f[i][0] = low_rowpart(a0, nested); r.f[i][1] = low_rowpart(a1, nested);
+  }
+  return r;
 }
+__device__ __forceinline__ PostCol post_col(int ox, float s1, float s2x, int in_w, int nested) {
+  PostCol c;
+  int x[2];
+  bil_coord(ox, s2x, in_w, x[0], x[1], c.w[0], c.w[1]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int c0, c1;
+    bil_coord(x[i], s1, 256, c0, c1, c.v[i][0], c.v[i][1]);
+    c.g[i][0] = low_colpart(c0, nested); c.g[i][1] = low_colpart(c1, nested);
+  }
+  return c;
+}
+// The low-resolution samples of a column change only when a row offset changes (every ~4th output row at 256 -> 1024): they are kept in
+// registers and reloaded per changed row offset (a wave-uniform decision).  16 gathers per pixel, each touching 16 cache lines per wave,
+// made the first form of these kernels bound by the texture addresser (262 CU clocks per 64 pixels).
+struct PostCache { int f[2][2]; float L[2][2][2][2]; };          // [y0 / y1][a0 / a1] row offset held, samples [..][..][x0 / x1][c0 / c1]
+__device__ __forceinline__ void post_cache_reset(PostCache& k) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int a = 0; a < 2; ++a) k.f[i][a] = -1;
+}
+__device__ __forceinline__ float post_value(const float* __restrict__ m, const PostRow& r, const PostCol& c, PostCache& k) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+      if (r.f[i][a] != k.f[i][a]) {
+        k.f[i][a] = r.f[i][a];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc) k.L[i][a][j][cc] = m[r.f[i][a] + c.g[j][cc]];
+      }
+  float s[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      s[i][j] = __fadd_rn(__fmul_rn(r.u[i][0], __fadd_rn(__fmul_rn(c.v[j][0], k.L[i][0][j][0]), __fmul_rn(c.v[j][1], k.L[i][0][j][1]))),
+                          __fmul_rn(r.u[i][1], __fadd_rn(__fmul_rn(c.v[j][0], k.L[i][1][j][0]), __fmul_rn(c.v[j][1], k.L[i][1][j][1]))));
+  return __fadd_rn(__fmul_rn(r.w[0], __fadd_rn(__fmul_rn(c.w[0], s[0][0]), __fmul_rn(c.w[1], s[0][1]))),
+                   __fmul_rn(r.w[1], __fadd_rn(__fmul_rn(c.w[0], s[1][0]), __fmul_rn(c.w[1], s[1][1]))));
+}
+constexpr int POST_ROWS = 64;
 
 __global__ __launch_bounds__(256) void sam_mask_stats_kernel(const float* __restrict__ low, const float* __restrict__ iou, float iou_thr, int32_t* __restrict__ st,
                                                             int img, int in_h, int in_w, int oh, int ow, int nested, float thr, float off) {
-  const int c = blockIdx.y;
+  const int c = blockIdx.z;
   if (iou && !(iou[c] > iou_thr)) return;                  // predicted-IoU filter first (automatic_mask_generator.py:290-292)
+  __shared__ PostRow rows[POST_ROWS];
   const float* m = low + (long)c * 65536;
   const float s1 = 256.f / (float)img, s2y = (float)in_h / (float)oh, s2x = (float)in_w / (float)ow;
-  int hi = 0, lo = 0, ar = 0, mnx = 1 << 30, mny = 1 << 30, mxx = -1, mxy = -1;
-  const long n = (long)oh * ow;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const int oy = (int)(i / ow), ox = (int)(i - (long)oy * ow);
-    const float v = sam_post_value(m, oy, ox, s1, s2y, s2x, in_h, in_w, nested);
-    hi += v > thr + off;
-    lo += v > thr - off;
-    if (v > thr) { ++ar; mnx = min(mnx, ox); mny = min(mny, oy); mxx = max(mxx, ox); mxy = max(mxy, oy); }
+  const int oy0 = blockIdx.y * POST_ROWS, nrow = min(POST_ROWS, oh - oy0);
+  const int ox = blockIdx.x * 256 + threadIdx.x;
+  if ((int)threadIdx.x < nrow) rows[threadIdx.x] = post_row(oy0 + threadIdx.x, s1, s2y, in_h, nested);
+  const PostCol pc = post_col(min(ox, ow - 1), s1, s2x, in_w, nested);
+  __syncthreads();
+  int hi = 0, lo = 0, ar = 0, mny = 1 << 30, mxy = -1;
+  if (ox < ow) {
+    PostCache pk;
+    post_cache_reset(pk);
+    for (int r = 0; r < nrow; ++r) {
+      const float v = post_value(m, rows[r], pc, pk);
+      hi += v > thr + off;
+      lo += v > thr - off;
+      if (v > thr) { ++ar; mny = min(mny, oy0 + r); mxy = max(mxy, oy0 + r); }
+    }
   }
+  int mnx = ar ? ox : 1 << 30, mxx = ar ? ox : -1;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     hi += __shfl_xor(hi, o, 64); lo += __shfl_xor(lo, o, 64); ar += __shfl_xor(ar, o, 64);
@@ -402,12 +460,20 @@ __global__ __launch_bounds__(256) void sam_mask_stats_kernel(const float* __rest
 // binary masks (uint8 0 / 1) of the selected candidates at the original resolution
 __global__ __launch_bounds__(256) void sam_binarize_kernel(const float* __restrict__ low, const int32_t* __restrict__ sel, uint8_t* __restrict__ out, int img, int in_h,
                                                           int in_w, int oh, int ow, int nested, float thr) {
-  const int k = blockIdx.z, oy = blockIdx.y;
-  const int ox = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ox >= ow) return;
+  __shared__ PostRow rows[POST_ROWS];
+  const int k = blockIdx.z;
   const float* m = low + (long)sel[k] * 65536;
-  const float v = sam_post_value(m, oy, ox, 256.f / (float)img, (float)in_h / (float)oh, (float)in_w / (float)ow, in_h, in_w, nested);
-  out[((long)k * oh + oy) * ow + ox] = v > thr ? 1 : 0;
+  const float s1 = 256.f / (float)img, s2y = (float)in_h / (float)oh, s2x = (float)in_w / (float)ow;
+  const int oy0 = blockIdx.y * POST_ROWS, nrow = min(POST_ROWS, oh - oy0);
+  const int ox = blockIdx.x * 256 + threadIdx.x;
+  if ((int)threadIdx.x < nrow) rows[threadIdx.x] = post_row(oy0 + threadIdx.x, s1, s2y, in_h, nested);
+  const PostCol pc = post_col(min(ox, ow - 1), s1, s2x, in_w, nested);
+  __syncthreads();
+  if (ox >= ow) return;
+  uint8_t* o = out + ((long)k * oh + oy0) * ow + ox;
+  PostCache pk;
+  post_cache_reset(pk);
+  for (int r = 0; r < nrow; ++r) o[(long)r * ow] = post_value(m, rows[r], pc, pk) > thr ? 1 : 0;
 }
 
 // Greedy box NMS (torchvision.ops.nms semantics, one category): `order` = candidate indices by decreasing score; keep[i] = 1 if box
@@ -437,9 +503,8 @@ extern "C" int llmseg_sam_mask_stats(const float* low, const float* iou, float i
                                      int32_t in_w, int32_t out_h, int32_t out_w, int32_t nested, float mask_threshold, float offset, void* stream) {
   LL_CHECK(low && stats && n_masks > 0 && img_size > 0 && in_h > 0 && in_w > 0 && in_h <= img_size && in_w <= img_size && out_h > 0 && out_w > 0,
            "sam_mask_stats: bad arguments");
-  const long n = (long)out_h * out_w;
-  const unsigned bx = (unsigned)std::min<long>((n + 256 * 8 - 1) / (256 * 8), 64);
-  hipLaunchKernelGGL(sam_mask_stats_kernel, dim3(bx, (unsigned)n_masks), dim3(256), 0, (hipStream_t)stream, low, iou, iou_thresh, stats, img_size, in_h, in_w, out_h,
+  LL_CHECK((out_h + POST_ROWS - 1) / POST_ROWS < 65536 && n_masks < 65536, "sam_mask_stats: grid limit");
+  hipLaunchKernelGGL(sam_mask_stats_kernel, dim3((unsigned)((out_w + 255) / 256), (unsigned)((out_h + POST_ROWS - 1) / POST_ROWS), (unsigned)n_masks), dim3(256), 0, (hipStream_t)stream, low, iou, iou_thresh, stats, img_size, in_h, in_w, out_h,
                      out_w, nested, mask_threshold, offset);
   LL_LAUNCH_CHECK("sam_mask_stats");
   return LLMSEG_OK;
@@ -448,7 +513,8 @@ extern "C" int llmseg_sam_mask_stats(const float* low, const float* iou, float i
 extern "C" int llmseg_sam_binarize(const float* low, const int32_t* sel, uint8_t* out, int32_t n_sel, int32_t img_size, int32_t in_h, int32_t in_w, int32_t out_h,
                                    int32_t out_w, int32_t nested, float mask_threshold, void* stream) {
   LL_CHECK(low && sel && out && n_sel > 0 && img_size > 0 && in_h > 0 && in_w > 0 && out_h > 0 && out_w > 0, "sam_binarize: bad arguments");
-  hipLaunchKernelGGL(sam_binarize_kernel, dim3((unsigned)((out_w + 255) / 256), (unsigned)out_h, (unsigned)n_sel), dim3(256), 0, (hipStream_t)stream, low, sel, out,
+  LL_CHECK(n_sel < 65536, "sam_binarize: grid limit");
+  hipLaunchKernelGGL(sam_binarize_kernel, dim3((unsigned)((out_w + 255) / 256), (unsigned)((out_h + POST_ROWS - 1) / POST_ROWS), (unsigned)n_sel), dim3(256), 0, (hipStream_t)stream, low, sel, out,
                      img_size, in_h, in_w, out_h, out_w, nested, mask_threshold);
   LL_LAUNCH_CHECK("sam_binarize");
   return LLMSEG_OK;

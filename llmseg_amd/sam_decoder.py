@@ -56,7 +56,7 @@ class SamDecoderMixin:
         G = P[PFX + "prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"].float()
         ar = (torch.arange(64, device=dev, dtype=torch.float32) + 0.5) / 64
         xy = 2 * torch.stack([ar[None, :].expand(64, 64), ar[:, None].expand(64, 64)], -1) - 1           # (x, y) per pixel
-        c = 2 * math.pi * (xy @ G)
+        c = 2 * math.pi * (xy[..., :1] * G[0] + xy[..., 1:] * G[1])                # the 2-term contraction spelled out: no BLAS call on the path
         s["pos"] = torch.cat([c.sin(), c.cos()], -1).reshape(4096, 256).to(BF16).contiguous()
         t = PFX + "mask_decoder.transformer."
         for p in [f"{t}layers.{i}.{a}." for i in range(2) for a in ("cross_attn_token_to_image", "cross_attn_image_to_token")] + [t + "final_attn_token_to_image."]:
