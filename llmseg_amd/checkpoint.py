@@ -10,7 +10,8 @@ The reference saves with `model_engine.save_checkpoint(log_dir/ckpt_model)` and 
 
 The module is `PeftModel(LISAForCausalLM)`: its keys carry the prefix `base_model.model.`; LoRA keys are `...q_proj.lora_A.default.weight`.
 Everything after the prefix is a key of this package's state dict (llmseg_amd/params.py keeps the reference's names), except buffers that
-are recomputed here (`rotary_emb.inv_freq`) and SAM's prompt encoder / mask decoder (not on the `model_forward` path).
+are recomputed here (`rotary_emb.inv_freq`, `pixel_mean` / `pixel_std`).  SAM's prompt encoder / mask decoder are loaded when the model
+was built with `LisaConfig(sam_decoder=True)` (`evaluate()` reads them) and reported under `ignored` otherwise.
 
 Written by this package: the same directory layout and the same `module` key names, so the reference's loader (and ours) can read the
 weights; the optimizer state is ONE file in this package's own format (`llmseg_optim_states.pt`: fp32 master weights, Adam moments, step
@@ -18,16 +19,19 @@ counters) -- DeepSpeed's rank-partitioned flat buffers are not reproduced (PARIT
 """
 import os
 import re
+import warnings
 
 import torch
 
 PEFT_PREFIX = "base_model.model."
-_DROP = (re.compile(r"\.rotary_emb\.inv_freq$"), re.compile(r"^model\.visual_model\.(prompt_encoder|mask_decoder)\."), re.compile(r"^model\.visual_model\.pixel_(mean|std)$"))
+_DROP = (re.compile(r"\.rotary_emb\.inv_freq$"), re.compile(r"^model\.visual_model\.pixel_(mean|std)$"))      # buffers recomputed here
+_LORA = re.compile(r"\.lora_[AB]\.")
 
 
 def reference_key(name):
-    """Key of a reference checkpoint (`module` dict of mp_rank_00_model_states.pt) -> key of this package's state dict, or None when
-    the entry is not used on the `model_forward` path."""
+    """Key of a reference checkpoint (`module` dict of mp_rank_00_model_states.pt) -> key of this package's state dict, or None for a
+    buffer this package recomputes.  Whether the model HAS the key (e.g. the SAM decoder tensors) is decided against the model's own
+    parameter set in `load_reference_checkpoint`, not here."""
     for pfx in ("module.", PEFT_PREFIX):
         if name.startswith(pfx):
             name = name[len(pfx):]
@@ -49,7 +53,8 @@ def resolve(path):
 
 def load_reference_checkpoint(model, path, strict=False):
     """Load the weights of a DeepSpeed checkpoint of the reference (or one written by `save_checkpoint`) into `model`.
-    -> dict(missing=[...], ignored=[...], tag=..., global_steps=...)."""
+    -> dict(missing=[...], ignored=[...], tag=..., global_steps=...).  Tensors of the model that the checkpoint lacks are listed in
+    `missing`; anything but LoRA matrices among them raises a `RuntimeWarning` (they stay at their initial values), `strict=True` raises."""
     f, tag = resolve(path)
     try:
         blob = torch.load(f, map_location="cpu", weights_only=True)
@@ -67,8 +72,13 @@ def load_reference_checkpoint(model, path, strict=False):
     ignored += [k for k in sd if k not in own]
     sd = {k: v for k, v in sd.items() if k in own}
     missing, _ = model.load_state_dict(sd, strict=False)
+    missing = list(missing)
     if strict and missing:
         raise KeyError(f"checkpoint lacks {len(missing)} tensors, e.g. {missing[:5]}")
+    hard = [k for k in missing if not _LORA.search(k)]
+    if hard:
+        warnings.warn(f"checkpoint {f} lacks {len(hard)} non-LoRA tensors of the model (left at their initial values), e.g. {hard[:4]}",
+                      RuntimeWarning, stacklevel=2)
     return {"missing": missing, "ignored": ignored, "tag": tag, "global_steps": blob.get("global_steps") if isinstance(blob, dict) else None}
 
 
@@ -108,7 +118,9 @@ def load_checkpoint(load_dir, model, trainer=None, steps_per_epoch=500):
             assert st.get("param_names") == names, "optimizer state belongs to a different trainable set"
             trainer.load_state_dict(st)
             if "dropout_state" in st and hasattr(model, "dropout_state"):
-                model.dropout_state().copy_(st["dropout_state"])
+                from .train import rank_dropout_seed           # the file holds rank 0's stream; every rank re-derives its own
+                seed, off = (int(v) for v in st["dropout_state"].tolist())
+                model.set_dropout_seed(rank_dropout_seed(seed, getattr(trainer, "rank", 0)), off)
             restored = True
         elif hasattr(trainer.opt, "resync_master"):
             trainer.opt.resync_master()                 # a reference checkpoint: fresh Adam moments on the loaded weights

@@ -175,16 +175,42 @@ class HipAdamW:
                     d.copy_(s)
 
 
+# What a captured fwd+bwd micro-step reads from the batch (`TrainableMixin._model_forward`): everything else of the collate dict
+# (labels, attention masks, offset -> consumed on the host by `make_plan`; masks_list / label_list / resize_list -> pass-through)
+# never reaches a kernel, so it is neither copied into the graph's buffers nor part of the graph key.
+GRAPH_INPUTS = ("images", "images_clip", "input_ids", "sam_segs_list", "sam_ious_list", "sam_iops_list")
+
+
+def _graph_inputs(batch):
+    """-> {key: tensor | [tensors]} of the graph-read entries present in `batch`."""
+    return {k: batch[k] for k in GRAPH_INPUTS if batch.get(k) is not None}
+
+
+def _input_sig(batch):
+    """Shapes + dtypes of every graph-read tensor: part of the graph key, so a batch whose inputs differ in any shape gets its own graph
+    (or the eager path) instead of a failing `copy_`."""
+    def one(t):
+        return (tuple(t.shape), str(t.dtype))
+    return tuple((k, tuple(one(t) for t in v) if isinstance(v, (list, tuple)) else one(v)) for k, v in _graph_inputs(batch).items())
+
+
 def _copy_batch(dst, src):
-    for k, v in src.items():
+    """Copy the graph-read inputs of `src` into the captured tensors `dst` (same key set and shapes: guaranteed by the graph key)."""
+    for k, v in _graph_inputs(src).items():
         d = dst[k]
         if torch.is_tensor(v):
             if d.data_ptr() != v.data_ptr():
                 d.copy_(v, non_blocking=True)
-        elif isinstance(v, (list, tuple)):
+        else:
             for dd, vv in zip(d, v):
-                if torch.is_tensor(vv) and dd.data_ptr() != vv.data_ptr():
+                if dd.data_ptr() != vv.data_ptr():
                     dd.copy_(vv, non_blocking=True)
+
+
+def rank_dropout_seed(seed, rank):
+    """Per-rank LoRA-dropout stream: the Philox key of rank r (the reference draws independent masks per rank and per step: DeepSpeed
+    seeds every process's generator differently, training.py:369-381).  Rank 0 keeps `seed`."""
+    return (int(seed) + int(rank) * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
 
 
 class Trainer:
@@ -194,7 +220,8 @@ class Trainer:
     `LISAForCausalLM` (the gloo tests' toy modules), uses plain `.grad` tensors and torch DDP."""
 
     def __init__(self, module, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.0, clip=1.0, grad_accum=10, warmup=100, total_steps=5000,
-                 optimizer=None, device_ids=None, force_ddp=False, ddp_wrapper=False, use_graph=False, graph_warmup=2, use_arena=None):
+                 optimizer=None, device_ids=None, force_ddp=False, ddp_wrapper=False, use_graph=False, graph_warmup=2, use_arena=None,
+                 reduce_chunk_mb=128, sync_init=True):
         """optimizer: None = HipAdamW; or a factory `params -> optimizer` / an optimizer object (CPU tests).  use_arena: None = automatic
         (the HIP model with the built-in optimizer), True = force the fp32 gradient arena (the module's autograd Functions must honour `_g32`)."""
         self.module = module
@@ -226,14 +253,65 @@ class Trainer:
         self.graph_warmup = graph_warmup
         self._graphs = {}
         self.graph_error = None
+        self.reduce_chunk = max(1, int(reduce_chunk_mb * (1 << 20) // 4))       # fp32 elements per all-reduce chunk of the arena
+        self.rank = dist.get_rank() if self.dist_on else 0
+        if is_hip_model and self.dist_on:
+            st = module.dropout_state().tolist()                                   # every rank draws its own LoRA-dropout masks
+            module.set_dropout_seed(rank_dropout_seed(st[0], self.rank), st[1])
+        if self.dist_on and self.ddp is None and sync_init:
+            self.sync_params()                                                      # what DDP's constructor / DeepSpeed's engine do: rank 0's weights everywhere
+            if hasattr(module, "__dict__"):
+                module.__dict__.setdefault("_weight_hooks", []).append(self.sync_params)
+
+    # ------------------------------------------------------------------------------------------------ replica consistency
+    def sync_params(self, src=0):
+        """Broadcast rank `src`'s trainable parameters (one flat buffer, one collective), then re-read the fp32 masters from them.
+        Runs at construction and after every wholesale weight change (`load_state_dict` / checkpoint load -> `_weight_hooks`), so a
+        per-rank difference at init (LoRA init under different seeds, a partial load) cannot persist: only gradients are exchanged later."""
+        if not self.dist_on or not self.params:
+            return
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1) for p in self.params])
+            dist.broadcast(flat, src=src)
+            o = 0
+            for p in self.params:
+                n = p.numel()
+                p.detach().copy_(flat[o:o + n].view(p.shape))
+                o += n
+        if hasattr(self.opt, "resync_master"):
+            self.opt.resync_master()
+
+    def replica_checksum(self):
+        """[sum, sum of squares] (float64) over the trainable parameters and -- when the optimizer keeps them -- its fp32 masters and
+        moments.  `check_replicas()` compares it across ranks."""
+        ts = [p.detach() for p in self.params]
+        for k in ("master", "m", "v"):
+            ts += list(getattr(self.opt, k, []))
+        acc = torch.zeros(2, dtype=torch.float64, device=ts[0].device)
+        for t in ts:
+            d = t.double()
+            acc[0] += d.sum()
+            acc[1] += (d * d).sum()
+        return acc
+
+    def check_replicas(self):
+        """Assert that every rank holds the same trainable state (all-reduce MIN / MAX of the checksum)."""
+        c = self.replica_checksum()
+        if self.dist_on:
+            lo, hi = c.clone(), c.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert torch.equal(lo, hi), f"replicas diverged: checksum range {lo.tolist()} .. {hi.tolist()}"
+        return c
 
     def close(self):
         """Detach from the model: arena views, weight hooks, captured graphs (a model can then be handed to another Trainer)."""
         if self.arena is not None:
             self.arena.detach()
         hooks = getattr(self.module, "__dict__", {}).get("_weight_hooks", [])
-        if hasattr(self.opt, "resync_master") and self.opt.resync_master in hooks:
-            hooks.remove(self.opt.resync_master)
+        for h in (getattr(self.opt, "resync_master", None), self.sync_params):
+            if h is not None and h in hooks:
+                hooks.remove(h)
         self._graphs = {}
 
     # ------------------------------------------------------------------------------------------------ micro-step
@@ -241,9 +319,9 @@ class Trainer:
         """Forward + backward of one micro-batch; runs the optimizer on every `grad_accum`-th call.  Returns the loss dict.
         `plan` (HIP model only): the batch's `BatchPlan`; built here when absent (one device synchronisation)."""
         last = (self.micro + 1) % self.accum == 0
+        if self.is_hip_model and getattr(self.module.config.llama, "lora_dropout", 0.0) > 0:
+            self.module.advance_dropout()                # a new mask every micro-step in EVERY gradient mode (arena, .grad, DDP wrapper)
         if self.arena is not None and self.is_hip_model:
-            if getattr(self.module.config.llama, "lora_dropout", 0.0) > 0:
-                self.module.advance_dropout()
             if plan is None:
                 plan = self.module.make_plan(**batch)
             out = self._graph_step(batch, plan) if self.use_graph else self._eager_step(batch, plan)
@@ -267,7 +345,7 @@ class Trainer:
         return out
 
     def _graph_step(self, batch, plan):
-        ent = self._graphs.setdefault(plan.sig, {"calls": 0, "graph": None})
+        ent = self._graphs.setdefault((plan.sig, _input_sig(batch)), {"calls": 0, "graph": None})
         if ent["graph"] is None and (ent["calls"] < self.graph_warmup or self.graph_error is not None):
             ent["calls"] += 1
             return self._eager_step(batch, plan)       # eager warm-up (lazy caches, workspace) -- also a real micro-step
@@ -289,7 +367,9 @@ class Trainer:
         """Capture fwd+bwd of one micro-step.  The graph reads its inputs from the tensors of THIS call (`batch`, `plan`): a caller that
         keeps feeding the same tensor objects (a loader writing each micro-batch into fixed device buffers, the benchmark's resident
         batch) pays no copy; any other tensor passed later is copied into them."""
-        sb = {k: ([x for x in v] if isinstance(v, (list, tuple)) else v) for k, v in batch.items()}
+        sb = {k: ([x for x in v] if isinstance(v, (list, tuple)) else v) for k, v in _graph_inputs(batch).items()}
+        for k in ("labels", "attention_masks", "offset"):          # positional arguments of model_forward that a planned forward never reads
+            sb[k] = batch.get(k)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -302,14 +382,9 @@ class Trainer:
         lr = warmup_decay_lr(self.opt_steps, self.lr, self.warmup, self.total)
         scale = 1.0 / self.accum
         if self.arena is not None:
-            if self.dist_on:                             # the data-parallel exchange: ONE all-reduce of the flat fp32 gradient arena
-                dist.all_reduce(self.arena.flat)         # (also issued at world size 1, where it is the identity)
+            ss = self._reduce_and_sumsq()
+            if self.dist_on:
                 scale /= self.world
-            if hasattr(self.opt, "sumsq_flat"):
-                ss = self.opt.sumsq_flat(self.arena.flat)
-            else:
-                ss = torch.zeros(1, device=self.arena.flat.device, dtype=torch.float32)
-                self.opt.ops.sumsq(self.arena.flat, ss)                                  # global gradient norm: ONE reduction over the arena
         else:
             ss = self.opt.grad_sumsq()                  # gradients hold the SUM over `accum` micro-steps (DDP already averaged over ranks)
         norm = torch.sqrt(ss) * scale
@@ -322,6 +397,26 @@ class Trainer:
                 p.grad = None
         self.opt_steps += 1
         return float(lr)
+
+    def _reduce_and_sumsq(self):
+        """The data-parallel exchange + the global gradient norm.  The flat fp32 arena is all-reduced in `reduce_chunk`-element pieces,
+        ALL issued asynchronously up front (RCCL runs them back to back on its own stream: per-link ring traffic is the same as one
+        call); the squared-norm reduction of piece i runs on the compute stream as soon as piece i has arrived, i.e. under the transfer
+        of pieces i+1...  Also issued at world size 1, where the collective is the identity.  -> device fp32 [1] sum of squares."""
+        flat = self.arena.flat
+        sumsq = self.opt.sumsq_flat if hasattr(self.opt, "sumsq_flat") else None
+        ss = torch.zeros(1, device=flat.device, dtype=torch.float32)
+        if not self.dist_on:
+            return sumsq(flat) if sumsq is not None else (self.opt.ops.sumsq(flat, ss), ss)[1]
+        pieces = [flat[o:o + self.reduce_chunk] for o in range(0, flat.numel(), self.reduce_chunk)]
+        works = [dist.all_reduce(pc, async_op=True) for pc in pieces]
+        for pc, w in zip(pieces, works):
+            w.wait()                                     # stream-level wait on a device backend: the host runs ahead
+            if sumsq is not None:
+                ss = ss + sumsq(pc)
+            else:
+                self.opt.ops.sumsq(pc, ss)
+        return ss
 
     # ------------------------------------------------------------------------------------------------ checkpoint (reference: training.py:404-421, 460-477)
     def state_dict(self):

@@ -404,7 +404,7 @@ def check_model_grads(golden_loader=None):
     return res
 
 
-def _lora_case(backbone="sam", p_drop=0.05):
+def _lora_case(backbone="sam", p_drop=0.05, K=16):
     from oracle import cases
     from tests import model_checks as mc
     cfg = cases.tiny_lisa_cfg(backbone, lora_r=8)
@@ -412,7 +412,7 @@ def _lora_case(backbone="sam", p_drop=0.05):
     m, sd = mc.build_pair(cfg)
     m.set_trainable()
     img = 896 if backbone == "dinov2" else cfg.sam.img
-    batch = mc._round_batch(cases.tiny_lisa_batch(img_size=img))
+    batch = mc._round_batch(cases.tiny_lisa_batch(img_size=img, K=K))
     return cfg, m, sd, batch
 
 
@@ -466,13 +466,14 @@ def check_model_grads_lora(backbone="sam"):
     return res
 
 
-def check_trainer(use_graph=False, opt_steps=3, accum=2):
+def check_trainer(use_graph=False, opt_steps=3, accum=2, K=16):
     """`Trainer` on the HIP model (arena, HipAdamW, clip, WarmupDecayLR, LoRA + dropout; optionally the hipGraph micro-step) against an
-    fp32 oracle-side loop with the same recipe: per-micro-step losses (they depend on the updated parameters) and the parameter updates."""
+    fp32 oracle-side loop with the same recipe: per-micro-step losses (they depend on the updated parameters) and the parameter updates.
+    K = 512, accum = 8: the workload shape of BASELINE configs[4] (512 candidate masks per image, grad-accum 8; training.py:79-82)."""
     from llmseg_amd.train import Trainer, warmup_decay_lr
     from oracle import lisa as olisa
     from tests import model_checks as mc
-    cfg, m, sd, batch = _lora_case("sam")
+    cfg, m, sd, batch = _lora_case("sam", K=K)
     names = [n for n, p in m.params.named_parameters() if p.requires_grad]
     lr, clip, betas, eps, seed = 2e-3, 1.0, (0.9, 0.95), 1e-8, 99
     tr = Trainer(m, lr=lr, betas=betas, clip=clip, grad_accum=accum, warmup=1, total_steps=10, use_graph=use_graph, graph_warmup=1)
@@ -512,7 +513,7 @@ def check_trainer(use_graph=False, opt_steps=3, accum=2):
             mom[n] = betas[0] * mom[n] + (1 - betas[0]) * gn
             var[n] = betas[1] * var[n] + (1 - betas[1]) * gn * gn
             master[n] = master[n] - lr_t * ((mom[n] / (1 - betas[0] ** t)) / ((var[n] / (1 - betas[1] ** t)).sqrt() + eps))
-    tag = "graph" if use_graph else "eager"
+    tag = ("graph" if use_graph else "eager") + (f" K={K} accum={accum}" if K != 16 else "")
     res = [(f"trainer[{tag}] loss at micro-step {i} (ref {r:.4f})", abs(h - r), 2e-2 * max(1.0, abs(r))) for i, (h, r) in enumerate(zip(hip_losses, ref_losses))]
     res.append((f"trainer[{tag}] the loss moved (|first - last| = {abs(ref_losses[0] - ref_losses[-1]):.3f})", 0.0 if abs(ref_losses[0] - ref_losses[-1]) > 0.05 else 1.0, 0.5))
     hip_master = {n: w.detach().cpu() for n, w in zip(names, tr.opt.master)}
@@ -596,6 +597,22 @@ def check_checkpoint_resume(tmp_dir):
     res.append(("reference-layout checkpoint: fp32 masters re-read from the loaded weights",
                 max((w.cpu() - p.detach().float().cpu()).abs().max().item() for w, p in zip(tr3.opt.master, tr3.opt.params)), 0.0))
     tr2.close(); tr3.close()
+    # a model built WITH the SAM prompt encoder / mask decoder (evaluate() reads them): save -> load must restore them too
+    import dataclasses
+    from llmseg_amd import lisa as hip_lisa
+    dcfg = dataclasses.replace(m2.config, sam_decoder=True)
+    md = hip_lisa.LISAForCausalLM(dcfg, device=mc.DEV).init_random(seed=21)
+    ddir = os.path.join(tmp_dir, "dec")
+    ck.save_checkpoint(ddir, md, None, global_step=7)
+    me = hip_lisa.LISAForCausalLM(dataclasses.replace(dcfg), device=mc.DEV).init_random(seed=22)
+    info = ck.load_reference_checkpoint(me, ddir, strict=True)
+    dec = [k for k in md.state_dict() if ".prompt_encoder." in k or ".mask_decoder." in k]
+    sde, sdd = me.state_dict(), md.state_dict()
+    ok = len(dec) > 40 and not info["missing"] and not info["ignored"] and all(torch.equal(sde[k], sdd[k]) for k in sdd)
+    res.append((f"sam_decoder=True checkpoint round trip: {len(dec)} prompt-encoder / mask-decoder tensors restored", 0.0 if ok else 1.0, 0.5))
+    # ... and the same file into a model WITHOUT the decoder: those keys are reported as ignored, nothing is missing
+    info = ck.load_reference_checkpoint(m3, ddir)
+    res.append(("decoder checkpoint into a decoder-less model: decoder keys ignored", 0.0 if (len(info["ignored"]) == len(dec) and not info["missing"]) else 1.0, 0.5))
     return res
 
 

@@ -96,13 +96,13 @@ def check_tiny_inference(backbone="dinov2", with_bf16_cpu=True):
     return res
 
 
-def check_tiny_train_losses(backbone="dinov2", ragged=False):
+def check_tiny_train_losses(backbone="dinov2", ragged=False, K=16):
     """ragged: the two images carry different proposal counts (16 and 24), so the head runs as two groups instead of one
     stacked pass and the mask pooling falls back to the per-image path."""
     cfg = cases.tiny_lisa_cfg(backbone)
     m, sd = build_pair(cfg)
     img = 896 if backbone == "dinov2" else cfg.sam.img
-    batch = cases.tiny_lisa_batch(img_size=img)
+    batch = cases.tiny_lisa_batch(img_size=img, K=K)
     if ragged:
         from oracle import seeded
         K1 = 24
@@ -117,7 +117,7 @@ def check_tiny_train_losses(backbone="dinov2", ragged=False):
     res = []
     for k in ("ce_loss", "align_loss", "regression_loss", "loss"):
         r = float(ref[k])
-        res.append((f"{backbone}{' ragged-K' if ragged else ''} train {k} (ref {r:.4f}, bf16-CPU err {abs(float(lo[k]) - r):.2e})", abs(float(got[k]) - r),
+        res.append((f"{backbone}{' ragged-K' if ragged else ''}{f' K={K}' if K != 16 else ''} train {k} (ref {r:.4f}, bf16-CPU err {abs(float(lo[k]) - r):.2e})", abs(float(got[k]) - r),
                     # scalar losses carry the bf16 rounding of the whole network (eps = 3.9e-3): 0.5 % of the value, or three
                     # times what the SAME fp32 oracle run in bf16 on the CPU deviates, whichever is larger
                     max(5e-3 * max(1.0, abs(r)), 1.5 * abs(float(lo[k]) - r))))

@@ -49,6 +49,14 @@ def test_trainer_eager_and_graph():
     _assert(bc.check_trainer_graph_vs_eager())
 
 
+def test_trainer_configs4_k512_accum8():
+    """BASELINE configs[4] as a workload: 512 candidate masks per image, gradient accumulation 8 (one optimizer step = 8 micro-steps),
+    hipGraph micro-step, against the fp32 oracle loop."""
+    from tests import backward_checks as bc
+    res, _ = bc.check_trainer(use_graph=True, opt_steps=2, accum=8, K=512)
+    _assert(res)
+
+
 def test_checkpoint_save_resume_and_reference_layout(tmp_path):
     from tests import backward_checks as bc
     _assert(bc.check_checkpoint_resume(str(tmp_path)))

@@ -12,8 +12,9 @@ def test_reference_key_mapping():
     assert ck.reference_key(p + "lm_head.weight") == "lm_head.weight"
     assert ck.reference_key("module." + p + "model.text_hidden_fcs.0.0.bias") == "model.text_hidden_fcs.0.0.bias"
     assert ck.reference_key(p + "model.layers.0.self_attn.rotary_emb.inv_freq") is None
-    assert ck.reference_key(p + "model.visual_model.mask_decoder.iou_token.weight") is None
-    assert ck.reference_key(p + "model.visual_model.prompt_encoder.pe_layer.positional_encoding_gaussian_matrix") is None
+    # SAM decoder tensors are model-dependent (LisaConfig.sam_decoder): the key maps through, the model's own key set decides
+    assert ck.reference_key(p + "model.visual_model.mask_decoder.iou_token.weight") == "model.visual_model.mask_decoder.iou_token.weight"
+    assert ck.reference_key(p + "model.visual_model.pixel_mean") is None
     assert ck.reference_key(p + "model.visual_model.image_encoder.blocks.7.attn.rel_pos_h") == "model.visual_model.image_encoder.blocks.7.attn.rel_pos_h"
     assert ck.reference_key(p + "model.vision_tower.vision_tower.vision_model.encoder.layers.0.self_attn.k_proj.bias").endswith("self_attn.k_proj.bias")
 
@@ -26,3 +27,52 @@ def test_resolve_layout(tmp_path):
     assert tag == "global_step5000" and f == os.path.join(str(d), "global_step5000", "mp_rank_00_model_states.pt")
     f2, tag2 = ck.resolve(os.path.join(str(d), "global_step5000"))
     assert f2 == f and tag2 == tag
+
+
+class _Fake:
+    """Duck-typed stand-in for the HIP model (which has no CPU path): `.params.named_parameters()` + `.load_state_dict`."""
+
+    def __init__(self, names):
+        self.params = torch.nn.ParameterDict()
+        self._names = names
+        self.t = {n: torch.zeros(2) for n in names}
+        self.params.named_parameters = lambda: [(n, torch.nn.Parameter(v, requires_grad=False)) for n, v in self.t.items()]
+
+    def load_state_dict(self, sd, strict=False):
+        for k, v in sd.items():
+            self.t[k] = v.clone()
+        return [n for n in self.t if n not in sd], []
+
+
+def _write(tmp_path, keys):
+    d = tmp_path / "global_step3"
+    d.mkdir(parents=True, exist_ok=True)
+    torch.save({"module": {ck.PEFT_PREFIX + k: torch.ones(2) for k in keys}, "global_steps": 3}, str(d / "mp_rank_00_model_states.pt"))
+    (tmp_path / "latest").write_text("global_step3")
+    return str(tmp_path)
+
+
+def test_decoder_keys_follow_the_model(tmp_path):
+    """prompt-encoder / mask-decoder tensors load when the model has them, are ignored when it has not; a model
+    tensor the file lacks is reported and (unless it is a LoRA matrix) warned about."""
+    import pytest
+    dec = "model.visual_model.mask_decoder.iou_token.weight"
+    base = ["lm_head.weight", "model.layers.0.self_attn.q_proj.lora_A.default.weight"]
+    path = _write(tmp_path, base + [dec, "model.layers.0.self_attn.rotary_emb.inv_freq"])
+    with_dec, without = _Fake(base + [dec]), _Fake(base)
+    info = ck.load_reference_checkpoint(with_dec, path, strict=True)
+    assert torch.equal(with_dec.t[dec], torch.ones(2)) and not info["missing"]
+    assert [k for k in info["ignored"] if "inv_freq" not in k] == []
+    info = ck.load_reference_checkpoint(without, path)
+    assert dec in info["ignored"] and not info["missing"]
+    path2 = _write(tmp_path / "b", base[:1])
+    with pytest.warns(RuntimeWarning, match="non-LoRA"):
+        info = ck.load_reference_checkpoint(_Fake(base + [dec]), path2)
+    assert dec in info["missing"]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        info = ck.load_reference_checkpoint(_Fake(base), path2)      # only a LoRA matrix is missing: no warning
+    assert info["missing"] == [base[1]]
+    with pytest.raises(KeyError):
+        ck.load_reference_checkpoint(_Fake(base), path2, strict=True)

@@ -32,6 +32,12 @@ def test_tiny_train_losses_ragged_proposal_counts():
     _assert(mc.check_tiny_train_losses("sam", ragged=True))
 
 
+def test_tiny_train_losses_k512():
+    """BASELINE configs[4]'s proposal count through the whole model_forward (mask pooling, stacked head, losses)."""
+    from tests import model_checks as mc
+    _assert(mc.check_tiny_train_losses("sam", K=512))
+
+
 def test_reference_api():
     from tests import model_checks as mc
     _assert(mc.check_reference_api())
@@ -55,3 +61,16 @@ def test_full_width_llama_layer():
 def test_full_width_sam_blocks():
     from tests import model_checks as mc
     _assert(mc.check_full_width_sam_blocks())
+
+
+def test_full_depth_configs1_inference():
+    """BASELINE configs[1] size: 32-layer Llama-7B + CLIP-L + 32-block SAM ViT-H, 1 image, K = 256, HIP vs the fp32 oracle on the host."""
+    import os
+    free_gb = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2 ** 30
+    if free_gb < 96:
+        pytest.skip(f"host has {free_gb:.0f} GB free; the full-depth oracle wants ~60 GB")
+    from tests import fulldepth_checks as fc
+    res = fc.check_full_depth_inference()
+    for n, e, t in res:
+        print(f"{n}: err {e:.3e} tol {t:.3e}")
+    _assert(res)

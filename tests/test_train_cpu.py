@@ -112,8 +112,15 @@ def _arena_worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     m = ArenaToy()
-    tr = Trainer(m, lr=1e-2, clip=1.0, grad_accum=3, warmup=2, total_steps=10, optimizer=lambda ps: CpuArenaAdamW(ps), use_arena=True)
-    assert tr.arena is not None and tr.ddp is None
+    if rank == 1:                                   # a replica that starts from different weights (different seed / partial load) ...
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.3)
+    # ... is overwritten by rank 0's at construction (no DDP wrapper in arena mode to do it); 100-element all-reduce chunks -> 3 pieces
+    tr = Trainer(m, lr=1e-2, clip=1.0, grad_accum=3, warmup=2, total_steps=10, optimizer=lambda ps: CpuArenaAdamW(ps), use_arena=True,
+                 reduce_chunk_mb=400 / (1 << 20))
+    assert tr.arena is not None and tr.ddp is None and tr.reduce_chunk == 100 and tr.arena.flat.numel() > 200
+    tr.check_replicas()
     import bench
     step_no = [0]
 
@@ -123,7 +130,18 @@ def _arena_worker(rank, world, port, ret):
         return tr.micro_step(dict(x=x, y=y))
     dt, out = bench.timed(step, 5, 1, dist, torch.device("cpu"))
     assert all(p.grad is None for p in m.parameters())
-    ret[rank] = (tr.opt_steps, torch.cat([p.detach().flatten() for p in m.parameters()]), dt, float(out["loss"]))
+    tr.check_replicas()
+    final = torch.cat([p.detach().flatten() for p in m.parameters()]).clone()
+    if rank == 1:                                   # a diverged replica is detected
+        with torch.no_grad():
+            m.a.bias.add_(1e-3)
+    try:
+        tr.check_replicas()
+        diverged = False
+    except AssertionError:
+        diverged = True
+    assert diverged
+    ret[rank] = (tr.opt_steps, final, dt, float(out["loss"]))
     dist.destroy_process_group()
 
 
@@ -181,3 +199,23 @@ def test_warmup_decay_lr():
     assert warmup_decay_lr(100, 1.0, 100, 5000) == 1.0
     assert abs(warmup_decay_lr(2550, 1.0, 100, 5000) - 0.5) < 1e-12
     assert warmup_decay_lr(5000, 1.0, 100, 5000) == 0.0
+
+
+def test_graph_inputs_and_rank_dropout_seed():
+    """What a replayed hipGraph copies: only the tensors the captured kernels read; pass-through entries (ground-truth masks of another
+    size, extra keys) neither break the copy nor enter the key, any shape change of a read tensor does (train.py:282)."""
+    from llmseg_amd import train as T
+    mk = lambda k, gt: dict(images=torch.zeros(2, 3, 8, 8), images_clip=torch.zeros(2, 3, 4, 4), input_ids=torch.zeros(2, 5, dtype=torch.int64),
+                            labels=torch.zeros(2, 5, dtype=torch.int64), attention_masks=torch.ones(2, 5, dtype=torch.bool), offset=torch.arange(3),
+                            sam_segs_list=[torch.zeros(k, 4, 4), torch.zeros(k, 4, 4)], sam_ious_list=[torch.zeros(1, k)] * 2,
+                            sam_iops_list=[torch.zeros(1, k)] * 2, masks_list=[torch.zeros(1, gt, gt)] * 2, label_list=[torch.zeros(gt, gt)] * 2,
+                            resize_list=[(gt, gt)] * 2, inference=False)
+    a, b, c = mk(3, 7), mk(3, 9), mk(4, 7)
+    b["extra_key"] = "x"
+    assert T._input_sig(a) == T._input_sig(b) != T._input_sig(c)
+    b["images"] += 1.0
+    b["sam_segs_list"][1] += 2.0
+    T._copy_batch(a, b)                                            # masks_list 7x7 vs 9x9: untouched, no error
+    assert float(a["images"].min()) == 1.0 and float(a["sam_segs_list"][1].min()) == 2.0 and a["masks_list"][0].shape[-1] == 7
+    seeds = {T.rank_dropout_seed(0x5EED, r) for r in range(8)}
+    assert len(seeds) == 8 and T.rank_dropout_seed(0x5EED, 0) == 0x5EED and all(0 <= v < 2 ** 63 for v in seeds)
