@@ -26,7 +26,15 @@ extern "C" {
 enum { LLMSEG_ACT_NONE = 0, LLMSEG_ACT_RELU = 1, LLMSEG_ACT_GELU = 2, LLMSEG_ACT_QUICKGELU = 3, LLMSEG_ACT_SILU = 4,
        LLMSEG_ACT_SIGMOID = 5 };
 
+/* ABI guard.  Every argument struct starts with `struct_size`: the caller writes sizeof() of the struct AS ITS OWN BINDING DECLARES IT;
+ * an entry point whose struct does not have exactly that size returns LLMSEG_EINVAL ("ABI mismatch") before reading any other field,
+ * so a binding written against an older header (fields were appended in every round) fails loudly instead of having the library read
+ * past the caller's struct.  llmseg_struct_size(which) returns the library's sizeof (0 = llmseg_gemm_args, 1 = llmseg_attn_args,
+ * 2 = llmseg_attn_bwd_args, 3 = llmseg_dropout; -1 for an unknown index) so a binding can assert at load time;
+ * llmseg_version() is bumped whenever a struct or a signature changes (3 = this header). */
+#define LLMSEG_ABI_VERSION 3
 int llmseg_version(void);
+int64_t llmseg_struct_size(int which);
 const char* llmseg_last_error(void);
 
 /* ---- GEMM ------------------------------------------------------------------------------------
@@ -39,6 +47,8 @@ const char* llmseg_last_error(void);
  * out_f32 != 0 writes fp32 C (ldc in elements of the output type).  batch/strides (in elements) give a strided-batched GEMM.
  */
 typedef struct {
+  uint32_t struct_size;  /* = sizeof(llmseg_gemm_args) of the caller's declaration (ABI guard, see above) */
+  uint32_t reserved0;    /* 0 */
   const void* A; const void* W; void* C;
   const void* bias;      /* bf16 [N] or NULL */
   const void* gamma;     /* bf16 [N] or NULL (DINOv2 LayerScale) */
@@ -88,6 +98,8 @@ int llmseg_gemm_set_variant(int variant);
  * o_stride_b); negative = skip.  Used to fold SAM's window_unpartition + crop (image_encoder.py:291-318) into the store.
  */
 typedef struct {
+  uint32_t struct_size;  /* = sizeof(llmseg_attn_args) (ABI guard) */
+  uint32_t reserved0;
   const void* Q; const void* K; const void* V; void* O;
   int64_t q_stride_b, q_stride_h, q_stride_row;
   int64_t k_stride_b, k_stride_h, k_stride_row;
@@ -121,6 +133,8 @@ int llmseg_attn_set_variant(int variant);
  * Every tensor is addressed as base + b*stride_b + h*stride_h + row*stride_row (elements); dQ/dK/dV may be strided views of
  * one packed buffer.  delta is an fp32 [batch][heads][Nq] workspace (rowsum(dO * O), written by the dQ pass). */
 typedef struct {
+  uint32_t struct_size;  /* = sizeof(llmseg_attn_bwd_args) (ABI guard) */
+  uint32_t reserved0;
   const void* Q; const void* K; const void* V; const void* O; const void* dO;
   void* dQ; void* dK; void* dV;
   int64_t q_stride_b, q_stride_h, q_stride_row;

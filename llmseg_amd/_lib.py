@@ -10,11 +10,21 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LLMSEG_LIB") or os.path.join(_HERE, "libllmseg_hip.so")     # LLMSEG_LIB: side builds of the same ABI (tools/ experiments)
 
+ABI_VERSION = 3          # == LLMSEG_ABI_VERSION of include/llmseg_hip.h
+
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SILU, ACT_SIGMOID = range(6)
 
 
-class GemmArgs(C.Structure):
-    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p),
+class _Sized(C.Structure):
+    """Argument struct that starts with the ABI guard: `struct_size` = sizeof of THIS declaration, filled in on construction."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(self)
+
+
+class GemmArgs(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32), ("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p),
                 ("bias", C.c_void_p), ("gamma", C.c_void_p), ("residual", C.c_void_p),
                 ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
                 ("lda", C.c_int64), ("ldw", C.c_int64), ("ldc", C.c_int64), ("ldr", C.c_int64),
@@ -26,8 +36,8 @@ class GemmArgs(C.Structure):
                 ("a_norm_w", C.c_void_p), ("a_norm_eps", C.c_float), ("a_swiglu", C.c_int)]
 
 
-class AttnArgs(C.Structure):
-    _fields_ = [("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p),
+class AttnArgs(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32), ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p),
                 ("q_stride_b", C.c_int64), ("q_stride_h", C.c_int64), ("q_stride_row", C.c_int64),
                 ("k_stride_b", C.c_int64), ("k_stride_h", C.c_int64), ("k_stride_row", C.c_int64),
                 ("v_stride_b", C.c_int64), ("v_stride_h", C.c_int64), ("v_stride_row", C.c_int64),
@@ -39,8 +49,8 @@ class AttnArgs(C.Structure):
                 ("o_row_map", C.c_void_p), ("rel_tab_h", C.c_void_p), ("rel_tab_w", C.c_void_p), ("lse", C.c_void_p), ("nk_dev", C.c_void_p)]
 
 
-class AttnBwdArgs(C.Structure):
-    _fields_ = ([(n, C.c_void_p) for n in ("Q", "K", "V", "O", "dO", "dQ", "dK", "dV")] +
+class AttnBwdArgs(_Sized):
+    _fields_ = ([("struct_size", C.c_uint32), ("reserved0", C.c_uint32)] + [(n, C.c_void_p) for n in ("Q", "K", "V", "O", "dO", "dQ", "dK", "dV")] +
                 [(f"{t}_stride_{s}", C.c_int64) for t in ("q", "k", "v", "o", "do", "dq", "dk", "dv") for s in ("b", "h", "row")] +
                 [("batch", C.c_int32), ("heads", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("head_dim", C.c_int32),
                  ("scale", C.c_float), ("causal", C.c_int32), ("key_mask", C.c_void_p), ("lse", C.c_void_p), ("delta", C.c_void_p)])
@@ -56,6 +66,7 @@ _dp = C.POINTER(Dropout)
 # name -> argtypes (restype is int unless noted); must list EVERY symbol of include/llmseg_hip.h
 SIGNATURES = {
     "llmseg_version": [],
+    "llmseg_struct_size": [C.c_int],
     "llmseg_last_error": [],
     "llmseg_gemm_bf16": [C.POINTER(GemmArgs), _p],
     "llmseg_gemm_set_variant": [C.c_int],
@@ -129,7 +140,13 @@ def load():
         fn = getattr(lib, name)            # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = (C.c_char_p if name in ("llmseg_last_error", "llmseg_prof_dominant_kernel") else
-                      C.c_double if name == "llmseg_prof_dominant_bytes" else C.c_int)
+                      C.c_double if name == "llmseg_prof_dominant_bytes" else C.c_int64 if name == "llmseg_struct_size" else C.c_int)
+    # ABI guard at load time: this binding's structs must be the library's (the entry points check `struct_size` per call as well)
+    if lib.llmseg_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH}: ABI version {lib.llmseg_version()} != {ABI_VERSION} of this binding (rebuild: llmseg_amd/csrc/build.sh)")
+    for which, st in enumerate((GemmArgs, AttnArgs, AttnBwdArgs, Dropout)):
+        if lib.llmseg_struct_size(which) != C.sizeof(st):
+            raise RuntimeError(f"{LIB_PATH}: sizeof({st.__name__}) = {C.sizeof(st)} here, {lib.llmseg_struct_size(which)} in the library")
     _lib = lib
     return lib
 

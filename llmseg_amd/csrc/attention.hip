@@ -804,6 +804,8 @@ extern "C" int llmseg_attn_set_variant(int v) {
 }
 
 extern "C" int llmseg_attn_fwd(const llmseg_attn_args* a, void* stream) {
+  LL_CHECK(a && a->struct_size == sizeof(*a), "%s: ABI mismatch: caller's struct_size %u != %zu (bind against include/llmseg_hip.h version %d)",
+           "attn", a ? a->struct_size : 0u, sizeof(*a), LLMSEG_ABI_VERSION);
   LL_CHECK(a && a->Q && a->K && a->V && a->O, "attn: null pointer");
   LL_CHECK(a->batch > 0 && a->heads > 0 && a->Nq > 0 && a->Nk > 0, "attn: bad sizes");
   LL_CHECK(a->head_dim == 32 || a->head_dim == 64 || a->head_dim == 80 || a->head_dim == 128, "attn: head_dim %d unsupported", a->head_dim);

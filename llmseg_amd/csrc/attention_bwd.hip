@@ -240,6 +240,8 @@ void launch_bwd(const BwdP& p, hipStream_t s) {
 }  // namespace
 
 extern "C" int llmseg_attn_bwd(const llmseg_attn_bwd_args* a, void* stream) {
+  LL_CHECK(a && a->struct_size == sizeof(*a), "%s: ABI mismatch: caller's struct_size %u != %zu (bind against include/llmseg_hip.h version %d)",
+           "attn_bwd", a ? a->struct_size : 0u, sizeof(*a), LLMSEG_ABI_VERSION);
   LL_CHECK(a && a->Q && a->K && a->V && a->O && a->dO && a->dQ && a->dK && a->dV && a->lse && a->delta, "attn_bwd: null pointer");
   LL_CHECK(a->batch > 0 && a->heads > 0 && a->Nq > 0 && a->Nk > 0, "attn_bwd: bad sizes");
   LL_CHECK(a->head_dim == 32 || a->head_dim == 64 || a->head_dim == 128, "attn_bwd: head_dim %d unsupported (32, 64, 128)", a->head_dim);

@@ -21,7 +21,16 @@ void llmseg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* llmseg_last_error(void) { return g_err; }
-extern "C" int llmseg_version(void) { return 1; }
+extern "C" int llmseg_version(void) { return LLMSEG_ABI_VERSION; }
+extern "C" int64_t llmseg_struct_size(int which) {
+  switch (which) {
+    case 0: return (int64_t)sizeof(llmseg_gemm_args);
+    case 1: return (int64_t)sizeof(llmseg_attn_args);
+    case 2: return (int64_t)sizeof(llmseg_attn_bwd_args);
+    case 3: return (int64_t)sizeof(llmseg_dropout);
+    default: return -1;
+  }
+}
 
 // ---- GEMM timing: one (start, stop) event pair per launch, recorded on the launch stream -----------------------
 namespace {

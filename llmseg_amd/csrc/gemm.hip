@@ -971,6 +971,8 @@ inline bool split_ok(int nt, int S) {       // every slice needs >= 2 K-tiles (t
 }  // namespace
 
 extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
+  LL_CHECK(a && a->struct_size == sizeof(*a), "%s: ABI mismatch: caller's struct_size %u != %zu (bind against include/llmseg_hip.h version %d)",
+           "gemm", a ? a->struct_size : 0u, sizeof(*a), LLMSEG_ABI_VERSION);
   LL_CHECK(a && a->A && a->W && a->C, "gemm: null pointer");
   LL_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "gemm: bad shape M=%ld N=%ld K=%ld", (long)a->M, (long)a->N, (long)a->K);
   const bool ta = a->trans_a != 0, tw = a->trans_w != 0;

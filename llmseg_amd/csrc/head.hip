@@ -549,6 +549,7 @@ extern "C" int llmseg_upsample_maskpool(const void* feat, const void* segs, void
   if (rc != LLMSEG_OK) return rc;
   // pooled[K][C] = wn[K][g*g] . feat[g*g][C]
   llmseg_gemm_args ga = {};
+  ga.struct_size = sizeof(ga);
   ga.A = ws; ga.W = feat; ga.C = pooled;
   ga.M = K; ga.N = C; ga.K = (int64_t)g * g;
   ga.lda = (int64_t)g * g; ga.ldw = C; ga.ldc = C;
