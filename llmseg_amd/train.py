@@ -253,6 +253,7 @@ class Trainer:
         self.graph_warmup = graph_warmup
         self._graphs = {}
         self.graph_error = None
+        self.grad_hook = None
         self.reduce_chunk = max(1, int(reduce_chunk_mb * (1 << 20) // 4))       # fp32 elements per all-reduce chunk of the arena
         self.rank = dist.get_rank() if self.dist_on else 0
         if is_hip_model and self.dist_on:
@@ -387,6 +388,13 @@ class Trainer:
                 scale /= self.world
         else:
             ss = self.opt.grad_sumsq()                  # gradients hold the SUM over `accum` micro-steps (DDP already averaged over ranks)
+        if self.dist_on and self.ddp is None:
+            # every rank must apply THE SAME clip coefficient: the arena is bit-identical after the all-reduce, but the squared-norm kernel
+            # adds its partial sums with fp32 atomics, so two ranks can differ in the last bit -- and replicas would then drift apart.
+            # One 4-byte collective per optimizer step settles it.
+            dist.all_reduce(ss, op=dist.ReduceOp.MAX)
+        if self.grad_hook is not None:                   # observer (tests): the reduced gradient sum + its squared norm, before the update consumes them
+            self.grad_hook(self, ss)
         norm = torch.sqrt(ss) * scale
         coef = torch.clamp(self.clip / (norm + 1e-6), max=1.0) * scale if self.clip and self.clip > 0 else torch.full_like(norm, scale)
         self.opt.step(lr, coef.reshape(1).float().contiguous())

@@ -85,8 +85,15 @@ def check_full_depth_inference(K=256, L=64, with_bf16_cpu=True, log=print):
     agree_lo = (am_r == lo["logits"].float().argmax(-1)).float().mean().item() if lo is not None else 0.9
     res.append((f"full-depth next-token arg-max agreement with the fp32 oracle = {agree:.4f} (bf16-CPU oracle: {agree_lo:.4f}); shown as 1 - agreement",
                 1.0 - agree, max(0.02, 1.5 * (1.0 - agree_lo))))
-    top = ref["pred_similarity"][0].flatten().argmax().item() == got["pred_similarity"][0].float().cpu().flatten().argmax().item()
-    res.append(("full-depth best-matching proposal (arg-max similarity, what `validate` selects) identical", 0.0 if top else 1.0, 0.5))
+    # the proposal `validate` would select (arg-max similarity): random weights put all 256 similarities within a few 1e-3 of each other,
+    # so "the same index" is not a meaningful bar; the bar is that the HIP pick is, under the fp32 oracle, as good as the oracle's own
+    # pick to within the similarity tolerance above (regret), with the bf16-CPU oracle's regret printed beside it
+    rs = ref["pred_similarity"][0].flatten().float()
+    pick = got["pred_similarity"][0].float().cpu().flatten().argmax().item()
+    regret = (rs.max() - rs[pick]).item()
+    regret_lo = (rs.max() - rs[lo["pred_similarity"][0].flatten().float().argmax().item()]).item() if lo is not None else 0.0
+    res.append((f"full-depth regret of the selected proposal under the fp32 oracle (same index: {pick == rs.argmax().item()}; bf16-CPU oracle's regret {regret_lo:.2e})",
+                regret, 2.0 * res[4][2]))
     del m
     torch.cuda.empty_cache()
     return res

@@ -89,7 +89,7 @@ def _rank_batch(batch, r):
     return b
 
 
-def _two_rank_worker(rank, world, port, ret):
+def _two_rank_worker(rank, world, port, ret, tmp):
     import sys
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -108,41 +108,50 @@ def _two_rank_worker(rank, world, port, ret):
         assert tr.arena is not None and tr.dist_on and tr.arena.flat.numel() > 2 * tr.reduce_chunk, (tr.arena.flat.numel(), tr.reduce_chunk)
         assert int(m.dropout_state()[0]) == rank_dropout_seed(SEED, rank)
         tr.check_replicas()
+        first = {}
+        tr.grad_hook = lambda t, ss: first.setdefault("g", (t.arena.flat.detach().cpu().clone(), float(ss)))     # the reduced arena of step 0
         db = mc._dev(_rank_batch(batch, rank))
-        losses = [float(tr.micro_step(db)["loss"]) for _ in range(OPT_STEPS * ACCUM)]
-        tr.check_replicas()
-        ret[rank] = (losses, torch.cat([w.detach().flatten().cpu() for w in tr.opt.master]), tr.opt_steps)
+        losses = [float(tr.micro_step(db)["loss"].detach()) for _ in range(OPT_STEPS * ACCUM)]
+        tr.check_replicas()                             # still identical after two optimizer steps (incl. the clip coefficient)
+        if rank == 0:
+            torch.save(first["g"][0], os.path.join(tmp, "arena0.pt"))
+        ret[rank] = (losses, torch.cat([w.detach().flatten().cpu() for w in tr.opt.master]), tr.opt_steps, first["g"][1])
         tr.close()
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_share_one_gpu_gloo():
+def test_two_ranks_share_one_gpu_gloo(tmp_path):
     import torch.multiprocessing as mp
     from llmseg_amd.train import Trainer, rank_dropout_seed
     from tests import backward_checks as bc, model_checks as mc
     world = 2
     ret = mp.Manager().dict()
-    mp.spawn(_two_rank_worker, args=(world, 29581, ret), nprocs=world, join=True)
-    (l0, p0, n0), (l1, p1, n1) = ret[0], ret[1]
-    assert n0 == n1 == OPT_STEPS
+    mp.spawn(_two_rank_worker, args=(world, 29581, ret, str(tmp_path)), nprocs=world, join=True)
+    (l0, p0, n0, ss0), (l1, p1, n1, ss1) = ret[0], ret[1]
+    assert n0 == n1 == OPT_STEPS and ss0 == ss1
     assert torch.equal(p0, p1), (p0 - p1).abs().max().item()           # replicas bit-identical after the exchanges
     assert max(abs(a - b) for a, b in zip(l0, l1)) > 1e-4, "the two ranks saw the same data / masks"
-    # one process over the union: accumulation window = ACCUM x world micro-batches, each under the dropout stream its rank used
+    # one process over the union: accumulation window = ACCUM x world micro-batches, each under the dropout stream its rank used.  Compared
+    # at the level of what is exchanged -- the accumulated fp32 gradient arena of optimizer step 0 (same weights on both sides) -- because
+    # parameters after AdamW amplify rounding noise of near-zero gradients into +-lr steps.
     cfg, m, sd, batch = bc._lora_case("sam", p_drop=0.05)
     tr = Trainer(m, lr=LR, grad_accum=ACCUM * world, warmup=0, total_steps=20)
+    first = {}
+    tr.grad_hook = lambda t, ss: first.setdefault("g", (t.arena.flat.detach().cpu().clone(), float(ss)))
     dbs = [mc._dev(_rank_batch(batch, r)) for r in range(world)]
     losses = {0: [], 1: []}
-    for s in range(OPT_STEPS * ACCUM):
+    for s in range(ACCUM):
         for r in range(world):
             m.set_dropout_seed(rank_dropout_seed(SEED, r), s)          # micro_step advances to s + 1, as on rank r
-            losses[r].append(float(tr.micro_step(dbs[r])["loss"]))
+            losses[r].append(float(tr.micro_step(dbs[r])["loss"].detach()))
     pu = torch.cat([w.detach().flatten().cpu() for w in tr.opt.master])
     tr.close()
-    assert tr.opt_steps == OPT_STEPS
+    assert tr.opt_steps == 1
     for r, lr_ in ((0, l0), (1, l1)):
-        assert max(abs(a - b) for a, b in zip(losses[r], lr_)) < 5e-3, (losses[r], lr_)
-    # same policy as the resume test: fp32 atomics / summation order differ, an element with a vanishing gradient may take an Adam step
-    # of the opposite sign (<= 2 lr per step); anything systematic (a missing exchange, a wrong scale) moves every element
-    assert ((pu - p0).abs() > 5e-4).float().mean().item() < 1e-4
-    assert (pu - p0).abs().max().item() <= 2.05 * LR * OPT_STEPS
+        assert max(abs(a - b) for a, b in zip(losses[r], lr_[:ACCUM])) < 2e-3, (losses[r], lr_)
+    g_dist, g_union = torch.load(os.path.join(str(tmp_path), "arena0.pt")), first["g"][0]
+    # identical up to the fp32 summation order (atomics of the skinny weight-gradient kernels; (a + b) + (c + d) vs ((a + b) + c) + d)
+    scale = g_union.abs().max().item()
+    assert scale > 1e-3 and (g_dist - g_union).abs().max().item() <= 2e-5 * scale + 1e-7, ((g_dist - g_union).abs().max().item(), scale)
+    assert abs(ss0 - first["g"][1]) <= 1e-4 * first["g"][1]
