@@ -18,7 +18,9 @@
 // MFMA as the B operand in exactly the k-slot order they already have (no lane movement), as in the forward kernel; the staged
 // operand of that MFMA is transposed while it is staged (4x8 register transposes, 8-byte LDS writes).  Row statistics are
 // per-lane scalars in mode dQ and come from a 64-entry LDS table in the key-owner modes.  dQ also writes D for the dK pass.
-// 8 tile-GEMMs instead of the minimal 5 buy three simple kernels at 2 waves/SIMD without a dQ atomic-add pass.
+// 8 tile-GEMMs instead of the minimal 5 buy three simple passes at 2 waves/SIMD without a dQ atomic-add pass; the three passes share ONE
+// launch (attn_bwd_all_kernel), D = rowsum(dO * O) comes from a small launch ahead of it.
+#include <cstdlib>
 #include "common.h"
 #include "llmseg_hip.h"
 
@@ -42,15 +44,18 @@ struct BwdP {
 __device__ __forceinline__ uint32_t bperm_lo(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }
 __device__ __forceinline__ uint32_t bperm_hi(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xffff0000u); }
 
+template <int HD>
+constexpr int bwd_smem_bytes(bool has2) { return BT * ((HD + 8) * 2) * (has2 ? 2 : 1) + HD * ((BT + 4) * 2) + BT * 8; }
+
+// One owner block (128 owner rows) of one mode.  `smem`: bwd_smem_bytes<HD>(MODE != MODE_DV) bytes of LDS, 16-byte aligned.
 template <int HD, int MODE>
-__global__ __launch_bounds__(NT, 2) void attn_bwd_kernel(BwdP p) {
+__device__ __forceinline__ void attn_bwd_body(const BwdP& p, const int own_block, char* smem) {
   constexpr int KS = HD / 16, DT = HD / 32, CH = HD / 8;
   constexpr int PK = (HD + 8) * 2;            // natural tile row pitch (bytes): CH + 1 chunks -> conflict-free ds_read_b128
   constexpr int PV = (BT + 4) * 2;            // transposed tile row pitch (bytes)
   constexpr bool OWNER_Q = MODE == MODE_DQ;
   constexpr bool HAS2 = MODE != MODE_DV;      // second natural tile + second owner fragment set (the dP product)
   static_assert(HD % 32 == 0 && 16 * CH <= NT, "head_dim in {32, 64, 128}");
-  __shared__ __attribute__((aligned(16))) char smem[BT * PK * (HAS2 ? 2 : 1) + HD * PV + BT * 8];
   char* Y1 = smem;
   char* Y2 = smem + BT * PK;
   char* Yt = smem + BT * PK * (HAS2 ? 2 : 1);
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_kernel(BwdP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, half = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int own0 = blockIdx.x * BO;
+  const int own0 = own_block * BO;
   const int Nown = OWNER_Q ? p.Nq : p.Nk, Nst = OWNER_Q ? p.Nk : p.Nq;
   const int wo0 = own0 + wave * 32;
   const int ow = wo0 + ql;
@@ -95,8 +100,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_kernel(BwdP p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) part = fmaf(of[e], df[e], part);
     }
-    d_o = part + __shfl_xor(part, 32, 64);
-    if (half == 0 && own_ok) p.delta[stat0 + ow] = d_o;
+    d_o = part + __shfl_xor(part, 32, 64);              // = delta[ow] (attn_delta_kernel writes the table the dK blocks read)
   } else if (p.key_mask) {
     own_ok = own_ok && (p.key_mask[(long)b * p.Nk + owc] != 0);
   }
@@ -229,12 +233,64 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_kernel(BwdP p) {
   }
 }
 
+template <int HD, int MODE>
+__global__ __launch_bounds__(NT, 2) void attn_bwd_kernel(BwdP p) {
+  __shared__ __attribute__((aligned(16))) char smem[bwd_smem_bytes<HD>(MODE != MODE_DV)];
+  attn_bwd_body<HD, MODE>(p, blockIdx.x, smem);
+}
+
+// All three gradients in ONE launch: blockIdx.x = [dQ owner blocks | dK owner blocks | dV owner blocks].  At the Llama shape (T = 319,
+// 2 sequences x 32 heads) each pass is 192 workgroups on 256 CUs with a serial chain of <= 5 tiles -- latency-bound, 43 + 32 + 29 us as
+// three launches; side by side the 576 workgroups share the CUs (two resident per CU) and the launch costs what its longest pass costs.
+// The dK blocks read D = rowsum(dO * O) from `delta`, which therefore comes from its own small launch (attn_delta_kernel) ahead of this
+// one instead of from the dQ pass.  Causal: the heavy blocks (late query blocks, early key blocks) get the low workgroup ids.
+template <int HD>
+__global__ __launch_bounds__(NT, 2) void attn_bwd_all_kernel(BwdP p, int nbq, int nbk) {
+  __shared__ __attribute__((aligned(16))) char smem[bwd_smem_bytes<HD>(true)];
+  const int x = blockIdx.x;
+  if (x < nbq) attn_bwd_body<HD, MODE_DQ>(p, p.causal ? nbq - 1 - x : x, smem);
+  else if (x < nbq + nbk) attn_bwd_body<HD, MODE_DK>(p, x - nbq, smem);
+  else attn_bwd_body<HD, MODE_DV>(p, x - nbq - nbk, smem);
+}
+
+// delta[b][h][q] = sum_d dO[b][h][q][d] * O[b][h][q][d]: 16 lanes per row (one 16-byte load each per 128 d), 16 rows per workgroup
+template <int HD>
+__global__ __launch_bounds__(256) void attn_delta_kernel(BwdP p) {
+  const int tid = threadIdx.x, sub = tid & 15;
+  const long row = (long)blockIdx.x * 16 + (tid >> 4), rows = (long)p.batch * p.heads * p.Nq;
+  if (row >= rows) return;
+  const int q = (int)(row % p.Nq), h = (int)((row / p.Nq) % p.heads), b = (int)(row / ((long)p.Nq * p.heads));
+  const bf16_t* o = p.O + (long)b * p.os[0] + (long)h * p.os[1] + (long)q * p.os[2];
+  const bf16_t* g = p.dO + (long)b * p.dos[0] + (long)h * p.dos[1] + (long)q * p.dos[2];
+  float part = 0.f;
+#pragma unroll
+  for (int c = sub; c < HD / 8; c += 16) {
+    float of[8], df[8];
+    unpack8(*reinterpret_cast<const uint4*>(o + c * 8), of);
+    unpack8(*reinterpret_cast<const uint4*>(g + c * 8), df);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part = fmaf(of[e], df[e], part);
+  }
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
+  if (sub == 0) p.delta[row] = part;
+}
+
+static const bool g_bwd_split = getenv("LLMSEG_ATTN_BWD_SPLIT") != nullptr;       // A/B: the three passes as three launches
+
 template <int HD>
 void launch_bwd(const BwdP& p, hipStream_t s) {
-  const dim3 gq((p.Nq + BO - 1) / BO, p.heads, p.batch), gk((p.Nk + BO - 1) / BO, p.heads, p.batch);
-  hipLaunchKernelGGL((attn_bwd_kernel<HD, MODE_DQ>), gq, dim3(NT), 0, s, p);     // also writes delta for the dK pass
-  hipLaunchKernelGGL((attn_bwd_kernel<HD, MODE_DK>), gk, dim3(NT), 0, s, p);
-  hipLaunchKernelGGL((attn_bwd_kernel<HD, MODE_DV>), gk, dim3(NT), 0, s, p);
+  const int nbq = (p.Nq + BO - 1) / BO, nbk = (p.Nk + BO - 1) / BO;
+  const long rows = (long)p.batch * p.heads * p.Nq;
+  hipLaunchKernelGGL((attn_delta_kernel<HD>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, p);
+  if (g_bwd_split) {
+    const dim3 gq(nbq, p.heads, p.batch), gk(nbk, p.heads, p.batch);
+    hipLaunchKernelGGL((attn_bwd_kernel<HD, MODE_DQ>), gq, dim3(NT), 0, s, p);
+    hipLaunchKernelGGL((attn_bwd_kernel<HD, MODE_DK>), gk, dim3(NT), 0, s, p);
+    hipLaunchKernelGGL((attn_bwd_kernel<HD, MODE_DV>), gk, dim3(NT), 0, s, p);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_all_kernel<HD>), dim3(nbq + 2 * nbk, p.heads, p.batch), dim3(NT), 0, s, p, nbq, nbk);
+  }
 }
 
 }  // namespace

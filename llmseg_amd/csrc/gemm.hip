@@ -696,6 +696,113 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
   epilogue_lds<OUT_F32, MI>(p, Acc16<MI>{acc}, smem, wave, m0, n0, wm, wn, lane, bz);
 }
 
+// ---- variant Q2: 128 x 256 tile, TWO phases per K-tile, THREE LDS buffers -------------------------------------------------------
+// The 128 x 256 form of the ping-pong kernel above spends four phases of 8 MFMAs (128 matrix-pipe cycles per wave) per K-tile; a phase's
+// fixed cost (two barriers, the LDS-DMA issue, the exposed part of the fragment-read latency: ~130-190 cycles measured per phase on both
+// tile heights) is then as long as its MFMA burst -- 1.0 us per K-tile against 0.49 us of matrix time.  Here a K-tile is TWO phases of 16
+// MFMAs: phase A = {W0, W1} x A0 (12 fragment reads), phase B = {W1, W0} x A1 (4 reads); half as many barriers per K-tile, the same DMA
+// instruction count.  A half-tile can then no longer be re-issued two phases after its last read inside a two-buffer ring, so the ring is
+// three whole K-tiles (3 x 48 KiB = 144 KiB of the CU's 160 KiB): tile t + 2 is issued into the buffer tile t - 1 was read from, half of it
+// in each phase (A: A0 + W0, B: W1 + A1 -- each region >= 2 phases after its last read, the lagging group's reads included), and one
+// counted wait per K-tile (phase B: vmcnt(6) = tile t + 2 may stay in flight, tile t + 1 is complete) retires what phase A of the next
+// tile reads, one barrier later.
+template <bool OUT_F32, bool EXT>
+__global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp2_kernel(GemmP p) {
+  constexpr int MI = 2;
+  constexpr int BMB = 128, BNB = 256;
+  constexpr int A_BYTES = BMB * BK * 2, W_BYTES = BNB * BK * 2, BUF = A_BYTES + W_BYTES;     // 48 KiB per buffer
+  __shared__ __attribute__((aligned(16))) char smem[3 * BUF];
+  int bid = blockIdx.x;
+  const int nwg = p.tiles_m * p.tiles_n;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int len = q + (xcd < r ? 1 : 0);
+    const int idx = ((bid >> 3) + xcd * p.skew) % len;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int per_group = p.group_m * p.tiles_n;
+  const int first_m = (bid / per_group) * p.group_m;
+  const int gsz = min(p.tiles_m - first_m, p.group_m);
+  const int m0 = (first_m + (bid % per_group) % gsz) * BMB;
+  const int n0 = ((bid % per_group) / gsz) * BNB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const long b1 = blockIdx.y % p.batch1, b2 = blockIdx.y / p.batch1;
+  const long bz = b1 * p.sC + b2 * p.sC2;
+  const bf16_t* __restrict__ Ag = p.A + b1 * p.sA + b2 * p.sA2;
+  const bf16_t* __restrict__ Wg = p.W + b1 * p.sW + b2 * p.sW2;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ag + (long)m0 * p.lda), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Wg + (long)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
+  int a_off[2][2], w_off[2][2];
+  int a_lds[2][2], w_lds[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ra0 = i < MI / 2 ? PP_AROW0(h, i) : 0, ra = ra0 + (lane >> 3);
+      a_lds[h][i] = ra0 * 128;
+      a_off[h][i] = (int)(((long)min(ra, p.M - 1 - m0) * p.lda + (((lane & 7) ^ ((ra >> 1) & 7)) << 3)) * 2);
+      const int rw0 = PP_WROW0(h, i), rw = rw0 + (lane >> 3);
+      w_lds[h][i] = A_BYTES + rw0 * 128;
+      w_off[h][i] = (int)(((long)min(rw, p.N - 1 - n0) * p.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) << 3)) * 2);
+    }
+  }
+  int nt_main = p.K / BK;
+  if (p.kt_total > 0) nt_main = min(nt_main, p.kt_total - (int)b1 * nt_main);
+  const int nt = nt_main + (EXT ? 1 : 0);
+  auto ext_a = [&](int h, int i) {
+    const int ra = PP_AROW0(h, i) + (lane >> 3);
+    return p.A2 + (long)min(m0 + ra, p.M - 1) * p.lda2 + (((lane & 7) ^ ((ra >> 1) & 7)) << 3);
+  };
+  auto ext_w = [&](int h, int i) {
+    const int rw = PP_WROW0(h, i) + (lane >> 3);
+    return p.W2 + (long)min(n0 + rw, p.N - 1) * p.ldw2 + (((lane & 7) ^ ((rw >> 1) & 7)) << 3);
+  };
+
+  f32x4_t acc[4][2 * MI];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < 2 * MI; ++mb) acc[nb][mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t af[MI][2], wf0[2][2], wf1[2][2];
+  const int frow = lane & 15, fq = lane >> 4;
+
+  char* cur = smem;               // K-tile t
+  char* nxt = smem + BUF;         // K-tile t + 1
+  char* nn = smem + 2 * BUF;      // K-tile t + 2 (= the buffer K-tile t - 1 was read from)
+  // prologue: K-tiles 0 and 1 whole (6 + 6 DMA instructions per wave); K-tile 0 must have landed before the first barrier
+  if (EXT) { PP_ISSUE_AX(0, cur); PP_ISSUE_WX(0, cur); PP_ISSUE_WX(1, cur); PP_ISSUE_AX(1, cur); }
+  else { PP_ISSUE_A(0, 0, cur); PP_ISSUE_W(0, 0, cur); PP_ISSUE_W(1, 0, cur); PP_ISSUE_A(1, 0, cur); }
+  PP_ISSUE_A(0, 1, nxt); PP_ISSUE_W(0, 1, nxt); PP_ISSUE_W(1, 1, nxt); PP_ISSUE_A(1, 1, nxt);
+  PP_VMI(6);
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();            // the stagger
+  __builtin_amdgcn_sched_barrier(0);
+
+#define PP2_READ_A P16_READ_W(wf0, 0, cur); P16_READ_W(wf1, 1, cur); P16_READ_A(0, cur)
+#define PP2_MMA_A P16_MMA(wf0, 0, 0); P16_MMA(wf1, 2, 0)
+#define PP2_MMA_B P16_MMA(wf1, 2, MI); P16_MMA(wf0, 0, MI)
+  int t = 0;
+  for (; t < nt - 2; ++t) {
+    PP_PHASE(PP2_READ_A, PP_ISSUE_A(0, t + 2, nn); PP_ISSUE_W(0, t + 2, nn), PP_NOP, PP2_MMA_A);
+    PP_PHASE(P16_READ_A(MI, cur), PP_ISSUE_W(1, t + 2, nn); PP_ISSUE_A(1, t + 2, nn), PP_VMI(6), PP2_MMA_B);
+    char* const tmp = cur; cur = nxt; nxt = nn; nn = tmp;
+  }
+  // K-tile nt - 2: nothing left to issue, the queue drains (K-tile nt - 1 complete before its phase A)
+  PP_PHASE(PP2_READ_A, PP_NOP, PP_NOP, PP2_MMA_A);
+  PP_PHASE(P16_READ_A(MI, cur), PP_NOP, PP_VM_0, PP2_MMA_B);
+  cur = nxt;
+  PP_PHASE(PP2_READ_A, PP_NOP, PP_NOP, PP2_MMA_A);
+  PP_PHASE(P16_READ_A(MI, cur), PP_NOP, PP_NOP, PP2_MMA_B);
+#undef PP2_READ_A
+#undef PP2_MMA_A
+#undef PP2_MMA_B
+  if (wm == 0) __builtin_amdgcn_s_barrier();            // re-join: every wave's reads and DMA are retired past this point
+  epilogue_lds<OUT_F32, MI>(p, Acc16<MI>{acc}, smem, wave, m0, n0, wm, wn, lane, bz);
+}
+
 // ---- variant V: skinny GEMM, M <= 8 rows (the decode step of generation: one token per sequence) ---------------------------------
 // C[m][n] = epi(alpha * sum_k A[m][k] W[n][k]) is a WEIGHT STREAM: every W row is read once (13.2 GB per Llama-7B token), the few A
 // rows come from L1 / L2.  HBM-bound, so no MFMA and no LDS: one wave owns 4 consecutive W rows, its 64 lanes walk K in 16-byte
@@ -929,7 +1036,7 @@ void llmseg_prof_tag(long a, long b, long c, long d);
 
 // tuning knob (tools/gemm_bench.py): bits 0-3 kernel (0 = register staging 128x128; 2 = LDS-DMA 128x128; 8 / 9 = LDS-DMA ping-pong
 // 256x256 / 128x256; 5 (default) = cost model), bits 4-7 = XCD skew + 1, bits 8-12 = forced split-K slice count for 8 / 9.
-static int g_gemm_variant = 5, g_gemm_skew = 13, g_gemm_split = 0;
+static int g_gemm_variant = 5, g_gemm_skew = 13, g_gemm_split = 0, g_gemm_pp2 = 1;
 static int num_cus() {
   static int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
   return n;
@@ -938,6 +1045,7 @@ extern "C" int llmseg_gemm_set_variant(int v) {
   g_gemm_variant = v & 15;
   if ((v >> 4) & 15) g_gemm_skew = ((v >> 4) & 15) - 1;
   g_gemm_split = (v >> 8) & 31;
+  g_gemm_pp2 = (v >> 13) & 3 ? ((v >> 13) & 3) - 1 : g_gemm_pp2;     // bits 13-14: 128 x 256 kernel form + 1 (1 = four phases / two buffers, 2 = two phases / three buffers)
   return LLMSEG_OK;
 }
 
@@ -1110,6 +1218,7 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
     ps.c_vec = 1; ps.r_vec = 0; ps.b_vec = 1; ps.A2 = ps.W2 = nullptr;
     dim3 grid(p.tiles_m * p.tiles_n, (unsigned)split);
     if (variant == 8) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<true, false, 4>), grid, dim3(NTB), 0, s, ps);
+    else if (g_gemm_pp2) hipLaunchKernelGGL((gemm_bf16_tn_pp2_kernel<true, false>), grid, dim3(NTB), 0, s, ps);
     else hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<true, false, 2>), grid, dim3(NTB), 0, s, ps);
     const long total4 = (long)p.M * (p.N >> 2);
     const unsigned rg = (unsigned)std::min<long>((total4 + 255) / 256, 4096);
@@ -1124,6 +1233,12 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
         else hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, false, 4>), grid, dim3(NTB), 0, s, p);
         break;
       case 9:
+        if (g_gemm_pp2) {
+          if (p.A2) hipLaunchKernelGGL((gemm_bf16_tn_pp2_kernel<false, true>), grid, dim3(NTB), 0, s, p);
+          else if (f) hipLaunchKernelGGL((gemm_bf16_tn_pp2_kernel<true, false>), grid, dim3(NTB), 0, s, p);
+          else hipLaunchKernelGGL((gemm_bf16_tn_pp2_kernel<false, false>), grid, dim3(NTB), 0, s, p);
+          break;
+        }
         if (p.A2) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, true, 2>), grid, dim3(NTB), 0, s, p);
         else if (f) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<true, false, 2>), grid, dim3(NTB), 0, s, p);
         else hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, false, 2>), grid, dim3(NTB), 0, s, p);

@@ -26,16 +26,16 @@ if os.environ.get("GEMM_SET") == "dec":  # decode steps of generation (one token
 RACE_REPEATS = int(os.environ.get("RACE_REPEATS", "0"))
 if os.environ.get("GEMM_SHAPES"):
     SHAPES = [SHAPES[int(i)] for i in os.environ["GEMM_SHAPES"].split(",")]
-def _variant(spec):          # "8" | "9:3" (kernel 9, 3 K-slices) | "5" (auto)
-    v, _, sp = spec.partition(":")
-    return int(v) | (int(sp) << 8 if sp else 0)
+def _variant(spec):          # "8" | "9:3" (kernel 9, 3 K-slices) | "5" (auto) | "9:0:2" (kernel 9, no split, 128 x 256 kernel form 2 = two phases / three buffers)
+    f = spec.split(":")
+    return int(f[0]) | (int(f[1]) << 8 if len(f) > 1 and f[1] else 0) | ((int(f[2]) + 1) << 13 if len(f) > 2 and f[2] else 0)
 
 
 variants = [_variant(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "2", "8"])]
 lib = _lib.load()
 torch.manual_seed(0)
 print("variants: v & 15 = kernel variant, (v >> 4) - 1 = XCD skew (none = default 13)")
-print(f"{'shape':32s} " + " ".join(f"{'v%d:%d' % (v & 15, v >> 8 & 31):>9s}" for v in variants) + "   (TFLOP/s; check = max|v - v0|)")
+print(f"{'shape':32s} " + " ".join(f"{'v%d:%d:%d' % (v & 15, v >> 8 & 31, (v >> 13 & 3) - 1):>9s}" for v in variants) + "   (TFLOP/s; check = max|v - v0|)")
 for M, N, K, tag in SHAPES:
     a = (torch.rand(M, K, device="cuda") * 2 - 1).to(torch.bfloat16)
     w = (torch.rand(N, K, device="cuda") * 2 - 1).to(torch.bfloat16)
