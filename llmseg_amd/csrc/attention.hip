@@ -255,7 +255,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnP p) {
       const int key = k0 + jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;                                             \
       bool ok = key < p.Nk;                                                                                         \
       if (p.causal) ok = ok && (key <= q);                                                                          \
-      if (p.key_mask) ok = ok && (p.key_mask[(long)b * p.Nk + min(key, p.Nk - 1)] != 0);                            \
+      /* key-padding mask: bit (key - k0) of the tile's ballot, pre-shifted by this lane half's 4 (a constant bit test) */ \
+      ok = ok && (((jb ? km_hi : km_lo) >> ((r & 3) + 8 * (r >> 2))) & 1u);                                         \
       v = ok ? v : NEG;                                                                                             \
       s[jb][r] = v;                                                                                                 \
     }                                                                                                               \
@@ -284,6 +285,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnP p) {
     }                                                                                                               \
     float mx = NEG;                                                                                                 \
     const bool need_mask = p.causal || p.key_mask != nullptr || (k0 + BKV > p.Nk);                                  \
+    uint32_t km_lo = 0xffffffffu, km_hi = 0xffffffffu;                                                              \
+    if (p.key_mask) {       /* ONE byte load per lane per tile + a ballot instead of 32 broadcast byte loads per lane */ \
+      const unsigned long long kb = __ballot(p.key_mask[(long)b * p.Nk + min(k0 + lane, p.Nk - 1)] != 0) >> (4 * half); \
+      km_lo = (uint32_t)kb; km_hi = (uint32_t)(kb >> 32);                                                           \
+    }                                                                                                               \
     if (need_mask) { LL_SCORE_LOOP(true) } else { LL_SCORE_LOOP(false) }                                            \
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                         \
     const float m_new = fmaxf(m_run, mx);                                                                           \

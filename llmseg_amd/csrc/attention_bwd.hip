@@ -181,6 +181,12 @@ __device__ __forceinline__ void attn_bwd_body(const BwdP& p, const int own_block
           dp[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xf2[ks], dp[jb], 0, 0, 0);
         }
       }
+    // key-padding mask of the staged keys (mode dQ): one byte load per lane + a ballot per tile, pre-shifted by the lane half's 4
+    uint32_t km_lo = 0xffffffffu, km_hi = 0xffffffffu;
+    if (OWNER_Q && p.key_mask) {
+      const unsigned long long kb = __ballot(p.key_mask[(long)b * p.Nk + min(t0 + lane, p.Nk - 1)] != 0) >> (4 * half);
+      km_lo = (uint32_t)kb; km_hi = (uint32_t)(kb >> 32);
+    }
     // P (mode dV) or dS (modes dQ, dK), in place
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb)
@@ -190,7 +196,7 @@ __device__ __forceinline__ void attn_bwd_body(const BwdP& p, const int own_block
         const int sr = t0 + loc;
         bool ok = own_ok && sr < Nst;
         if (p.causal) ok = ok && (OWNER_Q ? sr <= ow : ow <= sr);
-        if (OWNER_Q && p.key_mask) ok = ok && (p.key_mask[(long)b * p.Nk + min(sr, p.Nk - 1)] != 0);
+        if (OWNER_Q) ok = ok && (((jb ? km_hi : km_lo) >> ((r & 3) + 8 * (r >> 2))) & 1u);
         const float lse = OWNER_Q ? lse_o : st_l[loc];
         const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(s[jb][r], p.scale_log2, -lse)) : 0.f;
         if (MODE == MODE_DV) {

@@ -102,7 +102,8 @@ extern "C" int llmseg_prof_collect(double* total_ms, double* total_flops, int64_
     for (auto& kv : by_shape) order.push_back({-kv.second[0], kv.first});
     std::sort(order.begin(), order.end());
     fprintf(stderr, "%8s %8s %8s %6s %8s %10s %9s %6s\n", "M", "N", "K", "var", "calls", "total_ms", "TFLOP/s", "%time");
-    for (size_t i = 0; i < order.size() && i < 40; ++i) {
+    const size_t top = (size_t)std::max(40, atoi(getenv("LLMSEG_PROF_TABLE")));
+    for (size_t i = 0; i < order.size() && i < top; ++i) {
       auto& e = by_shape[order[i].second];
       fprintf(stderr, "%8ld %8ld %8ld %6ld %8.0f %10.2f %9.1f %6.1f\n", order[i].second[0], order[i].second[1], order[i].second[2], order[i].second[3],
               e[2], e[0], e[1] / (e[0] * 1e-3) / 1e12, 100.0 * e[0] / ms);
@@ -114,7 +115,7 @@ extern "C" int llmseg_prof_collect(double* total_ms, double* total_flops, int64_
   // dominant kernel = the GEMM kernel class with the largest total time in this window
   long dom = -1;
   for (auto& kv : by_class) if (dom < 0 || kv.second[0] > by_class[dom][0]) dom = kv.first;
-  static const char* names[] = {"gemm_bf16_tn_kernel<*, ...> (register staging, 128x128)", "?", "gemm_bf16_tn_glds_kernel<*, 2, 1>", "gemm_skinny_kernel<M>", "?", "?", "?", "?",
+  static const char* names[] = {"gemm_bf16_tn_kernel<*, ...> (register staging, 128x128)", "?", "gemm_bf16_tn_glds_kernel<*, 2, 1>", "gemm_skinny_kernel<M>", "?", "?", "?", "gemm_bf16_tn_pp2_kernel<*, false>",
                                 "gemm_bf16_tn_pp_kernel<*, false, 4>", "gemm_bf16_tn_pp_kernel<*, false, 2>"};
   if (dom >= 0) {
     const long v = dom / 2;

