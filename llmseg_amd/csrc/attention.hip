@@ -17,10 +17,19 @@
 #include "common.h"
 #include "llmseg_hip.h"
 #include <algorithm>
+#include <cstdlib>
 #define AL16(p) ((((uintptr_t)(p)) & 15) == 0)
 
 namespace {
 
+#ifndef ATTN_ABLATE
+#define ATTN_ABLATE 0          // side builds (tools/attn_ablate.sh): 1 = exp -> identity, 2 = K/V staged once, 3 = 2 + no barrier, 4 = no PV MFMAs, 5 = no QK MFMAs
+#endif
+#if ATTN_ABLATE == 1
+#define ATTN_EXP(x) (x)
+#else
+#define ATTN_EXP(x) __builtin_amdgcn_exp2f(x)
+#endif
 constexpr int BKV = 64;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG = -1.0e30f;
@@ -38,6 +47,7 @@ struct AttnP {
   float* lse;                                   // optional [batch][heads][Nq]: row log2-sum-exp for llmseg_attn_bwd
   const bf16_t* rtab_h; const bf16_t* rtab_w;   // REL == 4: bf16 [32][head_dim] relative-position tables (rows >= 2*14-1 are zero)
   const int32_t* nk_dev;                        // optional: the key count is read from device memory (decode steps replayed from a hipGraph)
+  int xcd_nqb;                                  // > 0: 1-D grid, XCD-grouped (see attn_fwd_kernel); = query blocks per (batch, head)
 };
 
 __device__ __forceinline__ uint32_t perm_lo(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }
@@ -71,8 +81,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, half = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * BQ;
+  // Workgroup -> (batch, head, query block).  Long sequences (xcd_nqb > 0, 1-D grid): every query block of a (batch, head) re-reads ALL
+  // of that head's K / V (1.3 MB at 4096 x 80), so the blocks of one head must share an L2: workgroup id i runs on XCD i % 8, which
+  // therefore takes the heads {i % 8 + 8 j} and walks their query blocks consecutively (the 32 CUs of an XCD hold two heads' blocks at a
+  // time: 2.6 MB of K / V in its 4 MiB L2).  The 3-D grid put the 16 blocks of a head on 8 different XCDs: every block fetched K / V
+  // through the fabric again (5.7 x the algorithmic bytes, profiles/traffic.json round 2).
+  int b = blockIdx.z, h = blockIdx.y, qb = blockIdx.x;
+  if (p.xcd_nqb > 0) {
+    const int id = blockIdx.x, j = id >> 3;
+    const int bh = (j / p.xcd_nqb) * 8 + (id & 7);
+    if (bh >= p.batch * p.heads) return;
+    qb = j % p.xcd_nqb; b = bh / p.heads; h = bh - b * p.heads;
+  }
+  const int q0 = qb * BQ;
   const int q = q0 + wave * 32 + ql;
   const int qc = min(q, p.Nq - 1);
 
@@ -279,7 +300,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnP p) {
       _Pragma("unroll") for (int jb = 0; jb < 2; ++jb) {                                                            \
         if (!(LAST_WIN && jb == 1)) {                                                                               \
           const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (jb * 32 + ql) * PK + (2 * ks + half) * 16);  \
-          s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[jb], 0, 0, 0);                              \
+          if (ATTN_ABLATE != 5) s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[jb], 0, 0, 0);        \
+          else s[jb][ks] += (float)kf[0];                                                                               \
         }                                                                                                           \
       }                                                                                                             \
     }                                                                                                               \
@@ -300,7 +322,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnP p) {
     float lsum = 0.f;                                                                                               \
     _Pragma("unroll") for (int jb = 0; jb < 2; ++jb)                                                                \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                \
-      const float pv = __builtin_amdgcn_exp2f(fmaf(s[jb][r], p.scale_log2, nmc));                                  \
+      const float pv = ATTN_EXP(fmaf(s[jb][r], p.scale_log2, nmc));                                                 \
       s[jb][r] = pv;                                                                                                \
       lsum += pv;                                                                                                   \
     }                                                                                                               \
@@ -320,7 +342,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnP p) {
         const uint2 va = *reinterpret_cast<const uint2*>(vrow);                                                     \
         const uint2 vb = *reinterpret_cast<const uint2*>(vrow + 16);                                                \
         const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(va.x, va.y, vb.x, vb.y));                       \
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);                                      \
+        if (ATTN_ABLATE != 4) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);                \
+        else o[d][ss] += (float)vf[0] + (float)pf[0];                                                               \
       }                                                                                                             \
     }                                                                                                               \
   }
@@ -334,12 +357,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnP p) {
     LL_TILE_BODY(3, 3)
   } else if constexpr (DB) {
     for (int t = 0; t < ntiles; ++t) {
+#if ATTN_ABLATE == 2 || ATTN_ABLATE == 3
+      LL_TILE_BODY(t, 0)
+#if ATTN_ABLATE == 2
+      __syncthreads();
+#endif
+#else
       Ks = smem + (t & 1) * TILE_BYTES; Vt = Ks + BKV * PK;
       Ks_w = smem + ((t + 1) & 1) * TILE_BYTES; Vt_w = Ks_w + BKV * PK;
       if (t + 1 < ntiles) LL_STAGE_LOAD(t + 1)
       LL_TILE_BODY(t, 0)
       if (t + 1 < ntiles) LL_STAGE_STORE(t + 1)      // the other buffer: its last readers passed the barrier of iteration t-1
       __syncthreads();
+#endif
     }
   } else {
     for (int t = 0; t < ntiles; ++t) {
@@ -625,6 +655,7 @@ __global__ __launch_bounds__(512, 2) void attn_win14_kernel(AttnP p) {
 }
 
 static int g_attn_win_new = 1;
+static const int g_attn_xcd = getenv("LLMSEG_ATTN_NO_XCD") ? 0 : 1;
 static int g_attn_win_wgs = 256;    // persistent workgroups of the window kernel: one per CU      // tuning knob (tools): 0 = the general tiled kernel on the window shape
 
 template <int HD>
@@ -632,16 +663,19 @@ int launch_hd(const AttnP& p, hipStream_t s) {
   const bool wide = p.Nq >= 1024 && !p.causal;                       // long non-causal sequences: 256 queries per workgroup
   const int bq = wide ? 256 : 128;
   dim3 grid((p.Nq + bq - 1) / bq, p.heads, p.batch);
+  AttnP px = p;                                                        // wide kernels: 1-D XCD-grouped grid (g_attn_xcd = 0: the plain 3-D grid, A/B)
+  px.xcd_nqb = g_attn_xcd ? (int)grid.x : 0;
+  const dim3 xgrid = g_attn_xcd ? dim3((unsigned)(8 * ((p.batch * p.heads + 7) / 8) * (int)grid.x)) : grid;
   constexpr int NT4 = 256, NT8 = 512;
   if (p.rtab_h != nullptr && HD == 80 && g_attn_win_new && p.lse == nullptr) hipLaunchKernelGGL(attn_win14_kernel, dim3((unsigned)std::min(p.batch * p.heads, g_attn_win_wgs)), dim3(NT8), 0, s, p);
   else if (p.rtab_h != nullptr) hipLaunchKernelGGL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 4 : 0>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
   else if (p.rel_h == nullptr) {
-    if (wide) hipLaunchKernelGGL((attn_fwd_kernel<HD, 0, 8>), grid, dim3(NT8), 0, s, p);
+    if (wide) hipLaunchKernelGGL((attn_fwd_kernel<HD, 0, 8>), xgrid, dim3(NT8), 0, s, px);
     else hipLaunchKernelGGL((attn_fwd_kernel<HD, 0>), grid, dim3(NT4), 0, s, p);
   } else if (HD == 80 && p.gh == 14 && p.gw == 14 && p.Nk == 196 && !p.causal && !p.key_mask)
     hipLaunchKernelGGL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 3 : 1>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
   else if (p.gw == BKV && (p.Nk % BKV) == 0) {
-    if (wide) hipLaunchKernelGGL((attn_fwd_kernel<HD, 2, 8>), grid, dim3(NT8), 0, s, p);
+    if (wide) hipLaunchKernelGGL((attn_fwd_kernel<HD, 2, 8>), xgrid, dim3(NT8), 0, s, px);
     else hipLaunchKernelGGL((attn_fwd_kernel<HD, 2>), grid, dim3(NT4), 0, s, p);
   } else hipLaunchKernelGGL((attn_fwd_kernel<HD, 1>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
   return 0;
@@ -844,6 +878,7 @@ extern "C" int llmseg_attn_fwd(const llmseg_attn_args* a, void* stream) {
   p.lse = a->lse;
   p.rtab_h = (const bf16_t*)a->rel_tab_h; p.rtab_w = (const bf16_t*)a->rel_tab_w;
   p.nk_dev = a->nk_dev;
+  p.xcd_nqb = 0;
   LL_CHECK(!a->nk_dev || (!a->rel_tab_h && !a->rel_h && !a->causal), "attn: nk_dev is for plain (decode-step) attention");
   hipStream_t s = (hipStream_t)stream;
   switch (a->head_dim) {

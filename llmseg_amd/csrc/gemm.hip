@@ -1041,7 +1041,8 @@ void llmseg_prof_tag(long a, long b, long c, long d);
 // tuning knob (tools/gemm_bench.py): bits 0-3 kernel (0 = register staging 128x128; 2 = LDS-DMA 128x128; 8 / 9 = LDS-DMA ping-pong
 // 256x256 / 128x256; 5 (default) = cost model), bits 4-7 = XCD skew + 1, bits 8-12 = forced split-K slice count for 8 / 9.
 static int g_gemm_variant = 5, g_gemm_skew = 13, g_gemm_split = 0, g_gemm_pp2 = getenv("LLMSEG_GEMM_PP2") ? atoi(getenv("LLMSEG_GEMM_PP2")) : 1;
-static const int g_gemm_rsplit = getenv("LLMSEG_GEMM_NO_RSPLIT") ? 0 : 1;      // K-slices for the register-staging kernel (A/B switch)
+static const int g_gemm_rsplit = getenv("LLMSEG_GEMM_NO_RSPLIT") ? 0 : 1;
+static const int g_gemm_colsplit = getenv("LLMSEG_GEMM_NO_COLSPLIT") ? 0 : 1;      // column-split plan of the cost model (A/B switch)      // K-slices for the register-staging kernel (A/B switch)
 static int num_cus() {
   static int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
   return n;
@@ -1083,7 +1084,12 @@ inline bool split_ok(int nt, int S) {       // every slice needs >= 2 K-tiles (t
 }
 }  // namespace
 
-extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
+static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_variant);
+
+extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) { return gemm_dispatch(a, stream, -1); }
+
+// force_variant >= 0: the column-split plan below calls itself with the kernel fixed (8 / 9, one K-slice)
+static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_variant) {
   LL_CHECK(a && a->struct_size == sizeof(*a), "%s: ABI mismatch: caller's struct_size %u != %zu (bind against include/llmseg_hip.h version %d)",
            "gemm", a ? a->struct_size : 0u, sizeof(*a), LLMSEG_ABI_VERSION);
   LL_CHECK(a && a->A && a->W && a->C, "gemm: null pointer");
@@ -1121,7 +1127,7 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   static const int group_m_env = getenv("LLMSEG_GEMM_GROUP_M") ? atoi(getenv("LLMSEG_GEMM_GROUP_M")) : 0;   // tuning override
   const int nt = p.K / BK;
   const long ncu = num_cus();
-  int variant = (p.K % BK == 0 && !ta && !tw) ? g_gemm_variant : 0;
+  int variant = (p.K % BK == 0 && !ta && !tw) ? (force_variant >= 0 ? force_variant : g_gemm_variant) : 0;
   if (variant != 0 && variant != 2 && variant != 8 && variant != 9) variant = 5;
   if ((variant == 8 || variant == 9) && nt < (a->A2 ? 1 : 2)) variant = 2;
   // split-K needs a dense-enough problem for the slab layout [S][M][N], 4-column alignment and room in the caller's workspace
@@ -1142,9 +1148,36 @@ extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
         }
       }
     }
+    // Column-split plan: whole rounds of 256 x 256 tiles on the first c1 column tiles, the rest as 128 x 256 tiles, two launches.
+    // SAM lin1 at two images (8192 x 5120 x 1280) is 2.5 rounds of 256 x 256 tiles or 5 rounds of 128 x 256 tiles (what ran: 131 us);
+    // 16 column tiles x 32 row tiles = 512 big tiles = exactly 2 rounds, the last 4 column tiles x 64 = 256 small tiles = exactly 1.
+    if (g_gemm_colsplit && batch == 1 && !p.A2 && nt >= 2 && best.split == 1 && best.variant != 2) {
+      const int tn = (p.N + 255) / 256;
+      double hy_us = best.us;
+      int hy_c1 = 0;
+      for (int c1 = 1; c1 < tn; ++c1) {
+        const double us = pp_cost(p.M, 256L * c1, nt, 4, 1, ncu, a->out_f32 != 0) + pp_cost(p.M, p.N - 256L * c1, nt, 2, 1, ncu, a->out_f32 != 0);
+        if (us < hy_us) { hy_us = us; hy_c1 = c1; }
+      }
+      if (hy_c1 > 0 && hy_us < 0.93 * best.us) {
+        const long n1 = 256L * hy_c1;
+        const int esz2 = a->out_f32 ? 4 : 2;
+        llmseg_gemm_args g1 = *a, g2 = *a;
+        g1.N = n1;
+        g2.N = a->N - n1;
+        g2.W = (const char*)a->W + n1 * a->ldw * 2;
+        g2.C = (char*)a->C + n1 * esz2;
+        if (a->bias) g2.bias = (const char*)a->bias + n1 * 2;
+        if (a->gamma) g2.gamma = (const char*)a->gamma + n1 * 2;
+        if (a->residual) g2.residual = (const char*)a->residual + n1 * 2;
+        const int rc = gemm_dispatch(&g1, stream, 8);
+        if (rc != LLMSEG_OK) return rc;
+        return gemm_dispatch(&g2, stream, 9);
+      }
+    }
     variant = best.variant; split = best.split;
   } else if (variant == 8 || variant == 9) {
-    split = g_gemm_split > 1 ? g_gemm_split : 1;
+    split = (g_gemm_split > 1 && force_variant < 0) ? g_gemm_split : 1;
     if (split > 1) LL_CHECK(can_split && split_ok(nt, split) && ws_fits(split), "gemm: forced split-K %d not possible for this call", split);
   }
   if (p.A2) {
