@@ -178,6 +178,60 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
     return res
 
 
+def loader_in_loop(model, cfg, args, B, dev, dist, rank, world, local, trainer_cls, resident_ms):
+    """The same fwd+bwd micro-step fed the way a data loader feeds it (reference training.py:521-532, utils/dataset.py:33-170):
+    every micro-step gets a DIFFERENT batch -- token ids / labels / masks arrive as host tensors (what `collate_fn_new` returns), images and the
+    image's dense SAM proposals sit in device memory -- and, inside the timed region, per micro-step: N2 on the device
+    (`proposals_and_targets_dense`: top-K by area, IoU / IoP against the ground truth, antialiased 256 x 256 proposal maps), a fresh
+    `make_plan` (host index plumbing, no device->host sync: the ids are host tensors), the copy of the batch into the hipGraph's input
+    buffers, the graph replay.  `input_ms` = what all of that adds to the resident-batch step."""
+    import time
+    from llmseg_amd import synthetic, targets
+    img = 1024 if args.backbone == "sam" else 896
+    R = 3
+    g = torch.Generator(device=dev).manual_seed(4321 + rank)
+    sets = []
+    for r in range(R):
+        b = synthetic.make_batch(B, img_size=img, L=args.prompt_len, K=args.masks, device=dev, seed=777 + 13 * r + rank)
+        host = {k: b[k].cpu() for k in ("input_ids", "labels", "attention_masks", "offset")}
+        # dense proposals of every image at the image's resolution (what SAM everything mode emits, N1) + one ground-truth mask
+        props = [(torch.rand((args.masks, img, img), device=dev, generator=g) > 0.7).to(torch.uint8) for _ in range(B)]
+        areas = [p.flatten(1).sum(1) for p in props]
+        gts = [(torch.rand((img, img), device=dev, generator=g) > 0.6).to(torch.uint8) for _ in range(B)]
+        sets.append((b, host, props, areas, gts))
+    trainer = trainer_cls(model, lr=3e-4, grad_accum=args.accum, device_ids=[local], use_graph=True)
+    t_plan = [0.0, 0]
+    it = [0]
+
+    def step():
+        b, host, props, areas, gts = sets[it[0] % R]
+        it[0] += 1
+        tg = [targets.proposals_and_targets_dense(props[i], areas[i], [gts[i]], top=args.masks) for i in range(B)]
+        batch = dict(b)
+        batch["sam_segs_list"] = [t["sam_segs"] for t in tg]
+        batch["sam_ious_list"] = [t["sam_ious"] for t in tg]
+        batch["sam_iops_list"] = [t["sam_iops"] for t in tg]
+        t0 = time.perf_counter()
+        plan = model.make_plan(host["input_ids"], host["labels"], host["attention_masks"], host["offset"], sam_segs_list=batch["sam_segs_list"])
+        t_plan[0] += time.perf_counter() - t0
+        t_plan[1] += 1
+        return trainer.micro_step(batch, plan)
+
+    def first_optimizer_step():
+        trainer.optimizer_step()
+        trainer.micro = 0
+        t_plan[0], t_plan[1] = 0.0, 0
+    dt, out = timed(step, args.steps, args.warmup + 3, dist, dev, first_optimizer_step)
+    ms = dt / args.steps * 1e3
+    res = {"value": B * world * args.steps / dt, "unit": "images/s", "ms_per_step": ms, "input_ms": ms - resident_ms,
+           "make_plan_host_ms": t_plan[0] / max(1, t_plan[1]) * 1e3, "distinct_batches": R,
+           "graph": bool(trainer.graph_error is None and any(e["graph"] is not None for e in trainer._graphs.values())), "loss": float(out["loss"].detach()),
+           "what": "per micro-step inside the timed region: proposals_and_targets_dense on the device for every image (%d dense proposals at %dx%d), "
+                   "make_plan from host token tensors, copy into the captured graph's inputs, replay" % (args.masks, img, img)}
+    trainer.close()
+    return res
+
+
 def neighbours(model, cfg, dev, prompt_len):
     """Side measurements of the rows next to the path, same model, outside the timed region: N3 = `evaluate()`'s generation
     (KV-cache decode, ms per token vs the 13.2 GB weight stream), N1 = SAM everything mode from the image embedding (32 x 32 point grid).
@@ -246,6 +300,8 @@ def main():
     ap.add_argument("--lora-dropout", type=float, default=0.05, help="peft lora_dropout (reference training.py:91)")
     ap.add_argument("--no-neighbours", action="store_true", help="skip the generation / everything-mode side measurements (SURVEY.md 8f N3, N1)")
     ap.add_argument("--accum", type=int, default=10, help="gradient-accumulation micro-steps per optimizer step (reference: 10)")
+    ap.add_argument("--no-k512", action="store_true", help="skip the BASELINE configs[4] side measurement (512 candidate masks, grad-accum 8) reported under batch_<B>_k512")
+    ap.add_argument("--no-loader", action="store_true", help="skip the loader-in-the-loop side measurement (a different batch + device-side targets + a fresh plan every micro-step)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -288,6 +344,17 @@ def main():
     extra = None
     if args.extra_batch and args.extra_batch != args.batch:
         extra = measure(model, cfg, args, args.extra_batch, dev, dist, rank, world, local, use_graph, Trainer)
+    k512 = None
+    if train and not args.no_k512 and not args.small:
+        # BASELINE configs[4]'s workload shape on this model: 512 candidate masks per image, gradient accumulation 8 (training.py:79-82)
+        a4 = argparse.Namespace(**vars(args))
+        a4.masks, a4.accum, a4.no_fwd_only = 512, 8, True
+        a4.steps = max(a4.accum, (args.steps // a4.accum) * a4.accum)           # whole accumulation windows inside the timed region
+        k512 = measure(model, cfg, a4, args.batch, dev, dist, rank, world, local, use_graph, Trainer)
+        k512["workload"] = "BASELINE.json configs[4] shape: %d candidate masks per image, grad-accum %d, %d timed micro-steps" % (a4.masks, a4.accum, a4.steps)
+    loader = None
+    if train and use_graph and not args.no_loader and not args.small:
+        loader = loader_in_loop(model, cfg, args, args.batch, dev, dist, rank, world, local, Trainer, main_res["ms_per_step"])
 
     if rank == 0:
         img = 1024 if args.backbone == "sam" else 896
@@ -319,6 +386,10 @@ def main():
             res["fwd_only"] = main_res["fwd_only"]
         if extra is not None:
             res[f"batch_{args.extra_batch}"] = extra
+        if k512 is not None:
+            res[f"batch_{args.batch}_k512"] = k512
+        if loader is not None:
+            res["loader_in_loop"] = loader
         if world == 1 and not args.no_neighbours and not args.small and args.backbone == "sam":
             res["neighbours"] = neighbours(model, cfg, dev, args.prompt_len)
         if world == 1 and not args.no_cpu_baseline:

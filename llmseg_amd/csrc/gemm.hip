@@ -1041,8 +1041,7 @@ void llmseg_prof_tag(long a, long b, long c, long d);
 // tuning knob (tools/gemm_bench.py): bits 0-3 kernel (0 = register staging 128x128; 2 = LDS-DMA 128x128; 8 / 9 = LDS-DMA ping-pong
 // 256x256 / 128x256; 5 (default) = cost model), bits 4-7 = XCD skew + 1, bits 8-12 = forced split-K slice count for 8 / 9.
 static int g_gemm_variant = 5, g_gemm_skew = 13, g_gemm_split = 0, g_gemm_pp2 = getenv("LLMSEG_GEMM_PP2") ? atoi(getenv("LLMSEG_GEMM_PP2")) : 1;
-static const int g_gemm_rsplit = getenv("LLMSEG_GEMM_NO_RSPLIT") ? 0 : 1;
-static const int g_gemm_colsplit = getenv("LLMSEG_GEMM_NO_COLSPLIT") ? 0 : 1;      // column-split plan of the cost model (A/B switch)      // K-slices for the register-staging kernel (A/B switch)
+static const int g_gemm_rsplit = getenv("LLMSEG_GEMM_NO_RSPLIT") ? 0 : 1;      // K-slices for the register-staging kernel (A/B switch)
 static int num_cus() {
   static int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
   return n;
@@ -1088,7 +1087,7 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
 
 extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) { return gemm_dispatch(a, stream, -1); }
 
-// force_variant >= 0: the column-split plan below calls itself with the kernel fixed (8 / 9, one K-slice)
+// force_variant >= 0: an internal caller fixes the kernel (8 / 9, one K-slice)
 static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_variant) {
   LL_CHECK(a && a->struct_size == sizeof(*a), "%s: ABI mismatch: caller's struct_size %u != %zu (bind against include/llmseg_hip.h version %d)",
            "gemm", a ? a->struct_size : 0u, sizeof(*a), LLMSEG_ABI_VERSION);
@@ -1146,33 +1145,6 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
           const double us = pp_cost(p.M, p.N, nt, mi, S, ncu, a->out_f32 != 0) * (double)batch;
           if (us < best.us * 0.97 || (us < best.us && S == 1)) best = GemmPlan{mi == 4 ? 8 : 9, S, us};
         }
-      }
-    }
-    // Column-split plan: whole rounds of 256 x 256 tiles on the first c1 column tiles, the rest as 128 x 256 tiles, two launches.
-    // SAM lin1 at two images (8192 x 5120 x 1280) is 2.5 rounds of 256 x 256 tiles or 5 rounds of 128 x 256 tiles (what ran: 131 us);
-    // 16 column tiles x 32 row tiles = 512 big tiles = exactly 2 rounds, the last 4 column tiles x 64 = 256 small tiles = exactly 1.
-    if (g_gemm_colsplit && batch == 1 && !p.A2 && nt >= 2 && best.split == 1 && best.variant != 2) {
-      const int tn = (p.N + 255) / 256;
-      double hy_us = best.us;
-      int hy_c1 = 0;
-      for (int c1 = 1; c1 < tn; ++c1) {
-        const double us = pp_cost(p.M, 256L * c1, nt, 4, 1, ncu, a->out_f32 != 0) + pp_cost(p.M, p.N - 256L * c1, nt, 2, 1, ncu, a->out_f32 != 0);
-        if (us < hy_us) { hy_us = us; hy_c1 = c1; }
-      }
-      if (hy_c1 > 0 && hy_us < 0.93 * best.us) {
-        const long n1 = 256L * hy_c1;
-        const int esz2 = a->out_f32 ? 4 : 2;
-        llmseg_gemm_args g1 = *a, g2 = *a;
-        g1.N = n1;
-        g2.N = a->N - n1;
-        g2.W = (const char*)a->W + n1 * a->ldw * 2;
-        g2.C = (char*)a->C + n1 * esz2;
-        if (a->bias) g2.bias = (const char*)a->bias + n1 * 2;
-        if (a->gamma) g2.gamma = (const char*)a->gamma + n1 * 2;
-        if (a->residual) g2.residual = (const char*)a->residual + n1 * 2;
-        const int rc = gemm_dispatch(&g1, stream, 8);
-        if (rc != LLMSEG_OK) return rc;
-        return gemm_dispatch(&g2, stream, 9);
       }
     }
     variant = best.variant; split = best.split;
