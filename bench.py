@@ -184,7 +184,8 @@ def loader_in_loop(model, cfg, args, B, dev, dist, rank, world, local, trainer_c
     image's dense SAM proposals sit in device memory -- and, inside the timed region, per micro-step: N2 on the device
     (`proposals_and_targets_dense`: top-K by area, IoU / IoP against the ground truth, antialiased 256 x 256 proposal maps), a fresh
     `make_plan` (host index plumbing, no device->host sync: the ids are host tensors), the copy of the batch into the hipGraph's input
-    buffers, the graph replay.  `input_ms` = what all of that adds to the resident-batch step."""
+    buffers, the graph replay.  The targets of micro-step i + 1 are issued on a second stream beside micro-step i (a loader prefetches).
+    `input_ms` = what all of that adds to the resident-batch step; `targets_gpu_ms` = the N2 kernels' own duration per micro-step."""
     import time
     from llmseg_amd import synthetic, targets
     img = 1024 if args.backbone == "sam" else 896
@@ -202,11 +203,33 @@ def loader_in_loop(model, cfg, args, B, dev, dist, rank, world, local, trainer_c
     trainer = trainer_cls(model, lr=3e-4, grad_accum=args.accum, device_ids=[local], use_graph=True)
     t_plan = [0.0, 0]
     it = [0]
+    n2_events = []
+
+    side = torch.cuda.Stream(device=dev)
+
+    def prepare(i):
+        """The loader's device-side stage for micro-step i, issued on its own stream so that it runs beside the previous micro-step (a loader
+        prefetches): N2 targets of every image.  -> (targets, event)"""
+        b, host, props, areas, gts = sets[i % R]
+        with torch.cuda.stream(side):                     # no dependence on the main stream: the proposals are resident, the outputs are fresh tensors
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            tg = [targets.proposals_and_targets_dense(props[j], areas[j], [gts[j]], top=args.masks) for j in range(B)]
+            e1.record()
+        n2_events.append((e0, e1))
+        return tg, e1
+
+    pending = [prepare(0)]
 
     def step():
         b, host, props, areas, gts = sets[it[0] % R]
+        tg, ready = pending[0]
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ready)
+        for t_ in tg:
+            for k in ("sam_segs", "sam_ious", "sam_iops"):
+                t_[k].record_stream(cur)
         it[0] += 1
-        tg = [targets.proposals_and_targets_dense(props[i], areas[i], [gts[i]], top=args.masks) for i in range(B)]
         batch = dict(b)
         batch["sam_segs_list"] = [t["sam_segs"] for t in tg]
         batch["sam_ious_list"] = [t["sam_ious"] for t in tg]
@@ -215,7 +238,9 @@ def loader_in_loop(model, cfg, args, B, dev, dist, rank, world, local, trainer_c
         plan = model.make_plan(host["input_ids"], host["labels"], host["attention_masks"], host["offset"], sam_segs_list=batch["sam_segs_list"])
         t_plan[0] += time.perf_counter() - t0
         t_plan[1] += 1
-        return trainer.micro_step(batch, plan)
+        out = trainer.micro_step(batch, plan)
+        pending[0] = prepare(it[0])                       # the next micro-step's targets run beside this one's graph
+        return out
 
     def first_optimizer_step():
         trainer.optimizer_step()
@@ -225,9 +250,10 @@ def loader_in_loop(model, cfg, args, B, dev, dist, rank, world, local, trainer_c
     ms = dt / args.steps * 1e3
     res = {"value": B * world * args.steps / dt, "unit": "images/s", "ms_per_step": ms, "input_ms": ms - resident_ms,
            "make_plan_host_ms": t_plan[0] / max(1, t_plan[1]) * 1e3, "distinct_batches": R,
+           "targets_gpu_ms": sum(a.elapsed_time(b_) for a, b_ in n2_events[-args.steps:]) / max(1, min(args.steps, len(n2_events))),
            "graph": bool(trainer.graph_error is None and any(e["graph"] is not None for e in trainer._graphs.values())), "loss": float(out["loss"].detach()),
-           "what": "per micro-step inside the timed region: proposals_and_targets_dense on the device for every image (%d dense proposals at %dx%d), "
-                   "make_plan from host token tensors, copy into the captured graph's inputs, replay" % (args.masks, img, img)}
+           "what": "per micro-step inside the timed region: proposals_and_targets_dense on the device for every image (%d dense proposals at %dx%d; "
+                   "issued on a second stream one micro-step ahead), make_plan from host token tensors, copy into the captured graph's inputs, replay" % (args.masks, img, img)}
     trainer.close()
     return res
 

@@ -253,11 +253,13 @@ class TrainableMixin:
             plan.groups = {K: plan.groups[K] for K in sorted(plan.groups)}
             for K, members in plan.groups.items():
                 loss_w[K] = torch.tensor([1.0 / (rounds[b] + 1e-8) for b in members for _ in range(rounds[b])], dtype=torch.float32)
-        plan.tensors = dict(key_mask=key_mask.contiguous().to(dev), clip_index=clip_index.to(dev), tok_index=tok.reshape(-1).to(dev),
-                            seg_idx=seg_idx.to(dev), new_labels=None if new_labels is None else new_labels.contiguous().to(dev),
-                            ce_rows=None if ce_rows is None else ce_rows.to(dev), ce_labels=None if ce_labels is None else ce_labels.contiguous().to(dev))
+        # pinned staging + non-blocking copies: a pageable host->device copy makes the host wait until the stream has drained, i.e. until the
+        # previous micro-step's graph has finished -- with a loader in the loop that idles the GPU for the whole host side of a step
+        up = lambda t: None if t is None else t.contiguous().pin_memory().to(dev, non_blocking=True)
+        plan.tensors = dict(key_mask=up(key_mask), clip_index=up(clip_index), tok_index=up(tok.reshape(-1)), seg_idx=up(seg_idx),
+                            new_labels=up(new_labels), ce_rows=up(ce_rows), ce_labels=up(ce_labels))
         for K, w in loss_w.items():
-            plan.tensors[f"loss_w{K}"] = w.to(dev)
+            plan.tensors[f"loss_w{K}"] = up(w)
         return plan
 
     # ------------------------------------------------------------------------------------------------ language
