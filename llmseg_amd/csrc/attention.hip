@@ -25,6 +25,9 @@ namespace {
 #ifndef ATTN_ABLATE
 #define ATTN_ABLATE 0          // side builds (tools/attn_ablate.sh): 1 = exp -> identity, 2 = K/V staged once, 3 = 2 + no barrier, 4 = no PV MFMAs, 5 = no QK MFMAs
 #endif
+#ifndef WIN_ABLATE
+#define WIN_ABLATE 0           // side builds of attn_win14_kernel: 1 = exp -> identity, 2 = K/V staged once, 3 = no rel-pos, 4 = no P.V MFMAs, 5 = no Q.K^T MFMAs
+#endif
 #if ATTN_ABLATE == 1
 #define ATTN_EXP(x) (x)
 #else
@@ -50,6 +53,7 @@ struct AttnP {
   int xcd_nqb;                                  // > 0: 1-D grid, XCD-grouped (see attn_fwd_kernel); = query blocks per (batch, head)
 };
 
+typedef short short4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t perm_lo(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }
 __device__ __forceinline__ uint32_t perm_hi(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xffff0000u); }
 
@@ -502,8 +506,14 @@ __global__ __launch_bounds__(512, 2) void attn_win14_kernel(AttnP p) {
   while (true) {
   // ---- this item's K -> LDS row-major (padded pitch), V -> LDS transposed, Q -> fragments; then the NEXT item's loads are issued and
   //      fly behind this item's MFMAs (one workgroup per CU: without the prefetch HBM idles during compute and the CU during loads) ----
+#if WIN_ABLATE == 2
+  if (item == vwg) {
+#endif
   WIN_K_STORE(0, kr0) WIN_K_STORE(1, kr1) WIN_K_STORE(2, kr2) WIN_K_STORE(3, kr3) WIN_K_STORE(4, kr4)
   WIN_V_STORE(0, va0, va1, va2, va3) WIN_V_STORE(1, vb0, vb1, vb2, vb3)
+#if WIN_ABLATE == 2
+  }
+#endif
   bf16x8_t qf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
@@ -516,7 +526,9 @@ __global__ __launch_bounds__(512, 2) void attn_win14_kernel(AttnP p) {
     Qg = p.Q + (long)b * p.qsb + (long)h * p.qsh;
     Kg = p.K + (long)b * p.ksb + (long)h * p.ksh;
     Vg = p.V + (long)b * p.vsb + (long)h * p.vsh;
+#if WIN_ABLATE != 2
     WIN_LOAD_ALL()
+#endif
   }
 
   // ---- scores of the whole key range: s[kb][r] = S^T[key = 32 kb + (r&3) + 8 (r>>2) + 4 half][query], rel-pos bias added after (keeps the bias registers off the MFMA phase's peak) ----
@@ -530,11 +542,12 @@ __global__ __launch_bounds__(512, 2) void attn_win14_kernel(AttnP p) {
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {                               // 7 independent accumulators between dependent MFMAs
       const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (kb * 32 + ql) * PK + (2 * ks + half) * 16);
-      s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+      if (WIN_ABLATE != 5) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+      else s[kb][ks] += (float)kf[0] + (float)qf[ks][0];
     }
   // ---- decomposed rel-pos (image_encoder.py:354-392): G^T = R . Q^T on the matrix cores, bounced through a per-wave slab so that each
   //      lane can pick the entries at its own (qh - kh + 13) / (qw - kw + 13); the lane-half (key or key + 4) is folded into the LOAD ----
-  {
+  if (WIN_ABLATE != 3) {
   float bh_s[14], bh_x[13], bw_y[14];
   {
     float* gs = reinterpret_cast<float*>(smem + NKP * PK + DT * 32 * PV) + wave * (2 * G_SLAB);
@@ -589,8 +602,12 @@ __global__ __launch_bounds__(512, 2) void attn_win14_kernel(AttnP p) {
   for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
+#if WIN_ABLATE == 1
+      const float p0 = fmaf(s[kb][r], p.scale_log2, nmc), p1 = fmaf(s[kb][r + 1], p.scale_log2, nmc);
+#else
       const float p0 = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2, nmc));
       const float p1 = __builtin_amdgcn_exp2f(fmaf(s[kb][r + 1], p.scale_log2, nmc));
+#endif
       lsum += p0 + p1;
       pk[kb][r >> 1] = pack2bf(p0, p1);
     }
@@ -615,7 +632,8 @@ __global__ __launch_bounds__(512, 2) void attn_win14_kernel(AttnP p) {
         const uint2 va = *reinterpret_cast<const uint2*>(vrow);
         const uint2 vb = *reinterpret_cast<const uint2*>(vrow + 16);
         const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(va.x, va.y, vb.x, vb.y));
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+        if (WIN_ABLATE != 4) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+        else o[d][ss & 15] += (float)vf[0] + (float)pf[0];
       }
     }
 
@@ -654,7 +672,241 @@ __global__ __launch_bounds__(512, 2) void attn_win14_kernel(AttnP p) {
 #undef WIN_V_STORE
 }
 
-static int g_attn_win_new = 1;
+// ---- the same window attention with K / V arriving by LDS-DMA (round 3) -------------------------------------------------------------------
+// What bounded attn_win14_kernel (side builds with one section removed, 600 windows x 16 heads, tools/attn_ablate.sh): shipped 487 us; K / V
+// staged once 300 us (-38 %); no rel-pos 327 us (-33 %); exp -> identity, no P.V MFMAs, no Q.K^T MFMAs: -0..13 %.  I.e. the register
+// staging (13 16-byte loads, 5 + 16 LDS stores and 32 permutes per thread and item) and the rel-pos bounce (64 scattered 4-byte LDS stores +
+// 41 loads + 41 multiplies + 448 adds per lane and item), not the matrix pipe or the exponentials.  Here:
+//   * K and V rows go global -> LDS by `buffer_load ... lds` (1 KiB per wave-instruction, 4-5 per wave and operand), row-major at their
+//     natural 160-byte pitch, into the buffers of the NEXT item while this item computes (two K + two V buffers, one barrier per item);
+//     K rows 8..15 of every 16 are stored rotated by one 16-byte chunk (the DMA's per-lane SOURCE address is free) so that the
+//     `ds_read_b128` K fragments of a 16-lane service group touch 64 distinct banks; V^T fragments come from the row-major image through
+//     two `ds_read_b64_tr_b16` each (profiles/r02_tr_b16_probe.md: no transposes anywhere);
+//   * the rel-pos tables' MFMA fragments stay in registers for the whole kernel; G^T = R . Q^T is bounced through ONE per-wave slab (table h,
+//     then table w) with 16-byte stores; the bias enters the score accumulators as their INITIAL value (one add per score instead of two
+//     after the MFMAs).
+__global__ __launch_bounds__(512, 2) void attn_win14_dma_kernel(AttnP p) {
+  constexpr int HD = 80, KS = HD / 16, DT = 3, NKB = 7, NKEY = 196, ROWB = HD * 2;
+  constexpr int KBYTES = NKEY * ROWB;                    // 31360: rows >= 196 of the last key block are never real keys (masked below)
+  constexpr int VROWS = 208, VBYTES = VROWS * ROWB;      // 33280: 13 k-steps of 16 keys; rows 196..207 hold copies of row 195 (finite, times P = 0)
+  constexpr int K_DMA = (KBYTES + 1023) / 1024, V_DMA = (VBYTES + 1023) / 1024;      // 31 / 33 one-KiB pieces
+  constexpr int SPITCH = 28, SLAB = 32 * SPITCH;         // per-wave fp32 slab [32 queries][28 table rows]
+  __shared__ __attribute__((aligned(16))) char smem[2 * KBYTES + 2 * VBYTES + 8 * SLAB * 4];       // 157,952 B
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ql = lane & 31, half = lane >> 5;
+  const int q = wave * 32 + ql;
+  const int qc = min(q, NKEY - 1);
+  const int qh = qc / 14, qw = qc - qh * 14;
+  const int nitems = p.batch * p.heads;
+  const int wg = (int)blockIdx.x, nwg = (int)gridDim.x;
+  const int vwg = (nwg % 8 == 0) ? (wg % 8) * (nwg / 8) + wg / 8 : wg;
+  int item = vwg;
+  if (item >= nitems) return;
+  int b = item / p.heads, h = item - b * p.heads;
+
+  // per-lane DMA source offsets (bytes from the item's K / V base): piece j = wave + 8 k fills LDS bytes [1024 j, 1024 j + 1024)
+  int kvoff[4], vvoff[5];
+  bool kval[4], vval[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int j = wave + 8 * k, L = j * 1024 + lane * 16;
+    const int row = L / ROWB, slot = (L - row * ROWB) >> 4;
+    if (k < 4) {
+      int c = slot - ((row >> 3) & 1);                   // LDS slot `slot` of a rotated row holds global chunk slot - 1 (mod 10)
+      if (c < 0) c += HD / 8;
+      kvoff[k] = (min(row, NKEY - 1) * (int)p.ksr + c * 8) * 2;
+      kval[k] = j < K_DMA && L < KBYTES;
+    }
+    vvoff[k] = (min(row, NKEY - 1) * (int)p.vsr + slot * 8) * 2;
+    vval[k] = j < V_DMA && L < VBYTES;
+  }
+  // fragment read offsets: K row ql of a key block, chunk 2 ks + half at its (rotated) slot; V^T through the transposing read
+  int koff[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) koff[ks] = ql * ROWB + (((2 * ks + half + ((ql >> 3) & 1)) % (HD / 8)) << 4);
+  const int voff = (4 * half + ((lane & 15) >> 2)) * ROWB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  // rel-pos table fragments (A operands of G^T = R . Q^T), resident: rows >= 27 of the tables are zero
+  bf16x8_t rth[KS], rtw[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    rth[ks] = *reinterpret_cast<const bf16x8_t*>(p.rtab_h + ql * HD + ks * 16 + half * 8);
+    rtw[ks] = *reinterpret_cast<const bf16x8_t*>(p.rtab_w + ql * HD + ks * 16 + half * 8);
+  }
+  const int qoff = qc * (int)p.qsr + half * 8;
+  bf16x8_t qn[KS];
+  typedef __attribute__((address_space(3))) void* lds_p;
+  typedef __attribute__((address_space(3))) short4v* lds_tr;
+
+  // One 1-KiB LDS-DMA piece as an asm statement: hipcc must NOT see it -- a `buffer_load ... lds` builtin is tracked as a store to `smem`, and
+  // because the next item's buffers cannot be proven distinct from this item's, every fragment read after it got an `s_waitcnt vmcnt`
+  // that drained the DMA before the compute started (measured in the ISA: vmcnt(5) right behind the issue).  M0 is written in the same
+  // statement that reads it (cdna_hip_programming.md 5.7); completion is counted by the explicit vmcnt(0) at the top of the item loop.
+#define WIND_DMA16(LDS_BYTE_ADDR, GSRC)                                                                             \
+  {                                                                                                                 \
+    unsigned keep_;                                                                                                 \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"        \
+                 : "=&s"(keep_) : "v"(GSRC), "s"(LDS_BYTE_ADDR) : "memory");                                        \
+  }
+#define WIND_ISSUE(KD, VD)                                                                                          \
+  {                                                                                                                 \
+    const char* Kg = reinterpret_cast<const char*>(p.K + (long)b * p.ksb + (long)h * p.ksh);                        \
+    const char* Vg = reinterpret_cast<const char*>(p.V + (long)b * p.vsb + (long)h * p.vsh);                        \
+    const bf16_t* Qg = p.Q + (long)b * p.qsb + (long)h * p.qsh;                                                     \
+    const unsigned kd_ = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_p)(KD)) + wave * 1024;           \
+    const unsigned vd_ = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_p)(VD)) + wave * 1024;           \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                                   \
+      if (kval[k]) WIND_DMA16(kd_ + 8192 * k, Kg + kvoff[k])                                                        \
+    _Pragma("unroll") for (int k = 0; k < 5; ++k)                                                                   \
+      if (vval[k]) WIND_DMA16(vd_ + 8192 * k, Vg + vvoff[k])                                                        \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) qn[ks] = *reinterpret_cast<const bf16x8_t*>(Qg + (qoff + ks * 16)); \
+  }
+
+  char* Kc = smem;                                   // buffers of the item being computed
+  char* Vc = smem + 2 * KBYTES;
+  char* Kn = smem + KBYTES;                          // buffers the next item is DMA'd into
+  char* Vn = smem + 2 * KBYTES + VBYTES;
+  float* const gs = reinterpret_cast<float*>(smem + 2 * KBYTES + 2 * VBYTES) + wave * SLAB;
+  WIND_ISSUE(Kc, Vc)
+
+  while (true) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of the item (and its Q rows) have arrived
+    __syncthreads();                                           // ... everyone's have, and everyone is done with the previous item's buffers
+    bf16x8_t qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
+    const int cb = b, chd = h;
+    item += nwg;
+    const bool more = item < nitems;
+    if (more) {
+      b = item / p.heads; h = item - b * p.heads;
+      WIND_ISSUE(Kn, Vn)                                       // flies behind this item's compute
+    }
+
+    // ---- decomposed rel-pos: G^T = R . Q^T per table, bounced through the per-wave slab; lane-half folded into the LOAD index ----
+    float bh_s[14], bh_x[13], bw_y[14];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+      f32x16_t g;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) g[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tb == 0 ? rth[ks] : rtw[ks], qf[ks], g, 0, 0, 0);
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)                              // regs 4 gq .. + 3 = table rows 8 gq + 4 half + 0..3 of query ql
+        if (!(gq == 3 && half == 1))
+          *reinterpret_cast<float4*>(gs + ql * SPITCH + 8 * gq + 4 * half) = make_float4(g[4 * gq], g[4 * gq + 1], g[4 * gq + 2], g[4 * gq + 3]);
+      if (tb == 0) {
+        const float* gh = gs + ql * SPITCH + qh;
+#pragma unroll
+        for (int j = 0; j < 14; ++j) bh_s[j] = gh[13 - j] * p.inv_scale;
+#pragma unroll
+        for (int j = 0; j < 13; ++j) bh_x[j] = gh[13 - j - half] * p.inv_scale;
+      } else {
+        const float* gw = gs + ql * SPITCH + qw + 13;
+#pragma unroll
+        for (int j = 0; j < 14; ++j) bw_y[j] = gw[-((j + 4 * half) % 14)] * p.inv_scale;
+      }
+    }
+
+    // ---- scores: accumulators start at the bias, then 35 MFMAs (7 independent accumulators between dependent ones) ----
+    f32x16_t s[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key0 = kb * 32 + (r & 3) + 8 * (r >> 2);            // this register's key for half 0; half 1: + 4
+        const int kh0 = key0 / 14 > 13 ? 13 : key0 / 14, kw0 = key0 % 14;
+        const bool cross = kw0 >= 10 && kh0 < 13;                    // key0 + 4 falls into the next key row
+        s[kb][r] = (cross ? bh_x[kh0 > 12 ? 12 : kh0] : bh_s[kh0]) + bw_y[kw0];
+      }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Kc + kb * (32 * ROWB) + koff[ks]);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+      }
+    // keys >= 196 live in block 6 only: key = 192 + (r&3) + 8 (r>>2) + 4 half is valid for half 0, r < 4
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (half != 0 || r >= 4) s[NKB - 1][r] = NEG;
+    float mx = NEG;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float nmc = -mx * p.scale_log2;
+    float lsum = 0.f;
+    uint32_t pk[NKB][8];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2, nmc));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[kb][r + 1], p.scale_log2, nmc));
+        lsum += p0 + p1;
+        pk[kb][r >> 1] = pack2bf(p0, p1);
+      }
+
+    // ---- O^T = V^T . P^T: k-steps of 16 keys; V^T fragments = two transposing reads of the row-major V image ----
+    f32x16_t o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (kb == NKB - 1 && u == 1) continue;                         // keys 208..223: all padding
+        const int rb = 8 * u, ss = 2 * kb + u;
+        const uint4 pu = make_uint4(pk[kb][rb / 2 + 0], pk[kb][rb / 2 + 1], pk[kb][rb / 2 + 2], pk[kb][rb / 2 + 3]);
+        const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const char* va = Vc + ss * (16 * ROWB) + voff + d * 64;     // keys 16 ss + 4 half + 0..3 | + 8: the P fragment's k-slot order
+          const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)va);
+          const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(va + 8 * ROWB));
+          const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+        }
+      }
+
+    // ---- normalise and store through the window un-partition map ----
+    const float l_tot = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (q < NKEY) {
+      bf16_t* orow;
+      bool skip = false;
+      if (p.o_row_map) {
+        const int row = p.o_row_map[(long)cb * p.Nq + q];
+        skip = row < 0;
+        orow = p.O + (long)chd * p.osh + (long)(skip ? 0 : row) * p.osr;
+      } else {
+        orow = p.O + (long)cb * p.osb + (long)chd * p.osh + (long)q * p.osr;
+      }
+      if (!skip) {
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int dd = d * 32 + 8 * g + 4 * half;
+            if (dd < HD)
+              *reinterpret_cast<uint2*>(orow + dd) =
+                  make_uint2(pack2bf(o[d][4 * g] * inv, o[d][4 * g + 1] * inv), pack2bf(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv));
+          }
+      }
+    }
+    if (!more) break;
+    { char* x = Kc; Kc = Kn; Kn = x; x = Vc; Vc = Vn; Vn = x; }
+  }
+#undef WIND_ISSUE
+#undef WIND_DMA16
+}
+
+static int g_attn_win_new = 2;      // SAM 14 x 14 windows: 0 = the general tiled kernel, 1 = resident-window kernel (register staging), 2 = LDS-DMA form
 static const int g_attn_xcd = getenv("LLMSEG_ATTN_NO_XCD") ? 0 : 1;
 static int g_attn_win_wgs = 256;    // persistent workgroups of the window kernel: one per CU      // tuning knob (tools): 0 = the general tiled kernel on the window shape
 
@@ -667,7 +919,9 @@ int launch_hd(const AttnP& p, hipStream_t s) {
   px.xcd_nqb = g_attn_xcd ? (int)grid.x : 0;
   const dim3 xgrid = g_attn_xcd ? dim3((unsigned)(8 * ((p.batch * p.heads + 7) / 8) * (int)grid.x)) : grid;
   constexpr int NT4 = 256, NT8 = 512;
-  if (p.rtab_h != nullptr && HD == 80 && g_attn_win_new && p.lse == nullptr) hipLaunchKernelGGL(attn_win14_kernel, dim3((unsigned)std::min(p.batch * p.heads, g_attn_win_wgs)), dim3(NT8), 0, s, p);
+  if (p.rtab_h != nullptr && HD == 80 && g_attn_win_new == 2 && p.lse == nullptr && p.ksr == p.vsr)
+    hipLaunchKernelGGL(attn_win14_dma_kernel, dim3((unsigned)std::min(p.batch * p.heads, g_attn_win_wgs)), dim3(NT8), 0, s, p);
+  else if (p.rtab_h != nullptr && HD == 80 && g_attn_win_new && p.lse == nullptr) hipLaunchKernelGGL(attn_win14_kernel, dim3((unsigned)std::min(p.batch * p.heads, g_attn_win_wgs)), dim3(NT8), 0, s, p);
   else if (p.rtab_h != nullptr) hipLaunchKernelGGL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 4 : 0>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
   else if (p.rel_h == nullptr) {
     if (wide) hipLaunchKernelGGL((attn_fwd_kernel<HD, 0, 8>), xgrid, dim3(NT8), 0, s, px);
@@ -838,7 +1092,7 @@ extern "C" int llmseg_decode_attn(const void* qkv, int64_t ld, const float* cos,
 }
 
 extern "C" int llmseg_attn_set_variant(int v) {
-  g_attn_win_new = v & 1;
+  g_attn_win_new = v & 3;
   g_attn_win_wgs = (v >> 4) > 0 ? (v >> 4) : 256;
   return LLMSEG_OK;
 }

@@ -29,7 +29,7 @@ def run(batch, n, H, hd, rel=None, grid=(0, 0), causal=False, iters=5):
     print(f"{mode}: batch={batch} n={n} H={H} hd={hd}: {ms*1e3:.1f} us, {fl/ms/1e9:.0f} TFLOP/s (dense count)")
 if mode == "wint":
     from llmseg_amd import _lib
-    for v in (0, 1):
+    for v in (1, 2, 1, 2):
         _lib.load().llmseg_attn_set_variant(v)
         print("variant", v, end=" ")
         run(B * 25, 196, 16, 80, rel="tab", grid=(14, 14), iters=20)
