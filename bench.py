@@ -36,14 +36,19 @@ def cpu_baseline(threads=None, budget_s=45.0):
 def pmc_traffic(kernel, B):
     """HBM bytes per launch of `kernel` from the fabric counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x 2 on
     gfx950; tools/pmc_traffic.sh -> profiles/traffic.json, collected on an MI355X with this same bench command at the same batch).  The
-    counters cannot be read from inside this process: None when no record for this kernel and batch is committed."""
+    counters cannot be read from inside this process: (None, provenance) when no record for this kernel and batch is committed.
+    -> (bytes per launch | None, {"file", "sha1", "collected"}): which committed file the number comes from and what tree it was collected on."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"batch_{B}", {}).get("kernels", {})
+        raw = open(path, "rb").read()
+        doc = json.loads(raw)
     except (OSError, ValueError):
-        return None
-    key = kernel.replace("<*", "<false")
-    hit = rec.get(key)
-    return None if hit is None else hit["hbm_bytes_per_launch"]
+        return None, None
+    rec = doc.get(f"batch_{B}", {})
+    prov = {"file": "profiles/traffic.json", "sha1": hashlib.sha1(raw).hexdigest()[:16], "collected": rec.get("source")}
+    hit = rec.get("kernels", {}).get(kernel.replace("<*", "<false"))
+    return (None if hit is None else hit["hbm_bytes_per_launch"]), prov
 
 
 def attention_flops(cfg, B, T):
@@ -158,8 +163,9 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
     ach = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     ach_all = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     model_flops = gemm_flops / n_prof + attention_flops(cfg, B, T)
+    traffic, traffic_src = pmc_traffic(prof["dominant_kernel"], B)
     res["roofline"] = {"bound": "mfma", "kernel": prof["dominant_kernel"], "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                       "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(prof["dominant_kernel"], B),
+                       "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                        "algorithmic_bytes_per_launch": prof["dominant_alg_bytes"] / max(1, dom_launches), "launches_per_step": dom_launches / n_prof,
                        "avg_launch_us": dom_ms * 1e3 / max(1, dom_launches), "time_share_of_step": dom_ms / n_prof / res["ms_per_step"],
                        "timing": "HIP events around every GEMM launch, %d eager single-stream steps of the same micro-step after the timed region" % n_prof,

@@ -228,6 +228,27 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const bf16_t* __restrict__ 
     for (long i = threadIdx.x; i < V; i += blockDim.x) out[i] = 0;
     return;
   }
+  if (ce_row_fast(row, V, ldl) && (((uintptr_t)out) & 7) == 0) {      // one read of the row (registers), one 8-byte write per quad
+    CeRow r;
+    r.load(row, V);
+    float mx, s;
+    r.stats(red, mx, s);
+    const float c = coef[0], inv = 1.f / s;
+    const long nq = V >> 2;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const long k = threadIdx.x + 256L * i;
+      if (k < nq) {
+        const long e0 = 4 * k;
+        const float g0 = c * (__expf(__uint_as_float(r.q[i].x << 16) - mx) * inv - (e0 == lab ? 1.f : 0.f));
+        const float g1 = c * (__expf(__uint_as_float(r.q[i].x & 0xffff0000u) - mx) * inv - (e0 + 1 == lab ? 1.f : 0.f));
+        const float g2 = c * (__expf(__uint_as_float(r.q[i].y << 16) - mx) * inv - (e0 + 2 == lab ? 1.f : 0.f));
+        const float g3 = c * (__expf(__uint_as_float(r.q[i].y & 0xffff0000u) - mx) * inv - (e0 + 3 == lab ? 1.f : 0.f));
+        *reinterpret_cast<uint2*>(out + e0) = make_uint2(pack2bf(g0, g1), pack2bf(g2, g3));
+      }
+    }
+    return;
+  }
   float mx = -1e30f;
   for (long i = threadIdx.x; i < V; i += blockDim.x) mx = fmaxf(mx, bf2f(row[i]));
   mx = block_max(mx, red);

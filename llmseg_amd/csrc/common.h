@@ -87,6 +87,39 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return t;
 }
 
+// One logits row of a cross-entropy kernel, read ONCE: the row (V <= 32768 bf16, V % 4 == 0, 8-byte aligned) lives in registers as 32 x
+// 8-byte quads per thread of a 256-thread workgroup (the round-2 kernels walked the row twice / three times with 2-byte loads: counters
+// showed 2.0 x the algorithmic bytes at 1.0-1.5 TB/s).  -> row max and sum of exp(x - max), block-wide.
+struct CeRow {
+  uint2 q[32];
+  __device__ __forceinline__ void load(const bf16_t* __restrict__ row, long V) {
+    const long nq = V >> 2;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const long k = threadIdx.x + 256L * i;
+      q[i] = k < nq ? *reinterpret_cast<const uint2*>(row + 4 * k) : make_uint2(0xff80ff80u, 0xff80ff80u);     // -inf bf16 pairs: exp() = 0
+    }
+  }
+  __device__ __forceinline__ void stats(float* red, float& mx, float& s) const {
+    float m = -1e30f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      m = fmaxf(m, fmaxf(__uint_as_float(q[i].x << 16), __uint_as_float(q[i].x & 0xffff0000u)));
+      m = fmaxf(m, fmaxf(__uint_as_float(q[i].y << 16), __uint_as_float(q[i].y & 0xffff0000u)));
+    }
+    mx = block_max(m, red);
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+      t += __expf(__uint_as_float(q[i].x << 16) - mx) + __expf(__uint_as_float(q[i].x & 0xffff0000u) - mx) +
+           __expf(__uint_as_float(q[i].y << 16) - mx) + __expf(__uint_as_float(q[i].y & 0xffff0000u) - mx);
+    s = block_sum(t, red);
+  }
+};
+__device__ __forceinline__ bool ce_row_fast(const bf16_t* row, long V, long ldl) {
+  return V <= 32768 && (V & 3) == 0 && (ldl & 3) == 0 && (((uintptr_t)row) & 7) == 0 && blockDim.x == 256;
+}
+
 // ---- counter-based RNG for LoRA dropout (peft Linear: dropout(p = 0.05) on the LoRA branch input, reference training.py:91,218-226) ----
 // Philox4x32-10 (Salmon et al. 2011): counter = (idx_lo, idx_hi, stream, offset), key = (seed_lo, seed_hi).  One call yields the
 // keep bits of EIGHT consecutive elements: element e = 8 * idx + j uses the 16-bit field j of the 128-bit output (field j = bits

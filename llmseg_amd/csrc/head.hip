@@ -282,12 +282,17 @@ __global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logi
   const long lab = labels[(long)n * T + t + 1];
   if (lab < 0 || lab >= V) return;                        // ignore_index (-100)
   const bf16_t* row = logits + ((long)n * T + t) * ldl;
-  float mx = -1e30f;
-  for (long i = threadIdx.x; i < V; i += blockDim.x) mx = fmaxf(mx, bf2f(row[i]));
-  mx = block_max(mx, red);
-  float s = 0.f;
-  for (long i = threadIdx.x; i < V; i += blockDim.x) s += __expf(bf2f(row[i]) - mx);
-  s = block_sum(s, red);
+  float mx = -1e30f, s = 0.f;
+  if (ce_row_fast(row, V, ldl)) {                         // the row is read once (registers), 8-byte loads
+    CeRow r;
+    r.load(row, V);
+    r.stats(red, mx, s);
+  } else {
+    for (long i = threadIdx.x; i < V; i += blockDim.x) mx = fmaxf(mx, bf2f(row[i]));
+    mx = block_max(mx, red);
+    for (long i = threadIdx.x; i < V; i += blockDim.x) s += __expf(bf2f(row[i]) - mx);
+    s = block_sum(s, red);
+  }
   if (threadIdx.x == 0) {
     atomicAdd(&acc[0], mx + __logf(s) - bf2f(row[lab]));
     atomicAdd(&acc[1], 1.f);
