@@ -1,4 +1,5 @@
-"""gIoU / cIoU validation loop (reference `training.py:690-870` `validate_threshold`): per validation image run
+"""gIoU / cIoU validation loops (reference `training.py`: `validate` :605-687, `validate_threshold` :690-870, `validate_iou_iop` :872-967,
+`validate_threshold_from_topIoU` :969-1078 -- they differ only in WHICH proposals form the prediction): per validation image run
 `model_forward(inference=True)`, keep the proposals whose predicted IoP exceeds the threshold, score their union against the
 ground truth at 1024 x 1024.  The per-image body after the model call is ONE kernel (`llmseg_union_resize_iou`); the meters are
 integer sums, reduced across ranks with three `all_reduce`s like the reference's `AverageMeter.all_reduce` (utils/utils.py:76-97).
@@ -59,3 +60,41 @@ def validate_threshold(model, samples, threshold=0.5, out_size=1024):
         a = torch.where(u == 0, a + 1.0, a)                                             # no-object target (training.py:768)
         inter += i; union += u; acc += a; count += 1
     return _finish(inter, union, acc, count)
+
+
+def _selected_loop(model, samples, choose):
+    """Shared body of the two variants below: `choose(similarity [K], pred_iop [K]) -> uint8 [K]` selection mask; the union of the selected
+    proposals is scored at the ground truth's own resolution (nearest resize when the shapes differ)."""
+    dev = next(model.parameters()).device
+    inter, union, acc, count = _meters(dev)
+    for s in samples:
+        kw = {k: v for k, v in s.items() if k not in ("origin_segs", "gt_mask")}
+        out = model.model_forward(**kw, inference=True)
+        select = choose(out["pred_similarity"][0][0], out["pred_iou"][0][0])
+        iu = ops.union_resize_iou(s["origin_segs"], select, s["gt_mask"], out_size=None).double()
+        i, u = iu[0:2], iu[2:4]
+        a = i / (u + 1e-8)
+        a = torch.where(u == 0, a + 1.0, a)
+        inter += i; union += u; acc += a; count += 1
+    return _finish(inter, union, acc, count)
+
+
+@torch.no_grad()
+def validate_iou_iop(model, samples, threshold=0.5):
+    """Reference `training.py:872-967`: the arg-max-similarity proposal plus every proposal whose predicted IoP exceeds the threshold."""
+    def choose(sim, iop):
+        select = (iop > threshold).to(torch.uint8)
+        select[torch.argmax(sim)] = 1
+        return select
+    return _selected_loop(model, samples, choose)
+
+
+@torch.no_grad()
+def validate_threshold_from_topIoU(model, samples, threshold=0.5, top=5):
+    """Reference `training.py:969-1078`: of the 5 most similar proposals, those whose predicted IoP exceeds the threshold (possibly none)."""
+    def choose(sim, iop):
+        idx = torch.topk(sim, min(top, sim.shape[-1]), dim=0).indices
+        select = torch.zeros_like(iop, dtype=torch.uint8)
+        select[idx] = (iop[idx] > threshold).to(torch.uint8)
+        return select
+    return _selected_loop(model, samples, choose)

@@ -198,6 +198,18 @@ def check_validate_loop(backbone="dinov2"):
         I += i.double(); U += u.double(); A += a.double()
     res += [(f"{backbone} validate (arg-max) gIoU", abs(got2["giou"] - (A / 3)[1].item()), 1e-6),
             (f"{backbone} validate (arg-max) cIoU", abs(got2["ciou"] - (I / (U + 1e-10))[1].item()), 1e-6)]
+    # the two remaining selection rules (training.py:872-1078), fed with the model's own similarity / IoP rows
+    for name, loop, body in (("iou+iop", validate.validate_iou_iop, metric.iou_iop_iou), ("top-5 IoU", validate.validate_threshold_from_topIoU, metric.top_iou_iou)):
+        got3 = loop(m, samples, threshold=thr)
+        I = torch.zeros(2, dtype=torch.float64); U = torch.zeros(2, dtype=torch.float64); A = torch.zeros(2, dtype=torch.float64)
+        for s, segs, gt in zip(samples, segs_cpu, gts_cpu):
+            kw = {k: v for k, v in s.items() if k not in ("origin_segs", "gt_mask")}
+            with torch.no_grad():
+                o = m.model_forward(**kw, inference=True)
+            i, u, _, a = body(segs, o["pred_similarity"][0][0].float().cpu(), o["pred_iou"][0][0].float().cpu(), gt, threshold=thr)
+            I += i.double(); U += u.double(); A += a.double()
+        res += [(f"{backbone} validate ({name}) gIoU", abs(got3["giou"] - (A / 3)[1].item()), 1e-6),
+                (f"{backbone} validate ({name}) cIoU", abs(got3["ciou"] - (I / (U + 1e-10))[1].item()), 1e-6)]
     return res
 
 

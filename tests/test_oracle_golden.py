@@ -81,3 +81,26 @@ def test_lisa_tiny_grads(golden):
         assert close(got, g[k], 2e-4), k
     # softmax over a single key is constant -> exactly-zero grads (SURVEY.md §7 hard parts)
     assert sd["model.lisa_final_attn.q_proj.weight"].grad.abs().max().item() == 0.0
+
+
+def test_validation_selection_rules_cpu():
+    """The two remaining validation loops (reference training.py:872-1078) as oracle bodies: the arg-max proposal is always part of the
+    iou+iop prediction; the top-5 rule yields an EMPTY prediction when no IoP passes; both reduce to the arg-max body when exactly the
+    arg-max proposal passes."""
+    import torch
+    from oracle import metric
+    g = torch.Generator().manual_seed(0)
+    segs = (torch.rand(40, 50, 12, generator=g) > 0.7).to(torch.uint8)
+    gt = (torch.rand(80, 100, generator=g) > 0.5).to(torch.uint8)
+    sim, iop = torch.rand(12, generator=g), torch.rand(12, generator=g)
+    k = int(torch.argmax(sim))
+    only_k = torch.zeros(12)
+    only_k[k] = 1.0
+    a = metric.argmax_iou(segs, sim, gt)
+    for body in (metric.iou_iop_iou, metric.top_iou_iou):
+        b = body(segs, sim, only_k, gt, threshold=0.5)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    none = metric.top_iou_iou(segs, sim, iop, gt, threshold=2.0)
+    assert none[0][1] == 0 and none[1][1] == int((gt == 1).sum())          # empty prediction: class-1 intersection 0, union = the target
+    with_k = metric.iou_iop_iou(segs, sim, iop, gt, threshold=2.0)
+    assert torch.equal(with_k[0], a[0])                                    # nothing passes: the arg-max proposal alone
