@@ -1209,9 +1209,13 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
   const bool pp = variant == 8 || variant == 9;
   const int bm = variant == 8 ? 256 : 128, bn = pp ? 256 : BN;
   p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
-  // ping-pong tile walk (tools/gemm_bench.py sweep): short matrices (Llama, <= 32 row tiles) keep all of M in one group so a
-  // W column tile is fetched once per XCD; tall ones (SAM, 384+ row tiles) walk 4 row tiles per group (+3..6 % at K = 5120)
-  p.group_m = group_m_env > 0 ? group_m_env : (p.tiles_m <= 32 ? p.tiles_m : 4);
+  // ping-pong tile walk (tools/gemm_bench.py sweeps): short matrices (Llama, <= 32 row tiles) with few column tiles (N = 4096: o, down,
+  // the dX products) keep all of M in one group so a W column tile is fetched once per XCD; with many column tiles (qkv, gate|up, lm_head at
+  // 16-24 images: 20-30 row tiles x 48-126 column tiles) an XCD's 32 concurrent tiles would be ONE column tile deep and re-stream all of A
+  // (63 MB at 24 images) per column tile -- 8 row tiles per group make the concurrent set 8 x 4 (+5..8 %: qkv 1017 -> 1100, gate|up
+  // 1215 -> 1300, lm_head 1234 -> 1310 TF/s at 16 images); tall ones (SAM, 384+ row tiles) walk 4 row tiles per group (+3..6 % at K = 5120)
+  static const bool old_walk = getenv("LLMSEG_GEMM_OLD_WALK") != nullptr;     // A/B switch
+  p.group_m = group_m_env > 0 ? group_m_env : (p.tiles_m <= 32 ? ((p.tiles_n > 16 && p.tiles_m > 8 && !old_walk) ? 8 : p.tiles_m) : 4);
   hipStream_t s = (hipStream_t)stream;
   llmseg_prof_begin(s);
   llmseg_prof_tag(p.M, p.N, p.K, (variant == 9 && g_gemm_pp2 ? 7 : variant) * 1000 + (ta ? 200 : 0) + (tw ? 100 : 0) + (p.res ? 20 : 0) + p.act * 2 + (a->out_f32 ? 1 : 0) + 40 * (batch > 1) +
