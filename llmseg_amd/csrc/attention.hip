@@ -907,7 +907,185 @@ __global__ __launch_bounds__(512, 2) void attn_win14_dma_kernel(AttnP p) {
 }
 
 static int g_attn_win_new = 2;      // SAM 14 x 14 windows: 0 = the general tiled kernel, 1 = resident-window kernel (register staging), 2 = LDS-DMA form
+// ---- SAM global attention (4096 tokens on a 64 x 64 grid, head_dim 80, decomposed rel-pos) with K / V tiles arriving by LDS-DMA (round 3) ----
+// attn_fwd_kernel<80, 2, 8> spends 23 % of its time staging K / V through registers and 14 % at its per-tile barrier (side builds:
+// profiles/r03_attn_experiments.md).  Same arithmetic (8 waves x 32 queries, transposed scores, online softmax), but: a step is TWO key rows of
+// the grid (128 keys: half as many barriers and softmax updates per key); its K and V go global -> LDS by `global_load_lds_dwordx4` into the
+// OTHER of two 128-key buffers while this step computes (vmcnt(0) + one barrier per step); K rows 8..15 of every 16 are rotated by one
+// 16-byte chunk (conflict-free `ds_read_b128`), V^T fragments come from the row-major image through two `ds_read_b64_tr_b16` per MFMA
+// operand; the per-query rel-pos row of the key-row axis lives in LDS (a `ds_read_b32` per key row instead of a global load whose
+// compiler-counted wait would drain the DMA).
+__global__ __launch_bounds__(512, 2) void attn_glob80_dma_kernel(AttnP p) {
+  constexpr int HD = 80, KS = HD / 16, DT = 3, ROWB = HD * 2;
+  constexpr int KT = 2, KEYS = KT * BKV, TB = KEYS * ROWB;                              // 128 keys, 20480 B per K or V buffer
+  constexpr int NPIECE = TB / 1024;                                                     // 20 one-KiB pieces per step and operand
+  constexpr int BQ = 256, BHP = 65;                                                     // bias table pitch (floats)
+  __shared__ __attribute__((aligned(16))) char smem[4 * TB + BQ * BHP * 4];             // 81,920 + 66,560 B
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ql = lane & 31, half = lane >> 5;
+  int b = blockIdx.z, h = blockIdx.y, qb = blockIdx.x;
+  if (p.xcd_nqb > 0) {
+    const int id = blockIdx.x, j = id >> 3;
+    const int bh = (j / p.xcd_nqb) * 8 + (id & 7);
+    if (bh >= p.batch * p.heads) return;
+    qb = j % p.xcd_nqb; b = bh / p.heads; h = bh - b * p.heads;
+  }
+  const int q = qb * BQ + wave * 32 + ql;                   // Nq % 256 == 0: every slot is a real query
+  const int nsteps = p.Nk / KEYS;
+  const bf16_t* Qg = p.Q + (long)b * p.qsb + (long)h * p.qsh;
+  const char* Kg = reinterpret_cast<const char*>(p.K + (long)b * p.ksb + (long)h * p.ksh);
+  const char* Vg = reinterpret_cast<const char*>(p.V + (long)b * p.vsb + (long)h * p.vsh);
+
+  bf16x8_t qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(Qg + (long)q * p.qsr + ks * 16 + half * 8);
+  const int qh = q / p.gw, qw = q - qh * p.gw;
+  const long rrow = (((long)h * p.batch + b) * p.Nq + q) * p.rel_ld;
+  float bw_cache[32];
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bw_cache[jb * 16 + r] = p.rel_w[rrow + qw - (jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) + p.gw - 1] * p.inv_scale;
+  // key-row bias of this query for every key row: bh[kh] = rel_h[qh - kh + gh - 1]; half 0 writes the even rows, half 1 the odd ones
+  float* const bhs = reinterpret_cast<float*>(smem + 4 * TB) + (wave * 32 + ql) * BHP;
+  for (int t = half; t < p.gh; t += 2) bhs[t] = p.rel_h[rrow + qh - t + p.gh - 1] * p.inv_scale;
+
+  // DMA: piece j of a step covers LDS bytes [1024 j, +1024) of the buffer; this wave issues pieces wave, wave + 8 and (waves 0..3) wave + 16
+  int kvo[3], vvo[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int L = (wave + 8 * k) * 1024 + lane * 16;
+    const int row = L / ROWB, slot = (L - row * ROWB) >> 4;
+    int c = slot - ((row >> 3) & 1);
+    if (c < 0) c += HD / 8;
+    kvo[k] = (row * (int)p.ksr + c * 8) * 2;
+    vvo[k] = (row * (int)p.vsr + slot * 8) * 2;
+  }
+  const bool three = wave < NPIECE - 16;                    // waves 0..3 carry a third piece per operand
+  typedef __attribute__((address_space(3))) void* lds_p;
+  typedef __attribute__((address_space(3))) short4v* lds_tr;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_p)smem);
+#define GLOB_DMA16(LDS_BYTE_ADDR, GSRC)                                                                             \
+  {                                                                                                                 \
+    unsigned keep_;                                                                                                 \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"        \
+                 : "=&s"(keep_) : "v"(GSRC), "s"(LDS_BYTE_ADDR) : "memory");                                        \
+  }
+#define GLOB_ISSUE(T)                                                                                               \
+  {                                                                                                                 \
+    const unsigned sl_ = lds0 + (unsigned)(((T) & 1) * TB) + wave * 1024;                                           \
+    const long ko_ = (long)(T) * KEYS * p.ksr * 2, vo_ = (long)(T) * KEYS * p.vsr * 2;                              \
+    GLOB_DMA16(sl_, Kg + ko_ + kvo[0]) GLOB_DMA16(sl_ + 8192, Kg + ko_ + kvo[1])                                    \
+    GLOB_DMA16(sl_ + 2 * TB, Vg + vo_ + vvo[0]) GLOB_DMA16(sl_ + 2 * TB + 8192, Vg + vo_ + vvo[1])                  \
+    if (three) { GLOB_DMA16(sl_ + 16384, Kg + ko_ + kvo[2]) GLOB_DMA16(sl_ + 2 * TB + 16384, Vg + vo_ + vvo[2]) }   \
+  }
+  int koff[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) koff[ks] = ql * ROWB + (((2 * ks + half + ((ql >> 3) & 1)) % (HD / 8)) << 4);
+  const int voff = (4 * half + ((lane & 15) >> 2)) * ROWB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
+  f32x16_t o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+  float m_run = NEG, l_run = 0.f;
+
+  GLOB_ISSUE(0)
+  for (int t = 0; t < nsteps; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of step t (the only DMA in flight)
+    __syncthreads();                                        // everyone's pieces; everyone is done with step t - 1 (= the buffer step t + 1 goes into)
+    if (t + 1 < nsteps) GLOB_ISSUE(t + 1)
+    const char* Ks = smem + (t & 1) * TB;
+    const char* Vs = Ks + 2 * TB;
+    f32x16_t s[2 * KT];
+#pragma unroll
+    for (int kr = 0; kr < KT; ++kr) {
+      const float bh_row = bhs[KT * t + kr];
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[2 * kr + jb][r] = bh_row + bw_cache[jb * 16 + r];
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int jb = 0; jb < 2 * KT; ++jb) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + jb * (32 * ROWB) + koff[ks]);
+        s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[jb], 0, 0, 0);
+      }
+    float mx = NEG;
+#pragma unroll
+    for (int jb = 0; jb < 2 * KT; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[jb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+    const float nmc = -m_new * p.scale_log2;
+    const bool moved = m_new != m_run;
+    m_run = m_new;
+    float lsum = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < 2 * KT; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[jb][r], p.scale_log2, nmc));
+        s[jb][r] = pv;
+        lsum += pv;
+      }
+    l_run = l_run * alpha + lsum;
+    if (__any(moved)) {
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+    }
+#pragma unroll
+    for (int ss = 0; ss < 4 * KT; ++ss) {
+      const int jb = ss >> 1, rb = 8 * (ss & 1);
+      const uint4 pu = make_uint4(pack2bf(s[jb][rb + 0], s[jb][rb + 1]), pack2bf(s[jb][rb + 2], s[jb][rb + 3]),
+                                  pack2bf(s[jb][rb + 4], s[jb][rb + 5]), pack2bf(s[jb][rb + 6], s[jb][rb + 7]));
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const char* va = Vs + ss * (16 * ROWB) + voff + d * 64;
+        const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)va);
+        const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(va + 8 * ROWB));
+        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+      }
+    }
+  }
+#undef GLOB_ISSUE
+#undef GLOB_DMA16
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_tot;
+  bf16_t* orow;
+  bool skip = false;
+  if (p.o_row_map) {
+    const int row = p.o_row_map[(long)b * p.Nq + q];
+    skip = row < 0;
+    orow = p.O + (long)h * p.osh + (long)(skip ? 0 : row) * p.osr;
+  } else {
+    orow = p.O + (long)b * p.osb + (long)h * p.osh + (long)q * p.osr;
+  }
+  if (!skip) {
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = d * 32 + 8 * g + 4 * half;
+        if (dd < HD)
+          *reinterpret_cast<uint2*>(orow + dd) =
+              make_uint2(pack2bf(o[d][4 * g] * inv, o[d][4 * g + 1] * inv), pack2bf(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv));
+      }
+  }
+}
+
 static const int g_attn_xcd = getenv("LLMSEG_ATTN_NO_XCD") ? 0 : 1;
+static const int g_attn_glob_dma = getenv("LLMSEG_ATTN_NO_GLOB_DMA") ? 0 : 1;      // LDS-DMA form of SAM global attention (A/B switch)
 static int g_attn_win_wgs = 256;    // persistent workgroups of the window kernel: one per CU      // tuning knob (tools): 0 = the general tiled kernel on the window shape
 
 template <int HD>
@@ -929,7 +1107,9 @@ int launch_hd(const AttnP& p, hipStream_t s) {
   } else if (HD == 80 && p.gh == 14 && p.gw == 14 && p.Nk == 196 && !p.causal && !p.key_mask)
     hipLaunchKernelGGL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 3 : 1>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
   else if (p.gw == BKV && (p.Nk % BKV) == 0) {
-    if (wide) hipLaunchKernelGGL((attn_fwd_kernel<HD, 2, 8>), xgrid, dim3(NT8), 0, s, px);
+    if (HD == 80 && wide && g_attn_glob_dma && (p.Nq % 256) == 0 && p.Nk == p.gh * BKV && (p.gh & 1) == 0 && !p.causal && !p.key_mask && !p.lse && !p.nk_dev)
+      hipLaunchKernelGGL(attn_glob80_dma_kernel, xgrid, dim3(NT8), 0, s, px);
+    else if (wide) hipLaunchKernelGGL((attn_fwd_kernel<HD, 2, 8>), xgrid, dim3(NT8), 0, s, px);
     else hipLaunchKernelGGL((attn_fwd_kernel<HD, 2>), grid, dim3(NT4), 0, s, p);
   } else hipLaunchKernelGGL((attn_fwd_kernel<HD, 1>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
   return 0;
