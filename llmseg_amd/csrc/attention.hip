@@ -784,7 +784,8 @@ __global__ __launch_bounds__(512, 2) void attn_win14_dma_kernel(AttnP p) {
     }
 
     // ---- decomposed rel-pos: G^T = R . Q^T per table, bounced through the per-wave slab; lane-half folded into the LOAD index ----
-    float bh_s[14], bh_x[13], bw_y[14];
+    float bh_s[14], bh_x[13];
+    f32x2_t bw_y2[7];                                             // key-column bias as register PAIRS (columns 2j, 2j + 1): one v_pk_add_f32 per two accumulator slots
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb) {
       f32x16_t g;
@@ -805,7 +806,7 @@ __global__ __launch_bounds__(512, 2) void attn_win14_dma_kernel(AttnP p) {
       } else {
         const float* gw = gs + ql * SPITCH + qw + 13;
 #pragma unroll
-        for (int j = 0; j < 14; ++j) bw_y[j] = gw[-((j + 4 * half) % 14)] * p.inv_scale;
+        for (int j = 0; j < 7; ++j) bw_y2[j] = f32x2_t{gw[-((2 * j + 4 * half) % 14)], gw[-((2 * j + 1 + 4 * half) % 14)]} * p.inv_scale;
       }
     }
 
@@ -814,11 +815,12 @@ __global__ __launch_bounds__(512, 2) void attn_win14_dma_kernel(AttnP p) {
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 16; r += 2) {                             // slots r, r + 1 = keys key0, key0 + 1: same key row (key0 and 14 are even)
         const int key0 = kb * 32 + (r & 3) + 8 * (r >> 2);            // this register's key for half 0; half 1: + 4
         const int kh0 = key0 / 14 > 13 ? 13 : key0 / 14, kw0 = key0 % 14;
         const bool cross = kw0 >= 10 && kh0 < 13;                    // key0 + 4 falls into the next key row
-        s[kb][r] = (cross ? bh_x[kh0 > 12 ? 12 : kh0] : bh_s[kh0]) + bw_y[kw0];
+        const f32x2_t v = bw_y2[kw0 >> 1] + (cross ? bh_x[kh0 > 12 ? 12 : kh0] : bh_s[kh0]);
+        s[kb][r] = v.x; s[kb][r + 1] = v.y;
       }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -838,17 +840,19 @@ __global__ __launch_bounds__(512, 2) void attn_win14_dma_kernel(AttnP p) {
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float nmc = -mx * p.scale_log2;
-    float lsum = 0.f;
+    f32x2_t lsum2 = {0.f, 0.f};
+    const f32x2_t sc2 = {p.scale_log2, p.scale_log2}, nmc2 = {nmc, nmc};
     uint32_t pk[NKB][8];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2, nmc));
-        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[kb][r + 1], p.scale_log2, nmc));
-        lsum += p0 + p1;
-        pk[kb][r >> 1] = pack2bf(p0, p1);
+      for (int r = 0; r < 16; r += 2) {                             // packed fp32: one v_pk_fma / v_pk_add per two scores
+        const f32x2_t t2 = __builtin_elementwise_fma(f32x2_t{s[kb][r], s[kb][r + 1]}, sc2, nmc2);
+        const f32x2_t e2 = {__builtin_amdgcn_exp2f(t2.x), __builtin_amdgcn_exp2f(t2.y)};
+        lsum2 += e2;
+        pk[kb][r >> 1] = pack2bf(e2.x, e2.y);
       }
+    const float lsum = lsum2.x + lsum2.y;
 
     // ---- O^T = V^T . P^T: k-steps of 16 keys; V^T fragments = two transposing reads of the row-major V image ----
     f32x16_t o[DT];
@@ -942,11 +946,17 @@ __global__ __launch_bounds__(512, 2) void attn_glob80_dma_kernel(AttnP p) {
   for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(Qg + (long)q * p.qsr + ks * 16 + half * 8);
   const int qh = q / p.gw, qw = q - qh * p.gw;
   const long rrow = (((long)h * p.batch + b) * p.Nq + q) * p.rel_ld;
-  float bw_cache[32];
+  // key-column bias of this query, as register PAIRS in accumulator order (pair k of block jb = accumulator slots 2k, 2k + 1): the
+  // accumulators start a step as `pair + key-row bias` through one v_pk_add_f32 per pair, with no moves to re-order
+  f32x2_t bw2[16];
 #pragma unroll
   for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bw_cache[jb * 16 + r] = p.rel_w[rrow + qw - (jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) + p.gw - 1] * p.inv_scale;
+    for (int k = 0; k < 8; ++k) {
+      const int r = 2 * k;
+      const long at = rrow + qw - (jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) + p.gw - 1;
+      bw2[jb * 8 + k] = f32x2_t{p.rel_w[at] * p.inv_scale, p.rel_w[at - 1] * p.inv_scale};
+    }
   // key-row bias of this query for every key row: bh[kh] = rel_h[qh - kh + gh - 1]; half 0 writes the even rows, half 1 the odd ones
   float* const bhs = reinterpret_cast<float*>(smem + 4 * TB) + (wave * 32 + ql) * BHP;
   for (int t = half; t < p.gh; t += 2) bhs[t] = p.rel_h[rrow + qh - t + p.gh - 1] * p.inv_scale;
@@ -960,7 +970,10 @@ __global__ __launch_bounds__(512, 2) void attn_glob80_dma_kernel(AttnP p) {
     int c = slot - ((row >> 3) & 1);
     if (c < 0) c += HD / 8;
     kvo[k] = (row * (int)p.ksr + c * 8) * 2;
-    vvo[k] = (row * (int)p.vsr + slot * 8) * 2;
+    // V: the five 32-byte blocks of an EVEN row sit one block to the right (cyclically): the four rows x two blocks a 32-lane group of
+    // ds_read_b64_tr_b16 touches then fall on 64 distinct banks (pitch 160 B: rows 0 and 3 of a group shared 8 banks, 2x the LDS cycles)
+    const int vblk = ((slot >> 1) + ((row & 1) ? 0 : 4)) % 5;
+    vvo[k] = (row * (int)p.vsr + (vblk * 2 + (slot & 1)) * 8) * 2;
   }
   const bool three = wave < NPIECE - 16;                    // waves 0..3 carry a third piece per operand
   typedef __attribute__((address_space(3))) void* lds_p;
@@ -983,7 +996,13 @@ __global__ __launch_bounds__(512, 2) void attn_glob80_dma_kernel(AttnP p) {
   int koff[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) koff[ks] = ql * ROWB + (((2 * ks + half + ((ql >> 3) & 1)) % (HD / 8)) << 4);
-  const int voff = (4 * half + ((lane & 15) >> 2)) * ROWB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  int voff[DT];                                             // per 32-dim block of V: this lane's (row, rotated 32-byte block, 8-byte piece)
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    const int vrow = 4 * half + ((lane & 15) >> 2);
+    const int blk = min(2 * d + ((lane >> 4) & 1), HD / 16 - 1);      // dims 80..95 do not exist: those lanes re-read block 4 (a broadcast)
+    voff[d] = vrow * ROWB + ((blk + ((vrow & 1) ? 0 : 1)) % 5) * 32 + (lane & 3) * 8;
+  }
 
   f32x16_t o[DT];
 #pragma unroll
@@ -1006,7 +1025,10 @@ __global__ __launch_bounds__(512, 2) void attn_glob80_dma_kernel(AttnP p) {
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[2 * kr + jb][r] = bh_row + bw_cache[jb * 16 + r];
+        for (int k = 0; k < 8; ++k) {
+          const f32x2_t v = bw2[jb * 8 + k] + bh_row;
+          s[2 * kr + jb][2 * k] = v.x; s[2 * kr + jb][2 * k + 1] = v.y;
+        }
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -1026,16 +1048,18 @@ __global__ __launch_bounds__(512, 2) void attn_glob80_dma_kernel(AttnP p) {
     const float nmc = -m_new * p.scale_log2;
     const bool moved = m_new != m_run;
     m_run = m_new;
-    float lsum = 0.f;
+    f32x2_t lsum2 = {0.f, 0.f};
+    const f32x2_t sc2 = {p.scale_log2, p.scale_log2}, nmc2 = {nmc, nmc};
 #pragma unroll
     for (int jb = 0; jb < 2 * KT; ++jb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(s[jb][r], p.scale_log2, nmc));
-        s[jb][r] = pv;
-        lsum += pv;
+      for (int k = 0; k < 8; ++k) {                      // packed fp32: one v_pk_fma / v_pk_add per two scores
+        const f32x2_t t2 = __builtin_elementwise_fma(f32x2_t{s[jb][2 * k], s[jb][2 * k + 1]}, sc2, nmc2);
+        const f32x2_t e2 = {__builtin_amdgcn_exp2f(t2.x), __builtin_amdgcn_exp2f(t2.y)};
+        s[jb][2 * k] = e2.x; s[jb][2 * k + 1] = e2.y;
+        lsum2 += e2;
       }
-    l_run = l_run * alpha + lsum;
+    l_run = l_run * alpha + (lsum2.x + lsum2.y);
     if (__any(moved)) {
 #pragma unroll
       for (int d = 0; d < DT; ++d)
@@ -1050,7 +1074,7 @@ __global__ __launch_bounds__(512, 2) void attn_glob80_dma_kernel(AttnP p) {
       const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
-        const char* va = Vs + ss * (16 * ROWB) + voff + d * 64;
+        const char* va = Vs + ss * (16 * ROWB) + voff[d];
         const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)va);
         const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(va + 8 * ROWB));
         const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));

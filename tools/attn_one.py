@@ -43,7 +43,7 @@ elif mode == "wint0":
     th[:27] = torch.randn(27, hd, device="cuda") * 0.3; tw[:27] = torch.randn(27, hd, device="cuda") * 0.3
     out = torch.empty(batch * n, D, device="cuda", dtype=torch.bfloat16)
     st = (0, hd, 3 * D)
-    for v in (0, 1):
+    for v in (1, 2):
         _lib.load().llmseg_attn_set_variant(v)
         f = lambda: ops.attention(qkv, qkv[:, D:], qkv[:, 2 * D:], out, batch=batch, heads=H, Nq=n, Nk=n, head_dim=hd, q_strides=st, k_strides=st,
                                   v_strides=st, o_strides=(n * D, hd, D), rel_tab_h=th, rel_tab_w=tw, grid_hw=(14, 14))
