@@ -205,6 +205,29 @@ int llmseg_sam_mask_stats(const float* low, const float* iou, float iou_thresh, 
 int llmseg_sam_binarize(const float* low, const int32_t* sel, uint8_t* out, int32_t n_sel, int32_t img_size, int32_t in_h, int32_t in_w, int32_t out_h,
                         int32_t out_w, int32_t nested, float mask_threshold, void* stream);
 int llmseg_nms(const float* boxes, const int32_t* order, int32_t n, float iou_threshold, uint8_t* keep, void* stream);
+/* SAM everything mode beyond the default single crop (SURVEY.md 8f N1 remainder; csrc/image.hip), byte work on the device:
+ *   llmseg_image_resize_u8: `ResizeLongestSide.apply_image` (model/segment_anything/utils/transforms.py:27-35, called by
+ *     `SamPredictor.set_image`, predictor.py:34-60) = Pillow's 8-bit BILINEAR `Image.resize`, bit-identical.  in uint8 [in_h][in_w][channels]
+ *     with `in_row_stride` bytes between rows -- a crop of a crop layer (automatic_mask_generator.py:254-257) is an origin pointer + the full
+ *     image's row stride; out uint8 [out_h][out_w][channels] dense.  workspace >= llmseg_image_resize_workspace(...) bytes.
+ *   llmseg_sam_preprocess: `Sam.preprocess` (modeling/sam.py:174-186): in uint8 [h][w][3] -> out bf16 [3][img_size][img_size],
+ *     (x - mean[c]) / std[c] inside the image, zero in the padding; mean / std are HOST pointers to 3 floats.
+ *   llmseg_mask_small_regions: `remove_small_regions(mask, min_area, "holes")` then `(..., "islands")` (utils/amg.py:267-291, as
+ *     `postprocess_small_regions` applies them, automatic_mask_generator.py:347-350) on masks uint8 [K][H][W] IN PLACE (0 / non-zero in,
+ *     0 / 1 written where a pixel changes); changed uint8 [K] = 1 when either pass altered the mask.  8-connected components
+ *     (cv2.connectedComponentsWithStats(.., 8) in the reference) by union-find; when every island is below min_area the largest is kept
+ *     (first in raster order among equals).  workspace >= llmseg_mask_small_regions_workspace(K, H, W) bytes.
+ *   llmseg_mask_boxes: `batched_mask_to_box` (utils/amg.py:303-346): boxes int32 [K][4] XYXY (inclusive; zeros for an empty mask),
+ *     areas int32 [K] (optional); workspace >= 20 bytes per mask. */
+int64_t llmseg_image_resize_workspace(int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w, int32_t channels);
+int llmseg_image_resize_u8(const uint8_t* in, int64_t in_row_stride, uint8_t* out, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
+                           int32_t channels, void* workspace, int64_t workspace_bytes, void* stream);
+int llmseg_sam_preprocess(const uint8_t* in, void* out, int32_t h, int32_t w, int32_t img_size, const float* mean, const float* std_, void* stream);
+int64_t llmseg_mask_small_regions_workspace(int32_t K, int32_t H, int32_t W);
+int llmseg_mask_small_regions(uint8_t* masks, int32_t K, int32_t H, int32_t W, int32_t min_area, uint8_t* changed, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+int llmseg_mask_boxes(const uint8_t* masks, int32_t K, int32_t H, int32_t W, int32_t* boxes, int32_t* areas, void* workspace, int64_t workspace_bytes,
+                      void* stream);
 /* out[r][c] = silu(gu[r][c]) * gu[r][I + c]   (HF LlamaMLP: down(silu(gate(x)) * up(x)); gu = x.[Wgate;Wup]^T) */
 int llmseg_swiglu(const void* gu, void* out, int64_t rows, int64_t I, int64_t ldgu, int64_t ldo, void* stream);
 

@@ -83,6 +83,12 @@ SIGNATURES = {
     "llmseg_sam_mask_stats": [_p, _p, _f32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _p],
     "llmseg_sam_binarize": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _p],
     "llmseg_nms": [_p, _p, _i32, _f32, _p, _p],
+    "llmseg_image_resize_workspace": [_i32, _i32, _i32, _i32, _i32],
+    "llmseg_image_resize_u8": [_p, _i64, _p, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p],
+    "llmseg_sam_preprocess": [_p, _p, _i32, _i32, _i32, _p, _p, _p],
+    "llmseg_mask_small_regions_workspace": [_i32, _i32, _i32],
+    "llmseg_mask_small_regions": [_p, _i32, _i32, _i32, _i32, _p, _p, _i64, _p],
+    "llmseg_mask_boxes": [_p, _i32, _i32, _i32, _p, _p, _p, _i64, _p],
     "llmseg_add_rows": [_p, _p, _p, _i64, _i64, _i64, _p],
     "llmseg_patchify": [_p, _p, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _p],
     "llmseg_im2col3x3": [_p, _p, _i32, _i32, _i32, _i32, _p],
@@ -140,7 +146,7 @@ def load():
         fn = getattr(lib, name)            # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = (C.c_char_p if name in ("llmseg_last_error", "llmseg_prof_dominant_kernel") else
-                      C.c_double if name == "llmseg_prof_dominant_bytes" else C.c_int64 if name == "llmseg_struct_size" else C.c_int)
+                      C.c_double if name == "llmseg_prof_dominant_bytes" else C.c_int64 if name in ("llmseg_struct_size", "llmseg_image_resize_workspace", "llmseg_mask_small_regions_workspace") else C.c_int)
     # ABI guard at load time: this binding's structs must be the library's (the entry points check `struct_size` per call as well)
     if lib.llmseg_version() != ABI_VERSION:
         raise RuntimeError(f"{LIB_PATH}: ABI version {lib.llmseg_version()} != {ABI_VERSION} of this binding (rebuild: llmseg_amd/csrc/build.sh)")

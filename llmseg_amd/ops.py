@@ -235,6 +235,59 @@ def sam_binarize(low, sel, input_size, original_size, img_size=1024, mask_thresh
     return out
 
 
+def image_resize_u8(img, out_h, out_w, crop_box=None):
+    """img uint8 [H, W, C] on the device (contiguous) -> uint8 [out_h, out_w, C]: Pillow's BILINEAR `Image.resize`, bit-identical
+    (`ResizeLongestSide.apply_image`).  crop_box = (x0, y0, x1, y1) resizes that window of img without copying it."""
+    assert img.dtype == torch.uint8 and img.is_contiguous() and img.dim() == 3 and img.is_cuda
+    H, W, ch = img.shape
+    x0, y0, x1, y1 = (0, 0, W, H) if crop_box is None else [int(v) for v in crop_box]
+    assert 0 <= x0 < x1 <= W and 0 <= y0 < y1 <= H
+    lib = _lib.load()
+    nb = lib.llmseg_image_resize_workspace(y1 - y0, x1 - x0, int(out_h), int(out_w), ch)
+    ws = torch.empty((nb,), device=img.device, dtype=torch.uint8)
+    out = torch.empty((int(out_h), int(out_w), ch), device=img.device, dtype=torch.uint8)
+    _lib.check(lib.llmseg_image_resize_u8(img.data_ptr() + (y0 * W + x0) * ch, W * ch, _ptr(out), y1 - y0, x1 - x0, int(out_h), int(out_w), ch, _ptr(ws), nb,
+                                          _stream()), "image_resize_u8")
+    return out
+
+
+def sam_preprocess(img, img_size, mean, std):
+    """img uint8 [h, w, 3] -> bf16 [1, 3, img_size, img_size]: (x - mean) / std, zero padding (`Sam.preprocess`)."""
+    import ctypes
+    assert img.dtype == torch.uint8 and img.is_contiguous() and img.dim() == 3 and img.shape[2] == 3
+    out = torch.empty((1, 3, img_size, img_size), device=img.device, dtype=torch.bfloat16)
+    m3, s3 = (ctypes.c_float * 3)(*[float(v) for v in mean]), (ctypes.c_float * 3)(*[float(v) for v in std])
+    _lib.check(_lib.load().llmseg_sam_preprocess(_ptr(img), _ptr(out), img.shape[0], img.shape[1], int(img_size), ctypes.cast(m3, ctypes.c_void_p),
+                                                 ctypes.cast(s3, ctypes.c_void_p), _stream()), "sam_preprocess")
+    return out
+
+
+def mask_small_regions_(masks, min_area):
+    """masks uint8 [K, H, W] IN PLACE: holes below min_area filled, then islands below min_area removed (`remove_small_regions` twice, as
+    `postprocess_small_regions` applies it) -> uint8 [K] changed flags."""
+    assert masks.dtype == torch.uint8 and masks.is_contiguous() and masks.dim() == 3
+    K, H, W = masks.shape
+    changed = torch.zeros((K,), device=masks.device, dtype=torch.uint8)
+    if K:
+        lib = _lib.load()
+        nb = lib.llmseg_mask_small_regions_workspace(K, H, W)
+        ws = torch.empty((nb,), device=masks.device, dtype=torch.uint8)
+        _lib.check(lib.llmseg_mask_small_regions(_ptr(masks), K, H, W, int(min_area), _ptr(changed), _ptr(ws), nb, _stream()), "mask_small_regions")
+    return changed
+
+
+def mask_boxes(masks):
+    """masks uint8 [K, H, W] -> (boxes int32 [K, 4] XYXY inclusive, zeros when empty; areas int32 [K]) (`batched_mask_to_box`)."""
+    assert masks.dtype == torch.uint8 and masks.is_contiguous() and masks.dim() == 3
+    K, H, W = masks.shape
+    boxes = torch.zeros((K, 4), device=masks.device, dtype=torch.int32)
+    areas = torch.zeros((K,), device=masks.device, dtype=torch.int32)
+    if K:
+        ws = torch.empty((K * 5,), device=masks.device, dtype=torch.int32)
+        _lib.check(_lib.load().llmseg_mask_boxes(_ptr(masks), K, H, W, _ptr(boxes), _ptr(areas), _ptr(ws), K * 20, _stream()), "mask_boxes")
+    return boxes, areas
+
+
 def nms(boxes, order, iou_threshold):
     """boxes fp32 [*, 4] XYXY, order int32 [n] (candidate indices by decreasing score) -> uint8 [n] keep flags (torchvision.ops.nms semantics)."""
     n = order.shape[0]

@@ -127,3 +127,33 @@ def amg_embedding_case():
     coef = seeded.uniform((256, len(cen)), 61, -2.0, 2.0)
     emb = torch.einsum("ck,kyx->cyx", coef, bumps) + seeded.uniform((256, 1, 1), 62, -1.0, 1.0)       # + a constant background vector
     return emb[None]
+
+
+def amg_image_case(h=300, w=400):
+    """A seeded uint8 RGB image [h, w, 3] (numpy) for everything mode with crop layers: coloured Gaussian blobs over a grey gradient + mild
+    per-pixel noise, so that crops of it are images with structure of their own."""
+    import numpy as np
+    ys, xs = torch.meshgrid(torch.arange(float(h)), torch.arange(float(w)), indexing="ij")
+    img = torch.stack([90 + 40 * xs / w, 100 + 30 * ys / h, 110 - 30 * xs / w], -1)
+    blobs = [(0.22, 0.20, 0.09, (150, -60, -40)), (0.30, 0.72, 0.12, (-70, 120, -30)), (0.70, 0.30, 0.11, (-50, -40, 140)), (0.78, 0.80, 0.07, (120, 110, -80)),
+             (0.50, 0.50, 0.05, (-90, -90, -90)), (0.12, 0.90, 0.05, (100, -20, 100)), (0.90, 0.08, 0.06, (60, 130, 60))]
+    for cy, cx, sg, col in blobs:
+        g = torch.exp(-(((ys - cy * h) / (sg * h)) ** 2 + ((xs - cx * w) / (sg * h)) ** 2) / 2)
+        img = img + g[..., None] * torch.tensor(col, dtype=torch.float32)
+    img = img + seeded.uniform((h, w, 3), 71, -6.0, 6.0)
+    return img.clamp(0, 255).round().to(torch.uint8).numpy()
+
+
+def amg_standin_encoder():
+    """A seeded stand-in for the SAM image encoder in the crop-layer tests (the encoder itself is row A6, tested elsewhere): the preprocessed
+    frame [1, 3, 1024, 1024] -> [1, 256, 64, 64] = a fixed 256 x 9 map of 16 x 16-pooled colour features (r, g, b, their products and squares)
+    + a constant vector.  The SAME function stands in for the encoder of the imported reference generator and of the restatement."""
+    coef = seeded.uniform((256, 9), 72, -1.2, 1.2)
+    bias = seeded.uniform((256, 1, 1), 73, -1.0, 1.0)
+
+    def encode(x):
+        p = torch.nn.functional.avg_pool2d(x.float(), 16)[0]                       # [3, 64, 64]
+        r, g, b = p[0], p[1], p[2]
+        f = torch.stack([r, g, b, r * g, g * b, b * r, r * r, g * g, b * b], 0)
+        return (torch.einsum("ck,kyx->cyx", coef, f) + bias)[None]
+    return encode

@@ -271,6 +271,90 @@ def gold_amg():
                 "original_size": orig, "input_size": inp}, os.path.join(OUT, "amg.pt"))
 
 
+def gold_amg_crops():
+    """Everything mode beyond the default configuration: crop layers + small-region clean-up (automatic_mask_generator.py:199-262,326-372).
+    The imported generator runs end to end on a seeded uint8 image -- `set_image` per crop (Pillow resize through the two thin torchvision
+    wrappers the reference imports, spelled here with Pillow itself; `Sam.preprocess`), per-layer point grids, the crop-edge filter, un-cropping,
+    cross-crop NMS, `postprocess_small_regions` -- with a seeded stand-in for the image encoder (the same function on both sides) and three
+    shims for absent third-party code: torchvision's `batched_nms` / `box_area` (restated) and `cv2.connectedComponentsWithStats`
+    (scipy.ndimage.label): those three steps are NOT pinned, everything around them is."""
+    from oracle import amg as oamg, sam_decoder as sdec
+    import numpy as np
+    from PIL import Image
+    from scipy import ndimage
+    import sys
+    import types
+    import model.segment_anything.automatic_mask_generator as ramg
+    import model.segment_anything.utils.transforms as rtr
+    from model.segment_anything.modeling import MaskDecoder, PromptEncoder, TwoWayTransformer
+    from model.segment_anything.modeling.sam import Sam
+    ramg.batched_nms = lambda boxes, scores, idxs, iou_threshold: oamg.nms(boxes, scores, iou_threshold)
+    ramg.box_area = lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    rtr.to_pil_image = lambda a: Image.fromarray(a)                                    # torchvision: uint8 HWC ndarray -> mode RGB
+    rtr.resize = lambda im, size: im.resize((size[1], size[0]), Image.BILINEAR)       # torchvision: PIL image -> Image.resize(size[::-1], BILINEAR)
+
+    def cc_stats(working, connectivity):
+        assert connectivity == 8
+        regions, n = ndimage.label(working, structure=np.ones((3, 3), np.int32))
+        stats = np.zeros((n + 1, 5), np.int64)
+        stats[:, -1] = np.bincount(regions.ravel(), minlength=n + 1)
+        return n + 1, regions, stats, None
+    sys.modules["cv2"] = types.SimpleNamespace(connectedComponentsWithStats=cc_stats)
+    try:
+        pe = PromptEncoder(embed_dim=256, image_embedding_size=(64, 64), input_image_size=(1024, 1024), mask_in_chans=16)
+        md = MaskDecoder(num_multimask_outputs=3, transformer=TwoWayTransformer(depth=2, embedding_dim=256, mlp_dim=2048, num_heads=8),
+                         transformer_dim=256, iou_head_depth=3, iou_head_hidden_dim=256)
+        sd = cases.sam_decoder_state()
+        pe.load_state_dict({k[len(sdec.PFX + "prompt_encoder."):]: v for k, v in sd.items() if ".prompt_encoder." in k}, strict=False)
+        md.load_state_dict({k[len(sdec.PFX + "mask_decoder."):]: v for k, v in sd.items() if ".mask_decoder." in k}, strict=True)
+        encode = cases.amg_standin_encoder()
+
+        class Enc(torch.nn.Module):
+            img_size = 1024
+
+            def forward(self, x):
+                return encode(x)
+        sam = Sam(image_encoder=Enc(), prompt_encoder=pe, mask_decoder=md)
+        fwd = pe.forward                                              # see gold_amg: the vendored predictor omits LISA's `text_embeds` argument
+        pe.forward = lambda points, boxes, masks, text_embeds=None: fwd(points, boxes, masks, text_embeds)
+        thr = cases.amg_thresholds()
+        img = cases.amg_image_case()
+        gold = {}
+        for tag, min_area in (("crops", 0), ("crops_clean", 12)):
+            kw = dict(points_per_side=8, points_per_batch=16, crop_n_layers=1, crop_n_points_downscale_factor=2, min_mask_region_area=min_area)
+            gen = ramg.SamAutomaticMaskGenerator(sam, output_mode="binary_mask", **kw, **thr)
+            with torch.no_grad():
+                recs = gen.generate(img)
+                mine = oamg.generate_crops(sd, encode, img, **kw, **thr)
+            assert len(recs) == mine["masks"].shape[0] and len(recs) >= 8, (len(recs), mine["masks"].shape)
+            for k, r in enumerate(recs):
+                assert np.array_equal(r["segmentation"], mine["masks"][k].numpy()), (tag, k)
+                x0, y0, x1, y1 = mine["boxes"][k].tolist()
+                assert r["bbox"] == [x0, y0, x1 - x0, y1 - y0], (tag, k, r["bbox"], mine["boxes"][k])
+                assert r["area"] == int(mine["masks"][k].sum())
+                cx0, cy0, cx1, cy1 = mine["crop_boxes"][k].tolist()
+                assert r["crop_box"] == [cx0, cy0, cx1 - cx0, cy1 - cy0]
+                assert abs(r["predicted_iou"] - float(mine["iou_preds"][k])) < 1e-5 and abs(r["stability_score"] - float(mine["stability_score"][k])) < 1e-6
+                assert r["point_coords"] == [mine["points"][k].tolist()]
+            ncrop = len({tuple(c) for c in mine["crop_boxes"].tolist()})
+            print(f"   {tag}: {len(recs)} records from {ncrop} crops, areas {int(mine['masks'].flatten(1).sum(1).min())}..{int(mine['masks'].flatten(1).sum(1).max())}")
+            gold[tag] = {"boxes": mine["boxes"].long(), "crop_boxes": mine["crop_boxes"].long(), "points": mine["points"], "iou_preds": mine["iou_preds"],
+                         "stability_score": mine["stability_score"], "areas": mine["masks"].flatten(1).sum(1), "rle_counts": [r["counts"] for r in oamg.mask_to_rle(mine["masks"])]}
+        # the Pillow resize restatement (oracle/pil_resize.py) against Pillow on the crops of this image and on odd sizes
+        from oracle import pil_resize
+        for (x0, y0, x1, y1) in oamg.generate_crop_boxes(img.shape[:2], 1, 512 / 1500)[0]:
+            c = img[y0:y1, x0:x1]
+            nh, nw = oamg.preprocess_shape(*c.shape[:2])
+            assert np.array_equal(np.array(Image.fromarray(c).resize((nw, nh), Image.BILINEAR)), pil_resize.resize_bilinear_u8(c, nh, nw))
+        small = pil_resize.resize_bilinear_u8(img, 77, 131)
+        assert np.array_equal(np.array(Image.fromarray(img).resize((131, 77), Image.BILINEAR)), small)
+        gold["resize_77x131_sum"] = int(small.astype(np.int64).sum())
+        gold["resize_77x131_sample"] = torch.as_tensor(small[::9, ::11].copy())
+        torch.save(gold, os.path.join(OUT, "amg_crops.pt"))
+    finally:
+        del sys.modules["cv2"]
+
+
 def gold_lisa_tiny():
     cfg = cases.tiny_lisa_cfg()
     rh.setup(clip_cfg_kwargs=dict(hidden_size=cfg.clip.dim, intermediate_size=cfg.clip.mlp,
@@ -332,7 +416,7 @@ def main():
     rh.setup(clip_cfg_kwargs=dict(hidden_size=cfg.clip.dim, intermediate_size=cfg.clip.mlp,
                                   num_hidden_layers=cfg.clip.layers, num_attention_heads=cfg.clip.heads),
              dino_cfg_kwargs=dict(num_hidden_layers=cfg.dino.layers))
-    for f in (gold_losses, gold_iou_metric, gold_sam_small, gold_head, gold_lisa_tiny, gold_generate, gold_sam_decoder, gold_amg):
+    for f in (gold_losses, gold_iou_metric, gold_sam_small, gold_head, gold_lisa_tiny, gold_generate, gold_sam_decoder, gold_amg, gold_amg_crops):
         print(f.__name__)
         f()
     print("wrote", sorted(os.listdir(OUT)))

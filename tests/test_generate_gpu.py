@@ -32,3 +32,8 @@ def test_evaluate_end_to_end_matches_oracle():
 def test_everything_mode_proposals_match_oracle():
     from tests import amg_checks as ac
     _assert(ac.check_amg())
+
+
+def test_everything_mode_crop_layers_match_oracle():
+    from tests import amg_checks as ac
+    _assert(ac.check_amg_crops())
