@@ -117,3 +117,7 @@ def test_amg_records_have_the_reference_fields():
     assert set(recs[0]) == {"segmentation", "area", "bbox", "predicted_iou", "point_coords", "stability_score", "crop_box"}
     assert recs[0]["bbox"] == [3, 2, 3, 2] and recs[0]["area"] == 12 and recs[0]["crop_box"] == [0, 0, 10, 8] and recs[0]["segmentation"]["size"] == [8, 10]
     assert recs[1]["point_coords"] == [[0.5, 0.5]]
+    # crop layers: the record's crop_box is the XYWH form of the crop the mask came from (automatic_mask_generator.py:187)
+    out["crop_boxes"] = torch.tensor([[2, 1, 9, 7], [0, 0, 10, 8]])
+    recs = amg.to_records(out, (8, 10), output_mode="binary_mask")
+    assert recs[0]["crop_box"] == [2, 1, 7, 6] and recs[1]["crop_box"] == [0, 0, 10, 8] and recs[0]["segmentation"].dtype == bool and recs[0]["segmentation"].sum() == 12
