@@ -31,8 +31,16 @@ enum { LLMSEG_ACT_NONE = 0, LLMSEG_ACT_RELU = 1, LLMSEG_ACT_GELU = 2, LLMSEG_ACT
  * so a binding written against an older header (fields were appended in every round) fails loudly instead of having the library read
  * past the caller's struct.  llmseg_struct_size(which) returns the library's sizeof (0 = llmseg_gemm_args, 1 = llmseg_attn_args,
  * 2 = llmseg_attn_bwd_args, 3 = llmseg_dropout; -1 for an unknown index) so a binding can assert at load time;
- * llmseg_version() is bumped whenever a struct or a signature changes (3 = this header). */
-#define LLMSEG_ABI_VERSION 3
+ * llmseg_version() is bumped whenever a struct or a signature changes (4 = this header: the reduction entry points take a workspace). */
+#define LLMSEG_ABI_VERSION 4
+
+/* Determinism (round 4).  No kernel adds floating-point numbers with atomics: every sum whose terms come from several workgroups is
+ * written as per-workgroup partials into CALLER-OWNED scratch (`workspace`, `workspace_bytes`; any device memory, 256-byte aligned, not
+ * shared with a concurrently running stream) and folded in a fixed order by a second launch, so the same inputs give the same bits on
+ * every run (the reference's resume contract, training.py:404-421,460-477).  LLMSEG_REDUCE_WS_BYTES is enough for every call the model
+ * makes; entry points that can fall back to a single partial (llmseg_colsum, llmseg_norm_bwd* for rows <= 8 KiB, llmseg_lora_outer)
+ * accept NULL / a smaller buffer and stay deterministic (slower), the others return LLMSEG_EINVAL when it is too small. */
+#define LLMSEG_REDUCE_WS_BYTES (16 << 20)
 int llmseg_version(void);
 int64_t llmseg_struct_size(int which);
 const char* llmseg_last_error(void);
@@ -278,15 +286,17 @@ int llmseg_align_reg_loss(const void* e, const void* t, const float* gt_iou, con
 
 /* dice_loss + sigmoid_ce_loss (model/loss.py:4-47; named by the north_star, no caller in the reference):
  * logits bf16/fp32-as-float [M][HW] given as fp32, targets fp32; out[0] = dice (scale 1000, eps 1e-6), out[1] = bce,
- * both summed over masks / (num_masks + 1e-8).  out must be zeroed by the caller. */
-int llmseg_dice_bce(const float* logits, const float* targets, float* out, int32_t M, int64_t HW, float num_masks, void* stream);
+ * both summed over masks / (num_masks + 1e-8).  out must be zeroed by the caller.  workspace >= 8 M bytes (per-mask terms, folded in order). */
+int llmseg_dice_bce(const float* logits, const float* targets, float* out, int32_t M, int64_t HW, float num_masks, void* workspace,
+                    int64_t workspace_bytes, void* stream);
 /* gradient of g[0] * dice + g[1] * bce w.r.t. the logits (g: device fp32[2], the upstream gradients of the two losses) */
 int llmseg_dice_bce_bwd(const float* logits, const float* targets, const float* g, float* dlogits, int32_t M, int64_t HW, float num_masks, void* stream);
 
 /* Shifted cross-entropy over bf16 logits (llava_llama.py:108-118): rows = N*T positions, labels int64 [N][T] already in
- * spliced form; position (n,t) is scored against labels[n][t+1]; ignore_index -100.  acc fp32[2] += {sum nll, count}. */
+ * spliced form; position (n,t) is scored against labels[n][t+1]; ignore_index -100.  acc fp32[2] += {sum nll, count}.
+ * workspace >= 8 N (T - 1) bytes (per-position terms, folded in order). */
 int llmseg_ce_loss(const void* logits, const int64_t* labels, float* acc, int32_t N, int32_t T, int64_t V, int64_t ldl,
-                   void* stream);
+                   void* workspace, int64_t workspace_bytes, void* stream);
 
 
 /* gIoU / cIoU bookkeeping (reference utils/utils.py:119-132 `intersectionAndUnionGPU`, K = 2 classes): pred/target uint8 [n],
@@ -320,15 +330,17 @@ int llmseg_resize_aa(const uint8_t* segs, void* out, int32_t K, int32_t H, int32
 /* ---- backward pass + optimizer (trainable part: LoRA'd Llama stack, embed/lm_head, text_hidden_fcs, mask-selection head) -----
  * GEMM-shaped gradients use llmseg_gemm_bf16 with trans_a / trans_w (dX = dY W, dW = dY^T X); the kernels below are the
  * streaming pieces.  Gradients of the loss kernels: llmseg_align_reg_loss (d_e, d_t, d_pred). */
-/* out[n] += sum_m x[m][n]  (bias gradients, fp32 accumulation; caller zero-fills out) */
-int llmseg_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ld, void* stream);
-/* LayerNorm / RMSNorm backward (contiguous rows): dx bf16; dw/db fp32 accumulated (NULL = frozen weight) */
+/* out[n] += sum_m x[m][n]  (bias gradients, fp32 accumulation; caller zero-fills out).  workspace: up to 64 N floats (row slices). */
+int llmseg_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ld, void* workspace, int64_t workspace_bytes, void* stream);
+/* LayerNorm / RMSNorm backward (contiguous rows): dx bf16; dw/db fp32 accumulated (NULL = frozen weight).  workspace (only read when dw or
+ * db is given): rows of <= 1024 columns use up to 256 x 2 cols floats of partials (NULL: one workgroup); wider rows NEED 2 rows + 2 cols
+ * floats (row statistics) and use up to 64 x 2 cols more. */
 int llmseg_norm_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw, float* db, int64_t rows, int64_t cols,
-                    float eps, int rms, void* stream);
+                    float eps, int rms, void* workspace, int64_t workspace_bytes, void* stream);
 /* same, dx = norm backward + dres (bf16 [rows][cols] or NULL): x of a pre-norm block also feeds the residual connection, and the
  * gradient arriving that way is added here instead of in a separate pass (HF LlamaDecoderLayer: hidden = residual + sublayer(norm(hidden))) */
 int llmseg_norm_bwd_add(const void* dy, const void* x, const void* w, const void* dres, void* dx, float* dw, float* db, int64_t rows, int64_t cols,
-                        float eps, int rms, void* stream);
+                        float eps, int rms, void* workspace, int64_t workspace_bytes, void* stream);
 /* SwiGLU backward: gu [rows][2I] (gate|up), dout [rows][I] -> dgu [rows][2I] */
 int llmseg_swiglu_bwd(const void* gu, const void* dout, void* dgu, int64_t rows, int64_t I, void* stream);
 /* out = dy * f'(y) computed from the OUTPUT y of a fused GEMM epilogue (act = RELU or SIGMOID) */
@@ -343,7 +355,8 @@ int llmseg_attn_ds(const void* P, const float* dP, void* dS, int64_t rows, int32
 /* dlogits = coef[0] * (softmax(logits) - onehot(shifted label)); zero for ignored positions (llava_llama.py:108-118 backward) */
 int llmseg_ce_bwd(const void* logits, const int64_t* labels, const float* coef, void* dlogits, int32_t N, int32_t T, int64_t V,
                   int64_t ldl, void* stream);
-/* dst[idx[i]][:] += src[i][:] in fp32 (embedding / row-gather gradients; idx < 0 skipped) */
+/* dst[idx[i]][:] += src[i][:] in fp32 (embedding / row-gather gradients; idx < 0 skipped); source rows that share a destination are added
+ * in ascending source order by one workgroup (no atomics) */
 int llmseg_scatter_add_rows(const void* src, const int64_t* idx, float* dst, int64_t n, int64_t cols, void* stream);
 /* Rank-8 LoRA products (peft==0.4.0 Linear with r = 8, lora_dropout 0.05: training.py:91,218-226) -- skinny shapes a tiled GEMM
  * cannot fill.  Every kernel handles the q AND the v branch of one layer in one launch (second operand set NULL = one branch);
@@ -371,8 +384,9 @@ int llmseg_lora_down(const void* x0, const void* x1, int64_t ldx, const void* w0
  * split along K over several workgroups per 16-row tile so that the whole chip fetches the operand, a second launch adds the slices */
 int llmseg_lora_down_ws(const void* x0, const void* x1, int64_t ldx, const void* w0, const void* w1, void* y, int64_t ldy, int64_t M, int64_t K,
                         int32_t w_kr, float alpha, int32_t zero_cols, const llmseg_dropout* drop, void* scratch, int64_t scratch_bytes, void* stream);
+/* workspace: up to 32 row slices x (1 or 2 branches) x 8 N floats of partials (NULL: one slice) */
 int llmseg_lora_outer(const void* a0, const void* a1, int64_t lda, const void* b0, const void* b1, int64_t ldb, float* out0, float* out1, int64_t M,
-                      int64_t N, int32_t out_rn, float alpha, const llmseg_dropout* drop, void* stream);
+                      int64_t N, int32_t out_rn, float alpha, const llmseg_dropout* drop, void* workspace, int64_t workspace_bytes, void* stream);
 int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, int64_t ldxa, const void* w0, const void* w1, int64_t M, int64_t N, int32_t w_rn,
                       float alpha, const llmseg_dropout* drop, void* stream);
 int llmseg_lora_pack(const void* aq, const void* bq, const void* av, const void* bv, void* w2b, void* w2a, void* bt, int64_t H, float s, void* stream);
@@ -380,8 +394,9 @@ int llmseg_lora_pack(const void* aq, const void* bq, const void* av, const void*
  * source are taken as zero.  Lets the weight / input gradients of a wide trainable Linear (lm_head: dX = dY.W, dW = dY^T.X) run on
  * the K-contiguous LDS-DMA GEMM kernels with the contraction dimension padded to a multiple of 64. */
 int llmseg_transpose_pad(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, int64_t rows_pad, void* stream);
-/* out[0] += sum x^2 (global gradient-norm clipping, training.py:301 "gradient_clipping": 1.0) */
-int llmseg_sumsq(const void* x, int64_t n, int is_f32, float* out, void* stream);
+/* out[0] += sum x^2 (global gradient-norm clipping, training.py:301 "gradient_clipping": 1.0).  workspace: required, 8 KiB holds every
+ * workgroup's partial (fewer bytes = fewer workgroups). */
+int llmseg_sumsq(const void* x, int64_t n, int is_f32, float* out, void* workspace, int64_t workspace_bytes, void* stream);
 /* Fused AdamW on fp32 master weights + bf16 model copy (DeepSpeed config training.py:292-332: betas (0.9, 0.95), wd 0).
  * grad is bf16 (grad_f32 = 0) or fp32; grad_scale (device fp32 scalar or NULL) carries 1/accum and the clip coefficient. */
 int llmseg_adamw(void* p, float* master, const void* grad, int grad_f32, float* m, float* v, int64_t n, float lr, float beta1,

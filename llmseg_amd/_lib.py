@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LLMSEG_LIB") or os.path.join(_HERE, "libllmseg_hip.so")     # LLMSEG_LIB: side builds of the same ABI (tools/ experiments)
 
-ABI_VERSION = 3          # == LLMSEG_ABI_VERSION of include/llmseg_hip.h
+ABI_VERSION = 4          # == LLMSEG_ABI_VERSION of include/llmseg_hip.h
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SILU, ACT_SIGMOID = range(6)
 
@@ -98,17 +98,17 @@ SIGNATURES = {
     "llmseg_upsample_maskpool": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p],
     "llmseg_cosine_scores": [_p, _p, _p, _i32, _i32, _p],
     "llmseg_align_reg_loss": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
-    "llmseg_dice_bce": [_p, _p, _p, _i32, _i64, _f32, _p],
+    "llmseg_dice_bce": [_p, _p, _p, _i32, _i64, _f32, _p, _i64, _p],
     "llmseg_dice_bce_bwd": [_p, _p, _p, _p, _i32, _i64, _f32, _p],
-    "llmseg_ce_loss": [_p, _p, _p, _i32, _i32, _i64, _i64, _p],
+    "llmseg_ce_loss": [_p, _p, _p, _i32, _i32, _i64, _i64, _p, _i64, _p],
     "llmseg_intersection_union": [_p, _p, _i64, _i32, _p, _p],
     "llmseg_union_resize_iou": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p],
     "llmseg_rle_decode": [_p, _p, _p, _i32, _i32, _i32, _i32, _p],
     "llmseg_mask_targets": [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p],
     "llmseg_resize_aa": [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p],
-    "llmseg_colsum": [_p, _p, _i64, _i64, _i64, _p],
-    "llmseg_norm_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _f32, C.c_int, _p],
-    "llmseg_norm_bwd_add": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f32, C.c_int, _p],
+    "llmseg_colsum": [_p, _p, _i64, _i64, _i64, _p, _i64, _p],
+    "llmseg_norm_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _f32, C.c_int, _p, _i64, _p],
+    "llmseg_norm_bwd_add": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f32, C.c_int, _p, _i64, _p],
     "llmseg_swiglu_bwd": [_p, _p, _p, _i64, _i64, _p],
     "llmseg_act_bwd": [_p, _p, _p, _i64, C.c_int, _p],
     "llmseg_softmax_rows": [_p, _p, _i64, _i32, _i32, _i32, _f32, _i32, _p, _i32, _p],
@@ -117,11 +117,11 @@ SIGNATURES = {
     "llmseg_scatter_add_rows": [_p, _p, _p, _i64, _i64, _p],
     "llmseg_lora_down": [_p, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i32, _f32, _i32, _dp, _p],
     "llmseg_lora_down_ws": [_p, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i32, _f32, _i32, _dp, _p, _i64, _p],
-    "llmseg_lora_outer": [_p, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _i32, _f32, _dp, _p],
+    "llmseg_lora_outer": [_p, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _i32, _f32, _dp, _p, _i64, _p],
     "llmseg_lora_apply": [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i32, _f32, _dp, _p],
     "llmseg_lora_pack": [_p, _p, _p, _p, _p, _p, _p, _i64, _f32, _p],
     "llmseg_transpose_pad": [_p, _p, _i64, _i64, _i64, _i64, _i64, _p],
-    "llmseg_sumsq": [_p, _i64, C.c_int, _p, _p],
+    "llmseg_sumsq": [_p, _i64, C.c_int, _p, _p, _i64, _p],
     "llmseg_adamw": [_p, _p, _p, C.c_int, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _p, _p],
     "llmseg_prof_enable": [C.c_int],
     "llmseg_prof_dominant_kernel": [],

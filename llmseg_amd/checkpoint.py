@@ -45,7 +45,8 @@ def resolve(path):
     if os.path.isdir(path):
         latest = os.path.join(path, "latest")
         if os.path.exists(latest):
-            tag = open(latest).read().strip().splitlines()[0].strip()
+            with open(latest) as fh:
+                tag = fh.read().strip().splitlines()[0].strip()
             return os.path.join(path, tag, "mp_rank_00_model_states.pt"), tag
         return os.path.join(path, "mp_rank_00_model_states.pt"), os.path.basename(os.path.normpath(path))
     return path, os.path.basename(os.path.dirname(path))

@@ -13,8 +13,9 @@ inline unsigned grid_for(long total) {
   return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
 }
 
-// out[n] += sum_m x[m][n]   (bias gradients); block = 64 columns x 4 row-lanes, grid.y splits the rows
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, long M, long N, long ld) {
+// out[n] += sum_m x[m][n]   (bias gradients); block = 64 columns x 4 row-lanes, grid.y splits the rows.  part != NULL: the row slice's
+// sum goes to part[slice][N] (folded in slice order by fold_slices_kernel); part == NULL (one slice): the column's only writer adds it.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, float* __restrict__ part, long M, long N, long ld) {
   __shared__ float red[4][64];
   const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const long col = (long)blockIdx.x * 64 + c;
@@ -25,17 +26,24 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
     for (long r = r0 + rl; r < r1; r += 4) s += bf2f(x[r * ld + col]);
   red[rl][c] = s;
   __syncthreads();
-  if (rl == 0 && col < N) atomicAdd(&out[col], red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  if (rl == 0 && col < N) {
+    const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (part) part[(long)blockIdx.y * N + col] = v;
+    else out[col] += v;
+  }
 }
 
 // LayerNorm / RMSNorm backward, one wave per row.  CPL > 0: x and dy (<= 64*CPL 16-byte chunks per row) are read once and kept
-// in registers; CPL == 0: multi-pass fallback.  Weight / bias gradients (fp32, dw may be NULL): ACC = true (narrow rows, CPL <= 2)
-// walks rows grid-stride with per-lane register partial sums and issues ONE atomic per column per wave at the end - per-element
-// atomics from 6144 rows onto 256 addresses took 1.1 ms per call; ACC = false keeps per-element atomics (wide trainable norms).
+// in registers; CPL == 0: multi-pass fallback.  Weight / bias gradients (fp32, dw may be NULL), no atomics (fixed summation order):
+// ACC = true (narrow rows, CPL <= 2) walks rows grid-stride with per-lane register partial sums, folds the workgroup's 4 waves in LDS
+// and writes ONE partial per column per workgroup to part[workgroup][2][cols] (fold_slices_kernel adds them in workgroup order; a
+// single workgroup adds to dw / db itself); ACC = false (wide rows) stores the row's (mean, rstd) to `stats` and leaves the column
+// sums to norm_dwdb_kernel.
 template <int CPL, bool ACC>
 __global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                          bf16_t* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, long rows, int cols,
-                                                         float eps, int rms, const bf16_t* __restrict__ dres) {
+                                                         float eps, int rms, const bf16_t* __restrict__ dres, float* __restrict__ part,
+                                                         float* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
   const int nch = cols >> 3;
   constexpr int NR = CPL > 0 ? CPL : 1;
@@ -84,6 +92,7 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16_t* __restri
     LL_FOR_CHUNKS({ (void)gv; (void)i; unpack8(xv, f); _Pragma("unroll") for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; v += d * d; } })
     v = wave_sum(v);
     const float rstd = rsqrtf(v / (float)cols + eps);
+    if constexpr (!ACC) { if (stats && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; } }
     // c1 = mean(g), c2 = mean(g * xhat) with g = dy * w
     float c1 = 0.f, c2 = 0.f;
     LL_FOR_CHUNKS({
@@ -105,10 +114,6 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16_t* __restri
         const float xh = (f[e] - mean) * rstd;
         o[e] = rstd * (g[e] * ww[e] - c1 - xh * c2);
         if constexpr (ACC) { aw[i][e] += g[e] * xh; ab[i][e] += g[e]; }
-        else {
-          if (dw) atomicAdd(&dw[c * 8 + e], g[e] * xh);
-          if (db) atomicAdd(&db[c * 8 + e], g[e]);
-        }
       }
       if (dres) {                                            // + the gradient that reaches x through the residual connection
         float rr[8];
@@ -120,8 +125,7 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16_t* __restri
 #undef LL_FOR_CHUNKS
   }
   if constexpr (ACC) {
-    // fold the workgroup's 4 waves in LDS, then ONE atomic per column per workgroup (512 rows onto 256 columns used to issue 512 atomics
-    // per address: 100 us of serialised L2 atomics for a 260 KB tensor)
+    // fold the workgroup's 4 waves in LDS, then ONE partial per column per workgroup
     __shared__ float red[2][4][NR * 64 * 8];
     const int wv = threadIdx.x >> 6;
 #pragma unroll
@@ -136,10 +140,43 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16_t* __restri
       const int i = idx / (64 * 8), ln = (idx / 8) % 64, e = idx % 8;
       const int c = ln + 64 * i;
       if (c < nch) {
-        if (dw) atomicAdd(&dw[c * 8 + e], red[0][0][idx] + red[0][1][idx] + red[0][2][idx] + red[0][3][idx]);
-        if (db) atomicAdd(&db[c * 8 + e], red[1][0][idx] + red[1][1][idx] + red[1][2][idx] + red[1][3][idx]);
+        const float sw = (red[0][0][idx] + red[0][1][idx]) + (red[0][2][idx] + red[0][3][idx]);
+        const float sb = (red[1][0][idx] + red[1][1][idx]) + (red[1][2][idx] + red[1][3][idx]);
+        if (part) {
+          part[((long)blockIdx.x * 2 + 0) * cols + c * 8 + e] = sw;
+          part[((long)blockIdx.x * 2 + 1) * cols + c * 8 + e] = sb;
+        } else {
+          if (dw) dw[c * 8 + e] += sw;
+          if (db) db[c * 8 + e] += sb;
+        }
       }
     }
+  }
+}
+
+// Column sums of a wide norm's backward from the stored row statistics: dw[c] = sum_r dy[r][c] (x[r][c] - mean_r) rstd_r, db[c] = sum_r dy[r][c].
+// Block = 64 columns x 4 row-lanes, grid.y = row slices -> part[slice][2][cols] (slices folded in order), or straight into dw / db for one slice.
+__global__ __launch_bounds__(256) void norm_dwdb_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ stats,
+                                                       float* __restrict__ dw, float* __restrict__ db, float* __restrict__ part, long rows, long cols) {
+  __shared__ float red[2][4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const long col = (long)blockIdx.x * 64 + c;
+  const long rows_per = (rows + gridDim.y - 1) / gridDim.y;
+  const long r0 = (long)blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  float sw = 0.f, sb = 0.f;
+  if (col < cols)
+    for (long r = r0 + rl; r < r1; r += 4) {
+      const float g = bf2f(dy[r * cols + col]);
+      sw += g * (bf2f(x[r * cols + col]) - stats[2 * r]) * stats[2 * r + 1];
+      sb += g;
+    }
+  red[0][rl][c] = sw; red[1][rl][c] = sb;
+  __syncthreads();
+  if (rl == 0 && col < cols) {
+    const float vw = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    const float vb = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    if (part) { part[((long)blockIdx.y * 2 + 0) * cols + col] = vw; part[((long)blockIdx.y * 2 + 1) * cols + col] = vb; }
+    else { if (dw) dw[col] += vw; if (db) db[col] += vb; }
   }
 }
 
@@ -260,26 +297,69 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const bf16_t* __restrict__ 
 }
 
 // dst[idx[i]][:] += src[i][:]  (fp32 accumulation; embedding / gather gradients).  idx < 0 rows are skipped.
+// No atomics: workgroup i handles source row i and is the OWNER of destination row d = idx[i] iff no earlier source row has the same
+// destination (a scan of idx[0 .. i), 256 entries per step); the owner walks idx[i ..) in chunks of 1024, collects the source rows that
+// hit d IN ASCENDING ORDER (one ballot per wave, prefix over the 4 waves) and adds them column by column -- the sum of a destination
+// row is formed by one workgroup in source-row order, so the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const bf16_t* __restrict__ src, const int64_t* __restrict__ idx, float* __restrict__ dst,
                                                               long n, long cols) {
-  const long total = n * cols;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / cols, c = i % cols;
-    const long d = idx[r];
-    if (d >= 0) atomicAdd(&dst[d * cols + c], bf2f(src[i]));
+  __shared__ int s_list[1024];
+  __shared__ int s_cnt[4];
+  const long i = blockIdx.x;
+  const long d = idx[i];
+  if (d < 0) return;
+  for (long j0 = 0; j0 < i; j0 += 256) {
+    const long j = j0 + threadIdx.x;
+    if (__syncthreads_or(j < i && idx[j] == d)) return;          // an earlier source row owns this destination
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long base = i; base < n; base += 1024) {
+    // matches of this chunk, ascending: wave w scans rows base + 256 w + lane + 64 q (q = 0..3) -> per-thread 4 candidates out of order;
+    // simpler and ordered: four sub-steps of 256 consecutive rows each
+    int total = 0;
+    for (int q = 0; q < 4; ++q) {
+      const long j = base + 256 * q + threadIdx.x;
+      const bool hit = j < n && idx[j] == d;
+      const unsigned long long bal = __ballot(hit);
+      if (lane == 0) s_cnt[wave] = __popcll(bal);
+      __syncthreads();
+      int off = total;
+      for (int w2 = 0; w2 < wave; ++w2) off += s_cnt[w2];
+      if (hit) s_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (int)(j - base);
+      total += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+      __syncthreads();
+    }
+    if (total == 0) continue;
+    for (long c = threadIdx.x; c < cols; c += 256) {
+      float sacc = 0.f;
+      for (int t = 0; t < total; ++t) sacc += bf2f(src[(base + s_list[t]) * cols + c]);
+      dst[d * cols + c] += sacc;
+    }
+    __syncthreads();
   }
 }
 
-// sum of squares of a bf16 or fp32 buffer -> out[0] += (grad-norm clipping)
-__global__ __launch_bounds__(256) void sumsq_kernel(const void* __restrict__ x, long n, int is_f32, float* __restrict__ out) {
+// sum of squares of a bf16 or fp32 buffer: one partial per workgroup -> part[blockIdx.x] (fold_column_kernel adds them in a fixed order)
+__global__ __launch_bounds__(256) void sumsq_kernel(const void* __restrict__ x, long n, int is_f32, float* __restrict__ part) {
   __shared__ float red[16];
   float s = 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float v = is_f32 ? reinterpret_cast<const float*>(x)[i] : bf2f(reinterpret_cast<const bf16_t*>(x)[i]);
-    s += v * v;
+  if (is_f32 && (((uintptr_t)x) & 15) == 0) {
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+      const float4 v = x4[i];
+      s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    if (blockIdx.x == 0)
+      for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) { const float v = reinterpret_cast<const float*>(x)[i]; s += v * v; }
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+      const float v = is_f32 ? reinterpret_cast<const float*>(x)[i] : bf2f(reinterpret_cast<const bf16_t*>(x)[i]);
+      s += v * v;
+    }
   }
   s = block_sum(s, red);
-  if (threadIdx.x == 0) atomicAdd(out, s);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
 // Fused AdamW on fp32 master weights with bf16 model copy (DeepSpeed bf16 + AdamW(beta=(0.9,0.95), wd) semantics restated):
@@ -304,34 +384,65 @@ __global__ __launch_bounds__(256) void adamw_kernel(bf16_t* __restrict__ p, floa
 
 #define AL16(p) ((((uintptr_t)(p)) & 15) == 0)
 
-extern "C" int llmseg_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ld, void* stream) {
+extern "C" int llmseg_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ld, void* workspace, int64_t workspace_bytes, void* stream) {
   LL_CHECK(x && out && M > 0 && N > 0 && ld >= N, "colsum: bad arguments");
-  const unsigned gy = (unsigned)min((long)64, (long)((M + 255) / 256));
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64), gy < 1 ? 1 : gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, (long)M,
+  long gy = min((long)64, (long)((M + 255) / 256));
+  gy = min(gy, workspace ? (long)(workspace_bytes / (N * 4)) : 0L);          // row slices the scratch can hold; <= 1: one slice, no scratch
+  float* part = gy > 1 ? (float*)workspace : nullptr;
+  if (gy < 1) gy = 1;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, part, (long)M,
                      (long)N, (long)ld);
+  if (part)
+    hipLaunchKernelGGL(fold_slices_kernel, dim3(fold_grid(N)), dim3(256), 0, (hipStream_t)stream, (const float*)part, (int)gy, (long)N, (long)N, (long)N, out,
+                       (float*)nullptr);
   LL_LAUNCH_CHECK("colsum");
   return LLMSEG_OK;
 }
 
 extern "C" int llmseg_norm_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw, float* db, int64_t rows, int64_t cols, float eps,
-                               int rms, void* stream) {
-  return llmseg_norm_bwd_add(dy, x, w, nullptr, dx, dw, db, rows, cols, eps, rms, stream);
+                               int rms, void* workspace, int64_t workspace_bytes, void* stream) {
+  return llmseg_norm_bwd_add(dy, x, w, nullptr, dx, dw, db, rows, cols, eps, rms, workspace, workspace_bytes, stream);
 }
 
 extern "C" int llmseg_norm_bwd_add(const void* dy, const void* x, const void* w, const void* dres, void* dx, float* dw, float* db, int64_t rows, int64_t cols,
-                                   float eps, int rms, void* stream) {
+                                   float eps, int rms, void* workspace, int64_t workspace_bytes, void* stream) {
   LL_CHECK(dy && x && w && dx && rows > 0 && cols > 0 && (cols & 7) == 0 && AL16(dy) && AL16(x) && AL16(w) && AL16(dx) && AL16(dres), "norm_bwd: bad arguments");
   const int cpl = (int)(((cols >> 3) + 63) / 64);
-  const bool acc = (dw || db) && cpl <= 2;
+  const bool wgrad = dw || db;
+  const bool acc = wgrad && cpl <= 2;
   const long wgs = (rows + 3) / 4;
-  const dim3 grid((unsigned)(acc ? std::min<long>(std::max<long>(1, (rows + 31) / 32), 256) : wgs));     // ACC: every wave walks >= 8 rows
+  const long ws_floats = workspace ? workspace_bytes / 4 : 0;
+  long G = acc ? std::min<long>(std::max<long>(1, (rows + 31) / 32), 256) : wgs;                          // ACC: every wave walks >= 8 rows
+  float *part = nullptr, *stats = nullptr;
+  if (acc) {
+    G = std::min<long>(G, ws_floats / (2 * cols));                                                         // partial slots the scratch can hold
+    if (G > 1) part = (float*)workspace; else G = 1;
+  } else if (wgrad) {
+    LL_CHECK(ws_floats >= 2 * rows + 2 * cols, "norm_bwd: weight gradients of a wide norm need workspace >= (2 rows + 2 cols) floats (row statistics)");
+    stats = (float*)workspace;
+  }
+  const dim3 grid((unsigned)G);
 #define LL_NORMB(C, A)                                                                                                                       \
   hipLaunchKernelGGL((norm_bwd_kernel<C, A>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, \
-                     (bf16_t*)dx, dw, db, (long)rows, (int)cols, eps, rms, (const bf16_t*)dres)
+                     (bf16_t*)dx, dw, db, (long)rows, (int)cols, eps, rms, (const bf16_t*)dres, part, stats)
   if (acc) { if (cpl <= 1) LL_NORMB(1, true); else LL_NORMB(2, true); }
   else if (cpl <= 1) LL_NORMB(1, false); else if (cpl <= 2) LL_NORMB(2, false); else if (cpl <= 4) LL_NORMB(4, false);
   else if (cpl <= 8) LL_NORMB(8, false); else LL_NORMB(0, false);
 #undef LL_NORMB
+  if (acc && part)
+    hipLaunchKernelGGL(fold_slices_kernel, dim3(fold_grid(2 * cols)), dim3(256), 0, (hipStream_t)stream, (const float*)part, (int)G, (long)(2 * cols),
+                       (long)(2 * cols), (long)cols, dw, db);
+  if (stats) {                                                     // wide rows: column sums from the stored (mean, rstd), row slices folded in order
+    float* p2 = stats + ((2 * rows + 63) / 64) * 64;
+    long gy = std::min<long>(64, (rows + 255) / 256);
+    gy = std::min<long>(gy, (ws_floats - (p2 - stats)) / (2 * cols));
+    if (gy <= 1) { gy = 1; p2 = nullptr; }
+    hipLaunchKernelGGL(norm_dwdb_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
+                       (const float*)stats, dw, db, p2, (long)rows, (long)cols);
+    if (p2)
+      hipLaunchKernelGGL(fold_slices_kernel, dim3(fold_grid(2 * cols)), dim3(256), 0, (hipStream_t)stream, (const float*)p2, (int)gy, (long)(2 * cols),
+                         (long)(2 * cols), (long)cols, dw, db);
+  }
   LL_LAUNCH_CHECK("norm_bwd");
   return LLMSEG_OK;
 }
@@ -379,14 +490,19 @@ extern "C" int llmseg_ce_bwd(const void* logits, const int64_t* labels, const fl
 
 extern "C" int llmseg_scatter_add_rows(const void* src, const int64_t* idx, float* dst, int64_t n, int64_t cols, void* stream) {
   LL_CHECK(src && idx && dst && n > 0 && cols > 0, "scatter_add_rows: bad arguments");
-  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for(n * cols)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, idx, dst, (long)n, (long)cols);
+  LL_CHECK(n < (1L << 31), "scatter_add_rows: too many source rows");
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, idx, dst, (long)n, (long)cols);
   LL_LAUNCH_CHECK("scatter_add_rows");
   return LLMSEG_OK;
 }
 
-extern "C" int llmseg_sumsq(const void* x, int64_t n, int is_f32, float* out, void* stream) {
+extern "C" int llmseg_sumsq(const void* x, int64_t n, int is_f32, float* out, void* workspace, int64_t workspace_bytes, void* stream) {
   LL_CHECK(x && out && n > 0, "sumsq: bad arguments");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (long)n, is_f32, out);
+  LL_CHECK(workspace && workspace_bytes >= 4, "sumsq: workspace (>= 4 bytes, 8 KiB for every partial) is required");
+  long g = std::min<long>(2048, (n + 2047) / 2048);                       // >= 8 elements per thread
+  g = std::max<long>(1, std::min<long>(g, workspace_bytes / 4));
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (long)n, is_f32, (float*)workspace);
+  hipLaunchKernelGGL(fold_column_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (long)g, out, 1.f);
   LL_LAUNCH_CHECK("sumsq");
   return LLMSEG_OK;
 }
@@ -576,16 +692,16 @@ __global__ __launch_bounds__(256) void lora_down_finish_kernel(const float* __re
   }
 }
 
-// out(n,r) += alpha * sum_m drop(a)[m][n] * b[m][r]  (fp32 atomics onto `out`: the caller zero-fills it or accumulates into a
-// gradient arena).  out_rn = 0: out [N][8]; 1: out [8][N].  b has row pitch ldb.  blockIdx.z selects one of up to two independent
+// out(n,r) += alpha * sum_m drop(a)[m][n] * b[m][r]  (the caller zero-fills `out` or accumulates into a gradient arena; no atomics:
+// with several row slices a workgroup's 512 sums go to part[slice][branch][N * 8] and fold_slices_kernel adds the slices in order).  out_rn = 0: out [N][8]; 1: out [8][N].  b has row pitch ldb.  blockIdx.z selects one of up to two independent
 // products that share the shapes (the q and v branches of one layer: dAq / dAv read the same activation with their own dropout streams,
 // dBq / dBv two column blocks of dY).
 // Workgroup = 64 columns x one slice of rows, split again over its 4 waves: lane = (row-lane 0..7, column chunk 0..7), a wave reads 8
 // rows x 128 contiguous bytes per step (16 B per lane, three steps in flight); the 8 row-lanes are folded with shuffles, the 4 waves in
-// LDS, so ONE atomic per output cell per workgroup (the first version issued one per WAVE over 9 row slices: 590 K atomics per call
-// at M = 638, which was the whole 30 us).
+// LDS, so ONE partial per output cell per workgroup.
 struct OuterP { const bf16_t* a[2]; const bf16_t* b[2]; float* out[2]; };
-__global__ __launch_bounds__(256) void lora_outer_kernel(OuterP q, long lda, long ldb, long M, long N, int out_rn, float alpha, DropP dp) {
+__global__ __launch_bounds__(256) void lora_outer_kernel(OuterP q, long lda, long ldb, long M, long N, int out_rn, float alpha, DropP dp,
+                                                        float* __restrict__ part) {
   __shared__ float red[4][8][8 * LR];                  // [wave][column chunk][8 columns x 8 ranks]
   const int z = blockIdx.z;
   const bf16_t* __restrict__ a = q.a[z];
@@ -649,14 +765,16 @@ __global__ __launch_bounds__(256) void lora_outer_kernel(OuterP q, long lda, lon
       for (int r = 0; r < LR; ++r) red[wave][cl][j * LR + r] = acc[j][r];
   }
   __syncthreads();
-  // 512 outputs (64 columns x 8 ranks) per workgroup: two per thread, ONE atomic each (row slices of other workgroups add to the same cell)
+  // 512 outputs (64 columns x 8 ranks) per workgroup: two per thread (row slices of other workgroups hold the other terms of the same cell)
+  float* __restrict__ dstp = part ? part + ((long)blockIdx.y * gridDim.z + z) * N * LR : out;
   for (int idx = threadIdx.x; idx < 8 * 8 * LR; idx += blockDim.x) {
     const int c = idx / (8 * LR), jr = idx % (8 * LR), j = jr / LR, r = jr % LR;
     const long nn = ((long)blockIdx.x * 8 + c) * 8 + j;
     if (nn < N) {
-      const float v = red[0][c][jr] + red[1][c][jr] + red[2][c][jr] + red[3][c][jr];
-      if (out_rn) atomicAdd(&out[(long)r * N + nn], v);
-      else atomicAdd(&out[nn * LR + r], v);
+      const float v = (red[0][c][jr] + red[1][c][jr]) + (red[2][c][jr] + red[3][c][jr]);
+      const long cell = out_rn ? (long)r * N + nn : nn * LR + r;
+      if (part) dstp[cell] = v;
+      else dstp[cell] += v;
     }
   }
 }
@@ -821,17 +939,23 @@ extern "C" int llmseg_lora_down_ws(const void* x0, const void* x1, int64_t ldx, 
 }
 
 extern "C" int llmseg_lora_outer(const void* a0, const void* a1, int64_t lda, const void* b0, const void* b1, int64_t ldb, float* out0, float* out1, int64_t M,
-                                 int64_t N, int32_t out_rn, float alpha, const llmseg_dropout* drop, void* stream) {
+                                 int64_t N, int32_t out_rn, float alpha, const llmseg_dropout* drop, void* workspace, int64_t workspace_bytes, void* stream) {
   const int nz = (a1 && b1 && out1) ? 2 : 1;
   LL_CHECK(a0 && b0 && out0 && ((!a1) == (!b1)) && ((!a1) == (!out1)) && M > 0 && N > 0 && (N & 7) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && AL16(a0) &&
                AL16(a1) && AL16(b0) && AL16(b1) && LL_DROP_OK(drop), "lora_outer: bad arguments (N, lda, ldb multiples of 8)");
   // 64 columns per workgroup (its 4 waves split the rows): enough row slices to put >= 2 workgroups on every CU, each wave >= 24 rows
   const long colwg = (N + 63) / 64;
-  const unsigned gy = (unsigned)max(max((long)1, 256 / (colwg * nz)), min((long)32, M / 512));
+  long gy = max(max((long)1, 256 / (colwg * nz)), min((long)32, M / 512));
+  gy = min(gy, workspace ? (long)(workspace_bytes / (nz * N * LR * 4)) : 0L);          // row slices the scratch can hold; <= 1: one slice, no scratch
+  float* part = gy > 1 ? (float*)workspace : nullptr;
+  if (gy < 1) gy = 1;
   OuterP q;
   q.a[0] = (const bf16_t*)a0; q.a[1] = (const bf16_t*)a1; q.b[0] = (const bf16_t*)b0; q.b[1] = (const bf16_t*)b1; q.out[0] = out0; q.out[1] = out1;
-  hipLaunchKernelGGL(lora_outer_kernel, dim3((unsigned)colwg, gy, nz), dim3(256), 0, (hipStream_t)stream, q, (long)lda, (long)ldb, (long)M, (long)N,
-                     out_rn, alpha, make_drop(drop));
+  hipLaunchKernelGGL(lora_outer_kernel, dim3((unsigned)colwg, (unsigned)gy, nz), dim3(256), 0, (hipStream_t)stream, q, (long)lda, (long)ldb, (long)M, (long)N,
+                     out_rn, alpha, make_drop(drop), part);
+  if (part)
+    hipLaunchKernelGGL(fold_slices_kernel, dim3(fold_grid(nz * N * LR)), dim3(256), 0, (hipStream_t)stream, (const float*)part, (int)gy, (long)(nz * N * LR),
+                       (long)(nz * N * LR), (long)(N * LR), out0, out1);
   LL_LAUNCH_CHECK("lora_outer");
   return LLMSEG_OK;
 }

@@ -148,6 +148,36 @@ __device__ __forceinline__ void dropout8(float* f, unsigned long idx, uint32_t s
   }
 }
 
+
+// ---- fixed-order reductions (round 4) ------------------------------------------------------------------------------------------------
+// No kernel of the library adds floating-point numbers with atomics: a sum whose terms come from several workgroups is written as
+// per-workgroup PARTIALS into caller-owned scratch (`workspace`) and folded by one of the two kernels below in a fixed order, so a
+// training step is bit-reproducible (the reference's resume contract, training.py:404-421,460-477: same weights + optimizer state ->
+// the same continuation; with fp32 atomicAdd two runs from the same state differed in isolated elements).
+// (1) wide outputs, few partials: out[i] += sum_{p < P} part[p * pstride + i], p ascending, one thread per output element; outputs
+//     [0, n0) go to out0, [n0, n) to out1 (either may be NULL: skipped).
+static __global__ __launch_bounds__(256) void fold_slices_kernel(const float* __restrict__ part, int P, long pstride, long n, long n0,
+                                                                 float* __restrict__ out0, float* __restrict__ out1) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float* o = i < n0 ? (out0 ? out0 + i : nullptr) : (out1 ? out1 + (i - n0) : nullptr);
+    if (!o) continue;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += part[(long)p * pstride + i];
+    *o += s;
+  }
+}
+// (2) few outputs (n = gridDim.x), many partials: part[p * n + i]; thread t adds p = t, t + 256, ... in order, then a fixed shuffle /
+//     LDS tree over the 256 threads; out[i] += scale * sum.
+static __global__ __launch_bounds__(256) void fold_column_kernel(const float* __restrict__ part, long P, float* __restrict__ out, float scale) {
+  __shared__ float red[16];
+  const long n = gridDim.x, i = blockIdx.x;
+  float s = 0.f;
+  for (long p = threadIdx.x; p < P; p += 256) s += part[p * n + i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[i] += scale * s;
+}
+static inline unsigned fold_grid(long n) { const long g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g)); }
+
 void llmseg_set_error(const char* fmt, ...);
 #define LL_CHECK(cond, ...)                 \
   do {                                      \

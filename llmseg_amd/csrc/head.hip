@@ -230,7 +230,8 @@ __global__ __launch_bounds__(256) void align_reg_kernel(const bf16_t* __restrict
 }
 
 // ---- dice + BCE-with-logits, one workgroup per mask ----------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dice_bce_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, long HW,
+// part[m][2] = this mask's (dice, bce) terms; fold_column_kernel adds the masks in a fixed order (no atomics)
+__global__ __launch_bounds__(256) void dice_bce_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ part, long HW,
                                                       float num_masks) {
   __shared__ float red[16];
   const long m = blockIdx.x;
@@ -245,8 +246,8 @@ __global__ __launch_bounds__(256) void dice_bce_kernel(const float* __restrict__
   if (threadIdx.x == 0) {
     const float sc = 1000.f, eps = 1e-6f;
     const float dice = 1.f - (2.f * sxy / sc + eps) / (sx / sc + sy / sc + eps);
-    atomicAdd(&out[0], dice / (num_masks + 1e-8f));
-    atomicAdd(&out[1], bce / (float)HW / (num_masks + 1e-8f));
+    part[2 * m] = dice / (num_masks + 1e-8f);
+    part[2 * m + 1] = bce / (float)HW / (num_masks + 1e-8f);
   }
 }
 
@@ -275,12 +276,16 @@ __global__ __launch_bounds__(256) void dice_bce_bwd_kernel(const float* __restri
 }
 
 // ---- shifted CE: one workgroup per (n, t) with a valid label -------------------------------------------------------------
-__global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logits, const int64_t* __restrict__ labels, float* __restrict__ acc, int T,
+// part[row][2] = (nll, 1) of a scored position, (0, 0) of an ignored one; fold_column_kernel adds the rows in a fixed order (no atomics)
+__global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logits, const int64_t* __restrict__ labels, float* __restrict__ part, int T,
                                                 long V, long ldl) {
   __shared__ float red[16];
   const int n = blockIdx.x / (T - 1), t = blockIdx.x % (T - 1);
   const long lab = labels[(long)n * T + t + 1];
-  if (lab < 0 || lab >= V) return;                        // ignore_index (-100)
+  if (lab < 0 || lab >= V) {                              // ignore_index (-100)
+    if (threadIdx.x == 0) { part[2 * (long)blockIdx.x] = 0.f; part[2 * (long)blockIdx.x + 1] = 0.f; }
+    return;
+  }
   const bf16_t* row = logits + ((long)n * T + t) * ldl;
   float mx = -1e30f, s = 0.f;
   if (ce_row_fast(row, V, ldl)) {                         // the row is read once (registers), 8-byte loads
@@ -294,8 +299,8 @@ __global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logi
     s = block_sum(s, red);
   }
   if (threadIdx.x == 0) {
-    atomicAdd(&acc[0], mx + __logf(s) - bf2f(row[lab]));
-    atomicAdd(&acc[1], 1.f);
+    part[2 * (long)blockIdx.x] = mx + __logf(s) - bf2f(row[lab]);
+    part[2 * (long)blockIdx.x + 1] = 1.f;
   }
 }
 
@@ -580,9 +585,12 @@ extern "C" int llmseg_align_reg_loss(const void* e, const void* t, const float* 
   return LLMSEG_OK;
 }
 
-extern "C" int llmseg_dice_bce(const float* logits, const float* targets, float* out, int32_t M, int64_t HW, float num_masks, void* stream) {
+extern "C" int llmseg_dice_bce(const float* logits, const float* targets, float* out, int32_t M, int64_t HW, float num_masks, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
   LL_CHECK(logits && targets && out && M > 0 && HW > 0, "dice_bce: bad arguments");
-  hipLaunchKernelGGL(dice_bce_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, targets, out, (long)HW, num_masks);
+  LL_CHECK(workspace && workspace_bytes >= (int64_t)M * 8, "dice_bce: workspace of >= 8 M bytes (per-mask terms) is required");
+  hipLaunchKernelGGL(dice_bce_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, targets, (float*)workspace, (long)HW, num_masks);
+  hipLaunchKernelGGL(fold_column_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (long)M, out, 1.f);
   LL_LAUNCH_CHECK("dice_bce");
   return LLMSEG_OK;
 }
@@ -595,10 +603,14 @@ extern "C" int llmseg_dice_bce_bwd(const float* logits, const float* targets, co
   return LLMSEG_OK;
 }
 
-extern "C" int llmseg_ce_loss(const void* logits, const int64_t* labels, float* acc, int32_t N, int32_t T, int64_t V, int64_t ldl, void* stream) {
+extern "C" int llmseg_ce_loss(const void* logits, const int64_t* labels, float* acc, int32_t N, int32_t T, int64_t V, int64_t ldl, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
   LL_CHECK(logits && labels && acc && N > 0 && T > 1 && V > 0 && ldl >= V, "ce_loss: bad arguments");
-  hipLaunchKernelGGL(ce_kernel, dim3((unsigned)(N * (T - 1))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, labels, acc, T, (long)V,
+  const long rows = (long)N * (T - 1);
+  LL_CHECK(workspace && workspace_bytes >= rows * 8, "ce_loss: workspace of >= 8 N (T - 1) bytes (per-position terms) is required");
+  hipLaunchKernelGGL(ce_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, labels, (float*)workspace, T, (long)V,
                      (long)ldl);
+  hipLaunchKernelGGL(fold_column_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, rows, acc, 1.f);
   LL_LAUNCH_CHECK("ce_loss");
   return LLMSEG_OK;
 }

@@ -41,6 +41,19 @@ def _workspace(dev, stream):
     return ws
 
 
+REDUCE_WS_BYTES = 16 << 20          # == LLMSEG_REDUCE_WS_BYTES of include/llmseg_hip.h
+_RWS = {}
+
+
+def _reduce_ws(dev):
+    """(pointer, bytes) of the per-(device, stream) scratch that the fixed-order reductions write their per-workgroup partials to."""
+    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    ws = _RWS.get(key)
+    if ws is None:
+        ws = _RWS[key] = torch.zeros(REDUCE_WS_BYTES, device=dev, dtype=torch.uint8)
+    return C.c_void_p(ws.data_ptr()), ws.numel()
+
+
 def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alpha=1.0, out_f32=False, trans_a=False, trans_w=False,
          a2=None, w2=None, accumulate=False, a_norm_w=None, a_norm_eps=1e-6, a_swiglu=False):
     """out[M,N] = residual + gamma * act(alpha * A @ W^T + bias) with A = a [M,K] (or a^T when trans_a: a stored [K,M]) and
@@ -415,7 +428,7 @@ def dice_bce(logits, targets, num_masks):
     M = logits.shape[0]
     HW = logits[0].numel()
     out = torch.zeros((2,), device=logits.device, dtype=torch.float32)
-    _lib.check(_lib.load().llmseg_dice_bce(_ptr(logits), _ptr(targets), _ptr(out), M, HW, float(num_masks), _stream()), "dice_bce")
+    _lib.check(_lib.load().llmseg_dice_bce(_ptr(logits), _ptr(targets), _ptr(out), M, HW, float(num_masks), *_reduce_ws(logits.device), _stream()), "dice_bce")
     return out
 
 
@@ -432,7 +445,7 @@ def ce_loss(logits, labels):
     """logits bf16 [N,T,V(ld)], labels int64 [N,T] (spliced) -> fp32[2] = (sum nll, count)."""
     N, T, V = logits.shape
     acc = torch.zeros((2,), device=logits.device, dtype=torch.float32)
-    _lib.check(_lib.load().llmseg_ce_loss(_ptr(logits), _ptr(labels), _ptr(acc), N, T, V, logits.stride(1), _stream()), "ce_loss")
+    _lib.check(_lib.load().llmseg_ce_loss(_ptr(logits), _ptr(labels), _ptr(acc), N, T, V, logits.stride(1), *_reduce_ws(logits.device), _stream()), "ce_loss")
     return acc
 
 
@@ -464,7 +477,7 @@ def colsum(x, out=None):
     M, N = x.shape
     if out is None:
         out = torch.zeros((N,), device=x.device, dtype=torch.float32)
-    _lib.check(_lib.load().llmseg_colsum(_ptr(x), _ptr(out), M, N, x.stride(0), _stream()), "colsum")
+    _lib.check(_lib.load().llmseg_colsum(_ptr(x), _ptr(out), M, N, x.stride(0), *_reduce_ws(x.device), _stream()), "colsum")
     return out
 
 
@@ -474,7 +487,7 @@ def norm_bwd(dy, x, w, eps, rms, dw=None, db=None, dres=None):
     assert dy.is_contiguous() and x.is_contiguous() and (dres is None or (dres.is_contiguous() and dres.shape == x.shape))
     dx = torch.empty_like(x)
     _lib.check(_lib.load().llmseg_norm_bwd_add(_ptr(dy), _ptr(x), _ptr(w), _ptr(dres), _ptr(dx), _ptr(dw), _ptr(db), rows, cols, eps, 1 if rms else 0,
-                                               _stream()), "norm_bwd")
+                                               *_reduce_ws(x.device), _stream()), "norm_bwd")
     return dx
 
 
@@ -557,7 +570,8 @@ def lora_outer(a, b, out_rn=False, alpha=1.0, out=None, drop=None, a2=None, b2=N
             out2 = torch.zeros(shape, device=a.device, dtype=torch.float32)
         assert a2.shape == a.shape and a2.stride(0) == a.stride(0) and b2.stride(0) == b.stride(0) and out2.is_contiguous() and out2.numel() == 8 * N
     _lib.check(_lib.load().llmseg_lora_outer(_ptr(a), _ptr(a2 if b2 is not None else None), a.stride(0), _ptr(b), _ptr(b2), b.stride(0), _ptr(out),
-                                             _ptr(out2 if b2 is not None else None), M, N, 1 if out_rn else 0, alpha, _drop(drop), _stream()), "lora_outer")
+                                             _ptr(out2 if b2 is not None else None), M, N, 1 if out_rn else 0, alpha, _drop(drop), *_reduce_ws(a.device),
+                                             _stream()), "lora_outer")
     return out if b2 is None else (out, out2)
 
 
@@ -580,7 +594,7 @@ def lora_pack(aq, bq, av, bv, s, w2b=None, w2a=None, bt=None):
 
 
 def sumsq(x, out):
-    _lib.check(_lib.load().llmseg_sumsq(_ptr(x), x.numel(), 1 if x.dtype == torch.float32 else 0, _ptr(out), _stream()), "sumsq")
+    _lib.check(_lib.load().llmseg_sumsq(_ptr(x), x.numel(), 1 if x.dtype == torch.float32 else 0, _ptr(out), *_reduce_ws(x.device), _stream()), "sumsq")
     return out
 
 

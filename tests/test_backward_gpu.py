@@ -57,6 +57,11 @@ def test_trainer_configs4_k512_accum8():
     _assert(res)
 
 
+def test_micro_step_is_bit_reproducible():
+    from tests import backward_checks as bc
+    _assert(bc.check_determinism())
+
+
 def test_checkpoint_save_resume_and_reference_layout(tmp_path):
     from tests import backward_checks as bc
     _assert(bc.check_checkpoint_resume(str(tmp_path)))
