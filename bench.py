@@ -336,9 +336,28 @@ def main():
     ap.add_argument("--no-loader", action="store_true", help="skip the loader-in-the-loop side measurement (a different batch + device-side targets + a fresh plan every micro-step)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start N ranks ourselves (one process per GPU, the launch line the driver uses) and
+        # let rank 0 of THAT job print the line -- never time one GPU and report it as N (reference launch: scripts/train_10epoch.sh:10-22)
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} GPU(s); refusing to report a {args.gpus}-GPU figure")
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; the two must agree")
+    if local >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} (LOCAL_RANK {local}) has no GPU: this node exposes {torch.cuda.device_count()}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -350,6 +369,7 @@ def main():
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == world and dist.get_rank() == rank
 
     from llmseg_amd.lisa import LISAForCausalLM
     from llmseg_amd.params import LisaConfig, LlamaConfig, SamConfig, VitConfig
@@ -403,6 +423,7 @@ def main():
                                     "%s, %d candidate masks, %d-token prompt") % (
                 2 if train else 1, img, img, "SAM-ViT-H" if args.backbone == "sam" else "DINOv2-L", args.batch, what, args.masks, args.prompt_len),
                        "images_per_gpu_per_step": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "process_group_world_size": (dist.get_world_size() if dist else None),     # what RCCL reports (None: no process group at 1 GPU)
                        "graph": main_res.get("graph", False), "valid": not args.small},
             # dominant kernel = the GEMM kernel class with the largest total time; achieved = its algorithmic 2MNK per launch / its
             # HIP-event duration

@@ -98,7 +98,7 @@ def save_checkpoint(save_dir, model, trainer=None, global_step=0, trainable_only
         st = trainer.state_dict()
         st["param_names"] = [n for n, p in model.params.named_parameters() if p.requires_grad]
         if hasattr(model, "dropout_state"):
-            st["dropout_state"] = model.dropout_state().cpu()
+            st["dropout_state"] = torch.tensor([model.dropout_base_seed(), int(model.dropout_state()[1])], dtype=torch.int64)     # BASE seed + offset
         torch.save(st, os.path.join(d, "llmseg_optim_states.pt"))
     with open(os.path.join(save_dir, "latest"), "w") as fh:
         fh.write(tag)
@@ -119,9 +119,8 @@ def load_checkpoint(load_dir, model, trainer=None, steps_per_epoch=500):
             assert st.get("param_names") == names, "optimizer state belongs to a different trainable set"
             trainer.load_state_dict(st)
             if "dropout_state" in st and hasattr(model, "dropout_state"):
-                from .train import rank_dropout_seed           # the file holds rank 0's stream; every rank re-derives its own
-                seed, off = (int(v) for v in st["dropout_state"].tolist())
-                model.set_dropout_seed(rank_dropout_seed(seed, getattr(trainer, "rank", 0)), off)
+                seed, off = (int(v) for v in st["dropout_state"].tolist())      # the base seed; every rank's module derives its own key
+                model.set_dropout_seed(seed, off)
             restored = True
         elif hasattr(trainer.opt, "resync_master"):
             trainer.opt.resync_master()                 # a reference checkpoint: fresh Adam moments on the loaded weights

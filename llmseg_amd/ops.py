@@ -275,6 +275,9 @@ def sam_preprocess(img, img_size, mean, std):
     return out
 
 
+SMALL_REGIONS_WS_BYTES = 1 << 30
+
+
 def mask_small_regions_(masks, min_area):
     """masks uint8 [K, H, W] IN PLACE: holes below min_area filled, then islands below min_area removed (`remove_small_regions` twice, as
     `postprocess_small_regions` applies it) -> uint8 [K] changed flags."""
@@ -283,9 +286,16 @@ def mask_small_regions_(masks, min_area):
     changed = torch.zeros((K,), device=masks.device, dtype=torch.uint8)
     if K:
         lib = _lib.load()
-        nb = lib.llmseg_mask_small_regions_workspace(K, H, W)
+        # masks in chunks that keep the label workspace (8 bytes per pixel) under a fixed budget: 300 masks of a 1500 x 2250 photograph
+        # would otherwise ask for 8 GB at once (the reference cleans one mask at a time, amg.py:267-291)
+        per = max(1, int(lib.llmseg_mask_small_regions_workspace(1, H, W)))
+        kc = max(1, min(K, SMALL_REGIONS_WS_BYTES // per))
+        nb = lib.llmseg_mask_small_regions_workspace(kc, H, W)
         ws = torch.empty((nb,), device=masks.device, dtype=torch.uint8)
-        _lib.check(lib.llmseg_mask_small_regions(_ptr(masks), K, H, W, int(min_area), _ptr(changed), _ptr(ws), nb, _stream()), "mask_small_regions")
+        for k0 in range(0, K, kc):
+            k1 = min(K, k0 + kc)
+            _lib.check(lib.llmseg_mask_small_regions(_ptr(masks[k0:k1]), k1 - k0, H, W, int(min_area), _ptr(changed[k0:k1]), _ptr(ws), nb, _stream()),
+                       "mask_small_regions")
     return changed
 
 

@@ -107,7 +107,26 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-_TABLES = {}
+class _LRU(dict):
+    """Insertion-ordered dict capped at `cap` entries (oldest evicted): a dataset of arbitrary image sizes must not grow the device-table
+    cache without bound."""
+
+    def __init__(self, cap):
+        super().__init__()
+        self.cap = cap
+
+    def __getitem__(self, k):
+        v = super().pop(k)
+        super().__setitem__(k, v)           # most recently used last
+        return v
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, v)
+        while len(self) > self.cap:
+            super().pop(next(iter(self)))
+
+
+_TABLES = _LRU(64)
 
 
 def _dev_nearest(out_n, in_n, dev):

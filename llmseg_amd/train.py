@@ -9,7 +9,7 @@ itself is not installed here: PARITY UNPINNED for optimizer/schedule details (pu
 
 MI355X-first structure:
   * `GradArena`: ONE flat fp32 buffer holds the gradient of every trainable tensor.  The backward kernels accumulate into it directly
-    (`C += dY^T X` GEMM epilogue, fp32 atomics of the skinny LoRA / norm / bias / embedding kernels), so accumulation over micro-steps is
+    (`C += dY^T X` GEMM epilogue, fixed-order partial sums of the skinny LoRA / norm / bias / embedding kernels), so accumulation over micro-steps is
     fp32 end to end, there is no per-parameter bf16 `.grad`, the global norm is ONE reduction kernel and the data-parallel exchange is ONE
     `all_reduce` on a contiguous 1.2 GB buffer (what DDP's reducer does with its buckets, minus the copy into them).
   * `use_graph`: the whole fwd+bwd micro-step (~3000 kernel launches) is captured once per batch structure in a hipGraph and replayed;
@@ -24,6 +24,8 @@ import contextlib
 
 import torch
 import torch.distributed as dist
+
+from .trainable import rank_dropout_seed  # noqa: F401  (re-exported: the tests import it from here)
 
 
 def warmup_decay_lr(step, lr, warmup=100, total=5000):
@@ -207,12 +209,6 @@ def _copy_batch(dst, src):
                     dd.copy_(vv, non_blocking=True)
 
 
-def rank_dropout_seed(seed, rank):
-    """Per-rank LoRA-dropout stream: the Philox key of rank r (the reference draws independent masks per rank and per step: DeepSpeed
-    seeds every process's generator differently, training.py:369-381).  Rank 0 keeps `seed`."""
-    return (int(seed) + int(rank) * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
-
-
 class Trainer:
     """One process per GPU.  `module(**batch)` must return a dict with a scalar "loss".
 
@@ -221,7 +217,7 @@ class Trainer:
 
     def __init__(self, module, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.0, clip=1.0, grad_accum=10, warmup=100, total_steps=5000,
                  optimizer=None, device_ids=None, force_ddp=False, ddp_wrapper=False, use_graph=False, graph_warmup=2, use_arena=None,
-                 reduce_chunk_mb=128, sync_init=True):
+                 reduce_chunk_mb=128, sync_init=True, check_every=0):
         """optimizer: None = HipAdamW; or a factory `params -> optimizer` / an optimizer object (CPU tests).  use_arena: None = automatic
         (the HIP model with the built-in optimizer), True = force the fp32 gradient arena (the module's autograd Functions must honour `_g32`)."""
         self.module = module
@@ -255,10 +251,10 @@ class Trainer:
         self.graph_error = None
         self.grad_hook = None
         self.reduce_chunk = max(1, int(reduce_chunk_mb * (1 << 20) // 4))       # fp32 elements per all-reduce chunk of the arena
+        self.check_every = int(check_every)                                      # > 0: `check_replicas()` after every N-th optimizer step (two 16-byte all-reduces)
         self.rank = dist.get_rank() if self.dist_on else 0
         if is_hip_model and self.dist_on:
-            st = module.dropout_state().tolist()                                   # every rank draws its own LoRA-dropout masks
-            module.set_dropout_seed(rank_dropout_seed(st[0], self.rank), st[1])
+            module.set_dropout_rank(self.rank)                                      # every rank draws its own LoRA-dropout masks (idempotent: derived from the base seed)
         if self.dist_on and self.ddp is None and sync_init:
             self.sync_params()                                                      # what DDP's constructor / DeepSpeed's engine do: rank 0's weights everywhere
             if hasattr(module, "__dict__"):
@@ -268,7 +264,10 @@ class Trainer:
     def sync_params(self, src=0):
         """Broadcast rank `src`'s trainable parameters (one flat buffer, one collective), then re-read the fp32 masters from them.
         Runs at construction and after every wholesale weight change (`load_state_dict` / checkpoint load -> `_weight_hooks`), so a
-        per-rank difference at init (LoRA init under different seeds, a partial load) cannot persist: only gradients are exchanged later."""
+        per-rank difference at init (LoRA init under different seeds, a partial load) cannot persist: only gradients are exchanged later.
+        COLLECTIVE: while a Trainer with a process group is attached, `model.load_state_dict` / `load_checkpoint` must be called on EVERY
+        rank (as the reference's `model_engine.load_checkpoint` is, training.py:404-421); a rank-0-only load would wait here forever.
+        Pass `sync_init=False` and call `trainer.sync_params()` yourself to control when the broadcast happens."""
         if not self.dist_on or not self.params:
             return
         with torch.no_grad():
@@ -359,24 +358,34 @@ class Trainer:
                 ent["graph"] = None
                 return self._eager_step(batch, plan)
         _copy_batch(ent["batch"], batch)
-        if plan is not ent["plan"]:
+        if plan is not ent["last_plan"]:                 # plans are immutable once built: the same object again needs no second upload
             ent["plan"].copy_tensors_from(plan)
+            ent["last_plan"] = plan
         ent["graph"].replay()
         return ent["out"]
 
+    def graph_buffers(self, batch, plan):
+        """The captured graph's own input tensors for batches of this structure (None before the capture): passing THESE objects to
+        `micro_step` skips the copy."""
+        ent = self._graphs.get((plan.sig, _input_sig(batch)))
+        return None if ent is None or ent.get("graph") is None else ent["batch"]
+
     def _capture(self, ent, batch, plan):
-        """Capture fwd+bwd of one micro-step.  The graph reads its inputs from the tensors of THIS call (`batch`, `plan`): a caller that
-        keeps feeding the same tensor objects (a loader writing each micro-batch into fixed device buffers, the benchmark's resident
-        batch) pays no copy; any other tensor passed later is copied into them."""
-        sb = {k: ([x for x in v] if isinstance(v, (list, tuple)) else v) for k, v in _graph_inputs(batch).items()}
+        """Capture fwd+bwd of one micro-step.  The graph reads its inputs from buffers IT OWNS (clones of this call's tensors): every
+        later micro-step copies its batch into them (~80 MB at two images: 25 us of a 44 ms step), so a caller's tensors are never
+        aliased, overwritten or read stale (round 3 captured the caller's own tensors and skipped the copy on a pointer match: a loader
+        rotating several resident sets then replayed on the set that was present at capture).  A loader that wants zero copies writes
+        straight into `graph_buffers(batch, plan)`."""
+        sb = {k: ([x.clone() for x in v] if isinstance(v, (list, tuple)) else v.clone()) for k, v in _graph_inputs(batch).items()}
         for k in ("labels", "attention_masks", "offset"):          # positional arguments of model_forward that a planned forward never reads
             sb[k] = batch.get(k)
         torch.cuda.synchronize()
+        gplan = plan.clone()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            out = self.module.model_forward(**sb, plan=plan)
+            out = self.module.model_forward(**sb, plan=gplan)
             out["loss"].backward()
-        ent.update(graph=g, batch=sb, plan=plan, out={k: v.detach() for k, v in out.items() if torch.is_tensor(v)})
+        ent.update(graph=g, batch=sb, plan=gplan, last_plan=plan, out={k: v.detach() for k, v in out.items() if torch.is_tensor(v)})
 
     # ------------------------------------------------------------------------------------------------ optimizer step
     def optimizer_step(self):
@@ -388,11 +397,9 @@ class Trainer:
                 scale /= self.world
         else:
             ss = self.opt.grad_sumsq()                  # gradients hold the SUM over `accum` micro-steps (DDP already averaged over ranks)
-        if self.dist_on and self.ddp is None:
-            # every rank must apply THE SAME clip coefficient: the arena is bit-identical after the all-reduce, but the squared-norm kernel
-            # adds its partial sums with fp32 atomics, so two ranks can differ in the last bit -- and replicas would then drift apart.
-            # One 4-byte collective per optimizer step settles it.
-            dist.all_reduce(ss, op=dist.ReduceOp.MAX)
+        # Every rank applies THE SAME clip coefficient without a collective: the all-reduced arena is bit-identical on every rank and the
+        # squared-norm reduction has a fixed summation order (no atomics since round 4; round 3 needed a 4-byte all-reduce(MAX) here because
+        # the last bit of `ss` varied run to run and replicas drifted).  `check_every` re-verifies the replicas periodically.
         if self.grad_hook is not None:                   # observer (tests): the reduced gradient sum + its squared norm, before the update consumes them
             self.grad_hook(self, ss)
         norm = torch.sqrt(ss) * scale
@@ -404,6 +411,8 @@ class Trainer:
             for p in self.params:
                 p.grad = None
         self.opt_steps += 1
+        if self.check_every > 0 and self.dist_on and self.opt_steps % self.check_every == 0:
+            self.check_replicas()
         return float(lr)
 
     def _reduce_and_sumsq(self):

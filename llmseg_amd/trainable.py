@@ -108,11 +108,25 @@ class BatchPlan:
             return t[k]
         raise AttributeError(k)
 
+    def clone(self):
+        """A plan with its own device tensors (what a captured hipGraph keeps: the caller's plan is never written to)."""
+        p = BatchPlan()
+        p.__dict__.update({k: v for k, v in self.__dict__.items() if k != "tensors"})
+        p.tensors = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.tensors.items()}
+        return p
+
     def copy_tensors_from(self, other):
         assert self.sig == other.sig, "batch structure changed: capture a new graph"
         for k, v in other.tensors.items():
             if v is not None:
                 self.tensors[k].copy_(v, non_blocking=True)
+
+
+def rank_dropout_seed(seed, rank):
+    """Philox key of data-parallel rank r's LoRA-dropout stream; rank 0 keeps `seed`.  The reference never seeds (training.py:369-381
+    hands the model to DeepSpeed with torch's default generator, whose seed is the same on every rank), so its ranks draw the same mask
+    sequence on different data; here every rank draws its own stream.  Either way the masks are builder-defined (peft absent: unpinned)."""
+    return (int(seed) + int(rank) * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
 
 
 class TrainableMixin:
@@ -184,13 +198,30 @@ class TrainableMixin:
 
     # LoRA dropout state (peft lora_dropout, training.py:91): device {seed, offset}; the trainer advances `offset` every micro-step
     def dropout_state(self):
+        """Device int64 [2] = {Philox key of THIS rank's LoRA-dropout stream, offset}: what the kernels read (`llmseg_dropout.rng_state`)."""
         st = self.__dict__.get("_rng_state")
         if st is None:
             st = self.__dict__["_rng_state"] = torch.tensor([0x5EED, 0], device=self.device_, dtype=torch.int64)
+            self.__dict__.setdefault("_dropout_base", 0x5EED)
         return st
 
+    def dropout_base_seed(self):
+        """The seed as the caller set it (rank 0's key); what a checkpoint stores."""
+        self.dropout_state()
+        return int(self.__dict__["_dropout_base"])
+
     def set_dropout_seed(self, seed, offset=0):
-        self.dropout_state().copy_(torch.tensor([int(seed), int(offset)], dtype=torch.int64))
+        """`seed` is the BASE seed; the key in device memory is derived from it and the module's dropout rank (`set_dropout_rank`),
+        so calling this (or constructing a second Trainer) any number of times never derives a seed from a derived seed."""
+        self.__dict__["_dropout_base"] = int(seed)
+        key = rank_dropout_seed(seed, self.__dict__.get("_dropout_rank", 0))
+        self.dropout_state().copy_(torch.tensor([key, int(offset)], dtype=torch.int64))
+
+    def set_dropout_rank(self, rank):
+        """Data-parallel rank of this replica: re-derives the key from the base seed, keeps the offset."""
+        off = int(self.dropout_state()[1])
+        self.__dict__["_dropout_rank"] = int(rank)
+        self.set_dropout_seed(self.__dict__["_dropout_base"], off)
 
     def advance_dropout(self):
         self.dropout_state()[1:].add_(1)
@@ -342,7 +373,13 @@ class TrainableMixin:
         else:
             s = pooled.repeat(Cn, 1) if Cn > 1 else (pooled.clone() if not F.grad else pooled)  # row = c*K + k (LISA.py:372)
         t = text.contiguous()
-        lin = lambda x, p, act=ops.ACT_NONE, res=None: F.linear(x, self._w(p + ".weight", F), self._w(p + ".bias", F), act, res)
+        trace = self.__dict__.get("_relu_trace")            # tests only: the ReLU outputs by feeding Linear (gate patterns, see tests/backward_checks.py)
+
+        def lin(x, p, act=ops.ACT_NONE, res=None):
+            y = F.linear(x, self._w(p + ".weight", F), self._w(p + ".bias", F), act, res)
+            if trace is not None and act == ops.ACT_RELU:
+                trace.setdefault(p, []).append(y.detach())
+            return y
         for i in range(2):
             p = f"model.lisa_attention_layers.{i}."
             w, b = self._qkv_wb(p + "self_attn.", F)
@@ -438,6 +475,8 @@ class TrainableMixin:
         if plan.seg_idx.numel():
             hs = F.gather_rows(hidden.view(N * T, H), plan.seg_idx)
             hs = F.linear(hs, self._w("model.text_hidden_fcs.0.0.weight", F), self._w("model.text_hidden_fcs.0.0.bias", F), ops.ACT_RELU)
+            if self.__dict__.get("_relu_trace") is not None:
+                self.__dict__["_relu_trace"].setdefault("model.text_hidden_fcs.0.0", []).append(hs.detach())
             pred = F.linear(hs, self._w("model.text_hidden_fcs.0.2.weight", F), self._w("model.text_hidden_fcs.0.2.bias", F))
         else:
             pred = torch.empty((0, c.out_dim), device=hidden.device, dtype=BF16)

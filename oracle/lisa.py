@@ -138,6 +138,8 @@ def model_forward(sd, cfg: LisaCfg, images, images_clip, input_ids, labels, atte
         ce, logits, hidden = llava_forward(sd, cfg, clip_in, attention_masks, input_ids, labels, dropout_state)
 
     h = F.relu(F.linear(hidden, sd["model.text_hidden_fcs.0.0.weight"], sd["model.text_hidden_fcs.0.0.bias"]))
+    if mask_head.TRACE is not None:                                                # test hook: gates of the rows that are gathered below
+        mask_head.TRACE.setdefault("model.text_hidden_fcs.0.0", []).append(h.detach()[segmask])
     h = F.linear(h, sd["model.text_hidden_fcs.0.2.weight"], sd["model.text_hidden_fcs.0.2.bias"])
     pred = h[segmask]                                                              # [sum C, D]
     seg_off = torch.cat([torch.zeros(1, dtype=torch.long), segmask.int().sum(-1).cumsum(-1).cpu()])[offset.cpu()]

@@ -11,6 +11,19 @@ import torch
 import torch.nn.functional as F
 
 
+# Test hook (no arithmetic): when a dict, every ReLU on the path appends its OUTPUT, flattened to [samples, units], under the name of the
+# Linear that feeds it -- the gradient tests compare gate patterns (output > 0) between the HIP path and this restatement to tell a flipped
+# ReLU gate (pre-activation within rounding noise of zero) from a wrong gradient (tests/backward_checks.py::grad_err).
+TRACE = None
+
+
+def _relu(name, x):
+    y = F.relu(x)
+    if TRACE is not None:
+        TRACE.setdefault(name, []).append(y.detach().reshape(-1, y.shape[-1]))
+    return y
+
+
 def _lin(sd, name, x):
     return F.linear(x, sd[name + ".weight"], sd[name + ".bias"])
 
@@ -35,7 +48,7 @@ def two_way_block(sd, p, queries, keys):
     """transformer.py:255-283: post-LN; queries = mask feats [C,K,D], keys = text [C,1,D]."""
     queries = _ln(sd, p + "norm1", queries + mh_attention(sd, p + "self_attn.", queries, queries, queries))
     queries = _ln(sd, p + "norm2", queries + mh_attention(sd, p + "cross_attn_token_to_image.", queries, keys, keys))
-    m = _lin(sd, p + "mlp.lin2", F.relu(_lin(sd, p + "mlp.lin1", queries)))
+    m = _lin(sd, p + "mlp.lin2", _relu(p + "mlp.lin1", _lin(sd, p + "mlp.lin1", queries)))
     queries = _ln(sd, p + "norm3", queries + m)
     keys = _ln(sd, p + "norm4", keys + mh_attention(sd, p + "cross_attn_image_to_token.", keys, queries, queries))
     return queries, keys
@@ -64,8 +77,8 @@ def mask_head(sd, pfx, segs_feature, text_feature):
     for i in range(2):
         s, t = two_way_block(sd, f"{pfx}lisa_attention_layers.{i}.", s, t)
     s = _ln(sd, pfx + "lisa_norm_final_attn", s + mh_attention(sd, pfx + "lisa_final_attn.", s, t, t))
-    iou = torch.sigmoid(_lin(sd, pfx + "lisa_iou_head.2", F.relu(_lin(sd, pfx + "lisa_iou_head.0", s))))
-    emb = _lin(sd, pfx + "lisa_embedding_head.2", F.relu(_lin(sd, pfx + "lisa_embedding_head.0", s)))
+    iou = torch.sigmoid(_lin(sd, pfx + "lisa_iou_head.2", _relu(pfx + "lisa_iou_head.0", _lin(sd, pfx + "lisa_iou_head.0", s))))
+    emb = _lin(sd, pfx + "lisa_embedding_head.2", _relu(pfx + "lisa_embedding_head.0", _lin(sd, pfx + "lisa_embedding_head.0", s)))
     return iou, emb
 
 

@@ -374,62 +374,163 @@ def check_model_grads(golden_loader=None):
     for n in names:
         sd[n].requires_grad_(True)
     batch = mc._round_batch(cases.tiny_lisa_batch(img_size=896))
-    olisa.model_forward(sd, cfg, **batch, inference=False)["loss"].backward()
+    gt = GateTrace()
+    gt.oracle("ref", lambda: olisa.model_forward(sd, cfg, **batch, inference=False)["loss"].backward())
     # the same gradients from the bf16 CPU oracle: the error scale of bf16 arithmetic itself on this (ill-conditioned) tiny case
     sd_lo = {k: v.detach().to(BF) for k, v in sd.items()}
     for n in names:
         sd_lo[n].requires_grad_(True)
-    olisa.model_forward(sd_lo, cfg, **mc._bf16_batch(batch), inference=False)["loss"].backward()
+    gt.oracle("lo", lambda: olisa.model_forward(sd_lo, cfg, **mc._bf16_batch(batch), inference=False)["loss"].backward())
     for n, p in m.params.named_parameters():
         p.requires_grad_(n in names)
+    gt.hip_begin(m)
     out = m.model_forward(**mc._dev(batch), inference=False)
     out["loss"].backward()
-    res = []
+    gt.hip_collect(m)
+    gt.hip_end(m)
+    flips = gt.flipped_rows()
+    all_stats = []
+    res = [(f"ReLU gates recorded on both sides for {len(flips)} Linears ({sum(int(f.sum()) for f in flips.values())} units flipped)", 0.0 if len(flips) == len(GateTrace.NAMES) else 1.0, 0.5)]
     prm = dict(m.params.named_parameters())
     for n in names:
         ref = sd[n].grad
         got = prm[n].grad
         assert got is not None, n
-        ratio, desc = grad_err(got, ref, sd_lo[n].grad.float(), floor=3e-4)   # floor: tensors whose true gradient vanishes hold rounding noise only
+        ratio, desc = grad_err(got, ref, sd_lo[n].grad.float(), floor=3e-4, skip_rows=GateTrace.rows_for(n, flips), stats=all_stats)   # floor: tensors whose true gradient vanishes hold rounding noise only
         res.append((f"grad {n}: {desc}; shown as err / tol", ratio, 1.0))
+    res += ratio_summary(all_stats, "model grads")
     if golden_loader is not None:
         # gradients recorded from the imported reference (fp32, un-rounded weights): same policy, the bf16-CPU error as the scale
         g = golden_loader("lisa_tiny.pt")["grads"]
         for key, n in (("text_fc2_w", "model.text_hidden_fcs.0.2.weight"), ("iou_head0_w", "model.lisa_iou_head.0.weight")):
             ref = g[key]
-            ratio, desc = grad_err(prm[n].grad, ref, sd_lo[n].grad.float(), floor=3e-4)
+            ratio, desc = grad_err(prm[n].grad, ref, sd_lo[n].grad.float(), floor=3e-4, skip_rows=GateTrace.rows_for(n, flips))
             res.append((f"grad {key} vs reference fixture: {desc}; shown as err / tol", ratio, 1.0))
     return res
 
 
-def grad_err(gh, gr, gl, floor=3e-4, trim=0.02):
-    """Gradient tolerance policy.  gh: HIP, gr: fp32 oracle, gl: the same oracle run in bf16 on the CPU (the
-    reference's own arithmetic).  Statistics, because the maximum of a noise process is itself noisy (two draws of the same noise
-    differ by 2 x in their max easily) while its RMS is not:
-        RMS error  <= max(3 % of rms(ref), 2.5 x RMS error of the bf16-CPU oracle)     -- no systematic loss against the reference's dtype
-           (HIP and the bf16-CPU oracle are two independent draws of the rounding noise, and ReLU gates make it heavy-tailed: over ~100
-           tensors x 4 tests and three kernel revisions the ratio of their RMS errors reached 2.2 on single tensors, median 0.9)
-        max error  <= max(3 % of |ref|max, 4 x max error of the bf16-CPU oracle)      -- no outlier
-    both taken over the entries that remain after the largest `trim` (2 %) of |error| are set aside, on the HIP side and on the bf16-CPU
-    side alike: a bf16 pipeline flips a ReLU gate whose pre-activation is within rounding noise of zero (measured: a 1-ulp change in the
-    CLIP patch embedding -- a different fp32 summation order -- flips ONE unit of lisa_iou_head.0 on one sample and moves that row of
-    the weight gradient by 0.14 at |ref|max 0.36, every other row by < 0.006), and which gates flip differs between any two bf16
-    evaluations, the reference's own included.  The set-aside entries must still be finite and no larger than the gradient itself.
-    -> (worst ratio err / tol, description)."""
-    gh, gr, gl = gh.reshape(gr.shape).double().cpu().flatten(), gr.double().flatten(), gl.double().flatten()
-    rms = lambda x: float(x.pow(2).mean().sqrt()) if x.numel() else 0.0
-    keep = max(1, int(round(gh.numel() * (1.0 - trim)))) if gh.numel() >= 50 else gh.numel()
-    d_all, dl_all = (gh - gr).abs(), (gl - gr).abs()
-    d, dl = d_all.sort().values[:keep], dl_all.sort().values[:keep]
-    small = gh.numel() < 50                                   # a handful of entries (a bias of 1, a [1, 8] head): no statistics, one looser bound
-    t_rms = max((0.05 if small else 0.03) * rms(gr), (4.0 if small else 2.5) * rms(dl), floor / 4)
-    t_max = max((0.05 if small else 0.03) * float(gr.abs().max()), 4.0 * float(dl.max()), floor)
-    t_out = max(1.0 * float(gr.abs().max()), 4.0 * float(dl_all.max()), floor)          # the set-aside entries: bounded by the gradient's own scale (or, where the
-    # gradient is far below the bf16 noise -- k_proj of the last head layer: |ref| 5e-6, bf16-CPU error 2e-4 -- by the same 4 x max-of-noise rule as the kept entries)
+# Multipliers on the bf16-CPU oracle's own error for ONE tensor (no trimming; round 3: 2.5 / 4.0 after a blanket 2 % trim).  HIP and the bf16-CPU
+# oracle are two independent draws of bf16 rounding noise; measured over 6 dropout seeds x 92 tensors with the flipped-gate rows excluded
+# (profiles/r04b_spread_grads_K2.md): the ratio HIP error / bf16-CPU error has median 1.11, 90 % 1.40 (RMS) / 1.59 (max), 99 % 2.6, and a tail
+# to 3.5 on narrow tensors (a 128-entry bias) -- with ~1000 (tensor, step) comparisons per suite run a bound of 2 x fails 3 % of them by chance.
+# What the per-tensor bound cannot see -- a SYSTEMATIC loss of precision -- is bounded over all tensors of a test: median RMS ratio <= Q50_RMS,
+# 90 % quantile <= Q90_RMS (`ratio_summary`).
+K_RMS, K_MAX = 4.0, 4.0
+Q50_RMS, Q90_RMS = 1.5, 2.5
+
+
+def ratio_summary(stats, tag):
+    """stats: grad_err's `stats` tuples of every tensor of a test -> two result lines bounding the DISTRIBUTION of RMS err HIP / RMS err bf16-CPU
+    over the tensors that carry a gradient (|ref|max above 10 x the 3e-4 noise floor): no systematic loss against the reference's dtype."""
+    rr = sorted(st[0] / max(st[1], 1e-12) for st in stats if st[5] > 3e-3 and st[1] > 0)
+    if len(rr) < 30:                                      # quantiles of a dozen ratios are noise themselves
+        return []
+    q = lambda p: rr[min(len(rr) - 1, int(p * len(rr)))]
+    return [(f"{tag}: median over {len(rr)} tensors of RMS err HIP / RMS err bf16-CPU oracle", q(0.5), Q50_RMS),
+            (f"{tag}: 90 % quantile of the same ratio", q(0.9), Q90_RMS)]
+
+
+class GateTrace:
+    """ReLU gate patterns of one forward pass on each side.  The five ReLUs of the path (text_hidden_fcs.0.0, the two
+    MLP blocks' lin1, lisa_iou_head.0, lisa_embedding_head.0) follow a Linear; a unit whose pre-activation is within bf16 rounding noise
+    of zero is ON in one evaluation and OFF in another, and that moves ROW `unit` of the Linear's weight gradient (and element `unit` of
+    its bias gradient) by that sample's whole contribution -- measured in round 3: 0.14 at |ref|max 0.36, every other row < 0.006.
+    Instead of trimming the largest 2 % of every tensor's errors (round 3), the tests record the gates (output > 0) of the HIP forward and of
+    the fp32 / bf16 oracle forwards on the same inputs and exclude exactly the rows whose gate provably differs on some sample."""
+
+    NAMES = ("model.text_hidden_fcs.0.0", "model.lisa_attention_layers.0.mlp.lin1", "model.lisa_attention_layers.1.mlp.lin1",
+             "model.lisa_iou_head.0", "model.lisa_embedding_head.0")
+
+    def __init__(self):
+        self.gates = {"hip": {}, "ref": {}, "lo": {}}
+
+    def oracle(self, side, fn):
+        """Run fn() with the oracle's trace hook on; its ReLU outputs (all calls, in order) become side's gates of this pass."""
+        from oracle import mask_head
+        mask_head.TRACE = {}
+        try:
+            out = fn()
+            for n, ys in mask_head.TRACE.items():
+                self.gates[side].setdefault(n, []).append(torch.cat([y.float() for y in ys], 0) > 0)
+        finally:
+            mask_head.TRACE = None
+        return out
+
+    def hip_begin(self, model):
+        model.__dict__["_relu_trace"] = {}
+
+    def hip_collect(self, model, calls_per_pass=None):
+        """After a forward (or a hipGraph replay): the LAST pass's ReLU outputs.  calls_per_pass: head invocations per forward (groups of
+        images with equal proposal count; 1 for the uniform test batches) -- a replayed graph refreshes the tensors recorded at capture."""
+        tr = model.__dict__["_relu_trace"]
+        for n, ys in tr.items():
+            k = calls_per_pass or 1
+            self.gates["hip"].setdefault(n, []).append(torch.cat([y.float().cpu() for y in ys[-k:]], 0) > 0)
+
+    def hip_end(self, model):
+        model.__dict__.pop("_relu_trace", None)
+
+    def flipped_rows(self):
+        """name of the Linear -> bool [units]: the gate of that unit differs between fp32 oracle and HIP, or fp32 and bf16 oracle, on some
+        sample of some pass (the same rows are excluded from the HIP error and from the bf16-CPU yardstick)."""
+        out = {}
+        for n, ref in self.gates["ref"].items():
+            fl = torch.zeros(ref[0].shape[1], dtype=torch.bool)
+            for side in ("hip", "lo"):
+                got = self.gates[side].get(n, [])
+                assert len(got) == len(ref), (n, side, len(got), len(ref))
+                for a, b in zip(got, ref):
+                    assert a.shape == b.shape, (n, side, a.shape, b.shape)
+                    fl |= (a != b).any(0)
+            out[n] = fl
+        return out
+
+    @staticmethod
+    def rows_for(param_name, flips):
+        for n, fl in (flips or {}).items():
+            if param_name in (n + ".weight", n + ".bias"):
+                return fl
+        return None
+
+
+def grad_err(gh, gr, gl, floor=3e-4, skip_rows=None, stats=None):
+    """Gradient tolerance policy (round 4).  gh: HIP, gr: fp32 oracle, gl: the same oracle run in bf16 on the CPU (the
+    reference's own arithmetic).  Over ALL entries of the tensor except the rows of a Linear-before-ReLU whose gate provably flipped
+    (`skip_rows`, bool over dim 0, from `GateTrace.flipped_rows`):
+        RMS error  <= max(3 % of rms(ref), K_RMS x RMS error of the bf16-CPU oracle)
+        max error  <= max(3 % of |ref|max, K_MAX x max error of the bf16-CPU oracle)
+    and the excluded rows must stay finite and within 10 x the tensor's largest gradient.  No trimming: a kernel bug that corrupts one tile-edge row or one head of a weight gradient fails the max bound.
+    -> (worst ratio err / tol, description); `stats` (a list) receives (rms err, rms bf16-CPU err, max err, max bf16-CPU err, rms ref, max ref, skipped)."""
+    shp = gr.shape
+    gh, gr, gl = gh.reshape(shp).double().cpu(), gr.double(), gl.double().reshape(shp)
     finite = bool(torch.isfinite(gh).all())
-    r = max(rms(d) / t_rms, float(d.max()) / t_max, float(d_all.max()) / t_out, 0.0 if finite else 1e9)
-    return r, (f"rms err {rms(d):.2e} (tol {t_rms:.2e}, bf16-CPU {rms(dl):.2e}), max err {float(d.max()):.2e} (tol {t_max:.2e}, bf16-CPU {float(dl.max()):.2e}) "
-               f"over the {keep} of {gh.numel()} entries kept; largest set-aside error {float(d_all.max()):.2e} (bf16-CPU {float(dl_all.max()):.2e}), |ref| {float(gr.abs().max()):.2e}")
+    n_skip = 0
+    d_skip = 0.0
+    if skip_rows is not None and bool(skip_rows.any()):
+        keep = ~skip_rows
+        n_skip = int(skip_rows.sum())
+        d_skip = float((gh[skip_rows] - gr[skip_rows]).abs().max())
+        ref_max_all = float(gr.abs().max())
+        gh, gr, gl = gh[keep], gr[keep], gl[keep]
+    else:
+        ref_max_all = float(gr.abs().max()) if gr.numel() else 0.0
+    gh, gr, gl = gh.flatten(), gr.flatten(), gl.flatten()
+    rms = lambda x: float(x.pow(2).mean().sqrt()) if x.numel() else 0.0
+    d, dl = (gh - gr).abs(), (gl - gr).abs()
+    small = gh.numel() < 50                                   # a handful of entries (a bias of 1, a [1, 8] head): no statistics, one looser bound
+    d_max, dl_max = (float(d.max()), float(dl.max())) if d.numel() else (0.0, 0.0)
+    # small tensors: ONE bf16-CPU draw of one or a few numbers is no yardstick (the ratio of two such draws exceeds 9 in 7 % of cases): 10 % relative
+    t_rms = max((0.10 if small else 0.03) * rms(gr), (2 * K_RMS if small else K_RMS) * rms(dl), floor / 4)
+    t_max = max((0.10 if small else 0.03) * ref_max_all, (2 * K_MAX if small else K_MAX) * dl_max, floor)
+    # the excluded rows: a flipped gate moves a row by one sample's whole contribution, which for a bias (a sum of cancelling terms) exceeds the
+    # row's own gradient (measured 6.9e-3 at |ref|max 1.8e-3) -- they only have to stay finite and within an order of magnitude of the tensor
+    t_skip = max(10.0 * ref_max_all, floor)
+    if stats is not None:
+        stats.append((rms(d), rms(dl), d_max, dl_max, rms(gr), ref_max_all, n_skip))
+    r = max(rms(d) / t_rms, d_max / t_max, d_skip / t_skip, 0.0 if finite else 1e9)
+    return r, (f"rms err {rms(d):.2e} (tol {t_rms:.2e}, bf16-CPU {rms(dl):.2e}), max err {d_max:.2e} (tol {t_max:.2e}, bf16-CPU {dl_max:.2e}) "
+               f"over all {gh.numel()} entries" + (f" outside the {n_skip} rows with a flipped ReLU gate (largest error there {d_skip:.2e})" if n_skip else "") +
+               f", |ref| {ref_max_all:.2e}")
 
 
 def _lora_case(backbone="sam", p_drop=0.05, K=16):
@@ -444,7 +545,7 @@ def _lora_case(backbone="sam", p_drop=0.05, K=16):
     return cfg, m, sd, batch
 
 
-def check_model_grads_lora(backbone="sam"):
+def check_model_grads_lora(backbone="sam", dropout=None, all_tensors=False, stats=None):
     """The configuration the benchmark times, at tiny size: LoRA r = 8 (random B) with dropout 0.05 on q/v, trainable embed / lm_head /
     text_hidden_fcs / lisa_*, gradients accumulated by the kernels into the fp32 arena over TWO micro-steps -- against autograd through the
     fp32 oracle with the same dropout masks.  Covers the extension K-tile GEMMs, the rank-8 kernels, the fused weight-gradient blocks."""
@@ -455,21 +556,34 @@ def check_model_grads_lora(backbone="sam"):
     names = [n for n, p in m.params.named_parameters() if p.requires_grad]
     for n in names:
         sd[n].requires_grad_(True)
-    seed, off = 0x1234ABCD, 7
-    ref = olisa.model_forward(sd, cfg, **batch, inference=False, dropout_state=(seed, off))
-    ref["loss"].backward()
+    seed, off = (0x1234ABCD, 7) if dropout is None else dropout
+    gt = GateTrace()
+
+    def run_ref():
+        o = olisa.model_forward(sd, cfg, **batch, inference=False, dropout_state=(seed, off))
+        o["loss"].backward()
+        return o
+    ref = gt.oracle("ref", run_ref)
     sd_lo = {k: v.detach().to(BF) for k, v in sd.items()}
     for n in names:
         sd_lo[n].requires_grad_(True)
-    lo = olisa.model_forward(sd_lo, cfg, **mc._bf16_batch(batch), inference=False, dropout_state=(seed, off))
-    lo["loss"].backward()
+
+    def run_lo():
+        o = olisa.model_forward(sd_lo, cfg, **mc._bf16_batch(batch), inference=False, dropout_state=(seed, off))
+        o["loss"].backward()
+        return o
+    lo = gt.oracle("lo", run_lo)
     arena = GradArena(m)
     m.set_dropout_seed(seed, off)
     db = mc._dev(batch)
     plan = m.make_plan(**db)
-    for _ in range(2):
+    gt.hip_begin(m)
+    for _ in range(2):                                   # the same micro-step twice (same masks): the arena holds 2 x the gradient
         out = m.model_forward(**db, inference=False, plan=plan)
         out["loss"].backward()
+    gt.hip_collect(m)
+    gt.hip_end(m)
+    flips = gt.flipped_rows()
     res = []
     for k in ("ce_loss", "align_loss", "regression_loss", "loss"):
         r = float(ref[k])
@@ -482,13 +596,26 @@ def check_model_grads_lora(backbone="sam"):
                                                      "cross_attn_image_to_token.q_proj.weight", "lisa_final_attn.v_proj.weight", "lisa_attention_layers.0.norm2.weight",
                                                      "lisa_iou_head.2.weight", "lisa_embedding_head.0.bias"))]
     assert len(pick) >= 16, pick
+    all_stats = []
+    for n in names:                                      # every trainable tensor feeds the distribution bound; the picked ones are listed one by one
+        if not all_tensors and n not in pick:
+            grad_err(prm[n]._g32 / 2, sd[n].grad, sd_lo[n].grad.float(), floor=3e-4, skip_rows=GateTrace.rows_for(n, flips), stats=all_stats)
+    if all_tensors:
+        pick = names
     for n in pick:
         assert prm[n].grad is None, n
         got, r = prm[n]._g32 / 2, sd[n].grad
         # floor 3e-4 (other gradients here are 1e-2 .. 2): a tensor whose true gradient vanishes (k-projections: softmax is
         # shift-invariant, |ref| ~ 1e-6) holds rounding noise only, and that noise moves with every change of summation order upstream
-        ratio, desc = grad_err(got, r, sd_lo[n].grad.float(), floor=3e-4)
+        st = [] if stats is not None else None
+        ratio, desc = grad_err(got, r, sd_lo[n].grad.float(), floor=3e-4, skip_rows=GateTrace.rows_for(n, flips), stats=st)
+        if stats is not None:
+            stats.append((n, ratio) + st[0])
+            all_stats.append(st[0])
+        else:
+            grad_err(got, r, sd_lo[n].grad.float(), floor=3e-4, skip_rows=GateTrace.rows_for(n, flips), stats=all_stats)
         res.append((f"arena grad {n}: {desc}; shown as err / tol", ratio, 1.0))
+    res += ratio_summary(all_stats, "lora arena grads")
     arena.detach()
     return res
 
@@ -525,7 +652,13 @@ def check_trainer(use_graph=False, opt_steps=3, accum=2, K=16):
     for step in range(opt_steps):
         w0, m0, v0 = cpu(tr.opt.master), cpu(tr.opt.m), cpu(tr.opt.v)
         held = {n: prm[n].detach().float().cpu().clone() for n in names}          # the bf16 copies the forward reads
-        losses = [float(tr.micro_step(db, plan)["loss"].detach()) for _ in range(accum)]
+        gt = GateTrace()
+        if "_relu_trace" not in m.__dict__:
+            gt.hip_begin(m)                                                       # kept on across steps: a hipGraph refreshes the tensors recorded at capture
+        losses = []
+        for _ in range(accum):
+            losses.append(float(tr.micro_step(db, plan)["loss"].detach()))
+            gt.hip_collect(m)
         hip_losses += losses
         assert tr.opt_steps == step + 1 and "g" in seen
         w = {n: held[n].clone().requires_grad_(True) for n in names}
@@ -534,18 +667,22 @@ def check_trainer(use_graph=False, opt_steps=3, accum=2, K=16):
         ref_losses = []
         for a in range(accum):
             offset += 1
-            o = olisa.model_forward(sdw, cfg, **batch, inference=False, dropout_state=(seed, offset))
-            o["loss"].backward()
-            ref_losses.append(float(o["loss"]))
-            olisa.model_forward(sdl, cfg, **mc._bf16_batch(batch), inference=False, dropout_state=(seed, offset))["loss"].backward()
+            def run_ref():
+                o = olisa.model_forward(sdw, cfg, **batch, inference=False, dropout_state=(seed, offset))
+                o["loss"].backward()
+                return o
+            ref_losses.append(float(gt.oracle("ref", run_ref)["loss"]))
+            gt.oracle("lo", lambda: olisa.model_forward(sdl, cfg, **mc._bf16_batch(batch), inference=False, dropout_state=(seed, offset))["loss"].backward())
+        flips = gt.flipped_rows()
         first_last += [ref_losses[0], ref_losses[-1]]
         res.append((f"trainer[{tag}] step {step}: micro-step losses vs the oracle at the same weights (ref {ref_losses[0]:.4f} ..)",
                     max(abs(h - r) for h, r in zip(losses, ref_losses)), 5e-3 * max(1.0, abs(ref_losses[0]))))
         gmax = max(w[n].grad.abs().max().item() for n in names)
         worst_e, worst_c = (0.0, ""), (0.0, "")
+        step_stats = []
         for n in names:
             gr, gl, gh = w[n].grad, wl[n].grad.float(), seen["g"][n].reshape(w[n].shape)
-            ratio, desc = grad_err(gh, gr, gl, floor=3e-4 * accum)
+            ratio, desc = grad_err(gh, gr, gl, floor=3e-4 * accum, skip_rows=GateTrace.rows_for(n, flips), stats=step_stats)
             worst_e = max(worst_e, (ratio, f"{n}: {desc}"))
             if gr.abs().max().item() > 1e-3 * gmax:                                  # direction, for tensors that carry a gradient at all
                 cos = lambda x, y: float((x.flatten().double() @ y.flatten().double()) / (x.double().norm() * y.double().norm() + 1e-30))
@@ -554,6 +691,7 @@ def check_trainer(use_graph=False, opt_steps=3, accum=2, K=16):
                 worst_c = max(worst_c, (c_h / tol_c, f"{n}: 1-cos {c_h:.2e} tol {tol_c:.2e} (bf16-CPU {c_l:.2e})"))
         res.append((f"trainer[{tag}] step {step}: accumulated gradient, worst of {len(names)} tensors = {worst_e[1]}; shown as err / tol", worst_e[0], 1.0))
         res.append((f"trainer[{tag}] step {step}: gradient direction, worst tensor = {worst_c[1]}; shown as (1-cos) / tol", worst_c[0], 1.0))
+        res += ratio_summary(step_stats, f"trainer[{tag}] step {step}")
         # the update, from the arena's own gradient (float64 restatement of the recipe)
         g = [seen["g"][n].double().reshape(-1) / accum for n in names]
         norm = torch.sqrt(sum((x * x).sum() for x in g))
@@ -575,6 +713,7 @@ def check_trainer(use_graph=False, opt_steps=3, accum=2, K=16):
     if use_graph:
         assert tr.graph_error is None, tr.graph_error
         assert any(e["graph"] is not None for e in tr._graphs.values()), "the hipGraph path was never taken"
+    m.__dict__.pop("_relu_trace", None)
     tr.close()
     return res, hip_losses
 
@@ -583,7 +722,7 @@ def check_trainer_graph_vs_eager():
     r_e, l_e = check_trainer(False)
     r_g, l_g = check_trainer(True)
     res = r_e + r_g
-    res.append(("trainer graph vs eager: max loss difference over the micro-steps", max(abs(a - b) for a, b in zip(l_e, l_g)), 5e-3))
+    res.append((f"trainer graph vs eager: the losses of every micro-step are identical ({l_e} vs {l_g})", 0.0 if l_e == l_g else 1.0, 0.5))
     return res
 
 
@@ -623,6 +762,48 @@ def check_determinism():
                 res.append((f"determinism K={K}: {tag} repeat {rep}: arena elements that differ from the first run", float((a != ref_a).sum()), 0.0))
                 res.append((f"determinism K={K}: {tag} repeat {rep}: losses identical ({l} vs {ref_l})", 0.0 if l == ref_l else 1.0, 0.5))
     return res
+
+
+def check_graph_rotating_batches():
+    """A loader that rotates several resident batches (and their plans) through a hipGraph trainer: every micro-step must see ITS batch.
+    The graph owns its input buffers and its plan (the round-3 trainer aliased the tensors present at capture and skipped the
+    copy on a pointer match, so the set that was present at capture was replayed stale once another set had been copied over it).
+    Checked against the eager trainer on the same sequence: identical losses and master weights, bit for bit; the caller's tensors and
+    plans are unchanged afterwards."""
+    from llmseg_amd.train import Trainer
+    from tests import model_checks as mc
+
+    def run(use_graph):
+        cfg, m, sd, batch = _lora_case("sam")
+        m.set_dropout_seed(31, 0)
+        base = mc._dev(batch)
+        sets = []
+        for i in range(3):
+            b = dict(base)
+            b["images"] = (base["images"].float() * (1.0 - 0.3 * i) + 0.1 * i).to(base["images"].dtype)
+            b["images_clip"] = base["images_clip"].roll(i, -1).contiguous()
+            b["sam_ious_list"] = [(t * (1.0 - 0.2 * i)).contiguous() for t in base["sam_ious_list"]]
+            ids = base["input_ids"].clone()
+            ids[:, 10 + i] = 7 + i                                              # a different prompt token: the plan's tensors differ too
+            b["input_ids"] = ids
+            sets.append((b, m.make_plan(**b)))
+        keep = [(b["images"].clone(), b["input_ids"].clone(), {k: v.clone() for k, v in p.tensors.items() if torch.is_tensor(v)}) for b, p in sets]
+        tr = Trainer(m, lr=1e-3, grad_accum=3, warmup=0, total_steps=20, use_graph=use_graph, graph_warmup=1)
+        losses = [float(tr.micro_step(*sets[i % 3])["loss"]) for i in range(9)]
+        if use_graph:
+            assert tr.graph_error is None, tr.graph_error
+            assert any(e["graph"] is not None for e in tr._graphs.values()), "the hipGraph path was never taken"
+        same = all(torch.equal(b["images"], k[0]) and torch.equal(b["input_ids"], k[1]) and all(torch.equal(p.tensors[n], t) for n, t in k[2].items())
+                   for (b, p), k in zip(sets, keep))
+        w = torch.cat([x.flatten().cpu() for x in tr.opt.master])
+        tr.close()
+        return losses, w, same
+    le, we, se = run(False)
+    lg, wg, sg = run(True)
+    return [(f"rotating batches: the three sets give different losses ({le[:3]})", 0.0 if len(set(le[:3])) == 3 else 1.0, 0.5),
+            (f"rotating batches: hipGraph losses identical to eager ({lg} vs {le})", 0.0 if le == lg else 1.0, 0.5),
+            ("rotating batches: master weights after 3 optimizer steps, elements that differ graph vs eager", float((we != wg).sum()), 0.0),
+            ("rotating batches: the caller's batches and plans are untouched", 0.0 if (se and sg) else 1.0, 0.5)]
 
 
 def check_checkpoint_resume(tmp_dir):

@@ -37,14 +37,16 @@ def _e(a, b):
     return (a.detach().float().cpu() - b.detach().float().cpu()).abs().max().item()
 
 
-def check_full_depth_inference(K=256, L=64, with_bf16_cpu=True, log=print):
+def check_full_depth_inference(K=256, L=64, with_bf16_cpu=True, log=print, seed=0, raw=None):
+    """seed: weights (init_random(5 + seed)) and batch (4321 + seed) of this draw; raw: a list that receives (name, HIP err, bf16-CPU err) per
+    output (tools/probes/spread.py builds the multi-seed table that justifies K_CPU from it)."""
     dev = "cuda"
     hcfg = hp.LisaConfig(backbone="sam", build_unused_towers=False)
     hcfg.llama = hp.LlamaConfig(lora_r=8)
-    m = hip_lisa.LISAForCausalLM(hcfg, device=dev).init_random(seed=5)
+    m = hip_lisa.LISAForCausalLM(hcfg, device=dev).init_random(seed=5 + seed)
     m.eval()
     ocfg = olisa.LisaCfg(llama=ol.LlamaCfg(lora_r=8), clip=ovit.VitCfg(eps=1e-5, img=224), sam=osam.SamCfg(), backbone="sam")
-    batch = synthetic.make_batch(1, img_size=1024, L=L, K=K, device=dev, seed=4321, soft=True)
+    batch = synthetic.make_batch(1, img_size=1024, L=L, K=K, device=dev, seed=4321 + seed, soft=True)
     inf = dict(images=batch["images"], images_clip=batch["images_clip"], input_ids=batch["input_ids"], labels=None,
                attention_masks=batch["attention_masks"], offset=batch["offset"], sam_segs_list=batch["sam_segs_list"])
     with torch.no_grad():
@@ -70,6 +72,8 @@ def check_full_depth_inference(K=256, L=64, with_bf16_cpu=True, log=print):
     def add(name, g_, r_, l_, floor, rel=True):
         scale = max(1.0, r_.abs().max().item()) if rel else 1.0
         lo_e = _e(l_, r_) if l_ is not None else 0.0
+        if raw is not None:
+            raw.append((name, _e(g_, r_), lo_e))
         res.append((f"full-depth {name} (|ref| {r_.abs().max().item():.3g}, bf16-CPU err {lo_e:.2e}, flat-1e-3 {'met' if _e(g_, r_) <= 1e-3 else 'NOT met'})",
                     _e(g_, r_), max(floor * scale, K_CPU * lo_e)))
     L_ = lambda k: None if lo is None else lo[k]
@@ -82,6 +86,23 @@ def check_full_depth_inference(K=256, L=64, with_bf16_cpu=True, log=print):
     add("pred_embedding", got["pred_embeddings"][0], ref["pred_embeddings"][0], None if lo is None else lo["pred_embeddings"][0], 3e-2)
     add("pred_similarity", got["pred_similarity"][0], ref["pred_similarity"][0], None if lo is None else lo["pred_similarity"][0], 1e-3, rel=False)
     add("pred_iou", got["pred_iou"][0], ref["pred_iou"][0], None if lo is None else lo["pred_iou"][0], 1e-3, rel=False)
+    # A/B: how much of the score error is the bf16 HEAD and how much the bf16 TRUNK?  The oracle's fp32 upsample + mask
+    # pooling + mask-selection head + cosine evaluated on the HIP path's own trunk outputs (SAM features, [SEG] embedding): whatever error
+    # remains against the all-fp32 oracle comes from the trunk alone.  Informational lines (tolerance = the same bound as the HIP head's).
+    from oracle import mask_head as omh
+    with torch.no_grad():
+        hf = got["feats"].detach().float().cpu().view(B, g, g, C).permute(0, 3, 1, 2)
+        up = omh.upsample_feats(hf, 256)
+        pooled = omh.mask_pooling(up[0], inf["sam_segs_list"][0].detach().float().cpu())
+        pe = got["pred_embeddings"][0].detach().float().cpu()
+        iou32, emb32 = omh.mask_head(_LazyState(host, torch.float32), "model.", pooled, pe)
+        sim32 = omh.cosine_scores(pe, emb32[0])
+    for nm, a32, key, idx in (("pred_similarity", sim32, "pred_similarity", 4), ("pred_iou", iou32[0].t(), "pred_iou", 5)):
+        e32, eh = _e(a32, ref[key][0]), res[idx][1]
+        if raw is not None:
+            raw.append((nm + " [HIP trunk + fp32 head]", e32, res[idx][1]))
+        res.append((f"full-depth A/B {nm}: HIP bf16 trunk + fp32 pool/head/cosine on the host -> err {e32:.2e} vs all-HIP {eh:.2e} "
+                    f"(flat-1e-3 {'met' if e32 <= 1e-3 else 'NOT met'} with an fp32 head)", e32, res[idx][2]))
     # next-token agreement over the text positions: arg-max of the HIP logits vs the fp32 oracle, with the bf16-CPU oracle's own
     # agreement as the yardstick (random weights give flat logits, so ties flip easily: the yardstick, not 100 %, is the bar)
     am_r, am_g = ref["logits"].float().argmax(-1), got["logits"].float().cpu().argmax(-1)

@@ -57,6 +57,11 @@ def test_trainer_configs4_k512_accum8():
     _assert(res)
 
 
+def test_graph_trainer_with_rotating_batches():
+    from tests import backward_checks as bc
+    _assert(bc.check_graph_rotating_batches())
+
+
 def test_micro_step_is_bit_reproducible():
     from tests import backward_checks as bc
     _assert(bc.check_determinism())
