@@ -112,7 +112,7 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
     T = args.prompt_len - 1 + cfg.n_img_tokens
     if args.mode == "train":
         trainer = trainer_cls(model, lr=3e-4, grad_accum=args.accum, device_ids=[local], use_graph=use_graph, ddp_wrapper=args.ddp_wrapper,
-                              force_ddp=args.force_ddp)
+                              force_ddp=args.force_ddp, leaf_stream=not args.no_leaf_stream)
         # warm-up covers the eager warm-up calls of the graph path + the capture itself
         def first_optimizer_step():
             # the warm-up micro-steps never reach the optimizer (one step per --accum micro-steps): run it once untimed -- on a cold box its
@@ -130,9 +130,16 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
         # per-kernel timing: events cannot be recorded inside a replayed hipGraph, so the same micro-step runs eagerly (identical launches)
         # for a few steps right after the timed region, with an event pair around every GEMM launch on its stream
         trainer.use_graph = False
+        trainer.leaf_stream = False
         overlap, model.overlap_towers = model.overlap_towers, False      # one stream: a launch's duration must not include another stream's kernels
+        from llmseg_amd import _lib
+        trainer.micro = 0                                              # not the last micro-step of a window: no optimizer launches in the count
+        n0 = _lib.load().llmseg_launch_count()
         trainer.micro_step(batch, plan)
         torch.cuda.synchronize()
+        res["launches_per_micro_step"] = {"library_kernels": int(_lib.load().llmseg_launch_count() - n0),
+                                          "note": "kernels libllmseg_hip.so launches for one fwd+bwd micro-step (the hipGraph replays the same nodes plus "
+                                                  "PyTorch's glue kernels: zero-fills, casts, the loss sum)"}
         ops.prof_enable(True)
         n_prof = min(args.steps, 3)
         for _ in range(n_prof):
@@ -325,6 +332,7 @@ def main():
                          "forward-only pass (BASELINE configs[1]) reported under 'fwd_only'; fwd: forward only")
     ap.add_argument("--no-fwd-only", action="store_true", help="skip the forward-only measurement (profiling runs)")
     ap.add_argument("--no-overlap", action="store_true", help="issue the frozen backbone on the main stream instead of its own HIP stream")
+    ap.add_argument("--no-leaf-stream", action="store_true", help="issue the arena's weight-gradient kernels on the main stream (A/B of autograd.Leaves)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--ddp-wrapper", action="store_true", help="torch DDP wrapper + bf16 .grad instead of the fp32 gradient arena")
     ap.add_argument("--force-ddp", "--force-dist", dest="force_ddp", action="store_true",
@@ -431,6 +439,7 @@ def main():
             "model_tflop_per_image": main_res["model_tflop_per_image"],
             "model_mfma_frac": main_res["model_mfma_frac"],
             "loss": main_res["loss"],
+            "launches_per_micro_step": main_res.get("launches_per_micro_step"),
             "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
         }
         if "graph_error" in main_res:

@@ -42,6 +42,9 @@ enum { LLMSEG_ACT_NONE = 0, LLMSEG_ACT_RELU = 1, LLMSEG_ACT_GELU = 2, LLMSEG_ACT
  * accept NULL / a smaller buffer and stay deterministic (slower), the others return LLMSEG_EINVAL when it is too small. */
 #define LLMSEG_REDUCE_WS_BYTES (16 << 20)
 int llmseg_version(void);
+/* kernel launches issued by this library since it was loaded (all streams; a captured hipGraph counts at capture, not at replay):
+ * a benchmark reads the difference across one eager micro-step to report launches per step */
+int64_t llmseg_launch_count(void);
 int64_t llmseg_struct_size(int which);
 const char* llmseg_last_error(void);
 

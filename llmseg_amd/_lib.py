@@ -67,6 +67,7 @@ _dp = C.POINTER(Dropout)
 SIGNATURES = {
     "llmseg_version": [],
     "llmseg_struct_size": [C.c_int],
+    "llmseg_launch_count": [],
     "llmseg_last_error": [],
     "llmseg_gemm_bf16": [C.POINTER(GemmArgs), _p],
     "llmseg_gemm_set_variant": [C.c_int],
@@ -146,7 +147,7 @@ def load():
         fn = getattr(lib, name)            # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = (C.c_char_p if name in ("llmseg_last_error", "llmseg_prof_dominant_kernel") else
-                      C.c_double if name == "llmseg_prof_dominant_bytes" else C.c_int64 if name in ("llmseg_struct_size", "llmseg_image_resize_workspace", "llmseg_mask_small_regions_workspace") else C.c_int)
+                      C.c_double if name == "llmseg_prof_dominant_bytes" else C.c_int64 if name in ("llmseg_struct_size", "llmseg_launch_count", "llmseg_image_resize_workspace", "llmseg_mask_small_regions_workspace") else C.c_int)
     # ABI guard at load time: this binding's structs must be the library's (the entry points check `struct_size` per call as well)
     if lib.llmseg_version() != ABI_VERSION:
         raise RuntimeError(f"{LIB_PATH}: ABI version {lib.llmseg_version()} != {ABI_VERSION} of this binding (rebuild: llmseg_amd/csrc/build.sh)")

@@ -6,7 +6,7 @@ recompute kernel (`llmseg_attn_bwd`; the single-query cross attentions of the he
 
 Parameter gradients have two destinations:
   * arena mode (training, `llmseg_amd.train.GradArena`): a parameter tensor carries `_g32`, an fp32 view into the trainer's flat
-    gradient arena; the backward kernels ACCUMULATE into it (`C += ...` GEMM epilogue, fp32 atomics) and the Function returns None
+    gradient arena; the backward kernels ACCUMULATE into it (`C += ...` GEMM epilogue, fixed-order partial sums) and the Function returns None
     for that input, so gradients are summed over micro-steps in fp32 (the reference's DeepSpeed engine accumulates
     `gradient_accumulation_steps` micro-batches, training.py:79-82,292-332) and no bf16 `.grad` round trip exists;
   * plain autograd: without `_g32` the Function returns a bf16 gradient and autograd fills `.grad` as usual (parity tests).
@@ -23,6 +23,47 @@ BF16 = torch.bfloat16
 
 BIG_LINEAR = 1 << 34          # M*N*K above which LinearFn.backward transposes/pads its operands for the LDS-DMA GEMM kernels
 BIG_WEIGHT = 1 << 26          # N * K of a Linear whose dX / dW always take the transposed-operand route below (lm_head: 131 M)
+
+
+class Leaves:
+    """Weight-gradient kernels that accumulate into the trainer's fp32 arena are LEAVES of the backward pass: nothing later in the pass
+    reads what they write.  In arena mode (`Leaves.on`, set by `Trainer`) they are issued on ONE side stream that waits for the
+    producing kernels, so the dependent chain of the backward pass (dX GEMMs, norm / attention backward) does not queue behind them --
+    at two images per step the mask-selection head and the Llama layers' rank-8 gradient kernels are launch-latency-bound, and inside a
+    captured hipGraph the two streams become parallel branches.  One side stream keeps the leaves in issue order (a parameter used twice
+    accumulates in the same order every run: results stay bit-reproducible).  Operands are kept alive until `join()` -- the caching
+    allocator would otherwise hand a freed operand's block to the next main-stream allocation while the side kernel has not run."""
+    on = False
+    _streams = {}
+    _keep = []
+    _used = False
+
+    @classmethod
+    def run(cls, fn, *operands):
+        if not cls.on:
+            return fn()
+        cur = torch.cuda.current_stream()
+        key = cur.device.index
+        side = cls._streams.get(key)
+        if side is None:
+            side = cls._streams[key] = torch.cuda.Stream(device=cur.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            out = fn()
+        cls._keep.extend(operands)
+        cls._used = True
+        return out
+
+    @classmethod
+    def join(cls):
+        """The current stream waits for every leaf issued so far (end of a backward pass; inside a capture this closes the side branch)."""
+        if cls._used:
+            cur = torch.cuda.current_stream()
+            side = cls._streams.get(cur.device.index)
+            if side is not None:
+                cur.wait_stream(side)
+        cls._keep.clear()
+        cls._used = False
 
 
 def g32_of(t):
@@ -79,10 +120,13 @@ class LinearFn(Function):
             if ctx.needs_input_grad[0]:
                 dx = ops.gemm(dpp, ops.transpose_pad(w, Np))                             # [M, Np] @ [Np, Kin]   (W^T: [Kin, Np])
             if need_w:
-                dT, xT = ops.transpose_pad(dpp, Mp), ops.transpose_pad(x, Mp)            # [Np, Mp], [Kin, Mp]
                 if gw is not None:
-                    ops.gemm(dT[:N], xT, out=gw, accumulate=True)                         # fp32 arena += dY^T X
+                    def wgrad():
+                        dT, xT = ops.transpose_pad(dpp, Mp), ops.transpose_pad(x, Mp)    # [Np, Mp], [Kin, Mp]
+                        ops.gemm(dT[:N], xT, out=gw, accumulate=True)                     # fp32 arena += dY^T X
+                    Leaves.run(wgrad, dpp, x)
                 else:
+                    dT, xT = ops.transpose_pad(dpp, Mp), ops.transpose_pad(x, Mp)
                     dw = ops.gemm(dT, xT)[:N]
         else:
             if N % 8 != 0:                                   # tiny head (N = 1): pad the contraction/leading dims
@@ -94,13 +138,13 @@ class LinearFn(Function):
             if ctx.needs_input_grad[0]:
                 dx = ops.gemm(dpre, ctx.wt) if (ctx.wt is not None and N % 8 == 0) else ops.gemm(dpre_p, w_p, trans_w=True)   # [M,N] @ [N,K]
             if gw is not None:
-                ops.gemm(dpre_p[:, :N], x, out=gw, trans_a=True, trans_w=True, accumulate=True)   # [N,M] @ [M,K] -> fp32 arena
+                Leaves.run(lambda: ops.gemm(dpre_p[:, :N], x, out=gw, trans_a=True, trans_w=True, accumulate=True), dpre_p, x)   # [N,M] @ [M,K] -> fp32 arena
             elif need_w:
                 dw = ops.gemm(dpre_p, x, trans_a=True, trans_w=True)[:N]      # [N,M] @ [M,K]
                 if dw.shape[0] != N or not dw.is_contiguous():
                     dw = dw.contiguous()
         if ctx.gb is not None:
-            ops.colsum(dpre, out=ctx.gb)
+            Leaves.run(lambda: ops.colsum(dpre, out=ctx.gb), dpre)
         elif ctx.b_needs and ctx.needs_input_grad[2]:
             db = ops.colsum(dpre).to(BF16)
         dres = dy if (ctx.has_res and ctx.needs_input_grad[4]) else None
@@ -179,8 +223,14 @@ class LoraQKVFn(Function):
             else:                                                         # dropout masks the LoRA branches' dx element-wise
                 dx = ops.gemm(d, ctx.wqkv_t) if ctx.wqkv_t is not None else ops.gemm(d, wqkv, trans_w=True)
                 ops.lora_apply_(dx, t2, aq, w_rn=True, drop=drq, w2=av)
-            dbq, dbv = ops.lora_outer(dq, xaq, alpha=s, out=gbq, a2=dv, b2=xav, out2=gbv)               # [H, 8] = s d^T (drop(x) A^T)
-            daq, dav = ops.lora_outer(x, tq, out_rn=True, out=gaq, drop=drq, a2=x, b2=tv, out2=gav)      # [8, H] = t^T drop(x)
+            def wgrads():
+                b_ = ops.lora_outer(dq, xaq, alpha=s, out=gbq, a2=dv, b2=xav, out2=gbv)               # [H, 8] = s d^T (drop(x) A^T)
+                a_ = ops.lora_outer(x, tq, out_rn=True, out=gaq, drop=drq, a2=x, b2=tv, out2=gav)      # [8, H] = t^T drop(x)
+                return b_, a_
+            if all(g is not None for g in ctx.g):
+                (dbq, dbv), (daq, dav) = Leaves.run(wgrads, d, x, t2, xaq, xav)
+            else:
+                (dbq, dbv), (daq, dav) = wgrads()
             outs = [None if g is not None else t.to(BF16) for g, t in ((gaq, daq), (gbq, dbq), (gav, dav), (gbv, dbv))]
             return dx, None, outs[0], outs[1], outs[2], outs[3], None, None, None
         tq = ops.gemm(dq, bq, trans_w=True, alpha=s)                      # [M, r] = s dq Bq

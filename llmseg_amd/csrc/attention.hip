@@ -1122,20 +1122,20 @@ int launch_hd(const AttnP& p, hipStream_t s) {
   const dim3 xgrid = g_attn_xcd ? dim3((unsigned)(8 * ((p.batch * p.heads + 7) / 8) * (int)grid.x)) : grid;
   constexpr int NT4 = 256, NT8 = 512;
   if (p.rtab_h != nullptr && HD == 80 && g_attn_win_new == 2 && p.lse == nullptr && p.ksr == p.vsr)
-    hipLaunchKernelGGL(attn_win14_dma_kernel, dim3((unsigned)std::min(p.batch * p.heads, g_attn_win_wgs)), dim3(NT8), 0, s, p);
-  else if (p.rtab_h != nullptr && HD == 80 && g_attn_win_new && p.lse == nullptr) hipLaunchKernelGGL(attn_win14_kernel, dim3((unsigned)std::min(p.batch * p.heads, g_attn_win_wgs)), dim3(NT8), 0, s, p);
-  else if (p.rtab_h != nullptr) hipLaunchKernelGGL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 4 : 0>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
+    LL_LAUNCH_KERNEL(attn_win14_dma_kernel, dim3((unsigned)std::min(p.batch * p.heads, g_attn_win_wgs)), dim3(NT8), 0, s, p);
+  else if (p.rtab_h != nullptr && HD == 80 && g_attn_win_new && p.lse == nullptr) LL_LAUNCH_KERNEL(attn_win14_kernel, dim3((unsigned)std::min(p.batch * p.heads, g_attn_win_wgs)), dim3(NT8), 0, s, p);
+  else if (p.rtab_h != nullptr) LL_LAUNCH_KERNEL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 4 : 0>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
   else if (p.rel_h == nullptr) {
-    if (wide) hipLaunchKernelGGL((attn_fwd_kernel<HD, 0, 8>), xgrid, dim3(NT8), 0, s, px);
-    else hipLaunchKernelGGL((attn_fwd_kernel<HD, 0>), grid, dim3(NT4), 0, s, p);
+    if (wide) LL_LAUNCH_KERNEL((attn_fwd_kernel<HD, 0, 8>), xgrid, dim3(NT8), 0, s, px);
+    else LL_LAUNCH_KERNEL((attn_fwd_kernel<HD, 0>), grid, dim3(NT4), 0, s, p);
   } else if (HD == 80 && p.gh == 14 && p.gw == 14 && p.Nk == 196 && !p.causal && !p.key_mask)
-    hipLaunchKernelGGL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 3 : 1>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
+    LL_LAUNCH_KERNEL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 3 : 1>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
   else if (p.gw == BKV && (p.Nk % BKV) == 0) {
     if (HD == 80 && wide && g_attn_glob_dma && (p.Nq % 256) == 0 && p.Nk == p.gh * BKV && (p.gh & 1) == 0 && !p.causal && !p.key_mask && !p.lse && !p.nk_dev)
-      hipLaunchKernelGGL(attn_glob80_dma_kernel, xgrid, dim3(NT8), 0, s, px);
-    else if (wide) hipLaunchKernelGGL((attn_fwd_kernel<HD, 2, 8>), xgrid, dim3(NT8), 0, s, px);
-    else hipLaunchKernelGGL((attn_fwd_kernel<HD, 2>), grid, dim3(NT4), 0, s, p);
-  } else hipLaunchKernelGGL((attn_fwd_kernel<HD, 1>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
+      LL_LAUNCH_KERNEL(attn_glob80_dma_kernel, xgrid, dim3(NT8), 0, s, px);
+    else if (wide) LL_LAUNCH_KERNEL((attn_fwd_kernel<HD, 2, 8>), xgrid, dim3(NT8), 0, s, px);
+    else LL_LAUNCH_KERNEL((attn_fwd_kernel<HD, 2>), grid, dim3(NT4), 0, s, p);
+  } else LL_LAUNCH_KERNEL((attn_fwd_kernel<HD, 1>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
   return 0;
 }
 
@@ -1285,10 +1285,10 @@ extern "C" int llmseg_decode_attn(const void* qkv, int64_t ld, const float* cos,
   }
   DecP p{(const bf16_t*)qkv, (long)ld, cos, sin, (bf16_t*)kcache, (bf16_t*)vcache, (long)cache_stride_n, pos_dev, heads, splits, scale,
          (bf16_t*)out, (long)ldo, (float*)scratch};
-  hipLaunchKernelGGL(decode_attn_kernel, dim3(heads * splits, (unsigned)N), dim3(256), 0, (hipStream_t)stream, p);
+  LL_LAUNCH_KERNEL(decode_attn_kernel, dim3(heads * splits, (unsigned)N), dim3(256), 0, (hipStream_t)stream, p);
   LL_LAUNCH_CHECK("decode_attn");
   if (splits > 1) {
-    hipLaunchKernelGGL(decode_attn_merge_kernel, dim3(heads, (unsigned)N), dim3(128), 0, (hipStream_t)stream, (const float*)scratch, heads, splits,
+    LL_LAUNCH_KERNEL(decode_attn_merge_kernel, dim3(heads, (unsigned)N), dim3(128), 0, (hipStream_t)stream, (const float*)scratch, heads, splits,
                        (bf16_t*)out, (long)ldo);
     LL_LAUNCH_CHECK("decode_attn_merge");
   }

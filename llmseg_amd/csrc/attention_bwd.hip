@@ -288,14 +288,14 @@ template <int HD>
 void launch_bwd(const BwdP& p, hipStream_t s) {
   const int nbq = (p.Nq + BO - 1) / BO, nbk = (p.Nk + BO - 1) / BO;
   const long rows = (long)p.batch * p.heads * p.Nq;
-  hipLaunchKernelGGL((attn_delta_kernel<HD>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, p);
+  LL_LAUNCH_KERNEL((attn_delta_kernel<HD>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, p);
   if (g_bwd_split) {
     const dim3 gq(nbq, p.heads, p.batch), gk(nbk, p.heads, p.batch);
-    hipLaunchKernelGGL((attn_bwd_kernel<HD, MODE_DQ>), gq, dim3(NT), 0, s, p);
-    hipLaunchKernelGGL((attn_bwd_kernel<HD, MODE_DK>), gk, dim3(NT), 0, s, p);
-    hipLaunchKernelGGL((attn_bwd_kernel<HD, MODE_DV>), gk, dim3(NT), 0, s, p);
+    LL_LAUNCH_KERNEL((attn_bwd_kernel<HD, MODE_DQ>), gq, dim3(NT), 0, s, p);
+    LL_LAUNCH_KERNEL((attn_bwd_kernel<HD, MODE_DK>), gk, dim3(NT), 0, s, p);
+    LL_LAUNCH_KERNEL((attn_bwd_kernel<HD, MODE_DV>), gk, dim3(NT), 0, s, p);
   } else {
-    hipLaunchKernelGGL((attn_bwd_all_kernel<HD>), dim3(nbq + 2 * nbk, p.heads, p.batch), dim3(NT), 0, s, p, nbq, nbk);
+    LL_LAUNCH_KERNEL((attn_bwd_all_kernel<HD>), dim3(nbq + 2 * nbk, p.heads, p.batch), dim3(NT), 0, s, p, nbq, nbk);
   }
 }
 

@@ -390,10 +390,10 @@ extern "C" int llmseg_colsum(const void* x, float* out, int64_t M, int64_t N, in
   gy = min(gy, workspace ? (long)(workspace_bytes / (N * 4)) : 0L);          // row slices the scratch can hold; <= 1: one slice, no scratch
   float* part = gy > 1 ? (float*)workspace : nullptr;
   if (gy < 1) gy = 1;
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, part, (long)M,
+  LL_LAUNCH_KERNEL(colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, part, (long)M,
                      (long)N, (long)ld);
   if (part)
-    hipLaunchKernelGGL(fold_slices_kernel, dim3(fold_grid(N)), dim3(256), 0, (hipStream_t)stream, (const float*)part, (int)gy, (long)N, (long)N, (long)N, out,
+    LL_LAUNCH_KERNEL(fold_slices_kernel, dim3(fold_grid(N)), dim3(256), 0, (hipStream_t)stream, (const float*)part, (int)gy, (long)N, (long)N, (long)N, out,
                        (float*)nullptr);
   LL_LAUNCH_CHECK("colsum");
   return LLMSEG_OK;
@@ -423,24 +423,24 @@ extern "C" int llmseg_norm_bwd_add(const void* dy, const void* x, const void* w,
   }
   const dim3 grid((unsigned)G);
 #define LL_NORMB(C, A)                                                                                                                       \
-  hipLaunchKernelGGL((norm_bwd_kernel<C, A>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, \
+  LL_LAUNCH_KERNEL((norm_bwd_kernel<C, A>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, \
                      (bf16_t*)dx, dw, db, (long)rows, (int)cols, eps, rms, (const bf16_t*)dres, part, stats)
   if (acc) { if (cpl <= 1) LL_NORMB(1, true); else LL_NORMB(2, true); }
   else if (cpl <= 1) LL_NORMB(1, false); else if (cpl <= 2) LL_NORMB(2, false); else if (cpl <= 4) LL_NORMB(4, false);
   else if (cpl <= 8) LL_NORMB(8, false); else LL_NORMB(0, false);
 #undef LL_NORMB
   if (acc && part)
-    hipLaunchKernelGGL(fold_slices_kernel, dim3(fold_grid(2 * cols)), dim3(256), 0, (hipStream_t)stream, (const float*)part, (int)G, (long)(2 * cols),
+    LL_LAUNCH_KERNEL(fold_slices_kernel, dim3(fold_grid(2 * cols)), dim3(256), 0, (hipStream_t)stream, (const float*)part, (int)G, (long)(2 * cols),
                        (long)(2 * cols), (long)cols, dw, db);
   if (stats) {                                                     // wide rows: column sums from the stored (mean, rstd), row slices folded in order
     float* p2 = stats + ((2 * rows + 63) / 64) * 64;
     long gy = std::min<long>(64, (rows + 255) / 256);
     gy = std::min<long>(gy, (ws_floats - (p2 - stats)) / (2 * cols));
     if (gy <= 1) { gy = 1; p2 = nullptr; }
-    hipLaunchKernelGGL(norm_dwdb_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
+    LL_LAUNCH_KERNEL(norm_dwdb_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
                        (const float*)stats, dw, db, p2, (long)rows, (long)cols);
     if (p2)
-      hipLaunchKernelGGL(fold_slices_kernel, dim3(fold_grid(2 * cols)), dim3(256), 0, (hipStream_t)stream, (const float*)p2, (int)gy, (long)(2 * cols),
+      LL_LAUNCH_KERNEL(fold_slices_kernel, dim3(fold_grid(2 * cols)), dim3(256), 0, (hipStream_t)stream, (const float*)p2, (int)gy, (long)(2 * cols),
                          (long)(2 * cols), (long)cols, dw, db);
   }
   LL_LAUNCH_CHECK("norm_bwd");
@@ -449,7 +449,7 @@ extern "C" int llmseg_norm_bwd_add(const void* dy, const void* x, const void* w,
 
 extern "C" int llmseg_swiglu_bwd(const void* gu, const void* dout, void* dgu, int64_t rows, int64_t I, void* stream) {
   LL_CHECK(gu && dout && dgu && rows > 0 && I > 0 && (I & 7) == 0 && AL16(gu) && AL16(dout) && AL16(dgu), "swiglu_bwd: bad arguments");
-  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (I >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gu, (const bf16_t*)dout,
+  LL_LAUNCH_KERNEL(swiglu_bwd_kernel, dim3(grid_for(rows * (I >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gu, (const bf16_t*)dout,
                      (bf16_t*)dgu, (long)rows, (long)I);
   LL_LAUNCH_CHECK("swiglu_bwd");
   return LLMSEG_OK;
@@ -457,7 +457,7 @@ extern "C" int llmseg_swiglu_bwd(const void* gu, const void* dout, void* dgu, in
 
 extern "C" int llmseg_act_bwd(const void* dy, const void* y, void* out, int64_t n, int act, void* stream) {
   LL_CHECK(dy && y && out && n > 0 && (act == LLMSEG_ACT_RELU || act == LLMSEG_ACT_SIGMOID), "act_bwd: only relu/sigmoid are differentiated");
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)out, (long)n, act);
+  LL_LAUNCH_KERNEL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)out, (long)n, act);
   LL_LAUNCH_CHECK("act_bwd");
   return LLMSEG_OK;
 }
@@ -465,7 +465,7 @@ extern "C" int llmseg_act_bwd(const void* dy, const void* y, void* out, int64_t 
 extern "C" int llmseg_softmax_rows(const float* S, void* P, int64_t BH, int32_t Tq, int32_t Tk, int32_t ld, float scale, int32_t causal,
                                    const uint8_t* key_mask, int32_t heads, void* stream) {
   LL_CHECK(S && P && BH > 0 && Tq > 0 && Tk > 0 && ld >= Tk && heads > 0 && (!causal || Tq == Tk), "softmax_rows: bad arguments");
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((BH * Tq + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, (bf16_t*)P, (long)BH, Tq, Tk, ld,
+  LL_LAUNCH_KERNEL(softmax_rows_kernel, dim3((unsigned)((BH * Tq + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, (bf16_t*)P, (long)BH, Tq, Tk, ld,
                      scale, causal, key_mask, heads);
   LL_LAUNCH_CHECK("softmax_rows");
   return LLMSEG_OK;
@@ -473,7 +473,7 @@ extern "C" int llmseg_softmax_rows(const float* S, void* P, int64_t BH, int32_t 
 
 extern "C" int llmseg_attn_ds(const void* P, const float* dP, void* dS, int64_t rows, int32_t T, int32_t ld, float scale, void* stream) {
   LL_CHECK(P && dP && dS && rows > 0 && T > 0 && ld >= T, "attn_ds: bad arguments");
-  hipLaunchKernelGGL(attn_ds_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)P, dP, (bf16_t*)dS, (long)rows, T,
+  LL_LAUNCH_KERNEL(attn_ds_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)P, dP, (bf16_t*)dS, (long)rows, T,
                      ld, scale);
   LL_LAUNCH_CHECK("attn_ds");
   return LLMSEG_OK;
@@ -482,7 +482,7 @@ extern "C" int llmseg_attn_ds(const void* P, const float* dP, void* dS, int64_t 
 extern "C" int llmseg_ce_bwd(const void* logits, const int64_t* labels, const float* coef, void* dlogits, int32_t N, int32_t T, int64_t V, int64_t ldl,
                              void* stream) {
   LL_CHECK(logits && labels && coef && dlogits && N > 0 && T > 1 && V > 0 && ldl >= V, "ce_bwd: bad arguments");
-  hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)(N * T)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, labels, coef, (bf16_t*)dlogits, T,
+  LL_LAUNCH_KERNEL(ce_bwd_kernel, dim3((unsigned)(N * T)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, labels, coef, (bf16_t*)dlogits, T,
                      (long)V, (long)ldl);
   LL_LAUNCH_CHECK("ce_bwd");
   return LLMSEG_OK;
@@ -491,7 +491,7 @@ extern "C" int llmseg_ce_bwd(const void* logits, const int64_t* labels, const fl
 extern "C" int llmseg_scatter_add_rows(const void* src, const int64_t* idx, float* dst, int64_t n, int64_t cols, void* stream) {
   LL_CHECK(src && idx && dst && n > 0 && cols > 0, "scatter_add_rows: bad arguments");
   LL_CHECK(n < (1L << 31), "scatter_add_rows: too many source rows");
-  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, idx, dst, (long)n, (long)cols);
+  LL_LAUNCH_KERNEL(scatter_add_rows_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, idx, dst, (long)n, (long)cols);
   LL_LAUNCH_CHECK("scatter_add_rows");
   return LLMSEG_OK;
 }
@@ -501,8 +501,8 @@ extern "C" int llmseg_sumsq(const void* x, int64_t n, int is_f32, float* out, vo
   LL_CHECK(workspace && workspace_bytes >= 4, "sumsq: workspace (>= 4 bytes, 8 KiB for every partial) is required");
   long g = std::min<long>(2048, (n + 2047) / 2048);                       // >= 8 elements per thread
   g = std::max<long>(1, std::min<long>(g, workspace_bytes / 4));
-  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (long)n, is_f32, (float*)workspace);
-  hipLaunchKernelGGL(fold_column_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (long)g, out, 1.f);
+  LL_LAUNCH_KERNEL(sumsq_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (long)n, is_f32, (float*)workspace);
+  LL_LAUNCH_KERNEL(fold_column_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (long)g, out, 1.f);
   LL_LAUNCH_CHECK("sumsq");
   return LLMSEG_OK;
 }
@@ -511,7 +511,7 @@ extern "C" int llmseg_adamw(void* p, float* master, const void* grad, int grad_f
                             float eps, float weight_decay, int64_t step, const float* grad_scale, void* stream) {
   LL_CHECK(p && master && grad && m && v && n > 0 && step > 0, "adamw: bad arguments");
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p, master, grad, grad_f32, m, v, (long)n, lr, beta1, beta2,
+  LL_LAUNCH_KERNEL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p, master, grad, grad_f32, m, v, (long)n, lr, beta1, beta2,
                      eps, weight_decay, bc1, bc2, grad_scale);
   LL_LAUNCH_CHECK("adamw");
   return LLMSEG_OK;
@@ -923,16 +923,16 @@ extern "C" int llmseg_lora_down_ws(const void* x0, const void* x1, int64_t ldx, 
     int S = 1;
     while (tiles * S < 256 && (K % (4 * 32 * S * 2)) == 0 && scratch && (int64_t)S * 2 * M * 16 * 4 <= scratch_bytes && S < 32) S *= 2;
     float* part = S > 1 ? (float*)scratch : nullptr;
-    hipLaunchKernelGGL(lora_down_mfma_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, (hipStream_t)stream, X0, X1, (long)ldx, W0, W1, (bf16_t*)y, (long)ldy,
+    LL_LAUNCH_KERNEL(lora_down_mfma_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, (hipStream_t)stream, X0, X1, (long)ldx, W0, W1, (bf16_t*)y, (long)ldy,
                        (long)M, (int)K, alpha, zero_cols, nb, dp, part);
     if (S > 1)
-      hipLaunchKernelGGL(lora_down_finish_kernel, dim3(grid_for(M * (nb + zero_cols / 8))), dim3(256), 0, (hipStream_t)stream, (const float*)part, S, (bf16_t*)y,
+      LL_LAUNCH_KERNEL(lora_down_finish_kernel, dim3(grid_for(M * (nb + zero_cols / 8))), dim3(256), 0, (hipStream_t)stream, (const float*)part, S, (bf16_t*)y,
                          (long)ldy, (long)M, alpha * (dp.thr ? dp.scale : 1.f), zero_cols, nb);
   } else if (M <= 2048)
-    hipLaunchKernelGGL(lora_down_kernel<1>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X0, X1, (long)ldx, W0, W1, (bf16_t*)y, (long)ldy, (long)M,
+    LL_LAUNCH_KERNEL(lora_down_kernel<1>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X0, X1, (long)ldx, W0, W1, (bf16_t*)y, (long)ldy, (long)M,
                        (int)K, w_kr, alpha, zero_cols, nb, dp);
   else
-    hipLaunchKernelGGL(lora_down_kernel<4>, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, X0, X1, (long)ldx, W0, W1, (bf16_t*)y, (long)ldy, (long)M,
+    LL_LAUNCH_KERNEL(lora_down_kernel<4>, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, X0, X1, (long)ldx, W0, W1, (bf16_t*)y, (long)ldy, (long)M,
                        (int)K, w_kr, alpha, zero_cols, nb, dp);
   LL_LAUNCH_CHECK("lora_down");
   return LLMSEG_OK;
@@ -951,10 +951,10 @@ extern "C" int llmseg_lora_outer(const void* a0, const void* a1, int64_t lda, co
   if (gy < 1) gy = 1;
   OuterP q;
   q.a[0] = (const bf16_t*)a0; q.a[1] = (const bf16_t*)a1; q.b[0] = (const bf16_t*)b0; q.b[1] = (const bf16_t*)b1; q.out[0] = out0; q.out[1] = out1;
-  hipLaunchKernelGGL(lora_outer_kernel, dim3((unsigned)colwg, (unsigned)gy, nz), dim3(256), 0, (hipStream_t)stream, q, (long)lda, (long)ldb, (long)M, (long)N,
+  LL_LAUNCH_KERNEL(lora_outer_kernel, dim3((unsigned)colwg, (unsigned)gy, nz), dim3(256), 0, (hipStream_t)stream, q, (long)lda, (long)ldb, (long)M, (long)N,
                      out_rn, alpha, make_drop(drop), part);
   if (part)
-    hipLaunchKernelGGL(fold_slices_kernel, dim3(fold_grid(nz * N * LR)), dim3(256), 0, (hipStream_t)stream, (const float*)part, (int)gy, (long)(nz * N * LR),
+    LL_LAUNCH_KERNEL(fold_slices_kernel, dim3(fold_grid(nz * N * LR)), dim3(256), 0, (hipStream_t)stream, (const float*)part, (int)gy, (long)(nz * N * LR),
                        (long)(nz * N * LR), (long)(N * LR), out0, out1);
   LL_LAUNCH_CHECK("lora_outer");
   return LLMSEG_OK;
@@ -965,7 +965,7 @@ extern "C" int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, int64_t l
   LL_CHECK(y && xa && w0 && M > 0 && N > 0 && (N & 7) == 0 && (ldy & 7) == 0 && (ldxa & 7) == 0 && ldxa >= (w1 ? 16 : 8) && AL16(y) && AL16(xa) && AL16(w0) &&
                AL16(w1) && LL_DROP_OK(drop), "lora_apply: bad arguments");
   LL_CHECK(!(drop && drop->drop_thr) || ldy == N, "lora_apply: the dropout mask indexes y as a dense [M][N] matrix");
-  hipLaunchKernelGGL(lora_apply_kernel, dim3(grid_for(M * (N >> 3))), dim3(256), 0, (hipStream_t)stream, (bf16_t*)y, (long)ldy, (const bf16_t*)xa,
+  LL_LAUNCH_KERNEL(lora_apply_kernel, dim3(grid_for(M * (N >> 3))), dim3(256), 0, (hipStream_t)stream, (bf16_t*)y, (long)ldy, (const bf16_t*)xa,
                      (long)ldxa, (const bf16_t*)w0, (const bf16_t*)w1, (long)M, (long)N, w_rn, alpha, w1 ? 2 : 1, make_drop(drop));
   LL_LAUNCH_CHECK("lora_apply");
   return LLMSEG_OK;
@@ -974,7 +974,7 @@ extern "C" int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, int64_t l
 extern "C" int llmseg_lora_pack(const void* aq, const void* bq, const void* av, const void* bv, void* w2b, void* w2a, void* bt, int64_t H, float s, void* stream) {
   LL_CHECK(aq && bq && av && bv && (w2b || w2a || bt) && H > 0 && (H & 7) == 0 && AL16(aq) && AL16(bq) && AL16(av) && AL16(bv) && AL16(w2b) && AL16(w2a) && AL16(bt),
            "lora_pack: bad arguments");
-  hipLaunchKernelGGL(lora_pack_kernel, dim3(grid_for(4 * H * 8 + 2 * H)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)aq, (const bf16_t*)bq, (const bf16_t*)av,
+  LL_LAUNCH_KERNEL(lora_pack_kernel, dim3(grid_for(4 * H * 8 + 2 * H)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)aq, (const bf16_t*)bq, (const bf16_t*)av,
                      (const bf16_t*)bv, (bf16_t*)w2b, (bf16_t*)w2a, (bf16_t*)bt, (long)H, s);
   LL_LAUNCH_CHECK("lora_pack");
   return LLMSEG_OK;
@@ -984,7 +984,7 @@ extern "C" int llmseg_transpose_pad(const void* in, void* out, int64_t rows, int
   LL_CHECK(in && out && rows > 0 && cols > 0 && rows_pad >= rows && ld_out >= rows_pad && ld_in >= cols, "transpose_pad: bad arguments");
   LL_CHECK((cols & 7) == 0 && (ld_in & 7) == 0 && (ld_out & 7) == 0 && (rows_pad & 7) == 0 && AL16(in) && AL16(out),
            "transpose_pad: cols, rows_pad and leading dimensions must be multiples of 8, pointers 16-byte aligned");
-  hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)((rows_pad + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+  LL_LAUNCH_KERNEL(transpose_pad_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)((rows_pad + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)in, (bf16_t*)out, (long)rows, (long)cols, (long)ld_in, (long)ld_out, (long)rows_pad);
   LL_LAUNCH_CHECK("transpose_pad");
   return LLMSEG_OK;

@@ -21,6 +21,11 @@ void llmseg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* llmseg_last_error(void) { return g_err; }
+
+#include <atomic>
+static std::atomic<long> g_launches{0};
+void llmseg_count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
+extern "C" int64_t llmseg_launch_count(void) { return (int64_t)g_launches.load(std::memory_order_relaxed); }
 extern "C" int llmseg_version(void) { return LLMSEG_ABI_VERSION; }
 extern "C" int64_t llmseg_struct_size(int which) {
   switch (which) {

@@ -178,6 +178,14 @@ static __global__ __launch_bounds__(256) void fold_column_kernel(const float* __
 }
 static inline unsigned fold_grid(long n) { const long g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g)); }
 
+// every kernel launch of the library goes through this macro: llmseg_launch_count() lets a benchmark report launches per micro-step
+void llmseg_count_launch();
+#define LL_LAUNCH_KERNEL(...)              \
+  do {                                     \
+    llmseg_count_launch();                 \
+    hipLaunchKernelGGL(__VA_ARGS__);       \
+  } while (0)
+
 void llmseg_set_error(const char* fmt, ...);
 #define LL_CHECK(cond, ...)                 \
   do {                                      \

@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float
 
 template <bool OUT_F32, int MI, int NBUF>
 void launch_glds(const GemmP& p, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL((gemm_bf16_tn_glds_kernel<OUT_F32, MI, NBUF>), grid, dim3(NT), 0, s, p);
+  LL_LAUNCH_KERNEL((gemm_bf16_tn_glds_kernel<OUT_F32, MI, NBUF>), grid, dim3(NT), 0, s, p);
 }
 
 }  // namespace
@@ -1193,10 +1193,10 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
     const int of = a->out_f32 ? 1 : 0;
 #define LL_SKINNY_(AT, SKV)                                                                                   \
     do {                                                                                                      \
-      if (p.M == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1, AT, SKV>), grid, dim3(256), 0, s, p, of);      \
-      else if (p.M == 2) hipLaunchKernelGGL((gemm_skinny_kernel<2, AT, SKV>), grid, dim3(256), 0, s, p, of); \
-      else if (p.M <= 4) hipLaunchKernelGGL((gemm_skinny_kernel<4, AT, SKV>), grid, dim3(256), 0, s, p, of); \
-      else hipLaunchKernelGGL((gemm_skinny_kernel<8, AT, SKV>), grid, dim3(256), 0, s, p, of);               \
+      if (p.M == 1) LL_LAUNCH_KERNEL((gemm_skinny_kernel<1, AT, SKV>), grid, dim3(256), 0, s, p, of);      \
+      else if (p.M == 2) LL_LAUNCH_KERNEL((gemm_skinny_kernel<2, AT, SKV>), grid, dim3(256), 0, s, p, of); \
+      else if (p.M <= 4) LL_LAUNCH_KERNEL((gemm_skinny_kernel<4, AT, SKV>), grid, dim3(256), 0, s, p, of); \
+      else LL_LAUNCH_KERNEL((gemm_skinny_kernel<8, AT, SKV>), grid, dim3(256), 0, s, p, of);               \
     } while (0)
 #define LL_SKINNY(AT) do { if (sk) LL_SKINNY_(AT, true); else LL_SKINNY_(AT, false); } while (0)
     if (p.a_norm_w) LL_SKINNY(1); else if (p.a_swiglu) LL_SKINNY(2); else LL_SKINNY(0);
@@ -1249,14 +1249,14 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
       const dim3 grid(p.tiles_m * p.tiles_n, (unsigned)(S * batch));
       const int key = (ta ? 2 : 0) | (tw ? 1 : 0);
       switch (key) {
-        case 0: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, false, false>), grid, dim3(NT), 0, s, ps); break;
-        case 1: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, false, true>), grid, dim3(NT), 0, s, ps); break;
-        case 2: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, true, false>), grid, dim3(NT), 0, s, ps); break;
-        default: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, true, true>), grid, dim3(NT), 0, s, ps); break;
+        case 0: LL_LAUNCH_KERNEL((gemm_bf16_tn_kernel<true, false, false>), grid, dim3(NT), 0, s, ps); break;
+        case 1: LL_LAUNCH_KERNEL((gemm_bf16_tn_kernel<true, false, true>), grid, dim3(NT), 0, s, ps); break;
+        case 2: LL_LAUNCH_KERNEL((gemm_bf16_tn_kernel<true, true, false>), grid, dim3(NT), 0, s, ps); break;
+        default: LL_LAUNCH_KERNEL((gemm_bf16_tn_kernel<true, true, true>), grid, dim3(NT), 0, s, ps); break;
       }
       const long total4 = (long)p.M * (p.N >> 2);
       const unsigned rg = (unsigned)std::min<long>((total4 + 255) / 256, 4096);
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg, (unsigned)batch), dim3(256), 0, s, p, (const float*)a->workspace, S, f ? 1 : 0);
+      LL_LAUNCH_KERNEL(splitk_reduce_kernel, dim3(rg, (unsigned)batch), dim3(256), 0, s, p, (const float*)a->workspace, S, f ? 1 : 0);
       llmseg_prof_end(s, 2.0 * (double)a->M * (double)a->N * (double)a->K * (double)batch);
       LL_LAUNCH_CHECK("gemm_bf16_tn (K-sliced)");
       return LLMSEG_OK;
@@ -1272,43 +1272,43 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
     ps.bias = ps.gamma = ps.res = nullptr; ps.ldr = 0; ps.alpha = 1.f; ps.act = LLMSEG_ACT_NONE; ps.accum = 0;
     ps.c_vec = 1; ps.r_vec = 0; ps.b_vec = 1; ps.A2 = ps.W2 = nullptr;
     dim3 grid(p.tiles_m * p.tiles_n, (unsigned)split);
-    if (variant == 8) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<true, false, 4>), grid, dim3(NTB), 0, s, ps);
-    else if (g_gemm_pp2) hipLaunchKernelGGL((gemm_bf16_tn_pp2_kernel<true, false>), grid, dim3(NTB), 0, s, ps);
-    else hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<true, false, 2>), grid, dim3(NTB), 0, s, ps);
+    if (variant == 8) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<true, false, 4>), grid, dim3(NTB), 0, s, ps);
+    else if (g_gemm_pp2) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp2_kernel<true, false>), grid, dim3(NTB), 0, s, ps);
+    else LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<true, false, 2>), grid, dim3(NTB), 0, s, ps);
     const long total4 = (long)p.M * (p.N >> 2);
     const unsigned rg = (unsigned)std::min<long>((total4 + 255) / 256, 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, s, p, (const float*)a->workspace, split + (p.A2 ? 1 : 0), f ? 1 : 0);
+    LL_LAUNCH_KERNEL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, s, p, (const float*)a->workspace, split + (p.A2 ? 1 : 0), f ? 1 : 0);
   } else {
     dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);
     switch (variant) {
       case 2: f ? launch_glds<true, 2, 1>(p, grid, s) : launch_glds<false, 2, 1>(p, grid, s); break;
       case 8:
-        if (p.A2) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, true, 4>), grid, dim3(NTB), 0, s, p);      // bf16 out only (checked above)
-        else if (f) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<true, false, 4>), grid, dim3(NTB), 0, s, p);
-        else hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, false, 4>), grid, dim3(NTB), 0, s, p);
+        if (p.A2) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<false, true, 4>), grid, dim3(NTB), 0, s, p);      // bf16 out only (checked above)
+        else if (f) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<true, false, 4>), grid, dim3(NTB), 0, s, p);
+        else LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<false, false, 4>), grid, dim3(NTB), 0, s, p);
         break;
       case 9:
         if (g_gemm_pp2) {
-          if (p.A2) hipLaunchKernelGGL((gemm_bf16_tn_pp2_kernel<false, true>), grid, dim3(NTB), 0, s, p);
-          else if (f) hipLaunchKernelGGL((gemm_bf16_tn_pp2_kernel<true, false>), grid, dim3(NTB), 0, s, p);
-          else hipLaunchKernelGGL((gemm_bf16_tn_pp2_kernel<false, false>), grid, dim3(NTB), 0, s, p);
+          if (p.A2) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp2_kernel<false, true>), grid, dim3(NTB), 0, s, p);
+          else if (f) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp2_kernel<true, false>), grid, dim3(NTB), 0, s, p);
+          else LL_LAUNCH_KERNEL((gemm_bf16_tn_pp2_kernel<false, false>), grid, dim3(NTB), 0, s, p);
           break;
         }
-        if (p.A2) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, true, 2>), grid, dim3(NTB), 0, s, p);
-        else if (f) hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<true, false, 2>), grid, dim3(NTB), 0, s, p);
-        else hipLaunchKernelGGL((gemm_bf16_tn_pp_kernel<false, false, 2>), grid, dim3(NTB), 0, s, p);
+        if (p.A2) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<false, true, 2>), grid, dim3(NTB), 0, s, p);
+        else if (f) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<true, false, 2>), grid, dim3(NTB), 0, s, p);
+        else LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<false, false, 2>), grid, dim3(NTB), 0, s, p);
         break;
       default: {
         const int key = (f ? 4 : 0) | (ta ? 2 : 0) | (tw ? 1 : 0);
         switch (key) {
-          case 0: hipLaunchKernelGGL((gemm_bf16_tn_kernel<false, false, false>), grid, dim3(NT), 0, s, p); break;
-          case 1: hipLaunchKernelGGL((gemm_bf16_tn_kernel<false, false, true>), grid, dim3(NT), 0, s, p); break;
-          case 2: hipLaunchKernelGGL((gemm_bf16_tn_kernel<false, true, false>), grid, dim3(NT), 0, s, p); break;
-          case 3: hipLaunchKernelGGL((gemm_bf16_tn_kernel<false, true, true>), grid, dim3(NT), 0, s, p); break;
-          case 4: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, false, false>), grid, dim3(NT), 0, s, p); break;
-          case 5: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, false, true>), grid, dim3(NT), 0, s, p); break;
-          case 6: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, true, false>), grid, dim3(NT), 0, s, p); break;
-          default: hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, true, true>), grid, dim3(NT), 0, s, p); break;
+          case 0: LL_LAUNCH_KERNEL((gemm_bf16_tn_kernel<false, false, false>), grid, dim3(NT), 0, s, p); break;
+          case 1: LL_LAUNCH_KERNEL((gemm_bf16_tn_kernel<false, false, true>), grid, dim3(NT), 0, s, p); break;
+          case 2: LL_LAUNCH_KERNEL((gemm_bf16_tn_kernel<false, true, false>), grid, dim3(NT), 0, s, p); break;
+          case 3: LL_LAUNCH_KERNEL((gemm_bf16_tn_kernel<false, true, true>), grid, dim3(NT), 0, s, p); break;
+          case 4: LL_LAUNCH_KERNEL((gemm_bf16_tn_kernel<true, false, false>), grid, dim3(NT), 0, s, p); break;
+          case 5: LL_LAUNCH_KERNEL((gemm_bf16_tn_kernel<true, false, true>), grid, dim3(NT), 0, s, p); break;
+          case 6: LL_LAUNCH_KERNEL((gemm_bf16_tn_kernel<true, true, false>), grid, dim3(NT), 0, s, p); break;
+          default: LL_LAUNCH_KERNEL((gemm_bf16_tn_kernel<true, true, true>), grid, dim3(NT), 0, s, p); break;
         }
       }
     }

@@ -352,7 +352,7 @@ extern "C" int llmseg_sam_postprocess(const float* low, float* out, int32_t n_ma
                                       int32_t nested, void* stream) {
   LL_CHECK(low && out && n_masks > 0 && img_size > 0 && in_h > 0 && in_w > 0 && in_h <= img_size && in_w <= img_size && out_h > 0 && out_w > 0,
            "sam_postprocess: bad arguments");
-  hipLaunchKernelGGL(sam_postprocess_kernel, dim3((unsigned)((out_w + 255) / 256), (unsigned)out_h, (unsigned)n_masks), dim3(256), 0, (hipStream_t)stream, low, out,
+  LL_LAUNCH_KERNEL(sam_postprocess_kernel, dim3((unsigned)((out_w + 255) / 256), (unsigned)out_h, (unsigned)n_masks), dim3(256), 0, (hipStream_t)stream, low, out,
                      img_size, in_h, in_w, out_h, out_w, nested);
   LL_LAUNCH_CHECK("sam_postprocess");
   return LLMSEG_OK;
@@ -514,7 +514,7 @@ extern "C" int llmseg_sam_mask_stats(const float* low, const float* iou, float i
   LL_CHECK(low && stats && n_masks > 0 && img_size > 0 && in_h > 0 && in_w > 0 && in_h <= img_size && in_w <= img_size && out_h > 0 && out_w > 0,
            "sam_mask_stats: bad arguments");
   LL_CHECK((out_h + POST_ROWS - 1) / POST_ROWS < 65536 && n_masks < 65536, "sam_mask_stats: grid limit");
-  hipLaunchKernelGGL(sam_mask_stats_kernel, dim3((unsigned)((out_w + 255) / 256), (unsigned)((out_h + POST_ROWS - 1) / POST_ROWS), (unsigned)n_masks), dim3(256), 0, (hipStream_t)stream, low, iou, iou_thresh, stats, img_size, in_h, in_w, out_h,
+  LL_LAUNCH_KERNEL(sam_mask_stats_kernel, dim3((unsigned)((out_w + 255) / 256), (unsigned)((out_h + POST_ROWS - 1) / POST_ROWS), (unsigned)n_masks), dim3(256), 0, (hipStream_t)stream, low, iou, iou_thresh, stats, img_size, in_h, in_w, out_h,
                      out_w, nested, mask_threshold, offset);
   LL_LAUNCH_CHECK("sam_mask_stats");
   return LLMSEG_OK;
@@ -524,7 +524,7 @@ extern "C" int llmseg_sam_binarize(const float* low, const int32_t* sel, uint8_t
                                    int32_t out_w, int32_t nested, float mask_threshold, void* stream) {
   LL_CHECK(low && sel && out && n_sel > 0 && img_size > 0 && in_h > 0 && in_w > 0 && out_h > 0 && out_w > 0, "sam_binarize: bad arguments");
   LL_CHECK(n_sel < 65536, "sam_binarize: grid limit");
-  hipLaunchKernelGGL(sam_binarize_kernel, dim3((unsigned)((out_w + 255) / 256), (unsigned)((out_h + POST_ROWS - 1) / POST_ROWS), (unsigned)n_sel), dim3(256), 0, (hipStream_t)stream, low, sel, out,
+  LL_LAUNCH_KERNEL(sam_binarize_kernel, dim3((unsigned)((out_w + 255) / 256), (unsigned)((out_h + POST_ROWS - 1) / POST_ROWS), (unsigned)n_sel), dim3(256), 0, (hipStream_t)stream, low, sel, out,
                      img_size, in_h, in_w, out_h, out_w, nested, mask_threshold);
   LL_LAUNCH_CHECK("sam_binarize");
   return LLMSEG_OK;
@@ -532,7 +532,7 @@ extern "C" int llmseg_sam_binarize(const float* low, const int32_t* sel, uint8_t
 
 extern "C" int llmseg_nms(const float* boxes, const int32_t* order, int32_t n, float iou_threshold, uint8_t* keep, void* stream) {
   LL_CHECK(boxes && order && keep && n > 0 && n <= 8192, "nms: 1 <= n <= 8192 boxes");
-  hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), (size_t)n, (hipStream_t)stream, boxes, order, n, iou_threshold, keep);
+  LL_LAUNCH_KERNEL(nms_kernel, dim3(1), dim3(1024), (size_t)n, (hipStream_t)stream, boxes, order, n, iou_threshold, keep);
   LL_LAUNCH_CHECK("nms");
   return LLMSEG_OK;
 }
@@ -541,13 +541,13 @@ extern "C" int llmseg_mask_pullback(const void* segs, void* ws, float* pulled_ba
   LL_CHECK(segs && ws && K > 0 && g > 0 && S >= g, "mask_pullback: bad arguments");
   LL_CHECK(256 % g == 0 && ((g * g) & 7) == 0, "mask_pullback: feature grid %d must divide 256", g);
   if (S == 256 && g == 64 && ((((uintptr_t)segs) | ((uintptr_t)ws)) & 15) == 0 && (!pulled_back || (((uintptr_t)pulled_back) & 15) == 0)) {
-    hipLaunchKernelGGL(mask_pullback_s256_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)segs, (bf16_t*)ws, pulled_back, wsum);
+    LL_LAUNCH_KERNEL(mask_pullback_s256_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)segs, (bf16_t*)ws, pulled_back, wsum);
     LL_LAUNCH_CHECK("mask_pullback");
     return LLMSEG_OK;
   }
   const size_t lds = ((size_t)((S + 1) / 2) * g + (size_t)g * g + 16) * sizeof(float);
   LL_CHECK(lds <= 64 * 1024, "mask_pullback: S=%d g=%d need %zu bytes of LDS", S, g, lds);
-  hipLaunchKernelGGL(mask_pullback_kernel, dim3(K), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)segs, (bf16_t*)ws, pulled_back, wsum, g, S);
+  LL_LAUNCH_KERNEL(mask_pullback_kernel, dim3(K), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)segs, (bf16_t*)ws, pulled_back, wsum, g, S);
   LL_LAUNCH_CHECK("mask_pullback");
   return LLMSEG_OK;
 }
@@ -569,7 +569,7 @@ extern "C" int llmseg_upsample_maskpool(const void* feat, const void* segs, void
 
 extern "C" int llmseg_cosine_scores(const void* t, const void* e, float* sim, int32_t K, int32_t D, void* stream) {
   LL_CHECK(t && e && sim && K > 0 && D > 0, "cosine_scores: bad arguments");
-  hipLaunchKernelGGL(cosine_kernel, dim3((K + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)e, sim, K, D);
+  LL_LAUNCH_KERNEL(cosine_kernel, dim3((K + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)e, sim, K, D);
   LL_LAUNCH_CHECK("cosine_scores");
   return LLMSEG_OK;
 }
@@ -579,7 +579,7 @@ extern "C" int llmseg_align_reg_loss(const void* e, const void* t, const float* 
   LL_CHECK(e && t && gt_iou && pred_iou && gt_iop && out && K > 0 && D > 0 && tau > 0.f && items > 0, "align_reg_loss: bad arguments");
   const size_t lds = ((size_t)3 * K + 16) * sizeof(float);
   LL_CHECK(lds <= 64 * 1024, "align_reg_loss: K=%d too large", K);
-  hipLaunchKernelGGL(align_reg_kernel, dim3(items), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)e, (const bf16_t*)t, gt_iou,
+  LL_LAUNCH_KERNEL(align_reg_kernel, dim3(items), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)e, (const bf16_t*)t, gt_iou,
                      (const bf16_t*)pred_iou, gt_iop, out, d_e, d_t, d_pred, K, D, tau);
   LL_LAUNCH_CHECK("align_reg_loss");
   return LLMSEG_OK;
@@ -589,8 +589,8 @@ extern "C" int llmseg_dice_bce(const float* logits, const float* targets, float*
                                int64_t workspace_bytes, void* stream) {
   LL_CHECK(logits && targets && out && M > 0 && HW > 0, "dice_bce: bad arguments");
   LL_CHECK(workspace && workspace_bytes >= (int64_t)M * 8, "dice_bce: workspace of >= 8 M bytes (per-mask terms) is required");
-  hipLaunchKernelGGL(dice_bce_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, targets, (float*)workspace, (long)HW, num_masks);
-  hipLaunchKernelGGL(fold_column_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (long)M, out, 1.f);
+  LL_LAUNCH_KERNEL(dice_bce_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, targets, (float*)workspace, (long)HW, num_masks);
+  LL_LAUNCH_KERNEL(fold_column_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (long)M, out, 1.f);
   LL_LAUNCH_CHECK("dice_bce");
   return LLMSEG_OK;
 }
@@ -598,7 +598,7 @@ extern "C" int llmseg_dice_bce(const float* logits, const float* targets, float*
 extern "C" int llmseg_dice_bce_bwd(const float* logits, const float* targets, const float* g, float* dlogits, int32_t M, int64_t HW, float num_masks,
                                    void* stream) {
   LL_CHECK(logits && targets && g && dlogits && M > 0 && HW > 0, "dice_bce_bwd: bad arguments");
-  hipLaunchKernelGGL(dice_bce_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, targets, g, dlogits, (long)HW, num_masks);
+  LL_LAUNCH_KERNEL(dice_bce_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, targets, g, dlogits, (long)HW, num_masks);
   LL_LAUNCH_CHECK("dice_bce_bwd");
   return LLMSEG_OK;
 }
@@ -608,9 +608,9 @@ extern "C" int llmseg_ce_loss(const void* logits, const int64_t* labels, float* 
   LL_CHECK(logits && labels && acc && N > 0 && T > 1 && V > 0 && ldl >= V, "ce_loss: bad arguments");
   const long rows = (long)N * (T - 1);
   LL_CHECK(workspace && workspace_bytes >= rows * 8, "ce_loss: workspace of >= 8 N (T - 1) bytes (per-position terms) is required");
-  hipLaunchKernelGGL(ce_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, labels, (float*)workspace, T, (long)V,
+  LL_LAUNCH_KERNEL(ce_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, labels, (float*)workspace, T, (long)V,
                      (long)ldl);
-  hipLaunchKernelGGL(fold_column_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, rows, acc, 1.f);
+  LL_LAUNCH_KERNEL(fold_column_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, rows, acc, 1.f);
   LL_LAUNCH_CHECK("ce_loss");
   return LLMSEG_OK;
 }
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(256) void inter_union_kernel(const uint8_t* __restr
 extern "C" int llmseg_intersection_union(const uint8_t* pred, const uint8_t* target, int64_t n, int32_t ignore_index, int64_t* out, void* stream) {
   LL_CHECK(pred && target && out && n > 0, "intersection_union: bad arguments");
   long g = (n + 256 * 16 - 1) / (256 * 16);
-  hipLaunchKernelGGL(inter_union_kernel, dim3((unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g))), dim3(256), 0, (hipStream_t)stream, pred, target, (long)n,
+  LL_LAUNCH_KERNEL(inter_union_kernel, dim3((unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g))), dim3(256), 0, (hipStream_t)stream, pred, target, (long)n,
                      ignore_index, (unsigned long long*)out);
   LL_LAUNCH_CHECK("intersection_union");
   return LLMSEG_OK;
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void union_resize_iou_kernel(const uint8_t* __
 extern "C" int llmseg_union_resize_iou(const uint8_t* segs, const uint8_t* select, const uint8_t* gt, int32_t H, int32_t W, int32_t K, int32_t Hg,
                                        int32_t Wg, int32_t out_h, int32_t out_w, int32_t ignore_index, int64_t* out, void* stream) {
   LL_CHECK(segs && select && gt && out && H > 0 && W > 0 && K > 0 && Hg > 0 && Wg > 0 && out_h > 0 && out_w > 0, "union_resize_iou: bad arguments");
-  hipLaunchKernelGGL(union_resize_iou_kernel, dim3(1024), dim3(256), (size_t)K, (hipStream_t)stream, segs, select, gt, H, W, K, Hg, Wg, out_h, out_w,
+  LL_LAUNCH_KERNEL(union_resize_iou_kernel, dim3(1024), dim3(256), (size_t)K, (hipStream_t)stream, segs, select, gt, H, W, K, Hg, Wg, out_h, out_w,
                      ignore_index, (unsigned long long*)out);
   LL_LAUNCH_CHECK("union_resize_iou");
   return LLMSEG_OK;

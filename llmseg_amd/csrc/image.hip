@@ -243,14 +243,14 @@ extern "C" int llmseg_image_resize_u8(const uint8_t* in, int64_t in_row_stride, 
   }
   if (do_h) {
     uint8_t* dst = do_v ? mid : out;
-    hipLaunchKernelGGL(pil_taps_kernel, dim3((unsigned)((out_w + 255) / 256)), dim3(256), 0, s, tabw, in_w, out_w, kw);
-    hipLaunchKernelGGL(pil_pass_kernel<true>, dim3((unsigned)((out_w * channels + 255) / 256), (unsigned)in_h), dim3(256), 0, s, src, src_stride, dst, (long)out_w * channels,
+    LL_LAUNCH_KERNEL(pil_taps_kernel, dim3((unsigned)((out_w + 255) / 256)), dim3(256), 0, s, tabw, in_w, out_w, kw);
+    LL_LAUNCH_KERNEL(pil_pass_kernel<true>, dim3((unsigned)((out_w * channels + 255) / 256), (unsigned)in_h), dim3(256), 0, s, src, src_stride, dst, (long)out_w * channels,
                        tabw, kw, in_h, out_w, channels);
     src = dst; src_stride = (long)out_w * channels;
   }
   if (do_v) {
-    hipLaunchKernelGGL(pil_taps_kernel, dim3((unsigned)((out_h + 255) / 256)), dim3(256), 0, s, tabh, in_h, out_h, kh);
-    hipLaunchKernelGGL(pil_pass_kernel<false>, dim3((unsigned)((out_w * channels + 255) / 256), (unsigned)out_h), dim3(256), 0, s, src, src_stride, out, (long)out_w * channels,
+    LL_LAUNCH_KERNEL(pil_taps_kernel, dim3((unsigned)((out_h + 255) / 256)), dim3(256), 0, s, tabh, in_h, out_h, kh);
+    LL_LAUNCH_KERNEL(pil_pass_kernel<false>, dim3((unsigned)((out_w * channels + 255) / 256), (unsigned)out_h), dim3(256), 0, s, src, src_stride, out, (long)out_w * channels,
                        tabh, kh, out_h, out_w, channels);
   }
   LL_LAUNCH_CHECK("image_resize");
@@ -261,7 +261,7 @@ extern "C" int llmseg_sam_preprocess(const uint8_t* in, void* out, int32_t h, in
   LL_CHECK(in && out && mean && std_ && h > 0 && w > 0 && h <= img_size && w <= img_size && img_size < 65536, "sam_preprocess: bad arguments");
   Norm3 nm;
   for (int c = 0; c < 3; ++c) { nm.mean[c] = mean[c]; nm.inv_std_is_div[c] = std_[c]; }
-  hipLaunchKernelGGL(sam_preprocess_kernel, dim3((unsigned)((img_size + 255) / 256), (unsigned)img_size), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, h, w, img_size, nm);
+  LL_LAUNCH_KERNEL(sam_preprocess_kernel, dim3((unsigned)((img_size + 255) / 256), (unsigned)img_size), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, h, w, img_size, nm);
   LL_LAUNCH_CHECK("sam_preprocess");
   return LLMSEG_OK;
 }
@@ -286,13 +286,13 @@ extern "C" int llmseg_mask_small_regions(uint8_t* masks, int32_t K, int32_t H, i
   LL_CHECK(hipMemsetAsync(changed, 0, (size_t)K, s) == hipSuccess, "mask_small_regions: memset failed");
   for (int mode = 0; mode < 2; ++mode) {                     // "holes", then "islands" on its result (automatic_mask_generator.py:347-350)
     LL_CHECK(hipMemsetAsync(st, 0, (size_t)(align256((long)K * 8) + align256((long)K * 8)), s) == hipSuccess, "mask_small_regions: memset failed");
-    if (mode == 0) hipLaunchKernelGGL(cc_init_kernel<true>, flat, dim3(256), 0, s, masks, L, sz, n);
-    else hipLaunchKernelGGL(cc_init_kernel<false>, flat, dim3(256), 0, s, masks, L, sz, n);
-    hipLaunchKernelGGL(cc_merge_kernel, tile, dim3(256), 0, s, L, H, W);
-    hipLaunchKernelGGL(cc_count_kernel, flat, dim3(256), 0, s, L, sz, n);
-    hipLaunchKernelGGL(cc_stats_kernel, flat, dim3(256), 0, s, L, sz, n, min_area, st, best);
-    if (mode == 0) hipLaunchKernelGGL(cc_apply_kernel<true>, flat, dim3(256), 0, s, masks, L, sz, n, min_area, st, best, changed);
-    else hipLaunchKernelGGL(cc_apply_kernel<false>, flat, dim3(256), 0, s, masks, L, sz, n, min_area, st, best, changed);
+    if (mode == 0) LL_LAUNCH_KERNEL(cc_init_kernel<true>, flat, dim3(256), 0, s, masks, L, sz, n);
+    else LL_LAUNCH_KERNEL(cc_init_kernel<false>, flat, dim3(256), 0, s, masks, L, sz, n);
+    LL_LAUNCH_KERNEL(cc_merge_kernel, tile, dim3(256), 0, s, L, H, W);
+    LL_LAUNCH_KERNEL(cc_count_kernel, flat, dim3(256), 0, s, L, sz, n);
+    LL_LAUNCH_KERNEL(cc_stats_kernel, flat, dim3(256), 0, s, L, sz, n, min_area, st, best);
+    if (mode == 0) LL_LAUNCH_KERNEL(cc_apply_kernel<true>, flat, dim3(256), 0, s, masks, L, sz, n, min_area, st, best, changed);
+    else LL_LAUNCH_KERNEL(cc_apply_kernel<false>, flat, dim3(256), 0, s, masks, L, sz, n, min_area, st, best, changed);
   }
   LL_LAUNCH_CHECK("mask_small_regions");
   return LLMSEG_OK;
@@ -304,9 +304,9 @@ extern "C" int llmseg_mask_boxes(const uint8_t* masks, int32_t K, int32_t H, int
   LL_CHECK(workspace && workspace_bytes >= (int64_t)K * 20, "mask_boxes: workspace of 20 bytes per mask");
   hipStream_t s = (hipStream_t)stream;
   int* acc = (int*)workspace;
-  hipLaunchKernelGGL(mask_boxes_init_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, acc, K);
-  hipLaunchKernelGGL(mask_boxes_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H, (unsigned)K), dim3(256), 0, s, masks, H, W, acc);
-  hipLaunchKernelGGL(mask_boxes_finish_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, acc, K, boxes, areas);
+  LL_LAUNCH_KERNEL(mask_boxes_init_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, acc, K);
+  LL_LAUNCH_KERNEL(mask_boxes_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H, (unsigned)K), dim3(256), 0, s, masks, H, W, acc);
+  LL_LAUNCH_KERNEL(mask_boxes_finish_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, acc, K, boxes, areas);
   LL_LAUNCH_CHECK("mask_boxes");
   return LLMSEG_OK;
 }

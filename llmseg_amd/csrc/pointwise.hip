@@ -289,7 +289,7 @@ extern "C" int llmseg_norm(const void* x, const void* w, const void* b, void* y,
   const int cpl = (int)(((cols >> 3) + 63) / 64);
   const dim3 grid((unsigned)((rows + 3) / 4));
 #define LL_NORM(C)                                                                                                                   \
-  hipLaunchKernelGGL(norm_kernel<C>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, \
+  LL_LAUNCH_KERNEL(norm_kernel<C>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, \
                      (bf16_t*)y, (long)rows, (int)cols, (long)ldx, (long)ldy, eps, rms, row_map)
   if (cpl <= 1) LL_NORM(1); else if (cpl <= 2) LL_NORM(2); else if (cpl <= 3) LL_NORM(3); else if (cpl <= 4) LL_NORM(4);
   else if (cpl <= 8) LL_NORM(8); else if (cpl <= 16) LL_NORM(16); else LL_NORM(0);
@@ -303,7 +303,7 @@ extern "C" int llmseg_rope(void* x, const float* cos, const float* sin, int64_t 
   LL_CHECK(x && cos && sin && rows > 0 && T > 0 && heads > 0, "rope: bad arguments");
   LL_CHECK((head_dim & 15) == 0 && (ld & 7) == 0 && AL16(x), "rope: head_dim %% 16 and 16-byte alignment required");
   const long total = rows * heads * (head_dim >> 4);
-  hipLaunchKernelGGL(rope_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, cos, sin, (long)rows, (long)T, heads,
+  LL_LAUNCH_KERNEL(rope_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, cos, sin, (long)rows, (long)T, heads,
                      head_dim, (long)ld);
   LL_LAUNCH_CHECK("rope");
   return LLMSEG_OK;
@@ -315,7 +315,7 @@ extern "C" int llmseg_rope_kv_append(void* qkv, int64_t ld, const float* cos, co
   LL_CHECK((head_dim & 15) == 0 && (ld & 7) == 0 && (cache_stride_n & 7) == 0 && AL16(qkv) && AL16(kcache) && AL16(vcache),
            "rope_kv_append: head_dim %% 16 and 16-byte alignment required");
   const long total = N * 3 * heads * (head_dim >> 4);
-  hipLaunchKernelGGL(rope_kv_append_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv, (long)ld, cos, sin, (bf16_t*)kcache,
+  LL_LAUNCH_KERNEL(rope_kv_append_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv, (long)ld, cos, sin, (bf16_t*)kcache,
                      (bf16_t*)vcache, (long)cache_stride_n, pos_dev, (long)N, heads, head_dim);
   LL_LAUNCH_CHECK("rope_kv_append");
   return LLMSEG_OK;
@@ -323,14 +323,14 @@ extern "C" int llmseg_rope_kv_append(void* qkv, int64_t ld, const float* cos, co
 
 extern "C" int llmseg_act(const void* x, void* y, int64_t n, int32_t act, void* stream) {
   LL_CHECK(x && y && n > 0 && (n & 7) == 0 && AL16(x) && AL16(y), "act: n %% 8 and 16-byte alignment required");
-  hipLaunchKernelGGL(act_kernel, dim3(grid_for(n >> 3)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (long)(n >> 3), act);
+  LL_LAUNCH_KERNEL(act_kernel, dim3(grid_for(n >> 3)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (long)(n >> 3), act);
   LL_LAUNCH_CHECK("act");
   return LLMSEG_OK;
 }
 
 extern "C" int llmseg_swiglu(const void* gu, void* out, int64_t rows, int64_t I, int64_t ldgu, int64_t ldo, void* stream) {
   LL_CHECK(gu && out && rows > 0 && I > 0 && (I & 7) == 0 && (ldgu & 7) == 0 && (ldo & 7) == 0 && AL16(gu) && AL16(out), "swiglu: bad arguments");
-  hipLaunchKernelGGL(swiglu_kernel, dim3(grid_for(rows * (I >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gu, (bf16_t*)out,
+  LL_LAUNCH_KERNEL(swiglu_kernel, dim3(grid_for(rows * (I >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gu, (bf16_t*)out,
                      (long)rows, (long)I, (long)ldgu, (long)ldo);
   LL_LAUNCH_CHECK("swiglu");
   return LLMSEG_OK;
@@ -338,7 +338,7 @@ extern "C" int llmseg_swiglu(const void* gu, void* out, int64_t rows, int64_t I,
 
 extern "C" int llmseg_add_rows(const void* x, const void* add, void* y, int64_t rows, int64_t cols, int64_t add_rows, void* stream) {
   LL_CHECK(x && add && y && rows > 0 && (cols & 7) == 0 && add_rows > 0 && AL16(x) && AL16(add) && AL16(y), "add_rows: bad arguments");
-  hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(rows * (cols >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)add,
+  LL_LAUNCH_KERNEL(add_rows_kernel, dim3(grid_for(rows * (cols >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)add,
                      (bf16_t*)y, (long)rows, (long)cols, (long)add_rows);
   LL_LAUNCH_CHECK("add_rows");
   return LLMSEG_OK;
@@ -348,7 +348,7 @@ extern "C" int llmseg_patchify(const void* img, void* cols, int32_t B, int32_t H
                                int64_t out_row_offset, void* stream) {
   LL_CHECK(img && cols && B > 0 && p > 0 && H % p == 0 && W % p == 0 && ldo >= 3L * p * p, "patchify: bad arguments");
   const long total = (long)B * (H / p) * (W / p) * (3 * p + 1);
-  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)img, (bf16_t*)cols, B, H, W, p,
+  LL_LAUNCH_KERNEL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)img, (bf16_t*)cols, B, H, W, p,
                      (long)ldo, (long)out_rows_per_img, (long)out_row_offset);
   LL_LAUNCH_CHECK("patchify");
   return LLMSEG_OK;
@@ -356,7 +356,7 @@ extern "C" int llmseg_patchify(const void* img, void* cols, int32_t B, int32_t H
 
 extern "C" int llmseg_im2col3x3(const void* x, void* cols, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
   LL_CHECK(x && cols && B > 0 && H > 0 && W > 0 && (C & 7) == 0 && AL16(x) && AL16(cols), "im2col3x3: bad arguments");
-  hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for((long)B * H * W * 9 * (C >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+  LL_LAUNCH_KERNEL(im2col3x3_kernel, dim3(grid_for((long)B * H * W * 9 * (C >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                      (bf16_t*)cols, B, H, W, C);
   LL_LAUNCH_CHECK("im2col3x3");
   return LLMSEG_OK;
@@ -366,7 +366,7 @@ extern "C" int llmseg_embed_splice(const int64_t* ids, const void* embed, const 
                                    int32_t H, int64_t vocab, int64_t feats_stride_n, void* stream) {
   LL_CHECK(ids && embed && img_feats && out && N > 0 && L > 0 && P > 0 && (H & 7) == 0 && (feats_stride_n & 7) == 0 && AL16(embed) && AL16(img_feats) &&
            AL16(out), "embed_splice: bad arguments");
-  hipLaunchKernelGGL(embed_splice_kernel, dim3((unsigned)(N * (L - 1 + P))), dim3(256), 0, (hipStream_t)stream, ids, (const bf16_t*)embed,
+  LL_LAUNCH_KERNEL(embed_splice_kernel, dim3((unsigned)(N * (L - 1 + P))), dim3(256), 0, (hipStream_t)stream, ids, (const bf16_t*)embed,
                      (const bf16_t*)img_feats, (bf16_t*)out, N, L, P, H, (long)vocab, (long)feats_stride_n);
   LL_LAUNCH_CHECK("embed_splice");
   return LLMSEG_OK;
@@ -374,7 +374,7 @@ extern "C" int llmseg_embed_splice(const int64_t* ids, const void* embed, const 
 
 extern "C" int llmseg_gather_rows(const void* x, const int64_t* idx, void* out, int64_t n, int64_t cols, int64_t ldx, void* stream) {
   LL_CHECK(x && idx && out && n > 0 && (cols & 7) == 0 && (ldx & 7) == 0 && AL16(x) && AL16(out), "gather_rows: bad arguments");
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n * (cols >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, idx, (bf16_t*)out,
+  LL_LAUNCH_KERNEL(gather_rows_kernel, dim3(grid_for(n * (cols >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, idx, (bf16_t*)out,
                      (long)n, (long)cols, (long)ldx);
   LL_LAUNCH_CHECK("gather_rows");
   return LLMSEG_OK;

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void resize_aa_kernel(const uint8_t* __restric
 extern "C" int llmseg_rle_decode(const uint32_t* run_ends, const int64_t* offsets, uint8_t* out, int32_t K, int32_t H, int32_t W, int32_t hwk, void* stream) {
   LL_CHECK(run_ends && offsets && out && K > 0 && H > 0 && W > 0 && (long)H * W < (1L << 32), "rle_decode: bad arguments");
   const long n = (long)K * H * W;
-  hipLaunchKernelGGL(rle_decode_kernel, dim3((unsigned)((n + 255) / 256 > 65535 * 16 ? 65535 * 16 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, run_ends,
+  LL_LAUNCH_KERNEL(rle_decode_kernel, dim3((unsigned)((n + 255) / 256 > 65535 * 16 ? 65535 * 16 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, run_ends,
                      offsets, out, K, H, W, hwk);
   LL_LAUNCH_CHECK("rle_decode");
   return LLMSEG_OK;
@@ -116,9 +116,9 @@ extern "C" int llmseg_mask_targets(const uint8_t* segs, const uint8_t* gt, const
   LL_CHECK(segs && gt && gy && gx && counts && gt_area && iou && iop && K > 0 && H > 0 && W > 0 && Hg > 0 && Wg > 0, "mask_targets: bad arguments");
   const long n = (long)H * W;
   const unsigned bx = (unsigned)((n + 256 * 16 - 1) / (256 * 16));
-  hipLaunchKernelGGL(mask_targets_kernel, dim3(bx < 1 ? 1 : (bx > 256 ? 256 : bx), (unsigned)K), dim3(256), 0, (hipStream_t)stream, segs, gt, gy, gx, H, W, Wg,
+  LL_LAUNCH_KERNEL(mask_targets_kernel, dim3(bx < 1 ? 1 : (bx > 256 ? 256 : bx), (unsigned)K), dim3(256), 0, (hipStream_t)stream, segs, gt, gy, gx, H, W, Wg,
                      (unsigned long long*)counts, (unsigned long long*)gt_area);
-  hipLaunchKernelGGL(targets_finalize_kernel, dim3((unsigned)((K + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (const unsigned long long*)counts,
+  LL_LAUNCH_KERNEL(targets_finalize_kernel, dim3((unsigned)((K + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (const unsigned long long*)counts,
                      (const unsigned long long*)gt_area, iou, iop, K);
   LL_LAUNCH_CHECK("mask_targets");
   return LLMSEG_OK;
@@ -127,7 +127,7 @@ extern "C" int llmseg_mask_targets(const uint8_t* segs, const uint8_t* gt, const
 extern "C" int llmseg_resize_aa(const uint8_t* segs, void* out, int32_t K, int32_t H, int32_t W, int32_t out_size, const int32_t* y0, const int32_t* ny,
                                 const double* wy, const int32_t* x0, const int32_t* nx, const double* wx, int32_t taps, void* stream) {
   LL_CHECK(segs && out && y0 && ny && wy && x0 && nx && wx && K > 0 && H > 0 && W > 0 && out_size > 0 && taps > 0, "resize_aa: bad arguments");
-  hipLaunchKernelGGL(resize_aa_kernel, dim3((unsigned)((out_size + 255) / 256), (unsigned)out_size, (unsigned)K), dim3(256), 0, (hipStream_t)stream, segs,
+  LL_LAUNCH_KERNEL(resize_aa_kernel, dim3((unsigned)((out_size + 255) / 256), (unsigned)out_size, (unsigned)K), dim3(256), 0, (hipStream_t)stream, segs,
                      (bf16_t*)out, H, W, out_size, y0, ny, wy, x0, nx, wx, taps);
   LL_LAUNCH_CHECK("resize_aa");
   return LLMSEG_OK;

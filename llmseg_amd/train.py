@@ -217,7 +217,7 @@ class Trainer:
 
     def __init__(self, module, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.0, clip=1.0, grad_accum=10, warmup=100, total_steps=5000,
                  optimizer=None, device_ids=None, force_ddp=False, ddp_wrapper=False, use_graph=False, graph_warmup=2, use_arena=None,
-                 reduce_chunk_mb=128, sync_init=True, check_every=0):
+                 reduce_chunk_mb=128, sync_init=True, check_every=0, leaf_stream=True):
         """optimizer: None = HipAdamW; or a factory `params -> optimizer` / an optimizer object (CPU tests).  use_arena: None = automatic
         (the HIP model with the built-in optimizer), True = force the fp32 gradient arena (the module's autograd Functions must honour `_g32`)."""
         self.module = module
@@ -251,6 +251,7 @@ class Trainer:
         self.graph_error = None
         self.grad_hook = None
         self.reduce_chunk = max(1, int(reduce_chunk_mb * (1 << 20) // 4))       # fp32 elements per all-reduce chunk of the arena
+        self.leaf_stream = bool(leaf_stream)                                     # weight-gradient kernels of the arena on a side stream (autograd.Leaves)
         self.check_every = int(check_every)                                      # > 0: `check_replicas()` after every N-th optimizer step (two 16-byte all-reduces)
         self.rank = dist.get_rank() if self.dist_on else 0
         if is_hip_model and self.dist_on:
@@ -339,9 +340,19 @@ class Trainer:
             self.optimizer_step()
         return out
 
+    def _backward(self, loss):
+        """loss.backward() with the arena's weight-gradient kernels on the side stream (`autograd.Leaves`), joined before returning."""
+        from .autograd import Leaves
+        Leaves.on = self.leaf_stream
+        try:
+            loss.backward()
+        finally:
+            Leaves.join()
+            Leaves.on = False
+
     def _eager_step(self, batch, plan):
         out = self.module.model_forward(**batch, plan=plan)
-        out["loss"].backward()
+        self._backward(out["loss"])
         return out
 
     def _graph_step(self, batch, plan):
@@ -384,7 +395,7 @@ class Trainer:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             out = self.module.model_forward(**sb, plan=gplan)
-            out["loss"].backward()
+            self._backward(out["loss"])
         ent.update(graph=g, batch=sb, plan=gplan, last_plan=plan, out={k: v.detach() for k, v in out.items() if torch.is_tensor(v)})
 
     # ------------------------------------------------------------------------------------------------ optimizer step
