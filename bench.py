@@ -227,7 +227,7 @@ def loader_in_loop(model, cfg, args, B, dev, dist, rank, world, local, trainer_c
         with torch.cuda.stream(side):                     # no dependence on the main stream: the proposals are resident, the outputs are fresh tensors
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            tg = [targets.proposals_and_targets_dense(props[j], areas[j], [gts[j]], top=args.masks) for j in range(B)]
+            tg = [targets.proposals_and_targets_dense(props[j], areas[j], [gts[j]], top=args.masks, want_origin=False) for j in range(B)]
             e1.record()
         n2_events.append((e0, e1))
         return tg, e1

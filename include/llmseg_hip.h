@@ -324,6 +324,15 @@ int llmseg_union_resize_iou(const uint8_t* segs, const uint8_t* select, const ui
  * resize_aa: proposal maps (utils/reason_seg_dataset.py:166-173): masks uint8 [K][H][W], zero-padded bottom / right to the square of side
  *   max(H, W), resampled to out_size x out_size with torch's antialiased bilinear filter, written as bf16 [K][out][out].  Tap tables per
  *   output index (first source index, tap count, float64 weights [out][taps]) come from the host (aten `_compute_indices_weights_aa`). */
+/* One pass over the proposals (round 4): gt_resample writes the ground truth on the proposals' grid once (gtp uint8 [H][W] = gt[gy[y]][gx[x]] != 0);
+ * proposal_targets reads every selected proposal ONCE -- proposal k is masks[order[k]] (order int64 [K] or NULL = identity: no gathered copy) --
+ * and produces the bf16 [K][out][out] antialiased maps (the arithmetic of llmseg_resize_aa, evaluated separably: bit-identical) AND, for n_gt <= 4
+ * ground truths gtp [n_gt][H][W], counts int64 [n_gt][K][2] = {|seg & gt'|, |seg|}, gt_area int64 [n_gt], iou / iop double [n_gt][K] (all plainly
+ * written).  Limits: out_size <= 256, taps <= 28, W <= 2048; beyond them use llmseg_mask_targets + llmseg_resize_aa. */
+int llmseg_gt_resample(const uint8_t* gt, const int32_t* gy, const int32_t* gx, uint8_t* out, int32_t H, int32_t W, int32_t Hg, int32_t Wg, void* stream);
+int llmseg_proposal_targets(const uint8_t* masks, const int64_t* order, const uint8_t* gtp, int32_t n_gt, void* out, int32_t K, int32_t H, int32_t W,
+                            int32_t out_size, const int32_t* y0, const int32_t* ny, const double* wy, const int32_t* x0, const int32_t* nx,
+                            const double* wx, int32_t taps, int64_t* counts, int64_t* gt_area, double* iou, double* iop, void* stream);
 int llmseg_rle_decode(const uint32_t* run_ends, const int64_t* offsets, uint8_t* out, int32_t K, int32_t H, int32_t W, int32_t hwk, void* stream);
 int llmseg_mask_targets(const uint8_t* segs, const uint8_t* gt, const int32_t* gy, const int32_t* gx, int32_t K, int32_t H, int32_t W, int32_t Hg,
                         int32_t Wg, int64_t* counts, int64_t* gt_area, double* iou, double* iop, void* stream);
@@ -390,6 +399,13 @@ int llmseg_lora_down_ws(const void* x0, const void* x1, int64_t ldx, const void*
 /* workspace: up to 32 row slices x (1 or 2 branches) x 8 N floats of partials (NULL: one slice) */
 int llmseg_lora_outer(const void* a0, const void* a1, int64_t lda, const void* b0, const void* b1, int64_t ldb, float* out0, float* out1, int64_t M,
                       int64_t N, int32_t out_rn, float alpha, const llmseg_dropout* drop, void* workspace, int64_t workspace_bytes, void* stream);
+/* The four weight gradients of a LoRA'd q|k|v projection in ONE launch (+ one fold): with d = dqkv (dq, dv: column blocks at row pitch ldd),
+ * xa = [drop_q(x) Aq^T | drop_v(x) Av^T] [M][>= 16] (the forward's extension operand), t = [s dq Bq | s dv Bv] [M][>= 16]:
+ *   gbq [H][8] += s dq^T xa[:, 0:8],  gbv [H][8] += s dv^T xa[:, 8:16],  gaq [8][H] += t[:, 0:8]^T drop_q(x),  gav [8][H] += t[:, 8:16]^T drop_v(x)
+ * (dropout streams drop->stream / + 1, as llmseg_lora_down uses them).  workspace: up to 32 row slices x 4 x 8 H floats. */
+int llmseg_lora_wgrads(const void* dq, const void* dv, int64_t ldd, const void* x, int64_t ldx, const void* xa, int64_t ldxa, const void* t, int64_t ldt,
+                       float* gbq, float* gbv, float* gaq, float* gav, int64_t M, int64_t H, float s, const llmseg_dropout* drop, void* workspace,
+                       int64_t workspace_bytes, void* stream);
 int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, int64_t ldxa, const void* w0, const void* w1, int64_t M, int64_t N, int32_t w_rn,
                       float alpha, const llmseg_dropout* drop, void* stream);
 int llmseg_lora_pack(const void* aq, const void* bq, const void* av, const void* bv, void* w2b, void* w2a, void* bt, int64_t H, float s, void* stream);

@@ -106,6 +106,8 @@ SIGNATURES = {
     "llmseg_union_resize_iou": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p],
     "llmseg_rle_decode": [_p, _p, _p, _i32, _i32, _i32, _i32, _p],
     "llmseg_mask_targets": [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p],
+    "llmseg_gt_resample": [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p],
+    "llmseg_proposal_targets": [_p, _p, _p, _i32, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p],
     "llmseg_resize_aa": [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p],
     "llmseg_colsum": [_p, _p, _i64, _i64, _i64, _p, _i64, _p],
     "llmseg_norm_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _f32, C.c_int, _p, _i64, _p],
@@ -119,6 +121,7 @@ SIGNATURES = {
     "llmseg_lora_down": [_p, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i32, _f32, _i32, _dp, _p],
     "llmseg_lora_down_ws": [_p, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i32, _f32, _i32, _dp, _p, _i64, _p],
     "llmseg_lora_outer": [_p, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _i32, _f32, _dp, _p, _i64, _p],
+    "llmseg_lora_wgrads": [_p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _f32, _dp, _p, _i64, _p],
     "llmseg_lora_apply": [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i32, _f32, _dp, _p],
     "llmseg_lora_pack": [_p, _p, _p, _p, _p, _p, _p, _i64, _f32, _p],
     "llmseg_transpose_pad": [_p, _p, _i64, _i64, _i64, _i64, _i64, _p],

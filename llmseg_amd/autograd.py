@@ -200,12 +200,18 @@ class LoraQKVFn(Function):
             ops.gemm(xaq, bq, residual=qkv[:, :H], out=qkv[:, :H], alpha=s)
             ops.gemm(xav, bv, residual=qkv[:, 2 * H:], out=qkv[:, 2 * H:], alpha=s)
         ctx.s = s
-        ctx.save_for_backward(x, wqkv, aq, bq, av, bv, xaq, xav)
+        if ctx.fast:
+            ctx.save_for_backward(x, wqkv, aq, bq, av, bv, a2, None)      # the [M, 64] extension operand itself (xaq / xav are its first 16 columns)
+        else:
+            ctx.save_for_backward(x, wqkv, aq, bq, av, bv, xaq, xav)
         return qkv
 
     @staticmethod
     def backward(ctx, d):
         x, wqkv, aq, bq, av, bv, xaq, xav = ctx.saved_tensors
+        if ctx.fast:
+            a2 = xaq
+            xaq, xav = a2[:, :8], a2[:, 8:16]
         s, H = ctx.s, wqkv.shape[1]
         d = d.contiguous()
         M = d.shape[0]
@@ -227,11 +233,12 @@ class LoraQKVFn(Function):
                 b_ = ops.lora_outer(dq, xaq, alpha=s, out=gbq, a2=dv, b2=xav, out2=gbv)               # [H, 8] = s d^T (drop(x) A^T)
                 a_ = ops.lora_outer(x, tq, out_rn=True, out=gaq, drop=drq, a2=x, b2=tv, out2=gav)      # [8, H] = t^T drop(x)
                 return b_, a_
-            if all(g is not None for g in ctx.g):
-                (dbq, dbv), (daq, dav) = Leaves.run(wgrads, d, x, t2, xaq, xav)
+            if all(g is not None for g in ctx.g):                            # arena mode: the four gradients in ONE launch (+ one fold), off the main chain
+                Leaves.run(lambda: ops.lora_wgrads(d, H, x, a2, t2, gbq, gbv, gaq, gav, s, drop=drq), d, x, t2, a2)
+                dbq = dbv = daq = dav = None
             else:
                 (dbq, dbv), (daq, dav) = wgrads()
-            outs = [None if g is not None else t.to(BF16) for g, t in ((gaq, daq), (gbq, dbq), (gav, dav), (gbv, dbv))]
+            outs = [None if (g is not None or t is None) else t.to(BF16) for g, t in ((gaq, daq), (gbq, dbq), (gav, dav), (gbv, dbv))]
             return dx, None, outs[0], outs[1], outs[2], outs[3], None, None, None
         tq = ops.gemm(dq, bq, trans_w=True, alpha=s)                      # [M, r] = s dq Bq
         tv = ops.gemm(dv, bv, trans_w=True, alpha=s)

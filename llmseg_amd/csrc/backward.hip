@@ -154,6 +154,68 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16_t* __restri
   }
 }
 
+// Norm backward for a FROZEN weight (no dw / db) with a WORKGROUP per row: short, wide activations (Llama at two images per step: 638 rows x
+// 4096 columns) leave most of the chip idle with one wave per row (14 us for 21 MB); 4 waves per row keep 4 x the loads in flight.
+template <int CPT>
+__global__ __launch_bounds__(256) void norm_bwd_wg_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                         bf16_t* __restrict__ dx, long rows, int cols, float eps, int rms, const bf16_t* __restrict__ dres) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const int nch = cols >> 3;
+  const bf16_t* xr = x + row * cols;
+  const bf16_t* gr = dy + row * cols;
+  uint4 xc[CPT], gc[CPT], wc[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    const bool on = c < nch;
+    xc[i] = on ? *reinterpret_cast<const uint4*>(xr + c * 8) : make_uint4(0, 0, 0, 0);
+    gc[i] = on ? *reinterpret_cast<const uint4*>(gr + c * 8) : make_uint4(0, 0, 0, 0);
+    wc[i] = on ? *reinterpret_cast<const uint4*>(w + c * 8) : make_uint4(0, 0, 0, 0);
+  }
+  float f[8], g[8], ww[8];
+  float s = 0.f;
+  if (!rms) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) { unpack8(xc[i], f); _Pragma("unroll") for (int e = 0; e < 8; ++e) s += f[e]; }
+    s = block_sum(s, red);
+  }
+  const float mean = rms ? 0.f : s / (float)cols;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i)
+    if (threadIdx.x + 256 * i < nch) { unpack8(xc[i], f); _Pragma("unroll") for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; v += d * d; } }
+  v = block_sum(v, red);
+  const float rstd = rsqrtf(v / (float)cols + eps);
+  float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i)
+    if (threadIdx.x + 256 * i < nch) {
+      unpack8(xc[i], f); unpack8(gc[i], g); unpack8(wc[i], ww);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float xh = (f[e] - mean) * rstd, gg = g[e] * ww[e]; c1 += gg; c2 += gg * xh; }
+    }
+  c1 = rms ? 0.f : block_sum(c1, red) / (float)cols;
+  c2 = block_sum(c2, red) / (float)cols;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    if (c < nch) {
+      float o[8];
+      unpack8(xc[i], f); unpack8(gc[i], g); unpack8(wc[i], ww);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float xh = (f[e] - mean) * rstd; o[e] = rstd * (g[e] * ww[e] - c1 - xh * c2); }
+      if (dres) {
+        float rr[8];
+        unpack8(*reinterpret_cast<const uint4*>(dres + row * cols + c * 8), rr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += rr[e];
+      }
+      *reinterpret_cast<uint4*>(dx + row * cols + c * 8) = pack8(o);
+    }
+  }
+}
+
 // Column sums of a wide norm's backward from the stored row statistics: dw[c] = sum_r dy[r][c] (x[r][c] - mean_r) rstd_r, db[c] = sum_r dy[r][c].
 // Block = 64 columns x 4 row-lanes, grid.y = row slices -> part[slice][2][cols] (slices folded in order), or straight into dw / db for one slice.
 __global__ __launch_bounds__(256) void norm_dwdb_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ stats,
@@ -386,15 +448,18 @@ __global__ __launch_bounds__(256) void adamw_kernel(bf16_t* __restrict__ p, floa
 
 extern "C" int llmseg_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ld, void* workspace, int64_t workspace_bytes, void* stream) {
   LL_CHECK(x && out && M > 0 && N > 0 && ld >= N, "colsum: bad arguments");
-  long gy = min((long)64, (long)((M + 255) / 256));
+  // row slices: >= 32 rows each (8 per row-lane) and enough of them that the launch reaches ~256 workgroups -- the head's bias gradients are 512 rows
+  // x 256..2048 columns, and with 256-row slices every thread walked 64 rows one dependent load after the other (10-22 us per call)
+  const long colwg = (N + 63) / 64;
+  long gy = min((long)64, max((long)1, min((long)((M + 31) / 32), (long)((256 + colwg - 1) / colwg))));
   gy = min(gy, workspace ? (long)(workspace_bytes / (N * 4)) : 0L);          // row slices the scratch can hold; <= 1: one slice, no scratch
   float* part = gy > 1 ? (float*)workspace : nullptr;
   if (gy < 1) gy = 1;
   LL_LAUNCH_KERNEL(colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, part, (long)M,
                      (long)N, (long)ld);
   if (part)
-    LL_LAUNCH_KERNEL(fold_slices_kernel, dim3(fold_grid(N)), dim3(256), 0, (hipStream_t)stream, (const float*)part, (int)gy, (long)N, (long)N, (long)N, out,
-                       (float*)nullptr);
+    LL_LAUNCH_KERNEL(fold_slices_kernel, dim3(fold_grid(N)), dim3(256), 0, (hipStream_t)stream, (const float*)part, (int)gy, (long)N, (long)N, (long)N,
+                       FoldOut{{out, nullptr, nullptr, nullptr}});
   LL_LAUNCH_CHECK("colsum");
   return LLMSEG_OK;
 }
@@ -409,6 +474,16 @@ extern "C" int llmseg_norm_bwd_add(const void* dy, const void* x, const void* w,
   LL_CHECK(dy && x && w && dx && rows > 0 && cols > 0 && (cols & 7) == 0 && AL16(dy) && AL16(x) && AL16(w) && AL16(dx) && AL16(dres), "norm_bwd: bad arguments");
   const int cpl = (int)(((cols >> 3) + 63) / 64);
   const bool wgrad = dw || db;
+  if (!wgrad && rows >= 64 && rows < 2048 && cols >= 2048 && cols <= 8192) {        // short and wide, frozen weight: a workgroup per row
+    const int cpt = (int)(((cols >> 3) + 255) / 256);
+#define LL_NORMBW(C)                                                                                                                                    \
+  LL_LAUNCH_KERNEL(norm_bwd_wg_kernel<C>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, \
+                   (bf16_t*)dx, (long)rows, (int)cols, eps, rms, (const bf16_t*)dres)
+    if (cpt <= 1) LL_NORMBW(1); else if (cpt <= 2) LL_NORMBW(2); else LL_NORMBW(4);
+#undef LL_NORMBW
+    LL_LAUNCH_CHECK("norm_bwd");
+    return LLMSEG_OK;
+  }
   const bool acc = wgrad && cpl <= 2;
   const long wgs = (rows + 3) / 4;
   const long ws_floats = workspace ? workspace_bytes / 4 : 0;
@@ -431,7 +506,7 @@ extern "C" int llmseg_norm_bwd_add(const void* dy, const void* x, const void* w,
 #undef LL_NORMB
   if (acc && part)
     LL_LAUNCH_KERNEL(fold_slices_kernel, dim3(fold_grid(2 * cols)), dim3(256), 0, (hipStream_t)stream, (const float*)part, (int)G, (long)(2 * cols),
-                       (long)(2 * cols), (long)cols, dw, db);
+                       (long)(2 * cols), (long)cols, FoldOut{{dw, db, nullptr, nullptr}});
   if (stats) {                                                     // wide rows: column sums from the stored (mean, rstd), row slices folded in order
     float* p2 = stats + ((2 * rows + 63) / 64) * 64;
     long gy = std::min<long>(64, (rows + 255) / 256);
@@ -441,7 +516,7 @@ extern "C" int llmseg_norm_bwd_add(const void* dy, const void* x, const void* w,
                        (const float*)stats, dw, db, p2, (long)rows, (long)cols);
     if (p2)
       LL_LAUNCH_KERNEL(fold_slices_kernel, dim3(fold_grid(2 * cols)), dim3(256), 0, (hipStream_t)stream, (const float*)p2, (int)gy, (long)(2 * cols),
-                         (long)(2 * cols), (long)cols, dw, db);
+                         (long)(2 * cols), (long)cols, FoldOut{{dw, db, nullptr, nullptr}});
   }
   LL_LAUNCH_CHECK("norm_bwd");
   return LLMSEG_OK;
@@ -699,15 +774,20 @@ __global__ __launch_bounds__(256) void lora_down_finish_kernel(const float* __re
 // Workgroup = 64 columns x one slice of rows, split again over its 4 waves: lane = (row-lane 0..7, column chunk 0..7), a wave reads 8
 // rows x 128 contiguous bytes per step (16 B per lane, three steps in flight); the 8 row-lanes are folded with shuffles, the 4 waves in
 // LDS, so ONE partial per output cell per workgroup.
-struct OuterP { const bf16_t* a[2]; const bf16_t* b[2]; float* out[2]; };
-__global__ __launch_bounds__(256) void lora_outer_kernel(OuterP q, long lda, long ldb, long M, long N, int out_rn, float alpha, DropP dp,
-                                                        float* __restrict__ part) {
+// Up to FOUR products per launch (blockIdx.z), each with its own operands, pitches, output layout, scale and dropout stream (drop[z] = 0: no
+// mask, else stream id + 1): the whole weight-gradient work of a LoRA'd q|k|v projection -- dBq, dBv, dAq, dAv -- is one launch + one fold.
+struct OuterP { const bf16_t* a[4]; const bf16_t* b[4]; float* out[4]; long lda[4], ldb[4]; int out_rn[4]; float alpha[4]; uint32_t drop[4]; };
+__global__ __launch_bounds__(256) void lora_outer_kernel(OuterP q, long M, long N, DropP dp, float* __restrict__ part) {
   __shared__ float red[4][8][8 * LR];                  // [wave][column chunk][8 columns x 8 ranks]
   const int z = blockIdx.z;
   const bf16_t* __restrict__ a = q.a[z];
   const bf16_t* __restrict__ b = q.b[z];
   float* __restrict__ out = q.out[z];
-  const uint32_t dstream = dp.stream + z;
+  const long lda = q.lda[z], ldb = q.ldb[z];
+  const int out_rn = q.out_rn[z];
+  const float alpha = q.alpha[z];
+  if (q.drop[z] == 0) dp.thr = 0;
+  const uint32_t dstream = q.drop[z] - 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cl = lane & 7, rl = lane >> 3;
   const long n = ((long)blockIdx.x * 8 + cl) * 8;      // the workgroup's 4 waves cover the SAME 64 columns, each its own quarter of the row slice
@@ -938,26 +1018,49 @@ extern "C" int llmseg_lora_down_ws(const void* x0, const void* x1, int64_t ldx, 
   return LLMSEG_OK;
 }
 
-extern "C" int llmseg_lora_outer(const void* a0, const void* a1, int64_t lda, const void* b0, const void* b1, int64_t ldb, float* out0, float* out1, int64_t M,
-                                 int64_t N, int32_t out_rn, float alpha, const llmseg_dropout* drop, void* workspace, int64_t workspace_bytes, void* stream) {
-  const int nz = (a1 && b1 && out1) ? 2 : 1;
-  LL_CHECK(a0 && b0 && out0 && ((!a1) == (!b1)) && ((!a1) == (!out1)) && M > 0 && N > 0 && (N & 7) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && AL16(a0) &&
-               AL16(a1) && AL16(b0) && AL16(b1) && LL_DROP_OK(drop), "lora_outer: bad arguments (N, lda, ldb multiples of 8)");
+static int lora_outer_launch(const OuterP& q, int nz, int64_t M, int64_t N, const DropP& dp, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   // 64 columns per workgroup (its 4 waves split the rows): enough row slices to put >= 2 workgroups on every CU, each wave >= 24 rows
   const long colwg = (N + 63) / 64;
   long gy = max(max((long)1, 256 / (colwg * nz)), min((long)32, M / 512));
   gy = min(gy, workspace ? (long)(workspace_bytes / (nz * N * LR * 4)) : 0L);          // row slices the scratch can hold; <= 1: one slice, no scratch
   float* part = gy > 1 ? (float*)workspace : nullptr;
   if (gy < 1) gy = 1;
-  OuterP q;
-  q.a[0] = (const bf16_t*)a0; q.a[1] = (const bf16_t*)a1; q.b[0] = (const bf16_t*)b0; q.b[1] = (const bf16_t*)b1; q.out[0] = out0; q.out[1] = out1;
-  LL_LAUNCH_KERNEL(lora_outer_kernel, dim3((unsigned)colwg, (unsigned)gy, nz), dim3(256), 0, (hipStream_t)stream, q, (long)lda, (long)ldb, (long)M, (long)N,
-                     out_rn, alpha, make_drop(drop), part);
+  LL_LAUNCH_KERNEL(lora_outer_kernel, dim3((unsigned)colwg, (unsigned)gy, (unsigned)nz), dim3(256), 0, stream, q, (long)M, (long)N, dp, part);
   if (part)
-    LL_LAUNCH_KERNEL(fold_slices_kernel, dim3(fold_grid(nz * N * LR)), dim3(256), 0, (hipStream_t)stream, (const float*)part, (int)gy, (long)(nz * N * LR),
-                       (long)(nz * N * LR), (long)(N * LR), out0, out1);
+    LL_LAUNCH_KERNEL(fold_slices_kernel, dim3(fold_grid(nz * N * LR)), dim3(256), 0, stream, (const float*)part, (int)gy, (long)(nz * N * LR),
+                     (long)(nz * N * LR), (long)(N * LR), FoldOut{{q.out[0], q.out[1], q.out[2], q.out[3]}});
   LL_LAUNCH_CHECK("lora_outer");
   return LLMSEG_OK;
+}
+
+extern "C" int llmseg_lora_outer(const void* a0, const void* a1, int64_t lda, const void* b0, const void* b1, int64_t ldb, float* out0, float* out1, int64_t M,
+                                 int64_t N, int32_t out_rn, float alpha, const llmseg_dropout* drop, void* workspace, int64_t workspace_bytes, void* stream) {
+  const int nz = (a1 && b1 && out1) ? 2 : 1;
+  LL_CHECK(a0 && b0 && out0 && ((!a1) == (!b1)) && ((!a1) == (!out1)) && M > 0 && N > 0 && (N & 7) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && AL16(a0) &&
+               AL16(a1) && AL16(b0) && AL16(b1) && LL_DROP_OK(drop), "lora_outer: bad arguments (N, lda, ldb multiples of 8)");
+  OuterP q{};
+  const DropP dp = make_drop(drop);
+  for (int z = 0; z < nz; ++z) {
+    q.a[z] = (const bf16_t*)(z ? a1 : a0); q.b[z] = (const bf16_t*)(z ? b1 : b0); q.out[z] = z ? out1 : out0;
+    q.lda[z] = lda; q.ldb[z] = ldb; q.out_rn[z] = out_rn; q.alpha[z] = alpha; q.drop[z] = dp.thr ? dp.stream + z + 1 : 0;
+  }
+  return lora_outer_launch(q, nz, M, N, dp, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int llmseg_lora_wgrads(const void* dq, const void* dv, int64_t ldd, const void* x, int64_t ldx, const void* xa, int64_t ldxa, const void* t,
+                                  int64_t ldt, float* gbq, float* gbv, float* gaq, float* gav, int64_t M, int64_t H, float s, const llmseg_dropout* drop,
+                                  void* workspace, int64_t workspace_bytes, void* stream) {
+  LL_CHECK(dq && dv && x && xa && t && gbq && gbv && gaq && gav && M > 0 && H > 0 && (H & 7) == 0 && (ldd & 7) == 0 && (ldx & 7) == 0 && (ldxa & 7) == 0 &&
+               (ldt & 7) == 0 && ldxa >= 16 && ldt >= 16 && AL16(dq) && AL16(dv) && AL16(x) && AL16(xa) && AL16(t) && LL_DROP_OK(drop),
+           "lora_wgrads: bad arguments");
+  const DropP dp = make_drop(drop);
+  OuterP q{};
+  // dBq [H][8] += s dq^T (drop_q(x) Aq^T),  dBv likewise;  dAq [8][H] += (s dq Bq)^T drop_q(x),  dAv likewise (streams: q = drop->stream, v = + 1)
+  q.a[0] = (const bf16_t*)dq; q.b[0] = (const bf16_t*)xa;     q.out[0] = gbq; q.lda[0] = ldd; q.ldb[0] = ldxa; q.out_rn[0] = 0; q.alpha[0] = s;   q.drop[0] = 0;
+  q.a[1] = (const bf16_t*)dv; q.b[1] = (const bf16_t*)xa + 8; q.out[1] = gbv; q.lda[1] = ldd; q.ldb[1] = ldxa; q.out_rn[1] = 0; q.alpha[1] = s;   q.drop[1] = 0;
+  q.a[2] = (const bf16_t*)x;  q.b[2] = (const bf16_t*)t;      q.out[2] = gaq; q.lda[2] = ldx; q.ldb[2] = ldt;  q.out_rn[2] = 1; q.alpha[2] = 1.f; q.drop[2] = dp.thr ? dp.stream + 1 : 0;
+  q.a[3] = (const bf16_t*)x;  q.b[3] = (const bf16_t*)t + 8;  q.out[3] = gav; q.lda[3] = ldx; q.ldb[3] = ldt;  q.out_rn[3] = 1; q.alpha[3] = 1.f; q.drop[3] = dp.thr ? dp.stream + 2 : 0;
+  return lora_outer_launch(q, 4, M, H, dp, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, int64_t ldxa, const void* w0, const void* w1, int64_t M, int64_t N, int32_t w_rn,

@@ -154,16 +154,17 @@ __device__ __forceinline__ void dropout8(float* f, unsigned long idx, uint32_t s
 // per-workgroup PARTIALS into caller-owned scratch (`workspace`) and folded by one of the two kernels below in a fixed order, so a
 // training step is bit-reproducible (the reference's resume contract, training.py:404-421,460-477: same weights + optimizer state ->
 // the same continuation; with fp32 atomicAdd two runs from the same state differed in isolated elements).
-// (1) wide outputs, few partials: out[i] += sum_{p < P} part[p * pstride + i], p ascending, one thread per output element; outputs
-//     [0, n0) go to out0, [n0, n) to out1 (either may be NULL: skipped).
-static __global__ __launch_bounds__(256) void fold_slices_kernel(const float* __restrict__ part, int P, long pstride, long n, long n0,
-                                                                 float* __restrict__ out0, float* __restrict__ out1) {
+// (1) wide outputs, few partials: out[i] += sum_{p < P} part[p * pstride + i], p ascending, one thread per output element; the n outputs are
+//     up to four equal segments of n0 elements, each with its own destination (NULL: skipped).
+struct FoldOut { float* p[4]; };
+static __global__ __launch_bounds__(256) void fold_slices_kernel(const float* __restrict__ part, int P, long pstride, long n, long n0, FoldOut outs) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float* o = i < n0 ? (out0 ? out0 + i : nullptr) : (out1 ? out1 + (i - n0) : nullptr);
+    const long seg = i / n0;                       // outputs [seg n0, (seg + 1) n0) belong to outs.p[seg] (<= 4 equal segments; NULL = skipped)
+    float* o = outs.p[seg];
     if (!o) continue;
     float s = 0.f;
     for (int p = 0; p < P; ++p) s += part[(long)p * pstride + i];
-    *o += s;
+    o[i - seg * n0] += s;
   }
 }
 // (2) few outputs (n = gridDim.x), many partials: part[p * n + i]; thread t adds p = t, t + 256, ... in order, then a fixed shuffle /

@@ -585,6 +585,19 @@ def lora_outer(a, b, out_rn=False, alpha=1.0, out=None, drop=None, a2=None, b2=N
     return out if b2 is None else (out, out2)
 
 
+def lora_wgrads(d, H, x, a2, t2, gbq, gbv, gaq, gav, s, drop=None):
+    """The four LoRA weight gradients of a q|k|v projection in one launch: d = dqkv [M, 3H] (q block = columns 0..H, v block = 2H..3H),
+    x [M, H] the projection's input, a2 [M, >= 16] = [drop_q(x) Aq^T | drop_v(x) Av^T], t2 [M, >= 16] = [s dq Bq | s dv Bv];
+    gbq / gbv fp32 [H, 8] and gaq / gav fp32 [8, H] are accumulated into (arena views)."""
+    M = d.shape[0]
+    for g in (gbq, gbv, gaq, gav):
+        assert g.dtype == torch.float32 and g.is_contiguous() and g.numel() == 8 * H
+    assert d.stride(1) == 1 and x.stride(1) == 1 and a2.stride(1) == 1 and t2.stride(1) == 1 and x.shape == (M, H)
+    dq, dv = d[:, :H], d[:, 2 * H:]
+    _lib.check(_lib.load().llmseg_lora_wgrads(_ptr(dq), _ptr(dv), d.stride(0), _ptr(x), x.stride(0), _ptr(a2), a2.stride(0), _ptr(t2), t2.stride(0),
+                                              _ptr(gbq), _ptr(gbv), _ptr(gaq), _ptr(gav), M, H, s, _drop(drop), *_reduce_ws(d.device), _stream()), "lora_wgrads")
+
+
 def lora_apply_(y, xa, w, w_rn=False, alpha=1.0, drop=None, w2=None):
     """y [M, N] += alpha * mask * (xa [M, 8] @ W^T) in place; W stored [N, 8] (or [8, N] when w_rn).  y may be a column view.
     With w2: + alpha * mask2 * (xa[:, 8:16] @ W2^T) in the same pass (dropout stream + 1)."""

@@ -214,10 +214,58 @@ def proposals_and_targets(masks, gt_masks, device, top=50, out_size=256):
     return {"sam_segs": resize_square_aa(segs, out_size), "sam_ious": torch.stack(ious), "sam_iops": torch.stack(iops), "segs_origin": segs, "bbox": d["bbox"]}
 
 
-def proposals_and_targets_dense(masks, areas, gt_masks, top=50, out_size=256):
+FUSED_LIMITS = dict(out_size=256, taps=28, width=2048, n_gt=4)      # llmseg_proposal_targets' limits (csrc/targets.hip)
+
+
+def proposal_targets_fused(masks, order, gt_masks, out_size=256):
+    """One pass over the selected proposals masks[order] (uint8 [*, H, W] on the device; order int64 [K] or None): -> (maps bf16 [K, out, out],
+    ious, iops float64 [C, K], counts int64 [C, K, 2]).  None when the shape is outside the fused kernel's limits."""
+    Kall, H, W = masks.shape
+    K = Kall if order is None else int(order.numel())
+    dev = masks.device
+    side = max(H, W)
+    d_first, d_count, d_w, n_taps = _dev_taps(side, out_size, dev)
+    if out_size > FUSED_LIMITS["out_size"] or n_taps > FUSED_LIMITS["taps"] or W > FUSED_LIMITS["width"] or K == 0:
+        return None
+    lib = _lib.load()
+    gts = [torch.as_tensor(np.asarray(g) if not torch.is_tensor(g) else g).to(device=dev, dtype=torch.uint8).contiguous() for g in gt_masks]
+    C_ = len(gts)
+    out = torch.empty((K, out_size, out_size), device=dev, dtype=BF16)
+    ious = torch.empty((C_, K), device=dev, dtype=torch.float64)
+    iops = torch.empty((C_, K), device=dev, dtype=torch.float64)
+    cnts = torch.empty((C_, K, 2), device=dev, dtype=torch.int64)
+    masks = masks.contiguous()
+    first = True
+    for c0 in range(0, max(C_, 1), FUSED_LIMITS["n_gt"]):                      # groups of <= 4 ground truths; the maps come from the first launch
+        grp = gts[c0:c0 + FUSED_LIMITS["n_gt"]]
+        n = len(grp)
+        gtp = torch.empty((max(n, 1), H, W), device=dev, dtype=torch.uint8)
+        for i, g in enumerate(grp):
+            Hg, Wg = g.shape
+            _lib.check(lib.llmseg_gt_resample(_p(g), _p(_dev_nearest(H, Hg, dev)), _p(_dev_nearest(W, Wg, dev)), _p(gtp[i]), H, W, Hg, Wg, _stream()), "gt_resample")
+        garea = torch.empty((max(n, 1),), device=dev, dtype=torch.int64)
+        o = out if first else torch.empty_like(out)
+        _lib.check(lib.llmseg_proposal_targets(_p(masks), None if order is None else _p(order.contiguous()), _p(gtp), n, _p(o), K, H, W, out_size,
+                                               _p(d_first), _p(d_count), _p(d_w), _p(d_first), _p(d_count), _p(d_w), n_taps,
+                                               _p(cnts[c0:c0 + n]) if n else None, _p(garea) if n else None, _p(ious[c0:c0 + n]) if n else None,
+                                               _p(iops[c0:c0 + n]) if n else None, _stream()), "proposal_targets")
+        first = False
+    return out, ious, iops, cnts
+
+
+def proposals_and_targets_dense(masks, areas, gt_masks, top=50, out_size=256, want_origin=True):
     """The same for proposals that are already dense masks on the device (uint8 [K, H, W] + their areas, e.g. the output of
-    `LISAForCausalLM.generate_proposals`): largest `top` by area (sam_mask_reader.py:69-75), no RLE round trip."""
+    `LISAForCausalLM.generate_proposals`): largest `top` by area (sam_mask_reader.py:69-75), no RLE round trip.  The selected proposals are
+    read once, through the `order` index (`llmseg_proposal_targets`); `want_origin=False` skips the gathered uint8 copy `segs_origin`
+    (a loader that only feeds `model_forward` never reads it)."""
     order = torch.argsort(areas, descending=True, stable=True)[:top]
+    fused = proposal_targets_fused(masks, order, gt_masks, out_size)
+    if fused is not None:
+        maps, ious, iops, _ = fused
+        res = {"sam_segs": maps, "sam_ious": ious, "sam_iops": iops, "order": order}
+        if want_origin:
+            res["segs_origin"] = masks[order].contiguous()
+        return res
     segs = masks[order].contiguous()
     ious, iops = [], []
     for g in gt_masks:

@@ -369,6 +369,22 @@ def check_pointwise():
     xf = x.float()
     ref = w.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(BF).float()
     out.append(("rmsnorm", err(ops.norm(x.to(DEV), w.to(DEV), None, eps=1e-6, rms=True), ref), tol_bf16(ref)))
+    # short + wide (64 <= rows < 2048, cols >= 2048): the workgroup-per-row kernels, forward and backward (frozen weight, with the residual gradient)
+    for rows, cols in ((638, 4096), (70, 2048), (129, 5120)):
+        x, w, b = rnd(rows, cols, seed=40, scale=2.0), rnd(cols, seed=41), rnd(cols, seed=42)
+        xf = x.float()
+        ref = w.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(BF).float()
+        out.append((f"rmsnorm {rows}x{cols} (workgroup per row)", err(ops.norm(x.to(DEV), w.to(DEV), None, eps=1e-6, rms=True), ref), tol_bf16(ref)))
+        ref = F.layer_norm(xf, (cols,), w.float(), b.float(), 1e-5)
+        out.append((f"layernorm {rows}x{cols} (workgroup per row)", err(ops.norm(x.to(DEV), w.to(DEV), b.to(DEV), eps=1e-5), ref), tol_bf16(ref)))
+        dy, dres = rnd(rows, cols, seed=43), rnd(rows, cols, seed=44)
+        for rms in (True, False):
+            xr = xf.clone().requires_grad_(True)
+            yr = (w.float() * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6))) if rms else F.layer_norm(xr, (cols,), w.float(), b.float(), 1e-5)
+            yr.backward(dy.float())
+            ref = xr.grad + dres.float()
+            got = ops.norm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), 1e-6 if rms else 1e-5, rms, dres=dres.to(DEV))
+            out.append((f"{'rms' if rms else 'layer'}norm backward + residual gradient {rows}x{cols} (workgroup per row)", err(got, ref), tol_bf16(ref)))
     # row_map (window partition): map row r -> 2r+1, others stay zero
     x, w, b = rnd(50, 160, seed=6), rnd(160, seed=7), rnd(160, seed=8)
     rm = (torch.arange(50, dtype=torch.int32) * 2 + 1)

@@ -1,7 +1,9 @@
 """One micro-step of a rocprofv3 --kernel-trace run as a timeline: every kernel dispatch of the LAST complete step (between the last two
 launches of a once-per-step marker kernel) in start order -> CSV (t_start_us, dur_us, gap_us since the latest end of anything before it,
 stream / queue id, short kernel name).  For the latency analysis of the launch-bound parts (mask-selection head, Llama small kernels).
-usage: python tools/timeline.py <results.db> [marker-substring=embed_splice] > step.csv"""
+usage: python tools/timeline.py <results.db> [marker-substring=embed_splice] [steps-back=1] > step.csv
+steps-back: 1 = the last complete step, n = the n-th last (bench.py ends with eager single-stream profiling steps: go back past them to see a
+hipGraph replay)."""
 import re
 import sqlite3
 import sys
@@ -31,10 +33,11 @@ def main():
                 print(n, [c[1] for c in cur.execute(f"pragma table_info('{n}')")], file=sys.stderr)
         sys.exit(1)
     marks = [i for i, r in enumerate(rows) if marker in r[0]]
-    if len(marks) < 2:
+    if len(marks) < 2 + (int(sys.argv[3]) if len(sys.argv) > 3 else 1) - 1:
         print(f"marker {marker!r} seen {len(marks)} times", file=sys.stderr)
         sys.exit(1)
-    a, b = marks[-2], marks[-1]
+    back = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    a, b = marks[-1 - back], marks[-back]
     step = rows[a:b]
     t0 = step[0][1]
     print("t_start_us,dur_us,gap_us,stream,kernel")
