@@ -112,7 +112,7 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
     T = args.prompt_len - 1 + cfg.n_img_tokens
     if args.mode == "train":
         trainer = trainer_cls(model, lr=3e-4, grad_accum=args.accum, device_ids=[local], use_graph=use_graph, ddp_wrapper=args.ddp_wrapper,
-                              force_ddp=args.force_ddp, leaf_stream=not args.no_leaf_stream)
+                              force_ddp=args.force_ddp, leaf_stream=args.leaf_stream)
         # warm-up covers the eager warm-up calls of the graph path + the capture itself
         def first_optimizer_step():
             # the warm-up micro-steps never reach the optimizer (one step per --accum micro-steps): run it once untimed -- on a cold box its
@@ -332,7 +332,7 @@ def main():
                          "forward-only pass (BASELINE configs[1]) reported under 'fwd_only'; fwd: forward only")
     ap.add_argument("--no-fwd-only", action="store_true", help="skip the forward-only measurement (profiling runs)")
     ap.add_argument("--no-overlap", action="store_true", help="issue the frozen backbone on the main stream instead of its own HIP stream")
-    ap.add_argument("--no-leaf-stream", action="store_true", help="issue the arena's weight-gradient kernels on the main stream (A/B of autograd.Leaves)")
+    ap.add_argument("--leaf-stream", action="store_true", help="issue the arena's weight-gradient kernels on a side stream (A/B of autograd.Leaves; measured slower)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--ddp-wrapper", action="store_true", help="torch DDP wrapper + bf16 .grad instead of the fp32 gradient arena")
     ap.add_argument("--force-ddp", "--force-dist", dest="force_ddp", action="store_true",

@@ -27,10 +27,10 @@ BIG_WEIGHT = 1 << 26          # N * K of a Linear whose dX / dW always take the 
 
 class Leaves:
     """Weight-gradient kernels that accumulate into the trainer's fp32 arena are LEAVES of the backward pass: nothing later in the pass
-    reads what they write.  In arena mode (`Leaves.on`, set by `Trainer`) they are issued on ONE side stream that waits for the
-    producing kernels, so the dependent chain of the backward pass (dX GEMMs, norm / attention backward) does not queue behind them --
-    at two images per step the mask-selection head and the Llama layers' rank-8 gradient kernels are launch-latency-bound, and inside a
-    captured hipGraph the two streams become parallel branches.  One side stream keeps the leaves in issue order (a parameter used twice
+    reads what they write.  With `Trainer(leaf_stream=True)` (`Leaves.on`) they are issued on ONE side stream that waits for the
+    producing kernels, so the dependent chain of the backward pass (dX GEMMs, norm / attention backward) does not queue behind them; inside
+    a captured hipGraph the two streams become parallel branches.  MEASURED SLOWER (42.95 -> 43.81 ms at two images per step): a replayed
+    graph has no launch gaps to hide and the branch takes CUs from the GEMM chain -- off by default, kept as an A/B switch.  One side stream keeps the leaves in issue order (a parameter used twice
     accumulates in the same order every run: results stay bit-reproducible).  Operands are kept alive until `join()` -- the caching
     allocator would otherwise hand a freed operand's block to the next main-stream allocation while the side kernel has not run."""
     on = False

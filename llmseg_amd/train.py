@@ -217,7 +217,7 @@ class Trainer:
 
     def __init__(self, module, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.0, clip=1.0, grad_accum=10, warmup=100, total_steps=5000,
                  optimizer=None, device_ids=None, force_ddp=False, ddp_wrapper=False, use_graph=False, graph_warmup=2, use_arena=None,
-                 reduce_chunk_mb=128, sync_init=True, check_every=0, leaf_stream=True):
+                 reduce_chunk_mb=128, sync_init=True, check_every=0, leaf_stream=False):
         """optimizer: None = HipAdamW; or a factory `params -> optimizer` / an optimizer object (CPU tests).  use_arena: None = automatic
         (the HIP model with the built-in optimizer), True = force the fp32 gradient arena (the module's autograd Functions must honour `_g32`)."""
         self.module = module
@@ -251,7 +251,10 @@ class Trainer:
         self.graph_error = None
         self.grad_hook = None
         self.reduce_chunk = max(1, int(reduce_chunk_mb * (1 << 20) // 4))       # fp32 elements per all-reduce chunk of the arena
-        self.leaf_stream = bool(leaf_stream)                                     # weight-gradient kernels of the arena on a side stream (autograd.Leaves)
+        # weight-gradient kernels of the arena on a side stream (autograd.Leaves).  Measured (profiles/r04f): 43.81 ms with it vs 42.95 ms without at
+        # two images per step, 347.5 vs 346.6 ms at 24 -- a replayed hipGraph already runs its kernels back to back, and the second branch only
+        # takes CUs from the GEMM chain.  Off by default; kept as a switch.
+        self.leaf_stream = bool(leaf_stream)
         self.check_every = int(check_every)                                      # > 0: `check_replicas()` after every N-th optimizer step (two 16-byte all-reduces)
         self.rank = dist.get_rank() if self.dist_on else 0
         if is_hip_model and self.dist_on:
