@@ -474,7 +474,8 @@ extern "C" int llmseg_norm_bwd_add(const void* dy, const void* x, const void* w,
   LL_CHECK(dy && x && w && dx && rows > 0 && cols > 0 && (cols & 7) == 0 && AL16(dy) && AL16(x) && AL16(w) && AL16(dx) && AL16(dres), "norm_bwd: bad arguments");
   const int cpl = (int)(((cols >> 3) + 63) / 64);
   const bool wgrad = dw || db;
-  if (!wgrad && rows >= 64 && rows < 2048 && cols >= 2048 && cols <= 8192) {        // short and wide, frozen weight: a workgroup per row
+  if (!wgrad && rows >= 64 && cols >= 2048 && cols <= 8192) {        // wide rows, frozen weight: a workgroup per row (also for tall activations: the
+    // wave-per-row kernel holds x and dy of a 4096-wide row in 64 VGPRs per lane under a 128-VGPR bound and its counters showed 1.48 x the algorithmic bytes)
     const int cpt = (int)(((cols >> 3) + 255) / 256);
 #define LL_NORMBW(C)                                                                                                                                    \
   LL_LAUNCH_KERNEL(norm_bwd_wg_kernel<C>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, \

@@ -82,7 +82,8 @@ def check_tiny_inference(backbone="dinov2", with_bf16_cpu=True):
     def add(name, g_, r_, l_, floor):
         scale = max(1.0, r_.abs().max().item())
         lo_e = _e(l_, r_) if with_bf16_cpu else 0.0
-        res.append((f"{backbone} {name} (bf16-CPU err {lo_e:.2e})", _e(g_, r_), max(floor * scale, 1.5 * lo_e)))
+        flat = f", flat-1e-3 {'met' if _e(g_, r_) <= 1e-3 else 'NOT met'}" if name in ("pred_similarity", "pred_iou") else ""     # north_star's flat bound, kept visible
+        res.append((f"{backbone} {name} (bf16-CPU err {lo_e:.2e}{flat})", _e(g_, r_), max(floor * scale, 1.5 * lo_e)))
 
     rows_per = got["feats"].shape[0] // B
     gf = got["feats"].view(B, rows_per, C)[:, rows_per - g * g:].reshape(B * g * g, C)

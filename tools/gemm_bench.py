@@ -20,6 +20,9 @@ if os.environ.get("GEMM_SET") == "b2":   # BASELINE configs[2]: 2 images per mic
               (638, 4096, 12288, "llama dx(qkv)"), (638, 4096, 22016, "llama dx(gate_up)"), (638, 11008, 4096, "llama dx(down)"),
               (638, 32004, 4096, "lm_head"), (638, 4096, 32064, "lm_head dx"), (32064, 4096, 640, "lm_head dw"), (514, 3072, 1024, "clip qkv"),
               (514, 4096, 1024, "clip fc1")]
+if os.environ.get("GEMM_SET") == "clip":  # CLIP-L at two sequences per step (M = 2 x 257) and the mask-selection head's larger products
+    SHAPES = [(514, 3072, 1024, "clip qkv"), (514, 1024, 1024, "clip out"), (514, 4096, 1024, "clip fc1"), (514, 1024, 4096, "clip fc2"),
+              (512, 2048, 256, "head lin1"), (512, 256, 2048, "head lin2"), (512, 768, 256, "head qkv")]
 if os.environ.get("GEMM_SET") == "dec":  # decode steps of generation (one token per sequence): weight streams
     SHAPES = [(m, n, k, f"dec {t}") for m in (1, 4) for n, k, t in ((12288, 4096, "qkv"), (4096, 4096, "o"), (22016, 4096, "gate_up"), (4096, 11008, "down"),
                                                                      (32004, 4096, "lm_head"))]

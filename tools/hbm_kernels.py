@@ -38,9 +38,9 @@ r = lambda *s: torch.randn(*s, device=dev).to(BF)
 x = r(rows_sam, 1280); w, b = r(1280), r(1280); y = torch.empty_like(x)
 bench("SAM LayerNorm", "norm_kernel<3>", f"{rows_sam}x1280", 2 * x.numel() * 2, lambda: ops.norm(x, w, b, eps=1e-6, out=y))
 x = r(rows_llm, H); w = r(H); y = torch.empty_like(x)
-bench("Llama RMSNorm", "norm_kernel<8>", f"{rows_llm}x{H}", 2 * x.numel() * 2, lambda: ops.norm(x, w, None, eps=1e-6, rms=True, out=y))
+bench("Llama RMSNorm", "norm_kernel<8>" if rows_llm >= 2048 else "norm_wg_kernel<2>", f"{rows_llm}x{H}", 2 * x.numel() * 2, lambda: ops.norm(x, w, None, eps=1e-6, rms=True, out=y))
 dy = r(rows_llm, H)
-bench("Llama RMSNorm backward", "norm_bwd_kernel<8, false>", f"{rows_llm}x{H}", 3 * x.numel() * 2, lambda: ops.norm_bwd(dy, x, w, 1e-6, True))
+bench("Llama RMSNorm backward", "norm_bwd_wg_kernel<2>", f"{rows_llm}x{H}", 3 * x.numel() * 2, lambda: ops.norm_bwd(dy, x, w, 1e-6, True))
 gu = r(rows_llm, 2 * I); so = torch.empty(rows_llm, I, device=dev, dtype=BF)
 bench("SwiGLU", "swiglu_kernel", f"{rows_llm}x{I}", 3 * rows_llm * I * 2, lambda: ops.swiglu(gu, I, out=so))
 dso = r(rows_llm, I)
@@ -68,6 +68,14 @@ p = r(n); master = p.float(); g32 = torch.randn(n, device=dev); m1 = torch.zeros
 bench("AdamW (fp32 master + bf16 copy, fp32 grad)", "adamw_kernel", f"{n}", n * (4 + 4 * 2 + 4 * 2 + 4 * 2 + 2), lambda: ops.adamw_(p, master, g32, m1, v1, 1e-4, 0.9, 0.95, 1e-8, 0.0, 3))
 acc = torch.zeros(1, device=dev)
 bench("gradient norm (sum of squares, fp32)", "sumsq_kernel", f"{n}", n * 4, lambda: ops.sumsq(g32, acc))
+# N2 (round 4): the one-pass proposal kernel -- 256 proposals of one 1024 x 1024 image read once through the order index
+from llmseg_amd import targets as T_
+Kp = 256
+props = (torch.rand(Kp + 44, 1024, 1024, device=dev) > 0.7).to(torch.uint8)
+order = torch.argsort(props.flatten(1).sum(1), descending=True, stable=True)[:Kp]
+gtm = (torch.rand(1024, 1024, device=dev) > 0.5).to(torch.uint8)
+bench("N2 proposals: counts + 256x256 maps in one pass", "proposal_targets_kernel<16>", f"{Kp}x1024x1024", Kp * 1024 * 1024 + 1024 * 1024 + Kp * 256 * 256 * 2,
+      lambda: T_.proposal_targets_fused(props, order, [gtm]))
 M = rows_llm
 slab = torch.randn(3, M, H, device=dev)
 json.dump({"images_per_step": B, "kernels": out}, sys.stdout, indent=1)
