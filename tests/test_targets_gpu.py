@@ -86,3 +86,28 @@ def test_dense_proposals_equal_the_rle_route():
     assert np.array_equal(a["sam_ious"].cpu().numpy(), b["sam_ious"][:, perm].cpu().numpy(), equal_nan=True)
     assert np.array_equal(a["sam_iops"].cpu().numpy(), b["sam_iops"][:, perm].cpu().numpy(), equal_nan=True)
     assert torch.equal(a["sam_segs"], b["sam_segs"][perm])
+
+
+@pytest.mark.parametrize("h,w,hg,wg,k,n_gt", [(97, 130, 194, 260, 9, 2), (300, 420, 150, 210, 20, 5), (256, 96, 256, 96, 6, 1), (64, 1024, 64, 1024, 5, 3)])
+def test_one_pass_kernel_equals_the_three_kernel_route(h, w, hg, wg, k, n_gt):
+    """llmseg_proposal_targets (one pass through the order index) against gather + llmseg_mask_targets + llmseg_resize_aa, bit for bit: widths that are
+    not multiples of 16 (scalar staging path), tall / wide images (zero padding below / right of the image), several ground truths incl. an empty one and
+    more than the 4 one launch takes, an `order` that permutes and drops proposals."""
+    from llmseg_amd import targets as ht
+    rng = np.random.default_rng(h + 3 * w + k)
+    m = (rng.random((k + 3, h, w)) > 0.6).astype(np.uint8)
+    m[1] = 0                                                                     # an empty proposal: IoP = 0 / 0
+    m[2] *= 255                                                                  # 0 / 255 masks count like 0 / 1
+    masks = torch.from_numpy(m).to(DEV)
+    order = torch.from_numpy(rng.permutation(k + 3)[:k].astype(np.int64)).to(DEV)
+    gts = [torch.from_numpy((rng.random((hg, wg)) > 0.5).astype(np.uint8)).to(DEV) for _ in range(n_gt)]
+    gts[-1] = torch.zeros_like(gts[-1])
+    fused = ht.proposal_targets_fused(masks, order, gts)
+    assert fused is not None
+    maps, ious, iops, cnts = fused
+    segs = masks[order].contiguous()
+    assert torch.equal(maps, ht.resize_square_aa(segs, 256))
+    for c, g in enumerate(gts):
+        iou, iop, cnt = ht.mask_targets(segs, g)
+        assert torch.equal(cnts[c], cnt), c
+        assert np.array_equal(ious[c].cpu().numpy(), iou.cpu().numpy(), equal_nan=True) and np.array_equal(iops[c].cpu().numpy(), iop.cpu().numpy(), equal_nan=True)
