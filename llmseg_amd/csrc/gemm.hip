@@ -45,10 +45,6 @@ struct GemmP {
   int accum;                 // fp32 output only: C += result (gradient accumulation into an fp32 arena)
   int k_split_total;         // register-staging kernel as K-slices: total K (elements); blockIdx.y % batch1 = slice, p.K = elements per slice; 0 = off
   const bf16_t* a_norm_w; float a_norm_eps; int a_swiglu;     // skinny route: transform of the A rows while they are loaded (decode-step fusions)
-  // split-K with the reduction INSIDE the kernel (round 4): fz_S > 0 = number of K-slice workgroups per tile; the last of them to arrive (counted in
-  // fz_cnt[tile]) adds the fz_total fp32 slabs of its tile in slab order and applies the final epilogue described by the fz_* fields
-  int fz_S, fz_total; unsigned* fz_cnt; const float* fz_slab;
-  void* fz_C; const bf16_t* fz_bias; const bf16_t* fz_gamma; const bf16_t* fz_res; long fz_ldc, fz_ldr; float fz_alpha; int fz_act, fz_out_f32, fz_accum, fz_cvec;
 };
 
 // exact-erf GELU on a pair (packed fp32 VALU: v_pk_fma / v_pk_mul).  Same Abramowitz-Stegun 7.1.26 erf as apply_act, rearranged:
@@ -71,21 +67,6 @@ __device__ __forceinline__ f32x2_t gelu2(f32x2_t v) {
 }
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * (BK * 2) + (((chunk ^ (row >> 1)) & 7) << 4); }
-
-// Agent-scope (sc1) 16-byte store / load through a buffer descriptor: coherent across the 8 XCDs' L2 caches WITHOUT a fence (a device-scope fence
-// writes back and invalidates the whole L2 of the XCD: measured 44.6 -> 60.3 ms per step when the split-K tail used __threadfence()).  aux bit 4 = sc1
-// on gfx940+.  `base` must be wave-uniform, `byte_off` < 2^31.
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_f4_sc1(float* base, int byte_off, float a, float b, float c, float d) {
-  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
-  const u32x4_t v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 16);
-}
-__device__ __forceinline__ float4 load_f4_sc1(const float* base, int byte_off) {
-  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
-  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
-  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
 
 struct TileXY { int m0, n0; };
 
@@ -232,9 +213,7 @@ __device__ __forceinline__ void epilogue_lds_edge(const GemmP& p, const ACC& acc
 #pragma unroll
           for (int e = 0; e < 4; ++e) if (e < nv) v[e] += cp[e];
         }
-        if (p.fz_S > 0 && nv == 4) {             // split-K slab with the reduction inside the kernel: agent-scope store
-          store_f4_sc1(reinterpret_cast<float*>(p.C), (int)((bz + (long)m * p.ldc + n) * 4), v[0], v[1], v[2], v[3]);
-        } else if (vec_ok && nv == 4) {
+        if (vec_ok && nv == 4) {
           *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
@@ -308,8 +287,7 @@ __device__ __forceinline__ void epilogue_lds_body(const GemmP& p, const ACC& acc
           const float4 o4 = *reinterpret_cast<const float4*>(cp);
           v[0] += o4.x; v[1] += o4.y; v[2] += o4.z; v[3] += o4.w;
         }
-        if (p.fz_S > 0) store_f4_sc1(reinterpret_cast<float*>(p.C), (int)(cp - reinterpret_cast<char*>(p.C)), v[0], v[1], v[2], v[3]);
-        else *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
       } else *reinterpret_cast<uint2*>(cp) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
       cp += cstep;
     }
@@ -618,69 +596,6 @@ constexpr int NTB = 512;
       _Pragma("unroll") for (int mb = 0; mb < MI; ++mb)                                                                       \
           acc[(nb0) + nb][(mb0) + mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfx[nb][ks], af[mb][ks], acc[(nb0) + nb][(mb0) + mb], 0, 0, 0)
 
-// Split-K tail inside the GEMM kernel.  Every K-slice workgroup of a tile has just written its fp32 partial tile to its slab; each thread makes its
-// slab stores agent-scope (sc1: written through this XCD's L2) and waits for their acknowledgement, the workgroup takes a ticket, and the LAST workgroup
-// to arrive (whichever slice it is) reads the tile from ALL slabs in slab order 0 .. fz_total - 1 with agent-scope loads (its XCD's L2 may hold stale
-// lines of a workspace that every GEMM call reuses; no fence: a device-scope fence flushes the whole L2) and applies the epilogue with exactly the arithmetic of splitk_reduce_kernel -- the sum's order does not
-// depend on who arrives last, so the result is bit-reproducible and equal to the two-launch form.  The counter resets itself (the next launch and
-// every hipGraph replay find zero).  Saves the reduce launch (7.9 us x 236 per two-image micro-step) and its pass over slabs that are no longer cached.
-template <int BMB>
-__device__ __forceinline__ void splitk_tail(const GemmP& p, int tile, int m0, int n0) {
-  __shared__ int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's agent-scope slab stores are acknowledged
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = atomicAdd(p.fz_cnt + tile, 1u);
-    const int last = t == (unsigned)(p.fz_S - 1);
-    if (last) p.fz_cnt[tile] = 0u;
-    s_last = last;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  const int rows = min(BMB, p.M - m0), cols4 = min(256, p.N - n0) >> 2;
-  const long slab_sz = (long)p.M * p.N;
-  for (int i = threadIdx.x; i < rows * cols4; i += blockDim.x) {
-    const int r = i / cols4, c4 = i - r * cols4;
-    const long m = m0 + r;
-    const int n = n0 + c4 * 4;
-    const int off = (int)((m * p.N + n) * 4);
-    float4 a = load_f4_sc1(p.fz_slab, off);                    // agent-scope loads: never a stale line of this XCD's L2
-    for (int sl = 1; sl < p.fz_total; ++sl) {
-      const float4 b = load_f4_sc1(p.fz_slab, off + (int)(sl * slab_sz * 4));
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    }
-    float v[4] = {a.x * p.fz_alpha, a.y * p.fz_alpha, a.z * p.fz_alpha, a.w * p.fz_alpha};
-    if (p.fz_bias) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += bf2f(p.fz_bias[n + e]);
-    }
-    if (p.fz_act != LLMSEG_ACT_NONE) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.fz_act);
-    }
-    if (p.fz_gamma) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= bf2f(p.fz_gamma[n + e]);
-    }
-    if (p.fz_res) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += bf2f(p.fz_res[m * p.fz_ldr + n + e]);
-    }
-    if (p.fz_out_f32) {
-      float* cp = reinterpret_cast<float*>(p.fz_C) + m * p.fz_ldc + n;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) cp[e] = p.fz_accum ? cp[e] + v[e] : v[e];
-    } else {
-      bf16_t* cp = reinterpret_cast<bf16_t*>(p.fz_C) + m * p.fz_ldc + n;
-      if (p.fz_cvec) *reinterpret_cast<uint2*>(cp) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-      else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cp[e] = f2bf(v[e]);
-      }
-    }
-  }
-}
-
 template <bool OUT_F32, bool EXT, int MI>
 __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
   constexpr int BMB = 64 * MI, BNB = 256;
@@ -781,9 +696,6 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();            // re-join: every wave's reads and DMA are retired past this point
   epilogue_lds<OUT_F32, MI>(p, Acc16<MI>{acc}, smem, wave, m0, n0, wm, wn, lane, bz);
-  if constexpr (OUT_F32 && !EXT) {
-    if (p.fz_S > 0) splitk_tail<64 * MI>(p, bid, m0, n0);
-  }
 }
 
 // ---- variant Q2: 128 x 256 tile, TWO phases per K-tile, THREE LDS buffers -------------------------------------------------------
@@ -891,9 +803,6 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp2_kernel(GemmP p) {
 #undef PP2_MMA_B
   if (wm == 0) __builtin_amdgcn_s_barrier();            // re-join: every wave's reads and DMA are retired past this point
   epilogue_lds<OUT_F32, MI>(p, Acc16<MI>{acc}, smem, wave, m0, n0, wm, wn, lane, bz);
-  if constexpr (OUT_F32 && !EXT) {
-    if (p.fz_S > 0) splitk_tail<64 * MI>(p, bid, m0, n0);
-  }
 }
 
 // ---- variant V: skinny GEMM, M <= 8 rows (the decode step of generation: one token per sequence) ---------------------------------
@@ -1207,16 +1116,6 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
   p.sA2 = a->strideA2; p.sW2 = a->strideW2; p.sC2 = a->strideC2;
   p.alpha = a->alpha; p.act = a->act;
   p.kt_total = 0; p.k_split_total = 0; p.accum = a->accumulate ? 1 : 0;
-  p.fz_S = 0; p.fz_total = 0; p.fz_cnt = nullptr; p.fz_slab = nullptr; p.fz_C = nullptr; p.fz_bias = p.fz_gamma = p.fz_res = nullptr;
-  p.fz_ldc = p.fz_ldr = 0; p.fz_alpha = 1.f; p.fz_act = 0; p.fz_out_f32 = p.fz_accum = p.fz_cvec = 0;
-  // the LAST 64 KiB of the caller's workspace are the tile counters of the in-kernel split-K reduction (zero when first handed over, self-resetting);
-  // slabs of every split path stay below them
-  constexpr int64_t CNT_BYTES = 65536;
-  const int64_t ws_bytes = a->workspace_bytes >= (1 << 20) ? a->workspace_bytes - CNT_BYTES : a->workspace_bytes;
-  // A/B switch, OFF by default: measured on the two-image step 43.9-44.0 ms with the separate reduce launch, 45.7 ms with the in-kernel tail (a fence-based
-  // first version: 60.3 ms) -- the tail runs on one workgroup per tile (80 of 256 CUs) with write-through stores and L2-bypassing loads, the reduce launch on
-  // the whole chip out of L2 / MALL; 213 fewer launches do not pay for that (profiles/r04h_fused_reduce.txt)
-  static const int fused_reduce_env = getenv("LLMSEG_GEMM_FUSED_REDUCE") ? atoi(getenv("LLMSEG_GEMM_FUSED_REDUCE")) : 0;
   // vector stores/loads need 4-element alignment of every row start; otherwise the kernel goes element-wise
   p.c_vec = ((((uintptr_t)a->C) % (4 * esz)) == 0 && (a->ldc & 3) == 0 && ((a->strideC | a->strideC2) & 3) == 0) ? 1 : 0;
   p.r_vec = (p.res && (((uintptr_t)p.res) & 7) == 0 && (p.ldr & 3) == 0 && ((a->strideC | a->strideC2) & 3) == 0) ? 1 : 0;
@@ -1233,7 +1132,7 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
   // split-K needs a dense-enough problem for the slab layout [S][M][N], 4-column alignment and room in the caller's workspace
   const bool can_split = batch == 1 && (p.N & 3) == 0 && (p.ldc & 3) == 0 && a->workspace != nullptr &&
                          (((uintptr_t)a->workspace) & 15) == 0 && (!p.res || (p.ldr & 3) == 0);
-  auto ws_fits = [&](int S) { return (double)(S + (a->A2 ? 1 : 0)) * p.M * p.N * 4.0 <= (double)ws_bytes; };   // + the extension product's slab
+  auto ws_fits = [&](int S) { return (double)(S + (a->A2 ? 1 : 0)) * p.M * p.N * 4.0 <= (double)a->workspace_bytes; };   // + the extension product's slab
   int split = 1;
   if (variant == 5) {
     // auto: minimum of the cost model over {128 x 128 DMA kernel, ping-pong 256 x 256 / 128 x 256 with 1..16 K-slices}
@@ -1330,7 +1229,7 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
     const long tiles = (long)p.tiles_m * p.tiles_n * batch;
     const int ntr = (p.K + BK - 1) / BK;
     int S = (tiles * 4 <= ncu && ntr >= 8) ? (int)std::min<long>({(long)ncu / std::max<long>(tiles, 1), (long)ntr / 2, 32L}) : 1;
-    while (S > 1 && (double)S * batch * p.M * p.N * 4.0 > (double)ws_bytes) --S;
+    while (S > 1 && (double)S * batch * p.M * p.N * 4.0 > (double)a->workspace_bytes) --S;
     if (S > 1) {
       const int q = (ntr + S - 1) / S;
       S = (ntr + q - 1) / q;
@@ -1373,23 +1272,12 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
     ps.bias = ps.gamma = ps.res = nullptr; ps.ldr = 0; ps.alpha = 1.f; ps.act = LLMSEG_ACT_NONE; ps.accum = 0;
     ps.c_vec = 1; ps.r_vec = 0; ps.b_vec = 1; ps.A2 = ps.W2 = nullptr;
     dim3 grid(p.tiles_m * p.tiles_n, (unsigned)split);
-    // reduction inside the kernel (last-arriving K-slice workgroup of a tile; see splitk_tail) when the workspace carries the counter block
-    const bool fused = fused_reduce_env && a->workspace_bytes >= (1 << 20) && (long)p.tiles_m * p.tiles_n * 4 <= CNT_BYTES;
-    if (fused) {
-      ps.fz_S = split; ps.fz_total = split + (p.A2 ? 1 : 0);
-      ps.fz_cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(a->workspace) + a->workspace_bytes - CNT_BYTES);
-      ps.fz_slab = (const float*)a->workspace;
-      ps.fz_C = p.C; ps.fz_bias = p.bias; ps.fz_gamma = p.gamma; ps.fz_res = p.res; ps.fz_ldc = p.ldc; ps.fz_ldr = p.ldr; ps.fz_alpha = p.alpha;
-      ps.fz_act = p.act; ps.fz_out_f32 = f ? 1 : 0; ps.fz_accum = p.accum; ps.fz_cvec = p.c_vec;
-    }
     if (variant == 8) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<true, false, 4>), grid, dim3(NTB), 0, s, ps);
     else if (g_gemm_pp2) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp2_kernel<true, false>), grid, dim3(NTB), 0, s, ps);
     else LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<true, false, 2>), grid, dim3(NTB), 0, s, ps);
-    if (!fused) {
-      const long total4 = (long)p.M * (p.N >> 2);
-      const unsigned rg = (unsigned)std::min<long>((total4 + 255) / 256, 4096);
-      LL_LAUNCH_KERNEL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, s, p, (const float*)a->workspace, split + (p.A2 ? 1 : 0), f ? 1 : 0);
-    }
+    const long total4 = (long)p.M * (p.N >> 2);
+    const unsigned rg = (unsigned)std::min<long>((total4 + 255) / 256, 4096);
+    LL_LAUNCH_KERNEL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, s, p, (const float*)a->workspace, split + (p.A2 ? 1 : 0), f ? 1 : 0);
   } else {
     dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);
     switch (variant) {
