@@ -1,6 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/r04last; mkdir -p $OUT; cd $R
-bash tools/r04_suite.sh final2 | tail -6
+bash tools/r04_suite.sh ${1:-final3} | tail -6
 ( time python bench.py ) > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -3 $OUT/bench_default.err
 python - <<'PY'
 import json
