@@ -333,7 +333,6 @@ def main():
     ap.add_argument("--no-fwd-only", action="store_true", help="skip the forward-only measurement (profiling runs)")
     ap.add_argument("--no-overlap", action="store_true", help="issue the frozen backbone on the main stream instead of its own HIP stream")
     ap.add_argument("--leaf-stream", action="store_true", help="issue the arena's weight-gradient kernels on a side stream (A/B of autograd.Leaves; measured slower)")
-    ap.add_argument("--ce-stream", action="store_true", help="lm_head + CE branch on its own stream beside the mask-selection head (A/B)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--ddp-wrapper", action="store_true", help="torch DDP wrapper + bf16 .grad instead of the fp32 gradient arena")
     ap.add_argument("--force-ddp", "--force-dist", dest="force_ddp", action="store_true",
@@ -395,7 +394,6 @@ def main():
     model = LISAForCausalLM(cfg, device=dev).init_random(seed=0)
     model.prepare()
     model.overlap_towers = not args.no_overlap
-    model.ce_side_stream = bool(args.ce_stream)
     if os.environ.get("LLMSEG_CE_FULL"):
         model.ce_gather_first = False
     if train:

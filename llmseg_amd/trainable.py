@@ -345,20 +345,8 @@ class TrainableMixin:
         if want_logits or (plan.new_labels is not None and not gathered):
             logits = F.linear(hidden.view(N * T, H), self._w("lm_head.weight", F)).view(N, T, -1)
         if gathered:                                                       # lm_head + CE on the label-carrying rows only (see make_plan)
-            def ce_branch():
-                rows = F.gather_rows(hidden.view(N * T, H), plan.ce_rows)
-                return F.ce(F.linear(rows, self._w("lm_head.weight", F)).view(1, rows.shape[0], -1), plan.ce_labels)
-            if self.ce_side_stream and F.grad:
-                # the language-model loss branch (lm_head on the label rows, CE -- and, through autograd's stream bookkeeping, their backward:
-                # dX, the 32004 x 4096 weight gradient) is independent of the mask-selection head until the losses are summed: issue it on its own
-                # stream so that it runs beside the head's chain of tiny kernels (model_forward joins before the sum)
-                cur, st = torch.cuda.current_stream(), self._ce_stream()
-                st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    loss = ce_branch()
-                self.__dict__["_ce_pending"] = st
-            else:
-                loss = ce_branch()
+            rows = F.gather_rows(hidden.view(N * T, H), plan.ce_rows)
+            loss = F.ce(F.linear(rows, self._w("lm_head.weight", F)).view(1, rows.shape[0], -1), plan.ce_labels)
         elif plan.new_labels is not None:
             loss = F.ce(logits, plan.new_labels)
         return loss, logits, hidden
@@ -414,14 +402,6 @@ class TrainableMixin:
     # ------------------------------------------------------------------------------------------------ model_forward
     ce_gather_first = True         # lm_head + CE on the label-carrying rows only (class default; False = all N*T rows, as the reference computes them)
     overlap_towers = True          # issue the frozen segmentation backbone on its own HIP stream (class default; set False to serialise)
-
-    ce_side_stream = False         # lm_head + CE (+ their backward) on a third stream beside the mask-selection head (A/B switch; see llava_forward)
-
-    def _ce_stream(self):
-        st = self.__dict__.get("_ce_stream_obj")
-        if st is None:
-            st = self.__dict__["_ce_stream_obj"] = torch.cuda.Stream(device=self.device_)
-        return st
 
     def _tower_stream(self):
         st = self.__dict__.get("_side_stream")
@@ -562,9 +542,6 @@ class TrainableMixin:
             align = align + (o[:, 0] * w).sum()
             reg = reg + (o[:, 1] * w).sum()
         align, reg = align / B, reg / B
-        st = self.__dict__.pop("_ce_pending", None)
-        if st is not None:                                                 # join the language-model loss branch
-            torch.cuda.current_stream().wait_stream(st)
         ce = ce * c.ce_loss_weight
         align = align * c.align_loss_weight
         reg = reg * c.regression_loss_weight
