@@ -117,9 +117,13 @@ def _arena_worker(rank, world, port, ret):
             for p in m.parameters():
                 p.add_(0.3)
     # ... is overwritten by rank 0's at construction (no DDP wrapper in arena mode to do it); 100-element all-reduce chunks -> 3 pieces
+    # check_every=1: the trainer itself verifies the replicas after every optimizer step (round 4: the clip coefficient needs no collective any
+    # more, so a periodic check is the safety net); counted through a wrapper
     tr = Trainer(m, lr=1e-2, clip=1.0, grad_accum=3, warmup=2, total_steps=10, optimizer=lambda ps: CpuArenaAdamW(ps), use_arena=True,
-                 reduce_chunk_mb=400 / (1 << 20))
+                 reduce_chunk_mb=400 / (1 << 20), check_every=1)
     assert tr.arena is not None and tr.ddp is None and tr.reduce_chunk == 100 and tr.arena.flat.numel() > 200
+    checks, orig_check = [0], tr.check_replicas
+    tr.check_replicas = lambda: (checks.__setitem__(0, checks[0] + 1), orig_check())[1]
     tr.check_replicas()
     import bench
     step_no = [0]
@@ -130,6 +134,7 @@ def _arena_worker(rank, world, port, ret):
         return tr.micro_step(dict(x=x, y=y))
     dt, out = bench.timed(step, 5, 1, dist, torch.device("cpu"))
     assert all(p.grad is None for p in m.parameters())
+    assert checks[0] == 1 + tr.opt_steps == 3, checks             # the explicit call above + one per optimizer step
     tr.check_replicas()
     final = torch.cat([p.detach().flatten() for p in m.parameters()]).clone()
     if rank == 1:                                   # a diverged replica is detected
