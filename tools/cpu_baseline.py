@@ -3,10 +3,11 @@ arithmetic, pinned to the imported reference by oracle/make_goldens.py) timed on
 
 What is timed: the WHOLE restated `model_forward` (SAM ViT-H encoder -> CLIP-L -> splice -> Llama stack -> lm_head + CE -> [SEG] MLP ->
 upsample + mask pooling -> mask-selection head -> align / IoP losses) on ONE synthetic image of the benchmark's shape (1024 x 1024, 64-token
-prompt, 256 candidate masks), full width, at REDUCED DEPTH so that the default bench run stays within minutes: `DEPTH` layers of each tower
-are run end to end, the remaining layers are accounted for by per-layer times measured in the same process (one Llama layer, one windowed
-and one global SAM block, one CLIP layer -- every layer of a tower is the same arithmetic).  fp32: >= 3 timed forwards + one timed
-forward+backward (LoRA r = 8 + the reference's trainable set); bf16 (the reference's dtype): forwards within the remaining time budget.
+prompt, 256 candidate masks), full width.  In this order (round 4: the headline `value` is FORWARD+BACKWARD, the benchmark's metric):
+`DEPTH` layers of each tower end to end -- 3 fp32 forwards, ONE fp32 forward+backward (LoRA r = 8 + the reference's trainable set), 2 bf16
+forwards (the reference's dtype) -- per-layer times of one Llama layer / one windowed and one global SAM block / one CLIP layer for the
+remaining layers (every layer of a tower is the same arithmetic), then ONE full-depth fp32 forward as the anchor of the scaled figures.
+~65 s on the GPU box's 128 threads.
 The only consumer is bench.py's `cpu_baseline` leg; nothing here is on the product path."""
 import os
 import sys
