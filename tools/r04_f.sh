@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/r04f; mkdir -p $OUT; cd $R
 python tools/probes/targets_time.py 2>&1 | tail -6 > $OUT/targets_time.txt; cat $OUT/targets_time.txt
 B="--no-cpu-baseline --no-neighbours --no-k512 --no-loader --no-fwd-only"
-for v in "" "--no-leaf-stream"; do
+for v in "" "--leaf-stream"; do   # (when this script ran, the side stream was the default and the A/B flag was --no-leaf-stream)
   ( timeout 900 python bench.py $B --extra-batch 24 $v ) > $OUT/bench_ab$v.json 2> $OUT/bench_ab$v.err
   python - "$OUT/bench_ab$v.json" <<'PY'
 import json, sys
