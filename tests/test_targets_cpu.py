@@ -121,3 +121,15 @@ def test_amg_records_have_the_reference_fields():
     out["crop_boxes"] = torch.tensor([[2, 1, 9, 7], [0, 0, 10, 8]])
     recs = amg.to_records(out, (8, 10), output_mode="binary_mask")
     assert recs[0]["crop_box"] == [2, 1, 7, 6] and recs[1]["crop_box"] == [0, 0, 10, 8] and recs[0]["segmentation"].dtype == bool and recs[0]["segmentation"].sum() == 12
+
+
+def test_device_table_cache_is_bounded():
+    """the per-(size, size) device tables of the target computation are an LRU of 64 entries, not an ever-growing dict."""
+    from llmseg_amd.targets import _LRU
+    d = _LRU(3)
+    for i in range(5):
+        d[i] = i * i
+    assert list(d) == [2, 3, 4] and 0 not in d
+    assert d[2] == 4                      # a read refreshes the entry ...
+    d[9] = 81
+    assert list(d) == [4, 2, 9]           # ... so the oldest UNUSED one (3) was evicted
