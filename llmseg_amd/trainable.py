@@ -522,7 +522,8 @@ class TrainableMixin:
                 r0 += Cn
 
         if inference:
-            sims = [ops.cosine_scores(pred_embeddings[b][0], embs[b][0])[None] for b in range(B)]
+            # every conversation's [SEG] embedding against the FIRST conversation's mask features (LISA.py:394-403: [C, K]; C = 1 in the reference's loops)
+            sims = [torch.stack([ops.cosine_scores(pred_embeddings[b][c], embs[b][0]) for c in range(plan.rounds[b])]) for b in range(B)]
             out = {"pred_similarity": sims, "gt_masks": masks_list, "pred_iou": [ious[b][:1].float() for b in range(B)]}
             if return_aux:
                 out.update(logits=logits, hidden=hidden, feats=feat, pred_embeddings=pred_embeddings)

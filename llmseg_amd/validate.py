@@ -12,6 +12,19 @@ import torch.distributed as dist
 from . import ops
 
 
+def sample_from_collated(collated):
+    """A collated validation batch of ONE image (`collate_fn_new` -> `dict_to_cuda`, as `training.py:700-711` feeds the model) -> the sample
+    dict of the loops below: the `model_forward` kwargs + `origin_segs` (`origin_segs_list[0]`, training.py:722) + `gt_mask`
+    (`masks_list[0][0]`, training.py:719)."""
+    from .collate import model_kwargs
+    assert collated["images"].shape[0] == 1, "the reference validates one image per step (val_batch_size = 1)"
+    kw = {k: v for k, v in model_kwargs(collated).items() if k != "inference"}
+    dev = collated["images"].device
+    kw["origin_segs"] = torch.as_tensor(collated["origin_segs_list"][0]).to(device=dev, dtype=torch.uint8)
+    kw["gt_mask"] = collated["masks_list"][0][0].to(device=dev, dtype=torch.uint8)
+    return kw
+
+
 def _meters(dev):
     return (torch.zeros(2, device=dev, dtype=torch.float64), torch.zeros(2, device=dev, dtype=torch.float64),
             torch.zeros(2, device=dev, dtype=torch.float64), torch.zeros(1, device=dev, dtype=torch.float64))

@@ -157,3 +157,58 @@ def amg_standin_encoder():
         f = torch.stack([r, g, b, r * g, g * b, b * r, r * r, g * g, b * b], 0)
         return (torch.einsum("ck,kyx->cyx", coef, f) + bias)[None]
     return encode
+
+
+# ------------------------------------------------------------------------------------------------ A14: collate / prompt contract
+COLLATE_QUESTIONS = [
+    ("<image>\n What is the dog in this image? Please output segmentation mask.", "Sure, [SEG]."),
+    ("<image>\n the left chair Please respond with segmentation mask.", "It is [SEG]."),
+    ("<image>\n Can you segment the red car parked next to the tree in this image?", "Sure, the segmentation result is [SEG]."),
+    ("<image>\n " + " ".join(f"word{i} and then something number {i}," for i in range(60)) + " which object is it?", "[SEG]."),   # > 512 - 255 tokens: truncated in training
+    ("<image>\n the cup", "Sure, it is [SEG]."),
+]
+
+
+def collate_conversations(prompt):
+    """Conversation strings of 3 images: image 0 carries two single-turn conversations, image 1 ONE conversation of two rounds (two [SEG],
+    the second round without <image>) followed by a long single-turn one (hits the training truncation), image 2 a short one (right padding).
+    `prompt(messages)`: [(question, answer), ...] -> the conversation string (the reference's `conv.get_prompt()` or this package's template)."""
+    q = COLLATE_QUESTIONS
+    return [[prompt([q[0]]), prompt([q[1]])],
+            [prompt([q[2], ("And where is the other one?", "It is [SEG].")]), prompt([q[3]])],
+            [prompt([q[4]])]]
+
+
+def collate_samples(conversations, inference=False, K=6, img=16, clip=8, seg=4, ragged=True):
+    """Sample dicts in the datasets' format (`utils/reason_seg_dataset.py:266-282`; validation: `utils/dataset.py:640-656`, which has no
+    'iops' / 'questions') with tiny seeded tensors: what is under test is the collate, not the image pipeline."""
+    out = []
+    for b, convs in enumerate(conversations):
+        C = len(convs)
+        Kb = K + b if ragged else K
+        d = {"image_path": f"img{b}.jpg", "images": seeded.uniform((3, img, img), 200 + b, -2, 2), "images_clip": seeded.uniform((3, clip, clip), 210 + b, -2, 2),
+             "conversations": convs, "masks": (seeded.uniform((C, 5, 7), 220 + b) > 0).to(torch.uint8), "label": torch.ones(5, 7) * 255,
+             "resize": (12, 16), "segs": seeded.uniform((Kb, seg, seg), 230 + b, 0, 1), "inference": inference,
+             "segs_origin": None, "bbox": None}
+        if inference:
+            d.update(questions=None, sampled_classes=None, ious=None)
+        else:
+            d.update(questions=[f"q{b}{c}" for c in range(C)], sampled_classes=[f"c{b}{c}" for c in range(C)],
+                     ious=seeded.uniform((C, Kb), 240 + b, 0, 1).double(), iops=seeded.uniform((C, Kb), 250 + b, 0, 1).double())
+        out.append(d)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ N2: the reference's own target functions
+def target_case(n_masks=57, h=45, w=70, gt_hw=(61, 97)):
+    """Seeded binary proposals [n, h, w] with distinct-ish areas (some ties: the sort must be stable) + a ground truth at another resolution."""
+    import numpy as np
+    ys, xs = torch.meshgrid(torch.arange(float(h)), torch.arange(float(w)), indexing="ij")
+    cy, cx = seeded.uniform((n_masks,), 301, 0, h), seeded.uniform((n_masks,), 302, 0, w)
+    ry, rx = seeded.uniform((n_masks,), 303, 2, h / 2), seeded.uniform((n_masks,), 304, 2, w / 2)
+    m = (((ys[None] - cy[:, None, None]) / ry[:, None, None]) ** 2 + ((xs[None] - cx[:, None, None]) / rx[:, None, None]) ** 2) <= 1.0
+    m[5] = m[4]; m[20] = m[19]                                                     # area ties
+    m[9] = False                                                                   # an empty proposal: IoU 0 / IoP 0/0 = nan
+    gy, gx = torch.meshgrid(torch.arange(float(gt_hw[0])), torch.arange(float(gt_hw[1])), indexing="ij")
+    gt = (((gy - 30) / 14) ** 2 + ((gx - 50) / 25) ** 2 <= 1.0)
+    return m.to(torch.uint8).numpy(), gt.to(torch.uint8).numpy()

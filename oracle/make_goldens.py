@@ -409,6 +409,113 @@ def gold_lisa_tiny():
                 "feats_sample": o["feats"][0, ::8, ::4, ::4].clone()}, os.path.join(OUT, "lisa_tiny.pt"))
 
 
+def gold_collate():
+    """A14: the imported `collate_fn_new` (utils/dataset.py:33-170) + `tokenizer_image_token` + `conv_llava_v1.get_prompt()` against
+    `llmseg_amd.collate` on seeded sample dicts, with the SAME stand-in tokenizer on both sides (oracle/stub_tokenizer.py: the tokenization is
+    unpinned, the collate arithmetic is what is pinned).  Training (truncated to 512 - 255) and inference variants."""
+    from llmseg_amd import collate as mine
+    from oracle.stub_tokenizer import StubTokenizer
+    D, _, _ = rh.setup_utils()
+    import model.llava.conversation as CL
+    from model.llava.mm_utils import tokenizer_image_token as ref_tit
+    CL.default_conversation = CL.conv_templates["llava_v1"]                 # training.py:178-180
+
+    def ref_prompt(msgs):
+        conv = CL.default_conversation.copy()
+        conv.messages = []
+        for q, a in msgs:
+            conv.append_message(conv.roles[0], q)
+            conv.append_message(conv.roles[1], a)
+        return conv.get_prompt()
+    t = mine.CONV_TEMPLATES["llava_v1"]
+    my_prompt = lambda msgs: t.get_prompt([m for q, a in msgs for m in ((t.roles[0], q), (t.roles[1], a))])
+    convs = cases.collate_conversations(ref_prompt)
+    assert convs == cases.collate_conversations(my_prompt), "prompt template differs from conv_llava_v1"
+    assert mine.single_turn_prompt(*cases.COLLATE_QUESTIONS[0]) == ref_prompt([cases.COLLATE_QUESTIONS[0]])
+    tok = StubTokenizer(model_max_length=512)
+    for c in [x for cs in convs for x in cs]:
+        assert ref_tit(c, tok) == mine.tokenizer_image_token(c, tok), "tokenizer_image_token"
+        assert torch.equal(ref_tit(c, tok, return_tensors="pt"), mine.tokenizer_image_token(c, tok, return_tensors="pt"))
+    fix = {"conversations": convs, "model_max_length": 512}
+    for inference in (False, True):
+        ref = D.collate_fn_new(cases.collate_samples(convs, inference), tokenizer=tok, conv_type="llava_v1", use_mm_start_end=True, local_rank=0)
+        got = mine.collate_fn_new(cases.collate_samples(convs, inference), tokenizer=tok, conv_type="llava_v1", use_mm_start_end=True, local_rank=0)
+        assert list(ref.keys()) == list(got.keys()), (list(ref.keys()), list(got.keys()))
+        for k, v in ref.items():
+            g = got[k]
+            if torch.is_tensor(v):
+                assert v.dtype == g.dtype and torch.equal(v, g), k
+            elif isinstance(v, list) and v and torch.is_tensor(v[0]):
+                assert all(a.dtype == b.dtype and torch.equal(a, b) for a, b in zip(v, g)) and len(v) == len(g), k
+            else:
+                assert v == g, (k, v, g)
+        L = ref["input_ids"].shape[1]
+        n_seg = int((ref["input_ids"] == 32000).sum())
+        print(f"  collate inference={inference}: ids {tuple(ref['input_ids'].shape)}, labelled {int((ref['labels'] != -100).sum())} tokens, "
+              f"padded {int((~ref['attention_masks']).sum())}, [SEG] x {n_seg}, offset {ref['offset'].tolist()}")
+        assert (L == 512 - 255) == (not inference), L          # the long conversation is cut in training only
+        fix["infer" if inference else "train"] = {k: ref[k] for k in ("input_ids", "labels", "attention_masks", "offset")}
+    # use_mm_start_end=False and a conversation without <image> (plain tokenizer path of the label walk)
+    plain = [[ref_prompt([("What is shown here?", "A dog.")])]]
+    ref = D.collate_fn_new(cases.collate_samples(plain, False), tokenizer=tok, use_mm_start_end=False)
+    got = mine.collate_fn_new(cases.collate_samples(plain, False), tokenizer=tok, use_mm_start_end=False)
+    assert torch.equal(ref["input_ids"], got["input_ids"]) and torch.equal(ref["labels"], got["labels"])
+    fix["plain"] = {"conversations": plain, "input_ids": ref["input_ids"], "labels": ref["labels"]}
+    # dict_to_cuda's dtype contract (utils/utils.py:157-171; .cuda() is the identity under the harness)
+    import utils.utils as UU
+    r = UU.dict_to_cuda(D.collate_fn_new(cases.collate_samples(convs, False), tokenizer=tok), torch.bfloat16)
+    g = mine.dict_to_cuda(mine.collate_fn_new(cases.collate_samples(convs, False), tokenizer=tok), torch.bfloat16, device="cpu")
+    for k in r:
+        if torch.is_tensor(r[k]):
+            assert r[k].dtype == g[k].dtype, k
+        elif isinstance(r[k], list) and r[k] and torch.is_tensor(r[k][0]):
+            assert [x.dtype for x in r[k]] == [x.dtype for x in g[k]], k
+    fix["dtypes"] = {k: str(v.dtype if torch.is_tensor(v) else v[0].dtype) for k, v in r.items()
+                     if torch.is_tensor(v) or (isinstance(v, list) and v and torch.is_tensor(v[0]))}
+    torch.save(fix, os.path.join(OUT, "collate.pt"))
+
+
+def gold_targets():
+    """N2: the reference's OWN target functions -- `compute_iou` / `compute_iop` / `compute_all_iou` / `compute_all_iop` (utils/utils.py:174-272)
+    and `SAM_Mask_Reader.extract_sam_segs` (utils/sam_mask_reader.py:69-113: area sort, top 50, decode, pad to square) -- against
+    oracle/targets.py (skimage's nearest resize spelled with scipy, pycocotools' decode with the restated codec: see `ref_harness.setup_utils`)."""
+    import json
+    import tempfile
+    import numpy as np
+    from . import targets as ot
+    _, UU, SR = rh.setup_utils()
+    masks, gt = cases.target_case()
+    rles = [ot.rle_encode(m) for m in masks]
+    recs = [{"segmentation": r, "area": int(m.sum()), "bbox": [0, 0, 1, 1 + i]} for i, (r, m) in enumerate(zip(rles, masks))]
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "sam_masks.json")
+        with open(f, "w") as fh:
+            json.dump([{"image": "other.jpg", "masks": recs[:3]}, {"image": "img.jpg", "masks": recs}], fh)
+        reader = SR.SAM_Mask_Reader(f)
+        ref = reader.extract_sam_segs("img.jpg")
+    mine = ot.extract_sam_segs(recs)
+    assert ref["segs_origin"].shape == (masks.shape[1], masks.shape[2], 50) and ref["segs_square"].dtype == np.float64
+    for k in ("segs_origin", "segs_square"):
+        assert ref[k].dtype == mine[k].dtype and np.array_equal(ref[k], mine[k]), k
+    assert ref["bbox"] == mine["bbox"]
+    r_iou, r_iop = UU.compute_all_iou(ref["segs_origin"], gt), UU.compute_all_iop(ref["segs_origin"], gt)
+    m_iou, m_iop = ot.compute_all_iou_iop(mine["segs_origin"], gt)
+    assert np.array_equal(r_iou, m_iou, equal_nan=True) and np.array_equal(r_iop, m_iop, equal_nan=True)
+    one = UU.compute_iou(ref["segs_origin"][:, :, 0], ot.resize_nearest(gt, *ref["segs_origin"].shape[:2]))
+    assert one == m_iou[0]
+    # fewer than 50 proposals, one of them empty (|seg| = 0: IoP = 0 / 0 = nan, IoU = 0 as numpy gives the reference)
+    sub = ref["segs_origin"][:, :, :3].copy()
+    sub[:, :, 1] = 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s_iou, s_iop = UU.compute_all_iou(sub, gt), UU.compute_all_iop(sub, gt)
+    q_iou, q_iop = ot.compute_all_iou_iop(sub, gt)
+    assert np.array_equal(s_iou, q_iou, equal_nan=True) and np.array_equal(s_iop, q_iop, equal_nan=True) and np.isnan(s_iop[1]) and s_iou[1] == 0
+    print(f"  targets: 50 of {len(recs)} proposals kept, IoU max {np.nanmax(r_iou):.4f}; empty proposal: IoU {s_iou[1]}, IoP {s_iop[1]}")
+    torch.save({"order_bbox_h": torch.tensor([b[3] for b in ref["bbox"]]), "ious": torch.from_numpy(r_iou), "iops": torch.from_numpy(r_iop),
+                "square_sum": torch.from_numpy(ref["segs_square"].sum((0, 1))), "empty_ious": torch.from_numpy(s_iou), "empty_iops": torch.from_numpy(s_iop)},
+               os.path.join(OUT, "targets_ref.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -416,7 +523,12 @@ def main():
     rh.setup(clip_cfg_kwargs=dict(hidden_size=cfg.clip.dim, intermediate_size=cfg.clip.mlp,
                                   num_hidden_layers=cfg.clip.layers, num_attention_heads=cfg.clip.heads),
              dino_cfg_kwargs=dict(num_hidden_layers=cfg.dino.layers))
-    for f in (gold_losses, gold_iou_metric, gold_sam_small, gold_head, gold_lisa_tiny, gold_generate, gold_sam_decoder, gold_amg, gold_amg_crops):
+    every = (gold_losses, gold_iou_metric, gold_sam_small, gold_head, gold_lisa_tiny, gold_generate, gold_sam_decoder, gold_amg, gold_amg_crops,
+             gold_collate, gold_targets)
+    only = set(sys.argv[1:])                                 # `python -m oracle.make_goldens gold_collate gold_targets`: just these
+    for f in every:
+        if only and f.__name__ not in only:
+            continue
         print(f.__name__)
         f()
     print("wrote", sorted(os.listdir(OUT)))

@@ -85,6 +85,47 @@ def setup(clip_cfg_kwargs=None, dino_cfg_kwargs=None):
     _state.update(ready=True, clip_cfg=clip_cfg, dino_kwargs=dk)
 
 
+def setup_utils():
+    """Import the reference's `utils` package (datasets, collate, target functions).  Its modules import cv2, pycocotools, h5py,
+    skimage, matplotlib at the top: none is installed, none is called by `collate_fn_new`; two ARE called by the target functions and
+    are spelled with what they run on:
+      * `skimage.transform.resize(gt, (H, W), anti_aliasing=False, preserve_range=True, order=0)` (utils/utils.py:240,260) ==
+        `scipy.ndimage.zoom(float64 image, out / in, order=0, mode="mirror", grid_mode=True)` -- skimage 0.22's own implementation of that call;
+      * `pycocotools.mask.decode(list of RLE dicts) -> uint8 [H, W, K]` (utils/sam_mask_reader.py:87) by `oracle.targets.rle_decode`
+        (maskApi.c restated; PARITY UNPINNED for the codec -- what this import pins is the reader's ordering / top-50 / padding).
+    -> (utils.dataset, utils.utils, utils.sam_mask_reader) modules."""
+    setup()
+    import numpy as np
+    import scipy.ndimage as ndi
+    from . import targets as otargets
+
+    def sk_resize(image, output_shape, order=None, mode="reflect", cval=0, clip=True, preserve_range=False, anti_aliasing=None, **_):
+        assert order == 0 and not anti_aliasing and preserve_range, "only the call the reference makes is spelled out"
+        img = np.asarray(image).astype(np.float64)
+        return ndi.zoom(img, [o / i for o, i in zip(output_shape, img.shape)], order=0, mode="mirror", cval=cval, grid_mode=True)
+
+    def coco_decode(rles):
+        if isinstance(rles, dict):
+            return otargets.rle_decode(rles)
+        return np.stack([otargets.rle_decode(r) for r in rles], -1)
+
+    _stub("skimage.transform", resize=sk_resize)
+    sys.modules["skimage"].transform = sys.modules["skimage.transform"]
+    _stub("skimage.io")
+    _stub("pycocotools")
+    _stub("pycocotools.mask", decode=coco_decode)
+    sys.modules["pycocotools"].mask = sys.modules["pycocotools.mask"]
+    _stub("pycocotools.coco", COCO=object)
+    _stub("h5py")
+    _stub("matplotlib"); _stub("matplotlib.pyplot")
+    _stub("matplotlib.patches", Polygon=object, Rectangle=object)
+    _stub("matplotlib.collections", PatchCollection=object)
+    for m in ("utils.utils", "utils.sam_mask_reader"):          # imported earlier with the None stubs? re-import against the working ones
+        sys.modules.pop(m, None)
+    D = importlib.import_module("utils.dataset")
+    return D, importlib.import_module("utils.utils"), importlib.import_module("utils.sam_mask_reader")
+
+
 class _ClipHiddenStates(nn.Module):
     """transformers-5.x records `hidden_states` through forward hooks that get duplicated when the
     tower is re-entered from several call paths (observed: 7 entries for a 3-layer model), which

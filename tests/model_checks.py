@@ -292,3 +292,96 @@ def check_full_width_sam_blocks():
     lo_e = (lo - ref).abs().max().item()
     return [(f"full-width SAM-H windowed + global block + neck (bf16-CPU err {lo_e:.2e}, |ref| {ref.abs().max().item():.2f})", (got - ref).abs().max().item(),
              max(2e-2 * max(1.0, ref.abs().max().item()), 1.5 * lo_e))]
+
+
+# ------------------------------------------------------------------------------------------------ A14: collate -> make_plan -> model_forward
+_ORACLE_KEYS = ("images", "images_clip", "input_ids", "labels", "attention_masks", "offset", "sam_segs_list", "sam_ious_list", "sam_iops_list", "masks_list")
+
+
+def _collate_prompt(msgs):
+    from llmseg_amd import collate
+    t = collate.CONV_TEMPLATES["llava_v1"]
+    return t.get_prompt([m for q, a in msgs for m in ((t.roles[0], q), (t.roles[1], a))])
+
+
+def check_collate_batch(golden_loader, backbone="sam"):
+    """What the real collate emits -- unk right-padding with mask False, two [SEG] in one conversation, a conversation cut at 512 - 255 that lost
+    its [SEG], three images with different proposal counts -- through `make_plan` + `model_forward` against the oracle.  The token tensors are
+    asserted equal to the fixture recorded from the imported reference `collate_fn_new` (tests/golden/collate.pt) first."""
+    from llmseg_amd import collate
+    from oracle.stub_tokenizer import StubTokenizer
+    g = golden_loader("collate.pt")
+    cfg = cases.tiny_lisa_cfg(backbone)
+    m, sd = build_pair(cfg)
+    img = 896 if backbone == "dinov2" else cfg.sam.img
+    tok = StubTokenizer(model_max_length=g["model_max_length"])
+    convs = cases.collate_conversations(_collate_prompt)
+    res = []
+    # training batch: 3 images, 5 conversations, T = 512
+    col = collate.collate_fn_new(cases.collate_samples(convs, False, K=16, img=img, clip=224, seg=256), tokenizer=tok)
+    for k in ("input_ids", "labels", "attention_masks", "offset"):
+        assert torch.equal(col[k], g["train"][k]), k
+    batch = _round_batch({k: col[k] for k in _ORACLE_KEYS})
+    with torch.no_grad():
+        ref = olisa.model_forward(sd, cfg, **batch, inference=False)
+        lo = olisa.model_forward(_bf16_sd(sd), cfg, **_bf16_batch(batch), inference=False)
+    dev_batch = collate.model_kwargs(collate.dict_to_cuda(dict(col), torch.bfloat16, device=DEV))
+    assert dev_batch["sam_ious_list"][0].dtype == torch.float64 and dev_batch["images"].dtype == BF
+    with torch.no_grad():
+        got = m.model_forward(**dev_batch)
+    for k in ("ce_loss", "align_loss", "regression_loss", "loss"):
+        r = float(ref[k])
+        res.append((f"{backbone} collated train batch {k} (ref {r:.4f}, bf16-CPU err {abs(float(lo[k]) - r):.2e})", abs(float(got[k]) - r),
+                    max(5e-3 * max(1.0, abs(r)), 1.5 * abs(float(lo[k]) - r))))
+    # validation batch: one image, two conversations (the first one is scored, LISA.py:394-414), no truncation
+    col = collate.collate_fn_new(cases.collate_samples(convs[:1], True, K=16, img=img, clip=224, seg=256), tokenizer=tok)
+    assert torch.equal(col["input_ids"], g["infer"]["input_ids"][:2, :col["input_ids"].shape[1]])
+    batch = _round_batch({k: col[k] for k in _ORACLE_KEYS if k not in ("sam_ious_list", "sam_iops_list", "labels")})
+    with torch.no_grad():
+        ref = olisa.model_forward(sd, cfg, **batch, labels=None, inference=True)
+        lo = olisa.model_forward(_bf16_sd(sd), cfg, **_bf16_batch(batch), labels=None, inference=True)
+        got = m.model_forward(**collate.model_kwargs(collate.dict_to_cuda(dict(col), torch.bfloat16, device=DEV)))
+    for k in ("pred_similarity", "pred_iou"):
+        lo_e = _e(lo[k][0], ref[k][0])
+        res.append((f"{backbone} collated val batch {k} (bf16-CPU err {lo_e:.2e})", _e(got[k][0], ref[k][0]), max(1e-3, 1.5 * lo_e)))
+    return res
+
+
+def check_val_sample_flow(backbone="dinov2"):
+    """configs[0]'s plumbing on synthetic data: proposal records (COCO RLE + area) + a ground-truth mask -> `reason_seg_sample` (N2 on the device)
+    -> `collate_fn_new` -> `dict_to_cuda` -> `validate.sample_from_collated` -> `validate_threshold`, against the oracle's target path
+    (bit-exact proposal maps) and the oracle loop body fed with the model's own predicted-IoP rows."""
+    import numpy as np
+    from llmseg_amd import collate, targets, validate
+    from oracle import metric, seeded, targets as ot
+    from oracle.stub_tokenizer import StubTokenizer
+    cfg = cases.tiny_lisa_cfg(backbone)
+    m, _ = build_pair(cfg)
+    img = 896 if backbone == "dinov2" else cfg.sam.img
+    tok = StubTokenizer()
+    samples, keep, res = [], [], []
+    for n, (H, W, K) in enumerate([(120, 160, 9), (96, 64, 60)]):
+        masks = (seeded.uniform((K, H, W), 400 + n) > seeded.uniform((K, 1, 1), 410 + n, 0.2, 0.9)).to(torch.uint8)
+        gt = (seeded.uniform((H + 7, W + 5), 420 + n) > 0.4).to(torch.uint8)
+        recs = [{"segmentation": r, "area": int(mk.sum()), "bbox": [0, 0, 1, i]} for i, (r, mk) in enumerate(zip(targets.rle_encode_masks(masks), masks))]
+        s = collate.reason_seg_sample(seeded.uniform((3, img, img), 430 + n, -2, 2), seeded.uniform((3, 224, 224), 440 + n, -2, 2), ["the thing that matters "],
+                                      gt[None], recs, DEV, inference=True, image_path=f"val{n}.jpg", resize=(img, img))
+        o = ot.extract_sam_segs(recs)
+        assert torch.equal(s["segs"].cpu(), ot.proposal_maps(o["segs_square"])), "proposal maps differ from the oracle's (bit-exact path)"
+        assert np.array_equal(s["segs_origin"].cpu().numpy(), o["segs_origin"]) and s["bbox"] == o["bbox"]
+        col = collate.dict_to_cuda(collate.collate_fn_new([s], tokenizer=tok), torch.bfloat16, device=DEV)
+        assert col["inference"] is True and col["input_ids"].shape[0] == 1 and int((col["input_ids"] == cfg.seg_token_idx).sum()) == 1
+        samples.append(validate.sample_from_collated(col))
+        keep.append((torch.from_numpy(o["segs_origin"]), gt))
+    thr = 0.45
+    got = validate.validate_threshold(m, samples, threshold=thr)
+    I = torch.zeros(2, dtype=torch.float64); U = torch.zeros(2, dtype=torch.float64); A = torch.zeros(2, dtype=torch.float64)
+    for s, (segs, gt) in zip(samples, keep):
+        kw = {k: v for k, v in s.items() if k not in ("origin_segs", "gt_mask")}
+        with torch.no_grad():
+            row = m.model_forward(**kw, inference=True)["pred_iou"][0][0].float().cpu()
+        i, u, _, a = metric.union_resize_iou(segs, row, gt, threshold=thr)
+        I += i.double(); U += u.double(); A += a.double()
+    res += [(f"{backbone} val sample -> collate -> validate_threshold gIoU", abs(got["giou"] - (A / 2)[1].item()), 1e-6),
+            (f"{backbone} val sample -> collate -> validate_threshold cIoU", abs(got["ciou"] - (I / (U + 1e-10))[1].item()), 1e-6)]
+    return res

@@ -48,6 +48,19 @@ def test_validate_loop():
     _assert(mc.check_validate_loop("dinov2"))
 
 
+@pytest.mark.parametrize("backbone", ["sam", "dinov2"])
+def test_collated_batches_vs_oracle(golden, backbone):
+    """A14: the real collate's output (reference-pinned fixture) through make_plan + model_forward."""
+    from tests import model_checks as mc
+    _assert(mc.check_collate_batch(golden, backbone))
+
+
+def test_val_sample_through_collate_and_validate():
+    """BASELINE configs[0]'s plumbing on synthetic data."""
+    from tests import model_checks as mc
+    _assert(mc.check_val_sample_flow("dinov2"))
+
+
 def test_head_golden_k256_k512(golden):
     from tests import model_checks as mc
     _assert(mc.check_head_golden(golden))

@@ -133,3 +133,22 @@ def test_device_table_cache_is_bounded():
     assert d[2] == 4                      # a read refreshes the entry ...
     d[9] = 81
     assert list(d) == [4, 2, 9]           # ... so the oldest UNUSED one (3) was evicted
+
+
+def test_oracle_equals_the_references_own_target_functions(golden):
+    """tests/golden/targets_ref.pt was recorded from the imported `SAM_Mask_Reader.extract_sam_segs` + `compute_all_iou` / `compute_all_iop`
+    (oracle/make_goldens.py::gold_targets); the oracle must reproduce it exactly (float64 quotients of integer counts)."""
+    from oracle import cases
+    g = golden("targets_ref.pt")
+    masks, gt = cases.target_case()
+    recs = [{"segmentation": ot.rle_encode(m), "area": int(m.sum()), "bbox": [0, 0, 1, 1 + i]} for i, m in enumerate(masks)]
+    mine = ot.extract_sam_segs(recs)
+    assert [b[3] for b in mine["bbox"]] == g["order_bbox_h"].tolist()                  # area order (stable on ties), top 50
+    assert mine["segs_square"].shape[0] == mine["segs_square"].shape[1] == max(masks.shape[1:])
+    assert np.array_equal(mine["segs_square"].sum((0, 1)), g["square_sum"].numpy())
+    ious, iops = ot.compute_all_iou_iop(mine["segs_origin"], gt)
+    assert np.array_equal(ious, g["ious"].numpy()) and np.array_equal(iops, g["iops"].numpy())
+    sub = mine["segs_origin"][:, :, :3].copy()
+    sub[:, :, 1] = 0
+    ious, iops = ot.compute_all_iou_iop(sub, gt)
+    assert np.array_equal(ious, g["empty_ious"].numpy(), equal_nan=True) and np.array_equal(iops, g["empty_iops"].numpy(), equal_nan=True)
