@@ -49,8 +49,16 @@ class LISAForCausalLM(TrainableMixin, GenerateMixin, SamDecoderMixin, AmgMixin, 
         config.regression_loss_weight = kwargs.pop("regression_loss_weight", config.regression_loss_weight)
         config.seg_token_idx = kwargs.pop("seg_token_idx", config.seg_token_idx)
         config.out_dim = kwargs.pop("out_dim", config.out_dim)
-        for k in ("train_mask_decoder", "vision_pretrained", "vision_tower", "use_mm_start_end"):
-            kwargs.pop(k, None)
+        # the init half of the surface (training.py:140-171): kept and ACTED on by `initialize_vision_modules` / `initialize_lisa_modules` /
+        # `from_pretrained` (llmseg_amd/pretrained.py) -- round 4 dropped them silently
+        if kwargs.pop("train_mask_decoder", False):
+            raise NotImplementedError("train_mask_decoder=True: LLM-Seg never trains SAM's mask decoder (training.py:60 default False; the "
+                                      "decoder is only reached by evaluate()), and this package keeps it frozen")
+        self.vision_pretrained = kwargs.pop("vision_pretrained", None)      # path of the SAM ViT-H checkpoint (build_sam.py:98-107)
+        self.vision_tower = kwargs.pop("vision_tower", None)                # HF CLIP ViT-L/14: a LOCAL directory here (no network)
+        self.use_mm_start_end = kwargs.pop("use_mm_start_end", True)        # read by the collate (utils/dataset.py:73-83), stored for it
+        if kwargs:
+            raise TypeError(f"unexpected keyword arguments {sorted(kwargs)} (reference surface: model/LISA.py:150-161)")
         self.config = config
         self.seg_token_idx = config.seg_token_idx
         self.device_ = torch.device(device)
@@ -92,6 +100,53 @@ class LISAForCausalLM(TrainableMixin, GenerateMixin, SamDecoderMixin, AmgMixin, 
 
     def get_model(self):
         return self
+
+    def get_vision_tower(self):
+        """The reference returns the CLIP module (llava_arch.py:90-91); here the tower's parameters live under this prefix of `params`."""
+        return self.params._modules["model"]._modules["vision_tower"]
+
+    # ------------------------------------------------------------------------------------------ init half (training.py:139-243)
+    def initialize_vision_modules(self, config=None):
+        """`LlavaMetaModel.initialize_vision_modules` (llava_arch.py:43-82, called at training.py:168): build the CLIP tower and load its
+        weights.  The tower's tensors already exist (ParamTree); this loads them from `vision_tower` when that is a local HF directory."""
+        import os
+        from . import pretrained
+        if not (isinstance(self.vision_tower, str) and os.path.isdir(self.vision_tower)):
+            raise FileNotFoundError(f"vision_tower={self.vision_tower!r} is not a local directory: there is no network here, download "
+                                    "openai/clip-vit-large-patch14 and pass its path")
+        return pretrained.load_clip(self, self.vision_tower)
+
+    def initialize_lisa_modules(self, config=None, seed=0, dinov2_state=None):
+        """`LisaMetaModel.initialize_lisa_modules` (LISA.py:35-121, called at training.py:171): SAM ViT-H from `vision_pretrained`
+        (None leaves it as initialised, as `build_sam_vit_h(None)` does), DINOv2 from `dinov2_state` (the hub download of LISA.py:48 is
+        impossible offline: pass the state dict or a file), and the freshly initialised text_hidden_fcs / lisa_* modules."""
+        from . import pretrained
+        rep = {}
+        if self.vision_pretrained is not None:
+            rep["sam"] = pretrained.load_sam(self, self.vision_pretrained)
+        if dinov2_state is not None:
+            rep["dinov2"] = pretrained.load_dinov2(self, dinov2_state)
+        rep["fresh"] = pretrained.init_lisa_modules(self, seed)
+        return rep
+
+    @classmethod
+    def from_pretrained(cls, version, torch_dtype=BF16, device="cuda", dinov2_state=None, lora_r=8, lora_alpha=16, lora_dropout=0.05,
+                        backbone="dinov2", seed=0, new_rows="normal", vocab_size=None, sam_decoder=False, towers=None, **model_args):
+        """`init_LISA_model` (training.py:139-243) in one call: config.json of the HF LLaVA directory `version` -> model at the tokenizer's
+        final vocabulary (`vocab_size` = len(tokenizer) after training.py:130-135 added [SEG] / <im_start> / <im_end>; default: the file's + 1,
+        i.e. 32004 for the LLaVA-Lightning v1-1 checkpoints whose 32003 rows already hold the two image tags) -> weights
+        (`pretrained.load_pretrained`) -> LoRA -> resized embeddings -> trainable set.  `model_args`: the reference's kwargs
+        (`vision_pretrained`, `vision_tower`, `seg_token_idx`, loss weights, ...)."""
+        from . import pretrained
+        assert torch_dtype == BF16, "the HIP path computes in bf16 (training.py:151-156 `--precision bf16`)"
+        cfg = pretrained.config_from_hf(version, backbone=backbone, sam_decoder=sam_decoder, **(towers or {}))     # towers: {"clip" / "sam" / "dino": config} when not ViT-L / ViT-H / ViT-L
+        file_vocab = cfg.llama.vocab
+        cfg.llama.vocab = int(vocab_size) if vocab_size is not None else file_vocab + 1          # pass len(tokenizer); default: the file's + [SEG]
+        cfg.llama.lora_r, cfg.llama.lora_alpha, cfg.llama.lora_dropout = lora_r, lora_alpha, lora_dropout
+        m = cls(cfg, device=device, **model_args)
+        m.load_report = pretrained.load_pretrained(m, version, sam_ckpt=m.vision_pretrained, clip_dir=m.vision_tower, dinov2_sd=dinov2_state,
+                                                   seed=seed, new_rows=new_rows)
+        return m
 
     # ------------------------------------------------------------------------------------------ derived weights
     @torch.no_grad()

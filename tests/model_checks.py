@@ -7,6 +7,7 @@ about as close to fp32 as the reference's own arithmetic is (it accumulates in f
 """
 import dataclasses
 
+import pytest
 import torch
 
 from llmseg_amd import lisa as hip_lisa
@@ -384,4 +385,74 @@ def check_val_sample_flow(backbone="dinov2"):
         I += i.double(); U += u.double(); A += a.double()
     res += [(f"{backbone} val sample -> collate -> validate_threshold gIoU", abs(got["giou"] - (A / 2)[1].item()), 1e-6),
             (f"{backbone} val sample -> collate -> validate_threshold cIoU", abs(got["ciou"] - (I / (U + 1e-10))[1].item()), 1e-6)]
+    return res
+
+
+def check_from_pretrained(tmpdir):
+    """The init half of the boundary on the device: tiny checkpoints in the authors' formats (sharded safetensors LLaVA directory with a
+    smaller vocabulary, SAM .pth, HF CLIP directory) -> `LISAForCausalLM.from_pretrained` -> a training-mode forward that must equal the oracle
+    evaluated on the LOADED model's own state dict (so a mis-mapped, transposed or unloaded tensor shows up as a loss mismatch)."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    from oracle import seeded
+    cfg = cases.tiny_lisa_cfg("sam", lora_r=8)
+    full = cases.tiny_lisa_state(cfg)
+    file_vocab = cfg.llama.vocab - 4
+    d = os.path.join(tmpdir, "llava")
+    os.makedirs(d)
+    with open(os.path.join(d, "config.json"), "w") as fh:
+        json.dump(dict(hidden_size=cfg.llama.hidden, intermediate_size=cfg.llama.inter, num_hidden_layers=cfg.llama.layers,
+                       num_attention_heads=cfg.llama.heads, vocab_size=file_vocab, rms_norm_eps=cfg.llama.eps, mm_vision_select_layer=-2), fh)
+    lang = {k: v for k, v in full.items() if (k.startswith(("model.layers.", "model.embed_tokens.", "model.norm.", "lm_head.", "model.mm_projector.")) and ".lora_" not in k)}
+    lang["model.embed_tokens.weight"], lang["lm_head.weight"] = lang["model.embed_tokens.weight"][:file_vocab], lang["lm_head.weight"][:file_vocab]
+    names = sorted(lang)
+    wm = {}
+    for i in range(2):
+        f = f"model-0000{i + 1}-of-00002.safetensors"
+        save_file({k: lang[k].to(BF).contiguous() for k in names[i::2]}, os.path.join(d, f))
+        wm.update({k: f for k in names[i::2]})
+    with open(os.path.join(d, "model.safetensors.index.json"), "w") as fh:
+        json.dump({"weight_map": wm}, fh)
+    sp = "model.visual_model."
+    torch.save({k[len(sp):]: v for k, v in full.items() if k.startswith(sp)}, os.path.join(tmpdir, "sam.pth"))
+    cp = "model.vision_tower.vision_tower."
+    os.makedirs(os.path.join(tmpdir, "clip"))
+    torch.save({k[len(cp):]: v for k, v in full.items() if k.startswith(cp)}, os.path.join(tmpdir, "clip", "pytorch_model.bin"))
+    hc = to_hip_cfg(cfg)
+    m = hip_lisa.LISAForCausalLM.from_pretrained(d, device=DEV, backbone="sam", vocab_size=cfg.llama.vocab, lora_r=8, lora_dropout=0.0,
+                                                 towers=dict(clip=hc.clip, sam=hc.sam, dino=hc.dino, build_unused_towers=False),
+                                                 vision_pretrained=os.path.join(tmpdir, "sam.pth"), vision_tower=os.path.join(tmpdir, "clip"),
+                                                 seg_token_idx=cfg.seg_token_idx, use_mm_start_end=True)
+    rep = m.load_report
+    assert rep["llava"]["short"] == {"model.embed_tokens.weight": file_vocab, "lm_head.weight": file_vocab} and rep["resized"]["lm_head.weight"] == (file_vocab, cfg.llama.vocab)
+    assert m.vision_pretrained.endswith("sam.pth") and m.use_mm_start_end is True
+    own = dict(m.params.named_parameters())
+    on = {n for n, p in own.items() if p.requires_grad}
+    assert "model.layers.1.self_attn.v_proj.lora_B.default.weight" in on and "model.layers.1.self_attn.v_proj.weight" not in on
+    assert bool((own["model.layers.0.self_attn.q_proj.lora_B.default.weight"] == 0).all())                 # adapter starts as the identity
+    res = []
+    for k in ("model.layers.1.mlp.down_proj.weight", "model.visual_model.image_encoder.blocks.1.attn.rel_pos_w",
+              "model.vision_tower.vision_tower.vision_model.embeddings.class_embedding", "model.mm_projector.bias"):
+        res.append((f"from_pretrained {k} == file", _e(own[k], full[k].to(BF)), 0.0))
+    res.append(("from_pretrained embed rows of the file", _e(own["model.embed_tokens.weight"][:file_vocab], full["model.embed_tokens.weight"][:file_vocab].to(BF)), 0.0))
+    new = own["lm_head.weight"].detach()[file_vocab:].float()
+    res.append(("from_pretrained new lm_head rows ~ N(0, 0.02)", float(new.abs().max()), 0.12))
+    assert float(new.abs().max()) > 0
+    with pytest.raises(NotImplementedError):
+        hip_lisa.LISAForCausalLM(hc, device=DEV, train_mask_decoder=True)
+    with pytest.raises(TypeError):
+        hip_lisa.LISAForCausalLM(hc, device=DEV, not_a_reference_kwarg=1)
+    # the loaded model == the oracle on the loaded model's own tensors
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    batch = _round_batch(cases.tiny_lisa_batch(img_size=cfg.sam.img))
+    m.eval()
+    with torch.no_grad():
+        ref = olisa.model_forward(sd, cfg, **batch, inference=False)
+        lo = olisa.model_forward(_bf16_sd(sd), cfg, **_bf16_batch(batch), inference=False)
+        got = m.model_forward(**_dev(batch), inference=False)
+    for k in ("ce_loss", "align_loss", "regression_loss"):
+        r = float(ref[k])
+        res.append((f"from_pretrained model train {k} vs oracle on its state dict (ref {r:.4f})", abs(float(got[k]) - r),
+                    max(5e-3 * max(1.0, abs(r)), 1.5 * abs(float(lo[k]) - r))))
     return res

@@ -61,6 +61,12 @@ def test_val_sample_through_collate_and_validate():
     _assert(mc.check_val_sample_flow("dinov2"))
 
 
+def test_from_pretrained_tiny_checkpoints(tmp_path):
+    """The init half of the boundary (training.py:139-243): sharded safetensors LLaVA dir + SAM .pth + CLIP dir -> model == oracle on its own tensors."""
+    from tests import model_checks as mc
+    _assert(mc.check_from_pretrained(str(tmp_path)))
+
+
 def test_head_golden_k256_k512(golden):
     from tests import model_checks as mc
     _assert(mc.check_head_golden(golden))
