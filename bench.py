@@ -133,10 +133,14 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
         trainer.leaf_stream = False
         overlap, model.overlap_towers = model.overlap_towers, False      # one stream: a launch's duration must not include another stream's kernels
         from llmseg_amd import _lib
-        trainer.micro = 0                                              # not the last micro-step of a window: no optimizer launches in the count
         n0 = _lib.load().llmseg_launch_count()
-        trainer.micro_step(batch, plan)
+        trainer._eager_step(batch, plan)                               # fwd + bwd only: never the optimizer, whatever --accum is; the window counter is untouched
         torch.cuda.synchronize()
+        if trainer.arena is not None:                                  # (that extra gradient must not reach a later optimizer step)
+            trainer.arena.zero_()
+        else:
+            for p_ in trainer.params:
+                p_.grad = None
         res["launches_per_micro_step"] = {"library_kernels": int(_lib.load().llmseg_launch_count() - n0),
                                           "note": "kernels libllmseg_hip.so launches for one fwd+bwd micro-step (the hipGraph replays the same nodes plus "
                                                   "PyTorch's glue kernels: zero-fills, casts, the loss sum)"}
@@ -188,6 +192,32 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
         fdt, _ = timed(fstep, args.steps, max(1, args.warmup), dist, dev)
         res["fwd_only"] = {"value": B * world * args.steps / fdt, "unit": "images/s", "ms_per_step": fdt / args.steps * 1e3,
                            "workload": "BASELINE.json configs[1]: forward-only model_forward (incl. lm_head + CE + align + IoP losses), same batch"}
+    return res
+
+
+def accum_fused(model, cfg, args, B, dev, dist, rank, world, local, trainer_cls):
+    """The SAME optimizer step as the headline -- `--accum` micro-batches of B images, per-micro-batch loss normalisation, AdamW on the averaged
+    gradient -- with the accumulation window folded into ONE pass (`Trainer(fused_accum=k)`, `make_plan(micro_batches=k)`): every GEMM runs at
+    k x the rows (M = 638 -> 6380 at 2 x 10), the weights are read once per optimizer step instead of k times.  Gradient equality with the k
+    micro-steps: tests/backward_checks.py::check_fused_accum.  A timed step = one pass over k micro-batches + the optimizer step.  Reported beside the
+    headline, never as it: BASELINE configs[2] is batch_size = 2 per step."""
+    from llmseg_amd import synthetic
+    from llmseg_amd.train import merge_micro_batches
+    img = 1024 if args.backbone == "sam" else 896
+    k = args.accum
+    merged = merge_micro_batches([synthetic.make_batch(B, img_size=img, L=args.prompt_len, K=args.masks, device=dev, seed=1234 + rank + 101 * j) for j in range(k)])
+    plan = model.make_plan(**merged, micro_batches=k)
+    trainer = trainer_cls(model, lr=3e-4, grad_accum=1, device_ids=[local], use_graph=True, fused_accum=k)
+    steps = max(2, args.steps // 2)
+    dt, out = timed(lambda: trainer.micro_step(merged, plan), steps, 4, dist, dev)
+    res = {"value": B * k * world * steps / dt, "unit": "images/s", "ms_per_optimizer_step": dt / steps * 1e3, "ms_per_micro_batch": dt / steps / k * 1e3,
+           "micro_batches_per_pass": k, "images_per_pass_per_gpu": B * k, "timed_optimizer_steps": steps, "loss_sum_over_micro_batches": float(out["loss"].detach()),
+           "graph": bool(trainer.graph_error is None and any(e["graph"] is not None for e in trainer._graphs.values())),
+           "what": "one fused fwd+bwd pass over the %d micro-batches of an optimizer step (%d images, Llama GEMMs at M = %d) + AdamW, replayed from a hipGraph; "
+                   "same gradient as %d micro-steps (per-micro-batch CE / image means, per-micro-batch dropout masks)" % (k, B * k, B * k * (args.prompt_len - 1 + cfg.n_img_tokens), k)}
+    if trainer.graph_error:
+        res["graph_error"] = trainer.graph_error[:200]
+    trainer.close()
     return res
 
 
@@ -341,6 +371,7 @@ def main():
     ap.add_argument("--no-neighbours", action="store_true", help="skip the generation / everything-mode side measurements (SURVEY.md 8f N3, N1)")
     ap.add_argument("--accum", type=int, default=10, help="gradient-accumulation micro-steps per optimizer step (reference: 10)")
     ap.add_argument("--no-k512", action="store_true", help="skip the BASELINE configs[4] side measurement (512 candidate masks, grad-accum 8) reported under batch_<B>_k512")
+    ap.add_argument("--no-accum-fused", action="store_true", help="skip the fused-accumulation-window side measurement (the --accum micro-batches of an optimizer step as one pass)")
     ap.add_argument("--no-loader", action="store_true", help="skip the loader-in-the-loop side measurement (a different batch + device-side targets + a fresh plan every micro-step)")
     args = ap.parse_args()
 
@@ -350,13 +381,10 @@ def main():
         have = torch.cuda.device_count()
         if have < args.gpus:
             sys.exit(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} GPU(s); refusing to report a {args.gpus}-GPU figure")
-        import socket
         import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        # --standalone: the launcher picks a free rendezvous port itself (binding one here and releasing it can race with another process)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         sys.exit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
@@ -412,6 +440,9 @@ def main():
         a4.steps = max(a4.accum, (args.steps // a4.accum) * a4.accum)           # whole accumulation windows inside the timed region
         k512 = measure(model, cfg, a4, args.batch, dev, dist, rank, world, local, use_graph, Trainer)
         k512["workload"] = "BASELINE.json configs[4] shape: %d candidate masks per image, grad-accum %d, %d timed micro-steps" % (a4.masks, a4.accum, a4.steps)
+    fused = None
+    if train and use_graph and not args.no_accum_fused and args.accum > 1:
+        fused = accum_fused(model, cfg, args, args.batch, dev, dist, rank, world, local, Trainer)
     loader = None
     if train and use_graph and not args.no_loader and not args.small:
         loader = loader_in_loop(model, cfg, args, args.batch, dev, dist, rank, world, local, Trainer, main_res["ms_per_step"])
@@ -450,6 +481,8 @@ def main():
             res[f"batch_{args.extra_batch}"] = extra
         if k512 is not None:
             res[f"batch_{args.batch}_k512"] = k512
+        if fused is not None:
+            res["accum_fused"] = fused
         if loader is not None:
             res["loader_in_loop"] = loader
         if world == 1 and not args.no_neighbours and not args.small and args.backbone == "sam":

@@ -31,8 +31,9 @@ enum { LLMSEG_ACT_NONE = 0, LLMSEG_ACT_RELU = 1, LLMSEG_ACT_GELU = 2, LLMSEG_ACT
  * so a binding written against an older header (fields were appended in every round) fails loudly instead of having the library read
  * past the caller's struct.  llmseg_struct_size(which) returns the library's sizeof (0 = llmseg_gemm_args, 1 = llmseg_attn_args,
  * 2 = llmseg_attn_bwd_args, 3 = llmseg_dropout; -1 for an unknown index) so a binding can assert at load time;
- * llmseg_version() is bumped whenever a struct or a signature changes (4 = this header: the reduction entry points take a workspace). */
-#define LLMSEG_ABI_VERSION 4
+ * llmseg_version() is bumped whenever a struct or a signature changes (4: the reduction entry points take a workspace; 5 = this header:
+ * llmseg_dropout.seg_rows). */
+#define LLMSEG_ABI_VERSION 5
 
 /* Determinism (round 4).  No kernel adds floating-point numbers with atomics: every sum whose terms come from several workgroups is
  * written as per-workgroup partials into CALLER-OWNED scratch (`workspace`, `workspace_bytes`; any device memory, 256-byte aligned, not
@@ -384,11 +385,16 @@ int llmseg_scatter_add_rows(const void* src, const int64_t* idx, float* dst, int
  * Dropout (NULL = none, as in eval mode) is counter-based, nothing is stored: Philox4x32-10 with key = rng_state[0] (seed), counter
  * = (element index / 8, stream, rng_state[1] (offset)); the 16-bit field j of the 128-bit output decides element 8 idx + j, kept
  * when field >= drop_thr (= round(p * 65536)) and scaled by 65536 / (65536 - drop_thr); element index = row * width + column of
- * the dense [M][width] activation.  rng_state is DEVICE memory (a captured hipGraph reads a fresh offset on every replay). */
+ * the dense [M][width] activation.  rng_state is DEVICE memory (a captured hipGraph reads a fresh offset on every replay).
+ * seg_rows > 0 (ABI 5): the M rows are consecutive SEGMENTS of seg_rows rows -- the micro-batches of a gradient-accumulation window run as
+ * one pass -- and segment s = row / seg_rows draws the mask a separate pass over it would draw at offset + s: element index =
+ * (row % seg_rows) * width + column, counter offset = rng_state[1] + s. */
 typedef struct {
   const uint64_t* rng_state;   /* device: {seed, offset} */
   uint32_t stream;             /* which dropout module (layer * 2 + {q = 0, v = 1}) */
   uint32_t drop_thr;           /* round(p * 65536); 0 = no dropout */
+  uint32_t seg_rows;           /* 0 = one segment (all rows at rng_state[1]) */
+  uint32_t reserved0;          /* 0 */
 } llmseg_dropout;
 int llmseg_lora_down(const void* x0, const void* x1, int64_t ldx, const void* w0, const void* w1, void* y, int64_t ldy, int64_t M, int64_t K,
                      int32_t w_kr, float alpha, int32_t zero_cols, const llmseg_dropout* drop, void* stream);

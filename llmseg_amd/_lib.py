@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LLMSEG_LIB") or os.path.join(_HERE, "libllmseg_hip.so")     # LLMSEG_LIB: side builds of the same ABI (tools/ experiments)
 
-ABI_VERSION = 4          # == LLMSEG_ABI_VERSION of include/llmseg_hip.h
+ABI_VERSION = 5          # == LLMSEG_ABI_VERSION of include/llmseg_hip.h
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SILU, ACT_SIGMOID = range(6)
 
@@ -57,7 +57,7 @@ class AttnBwdArgs(_Sized):
 
 
 class Dropout(C.Structure):
-    _fields_ = [("rng_state", C.c_void_p), ("stream", C.c_uint32), ("drop_thr", C.c_uint32)]
+    _fields_ = [("rng_state", C.c_void_p), ("stream", C.c_uint32), ("drop_thr", C.c_uint32), ("seg_rows", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 _i64, _i32, _f32, _p = C.c_int64, C.c_int32, C.c_float, C.c_void_p

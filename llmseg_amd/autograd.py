@@ -160,7 +160,7 @@ def lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, drop=None, want_bt=False):
     ride in the qkv GEMM as one extra 64-wide K-tile: A2 = [x Aq^T | x Av^T | 0], W2 rows of the q block = [s Bq | 0], rows of the
     v block = [0 | s Bv | 0] (no read-modify-write pass over q and v).  Both operands are rebuilt from the current LoRA matrices
     on every call (two small kernels): nothing is cached, so an in-place optimizer update or a load_state_dict cannot leave a
-    stale operand behind.  drop = (rng_state, layer, p) or None.  -> (qkv, A2, B^T | None)"""
+    stale operand behind.  drop = (rng_state, layer, p[, seg_rows]) or None.  -> (qkv, A2, B^T | None)"""
     H = wqkv.shape[1]
     M = x.shape[0]
     a2 = torch.empty((M, 64), device=x.device, dtype=BF16)
@@ -174,8 +174,9 @@ def lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, drop=None, want_bt=False):
 def _drops(drop):
     if drop is None or drop[2] <= 0.0:
         return None, None
-    rng, layer, p = drop
-    return (rng, 2 * layer, p), (rng, 2 * layer + 1, p)
+    rng, layer, p = drop[:3]
+    seg = drop[3:]                                                   # optional rows-per-segment of a fused accumulation window
+    return (rng, 2 * layer, p) + tuple(seg), (rng, 2 * layer + 1, p) + tuple(seg)
 
 
 class LoraQKVFn(Function):

@@ -597,7 +597,18 @@ extern "C" int llmseg_adamw(void* p, float* master, const void* grad, int grad_f
 namespace {
 constexpr int LR = 8;
 
-struct DropP { const unsigned long* rng; uint32_t stream, thr; float scale; };     // thr == 0: no dropout
+struct DropP { const unsigned long* rng; uint32_t stream, thr; float scale; uint32_t seg; };     // thr == 0: no dropout; seg: rows per segment (0 = none)
+
+// Philox counter index of the 8 elements starting at (row m, column k) of a dense [M][width] activation, and what to add to the stream's
+// offset: with segments (llmseg_dropout.seg_rows) segment s = m / seg draws the mask of a separate pass at offset + s over its own rows.
+__device__ __forceinline__ unsigned long drop_index(const DropP& dp, unsigned long m, unsigned long width, unsigned long k, uint32_t& off_add) {
+  off_add = 0;
+  if (dp.seg) {
+    off_add = (uint32_t)(m / dp.seg);
+    m -= (unsigned long)off_add * dp.seg;
+  }
+  return (m * width + k) >> 3;
+}
 
 // Two rank-8 down-projections in ONE launch (q and v branches of a LoRA'd q|k|v projection):
 //   y[m][0..7] = alpha * drop0(x0)[m][:] . W0^T,   y[m][8..15] = alpha * drop1(x1)[m][:] . W1^T,   y[m][16..16+zero_cols) = 0
@@ -633,7 +644,11 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict
       for (int i = 0; i < RW; ++i) {
         const long m = min(m0 + i, M - 1);
         unpack8(*reinterpret_cast<const uint4*>(xb + m * ldx + k), xv[i]);
-        if (dp.thr) dropout8(xv[i], ((unsigned long)m * (unsigned long)K + (unsigned long)k) >> 3, dp.stream + b, dp.rng, dp.thr, dp.scale);
+        if (dp.thr) {
+          uint32_t oa;
+          const unsigned long di = drop_index(dp, (unsigned long)m, (unsigned long)K, (unsigned long)k, oa);
+          dropout8(xv[i], di, dp.stream + b, dp.rng, dp.thr, dp.scale, oa);
+        }
       }
       (void)same;
       if (w_kr) {
@@ -694,8 +709,8 @@ __global__ __launch_bounds__(256) void lora_down_mfma_kernel(const bf16_t* __res
   const int kbeg = ((int)blockIdx.y * 4 + wave) * kq;
   const bool same = x0 == x1;
   f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  auto masked = [&](uint4 v, unsigned long idx, uint32_t stream) {
-    const unsigned long seed = dp.rng[0], off = dp.rng[1];
+  auto masked = [&](uint4 v, unsigned long idx, uint32_t stream, uint32_t off_add) {
+    const unsigned long seed = dp.rng[0], off = dp.rng[1] + off_add;
     const Philox8 ph = philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), stream, (uint32_t)off, (uint32_t)seed, (uint32_t)(seed >> 32));
     uint32_t* u = reinterpret_cast<uint32_t*>(&v);
 #pragma unroll
@@ -712,9 +727,10 @@ __global__ __launch_bounds__(256) void lora_down_mfma_kernel(const bf16_t* __res
     const uint4 wa = r < LR ? *reinterpret_cast<const uint4*>(w0 + (long)r * K + k) : make_uint4(0, 0, 0, 0);
     const uint4 wb = (nb > 1 && r < LR) ? *reinterpret_cast<const uint4*>(w1 + (long)r * K + k) : make_uint4(0, 0, 0, 0);
     if (dp.thr) {
-      const unsigned long idx = ((unsigned long)m * (unsigned long)K + (unsigned long)k) >> 3;
-      xa = masked(xa, idx, dp.stream);
-      if (nb > 1) xb = masked(xb, idx, dp.stream + 1);
+      uint32_t oa;
+      const unsigned long idx = drop_index(dp, (unsigned long)m, (unsigned long)K, (unsigned long)k, oa);
+      xa = masked(xa, idx, dp.stream, oa);
+      if (nb > 1) xb = masked(xb, idx, dp.stream + 1, oa);
     }
     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, xa), acc0, 0, 0, 0);
     if (nb > 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wb), __builtin_bit_cast(bf16x8_t, xb), acc1, 0, 0, 0);
@@ -813,7 +829,11 @@ __global__ __launch_bounds__(256) void lora_outer_kernel(OuterP q, long M, long 
       for (int u = 0; u < 3; ++u) {
         float x[8], y[8];
         unpack8(av[u], x); unpack8(bv[u], y);
-        if (dp.thr) dropout8(x, ((unsigned long)(m + 8 * u) * (unsigned long)N + (unsigned long)n) >> 3, dstream, dp.rng, dp.thr, dp.scale);
+        if (dp.thr) {
+          uint32_t oa;
+          const unsigned long di = drop_index(dp, (unsigned long)(m + 8 * u), (unsigned long)N, (unsigned long)n, oa);
+          dropout8(x, di, dstream, dp.rng, dp.thr, dp.scale, oa);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -824,7 +844,11 @@ __global__ __launch_bounds__(256) void lora_outer_kernel(OuterP q, long M, long 
       float x[8], y[8];
       unpack8(*reinterpret_cast<const uint4*>(a + m * lda + n), x);
       unpack8(*reinterpret_cast<const uint4*>(b + m * ldb), y);
-      if (dp.thr) dropout8(x, ((unsigned long)m * (unsigned long)N + (unsigned long)n) >> 3, dstream, dp.rng, dp.thr, dp.scale);
+      if (dp.thr) {
+        uint32_t oa;
+        const unsigned long di = drop_index(dp, (unsigned long)m, (unsigned long)N, (unsigned long)n, oa);
+        dropout8(x, di, dstream, dp.rng, dp.thr, dp.scale, oa);
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -894,7 +918,11 @@ __global__ __launch_bounds__(256) void lora_apply_kernel(bf16_t* __restrict__ y,
           dv[j] = s;
         }
       }
-      if (dp.thr) dropout8(dv, (unsigned long)i, dp.stream + b, dp.rng, dp.thr, dp.scale);
+      if (dp.thr) {
+        uint32_t oa;
+        const unsigned long di = drop_index(dp, (unsigned long)m, (unsigned long)N, (unsigned long)(c * 8), oa);     // == i without segments
+        dropout8(dv, di, dp.stream + b, dp.rng, dp.thr, dp.scale, oa);
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) yv[j] += alpha * dv[j];
     }
@@ -974,9 +1002,9 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16_t* __rest
 }  // namespace
 
 static DropP make_drop(const llmseg_dropout* d) {
-  DropP dp{nullptr, 0u, 0u, 1.f};
+  DropP dp{nullptr, 0u, 0u, 1.f, 0u};
   if (d && d->rng_state && d->drop_thr > 0) {
-    dp.rng = (const unsigned long*)d->rng_state; dp.stream = d->stream; dp.thr = d->drop_thr;
+    dp.rng = (const unsigned long*)d->rng_state; dp.stream = d->stream; dp.thr = d->drop_thr; dp.seg = d->seg_rows;
     dp.scale = 65536.f / (65536.f - (float)d->drop_thr);
   }
   return dp;

@@ -138,8 +138,9 @@ __device__ __forceinline__ Philox8 philox4x32_10(uint32_t c0, uint32_t c1, uint3
   return Philox8{{c0, c1, c2, c3}};
 }
 // multiplies f[0..7] (elements 8 idx .. 8 idx + 7) by the dropout mask * scale
-__device__ __forceinline__ void dropout8(float* f, unsigned long idx, uint32_t stream, const unsigned long* rng, uint32_t thr, float scale) {
-  const unsigned long seed = rng[0], off = rng[1];
+// off_add: added to the stream's offset (the segment index of llmseg_dropout.seg_rows; 0 without segments)
+__device__ __forceinline__ void dropout8(float* f, unsigned long idx, uint32_t stream, const unsigned long* rng, uint32_t thr, float scale, uint32_t off_add = 0) {
+  const unsigned long seed = rng[0], off = rng[1] + off_add;
   const Philox8 r = philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), stream, (uint32_t)off, (uint32_t)seed, (uint32_t)(seed >> 32));
 #pragma unroll
   for (int j = 0; j < 8; ++j) {

@@ -274,8 +274,8 @@ extern "C" int llmseg_proposal_targets(const uint8_t* masks, const int64_t* orde
            "proposal_targets: out_size <= 256, taps <= 28, W <= 2048 (use llmseg_mask_targets + llmseg_resize_aa beyond)");
   LL_CHECK(n_gt >= 0 && n_gt <= TG_MAXG && (n_gt == 0 || (gtp && counts && gt_area && iou && iop)), "proposal_targets: 0..4 ground truths with their outputs");
   if (n_gt) {
-    hipMemsetAsync(counts, 0, (size_t)n_gt * K * 2 * sizeof(int64_t), (hipStream_t)stream);
-    hipMemsetAsync(gt_area, 0, (size_t)n_gt * sizeof(int64_t), (hipStream_t)stream);
+    LL_CHECK(hipMemsetAsync(counts, 0, (size_t)n_gt * K * 2 * sizeof(int64_t), (hipStream_t)stream) == hipSuccess, "proposal_targets: memset failed");
+    LL_CHECK(hipMemsetAsync(gt_area, 0, (size_t)n_gt * sizeof(int64_t), (hipStream_t)stream) == hipSuccess, "proposal_targets: memset failed");
   }
   // slices of output rows per proposal: enough workgroups for ~4 per CU (the kernel is latency-bound per workgroup), each >= 16 output rows
   int ns = (int)std::min<long>(std::max<long>(1, 1024 / K), std::max(1, out_size / 16));

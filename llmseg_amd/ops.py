@@ -541,12 +541,14 @@ def scatter_add_rows(src, idx, dst):
 
 
 def _drop(drop):
-    """drop = (rng_state int64[2] device tensor, stream id, p) or None -> ctypes pointer (or None)."""
+    """drop = (rng_state int64[2] device tensor, stream id, p[, seg_rows]) or None -> ctypes pointer (or None).  seg_rows: rows per
+    segment of a fused accumulation window (`llmseg_dropout.seg_rows`; 0 / absent = one segment)."""
     if drop is None or drop[2] <= 0.0:
         return None
-    rng, stream, p = drop
+    rng, stream, p = drop[:3]
+    seg = int(drop[3]) if len(drop) > 3 else 0
     assert rng.is_cuda and rng.dtype == torch.int64 and rng.numel() == 2
-    return C.byref(_lib.Dropout(rng_state=rng.data_ptr(), stream=int(stream), drop_thr=int(round(p * 65536))))
+    return C.byref(_lib.Dropout(rng_state=rng.data_ptr(), stream=int(stream), drop_thr=int(round(p * 65536)), seg_rows=seg, reserved0=0))
 
 
 def lora_down(x, w, w_kr=False, alpha=1.0, out=None, zero_cols=0, drop=None, x2=None, w2=None):

@@ -107,43 +107,54 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-class _LRU(dict):
-    """Insertion-ordered dict capped at `cap` entries (oldest evicted): a dataset of arbitrary image sizes must not grow the device-table
-    cache without bound."""
+class _LRU:
+    """Cache of device tables capped at `cap` entries (least recently used evicted): a dataset of arbitrary image sizes must not grow it without
+    bound.  `get(key, make)` is ONE locked lookup-or-build (loader threads share the cache).  Keys carry the device AND the stream the table was
+    built on: an evicted table goes back to that stream's pool of the caching allocator, where only later work of the SAME stream can reuse the
+    block -- a table shared across streams could be handed out again while a side stream's kernel still reads it (bench.py's loader runs the
+    target kernels on a side stream)."""
 
     def __init__(self, cap):
-        super().__init__()
-        self.cap = cap
+        import collections
+        import threading
+        self.cap, self._d, self._lock = cap, collections.OrderedDict(), threading.Lock()
 
-    def __getitem__(self, k):
-        v = super().pop(k)
-        super().__setitem__(k, v)           # most recently used last
-        return v
+    def get(self, key, make):
+        with self._lock:
+            if key in self._d:
+                self._d.move_to_end(key)
+                return self._d[key]
+        v = make()                                     # built outside the lock (a host -> device copy); a racing duplicate is harmless
+        with self._lock:
+            v = self._d.setdefault(key, v)
+            self._d.move_to_end(key)
+            while len(self._d) > self.cap:
+                self._d.popitem(last=False)
+            return v
 
-    def __setitem__(self, k, v):
-        super().__setitem__(k, v)
-        while len(self) > self.cap:
-            super().pop(next(iter(self)))
+    def __len__(self):
+        return len(self._d)
 
 
 _TABLES = _LRU(64)
 
 
+def _where(dev):
+    dev = torch.device(dev)
+    return (str(dev), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+
+
 def _dev_nearest(out_n, in_n, dev):
-    """`nearest_index` as a device tensor, built once per (sizes, device): a loader calls this every sample, and a pageable host->device copy
-    stalls the host until the stream has drained (measured: 5 ms of idle GPU per micro-step with the tables rebuilt per call)."""
-    key = ("nn", out_n, in_n, str(dev))
-    if key not in _TABLES:
-        _TABLES[key] = torch.from_numpy(nearest_index(out_n, in_n)).to(dev)
-    return _TABLES[key]
+    """`nearest_index` as a device tensor, built once per (sizes, device, stream): a loader calls this every sample, and a pageable host->device
+    copy stalls the host until the stream has drained (measured: 5 ms of idle GPU per micro-step with the tables rebuilt per call)."""
+    return _TABLES.get(("nn", out_n, in_n) + _where(dev), lambda: torch.from_numpy(nearest_index(out_n, in_n)).to(dev))
 
 
 def _dev_taps(in_size, out_size, dev):
-    key = ("aa", in_size, out_size, str(dev))
-    if key not in _TABLES:
+    def make():
         first, count, w = aa_taps(in_size, out_size)
-        _TABLES[key] = (torch.from_numpy(first).to(dev), torch.from_numpy(count).to(dev), torch.from_numpy(w).to(dev), w.shape[1])
-    return _TABLES[key]
+        return (torch.from_numpy(first).to(dev), torch.from_numpy(count).to(dev), torch.from_numpy(w).to(dev), w.shape[1])
+    return _TABLES.get(("aa", in_size, out_size) + _where(dev), make)
 
 
 def _p(t):
@@ -201,6 +212,11 @@ def extract_sam_segs(masks, device, top=50):
     return {"segs_origin": decode_rles([m["segmentation"] for m in ms], device), "bbox": [m["bbox"] for m in ms]}
 
 
+def _stack_targets(rows, K, dev):
+    """[C] list of float64 [K] -> [C, K]; no ground truth (validation samples carry none, utils/dataset.py:640-656) -> an empty [0, K], on every route."""
+    return torch.stack(rows) if rows else torch.empty((0, K), device=dev, dtype=torch.float64)
+
+
 def proposals_and_targets(masks, gt_masks, device, top=50, out_size=256):
     """Everything `model_forward` needs about one image's proposals: -> dict(sam_segs bf16 [K, 256, 256], sam_ious / sam_iops float64 [C, K]
     for the C sampled ground-truth masks (uint8 [Hg, Wg] tensors or arrays), segs_origin uint8 [K, H, W])."""
@@ -211,7 +227,9 @@ def proposals_and_targets(masks, gt_masks, device, top=50, out_size=256):
         g = torch.as_tensor(np.asarray(g) if not torch.is_tensor(g) else g).to(device=device, dtype=torch.uint8)
         iou, iop, _ = mask_targets(segs, g)
         ious.append(iou); iops.append(iop)
-    return {"sam_segs": resize_square_aa(segs, out_size), "sam_ious": torch.stack(ious), "sam_iops": torch.stack(iops), "segs_origin": segs, "bbox": d["bbox"]}
+    K = segs.shape[0]
+    return {"sam_segs": resize_square_aa(segs, out_size), "sam_ious": _stack_targets(ious, K, segs.device), "sam_iops": _stack_targets(iops, K, segs.device),
+            "segs_origin": segs, "bbox": d["bbox"]}
 
 
 FUSED_LIMITS = dict(out_size=256, taps=28, width=2048, n_gt=4)      # llmseg_proposal_targets' limits (csrc/targets.hip)
@@ -236,16 +254,22 @@ def proposal_targets_fused(masks, order, gt_masks, out_size=256):
     cnts = torch.empty((C_, K, 2), device=dev, dtype=torch.int64)
     masks = masks.contiguous()
     first = True
-    for c0 in range(0, max(C_, 1), FUSED_LIMITS["n_gt"]):                      # groups of <= 4 ground truths; the maps come from the first launch
+    for c0 in range(0, max(C_, 1), FUSED_LIMITS["n_gt"]):                      # the first <= 4 ground truths ride in the fused pass that also makes the maps
         grp = gts[c0:c0 + FUSED_LIMITS["n_gt"]]
+        if not first:
+            # further ground truths need counts only: the popcount kernel on the selected proposals (one gathered copy, shared by all of them)
+            # instead of re-running the whole resampling pass into a scratch map per group of four
+            segs_sel = masks if order is None else masks[order].contiguous()
+            for c in range(c0, C_):
+                ious[c], iops[c], cnts[c] = mask_targets(segs_sel, gts[c])
+            break
         n = len(grp)
         gtp = torch.empty((max(n, 1), H, W), device=dev, dtype=torch.uint8)
         for i, g in enumerate(grp):
             Hg, Wg = g.shape
             _lib.check(lib.llmseg_gt_resample(_p(g), _p(_dev_nearest(H, Hg, dev)), _p(_dev_nearest(W, Wg, dev)), _p(gtp[i]), H, W, Hg, Wg, _stream()), "gt_resample")
         garea = torch.empty((max(n, 1),), device=dev, dtype=torch.int64)
-        o = out if first else torch.empty_like(out)
-        _lib.check(lib.llmseg_proposal_targets(_p(masks), None if order is None else _p(order.contiguous()), _p(gtp), n, _p(o), K, H, W, out_size,
+        _lib.check(lib.llmseg_proposal_targets(_p(masks), None if order is None else _p(order.contiguous()), _p(gtp), n, _p(out), K, H, W, out_size,
                                                _p(d_first), _p(d_count), _p(d_w), _p(d_first), _p(d_count), _p(d_w), n_taps,
                                                _p(cnts[c0:c0 + n]) if n else None, _p(garea) if n else None, _p(ious[c0:c0 + n]) if n else None,
                                                _p(iops[c0:c0 + n]) if n else None, _stream()), "proposal_targets")
@@ -272,4 +296,6 @@ def proposals_and_targets_dense(masks, areas, gt_masks, top=50, out_size=256, wa
         g = torch.as_tensor(np.asarray(g) if not torch.is_tensor(g) else g).to(device=segs.device, dtype=torch.uint8)
         iou, iop, _ = mask_targets(segs, g)
         ious.append(iou); iops.append(iop)
-    return {"sam_segs": resize_square_aa(segs, out_size), "sam_ious": torch.stack(ious), "sam_iops": torch.stack(iops), "segs_origin": segs, "order": order}
+    K = segs.shape[0]
+    return {"sam_segs": resize_square_aa(segs, out_size), "sam_ious": _stack_targets(ious, K, segs.device), "sam_iops": _stack_targets(iops, K, segs.device),
+            "segs_origin": segs, "order": order}

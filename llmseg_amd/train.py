@@ -209,6 +209,30 @@ def _copy_batch(dst, src):
                     dd.copy_(vv, non_blocking=True)
 
 
+def merge_micro_batches(batches):
+    """The `grad_accum` micro-batches of one optimizer step (collated dicts of the SAME token length and sequences per micro-batch) as ONE
+    batch for a fused pass (`Trainer(fused_accum=k)`, `make_plan(micro_batches=k)`): tensors concatenated along the batch axis, `offset`
+    re-based, per-image lists extended.  Reference: the k micro-steps of `training.py:532-547` (`gradient_accumulation_steps`, :79-82)."""
+    b0 = batches[0]
+    out = {}
+    for key, v in b0.items():
+        vals = [b[key] for b in batches]
+        if key == "offset":
+            parts, base = [vals[0].reshape(-1)[:1]], 0
+            for o in vals:
+                o = o.reshape(-1)
+                parts.append(o[1:] + base)
+                base = base + int(o[-1])
+            out[key] = torch.cat(parts)
+        elif torch.is_tensor(v):
+            out[key] = torch.cat(vals, 0)
+        elif isinstance(v, (list, tuple)):
+            out[key] = [x for val in vals for x in val]
+        else:
+            out[key] = v
+    return out
+
+
 class Trainer:
     """One process per GPU.  `module(**batch)` must return a dict with a scalar "loss".
 
@@ -217,7 +241,7 @@ class Trainer:
 
     def __init__(self, module, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.0, clip=1.0, grad_accum=10, warmup=100, total_steps=5000,
                  optimizer=None, device_ids=None, force_ddp=False, ddp_wrapper=False, use_graph=False, graph_warmup=2, use_arena=None,
-                 reduce_chunk_mb=128, sync_init=True, check_every=0, leaf_stream=False):
+                 reduce_chunk_mb=128, sync_init=True, check_every=100, leaf_stream=False, fused_accum=1):
         """optimizer: None = HipAdamW; or a factory `params -> optimizer` / an optimizer object (CPU tests).  use_arena: None = automatic
         (the HIP model with the built-in optimizer), True = force the fp32 gradient arena (the module's autograd Functions must honour `_g32`)."""
         self.module = module
@@ -242,6 +266,12 @@ class Trainer:
         if hasattr(self.opt, "resync_master") and hasattr(module, "__dict__"):
             module.__dict__.setdefault("_weight_hooks", []).append(self.opt.resync_master)
         self.lr, self.clip, self.accum, self.warmup, self.total = lr, clip, grad_accum, warmup, total_steps
+        # fused_accum = k > 1: every `micro_step` receives the concatenation of k micro-batches (`merge_micro_batches`) and a plan built with
+        # `make_plan(..., micro_batches=k)`: ONE pass whose loss is the sum of the k micro-batch losses, so the arena holds what k micro-steps
+        # would have accumulated (every GEMM at k x the rows: M = 638 -> 6380 at 2 images x 10); an optimizer step then follows every
+        # `grad_accum` such passes (normally grad_accum = 1) and averages over grad_accum * k micro-batches.
+        self.fused = int(fused_accum)
+        assert self.fused >= 1
         self.micro = 0
         self.opt_steps = 0
         self.is_hip_model = is_hip_model
@@ -323,8 +353,12 @@ class Trainer:
         """Forward + backward of one micro-batch; runs the optimizer on every `grad_accum`-th call.  Returns the loss dict.
         `plan` (HIP model only): the batch's `BatchPlan`; built here when absent (one device synchronisation)."""
         last = (self.micro + 1) % self.accum == 0
-        if self.is_hip_model and getattr(self.module.config.llama, "lora_dropout", 0.0) > 0:
+        drop_on = self.is_hip_model and getattr(self.module.config.llama, "lora_dropout", 0.0) > 0
+        if drop_on:
             self.module.advance_dropout()                # a new mask every micro-step in EVERY gradient mode (arena, .grad, DDP wrapper)
+        if self.fused > 1:
+            assert self.arena is not None and self.is_hip_model and plan is not None and plan.micro == self.fused, \
+                "fused_accum: pass the merged batch with its plan (make_plan(..., micro_batches=fused_accum))"
         if self.arena is not None and self.is_hip_model:
             if plan is None:
                 plan = self.module.make_plan(**batch)
@@ -338,6 +372,8 @@ class Trainer:
             with sync_ctx:
                 out = fwd(**batch)
                 out["loss"].backward()
+        if drop_on and self.fused > 1:
+            self.module.advance_dropout(self.fused - 1)  # segment j of the fused pass used offset + j: the next pass starts after the window
         self.micro += 1
         if last:
             self.optimizer_step()
@@ -404,7 +440,7 @@ class Trainer:
     # ------------------------------------------------------------------------------------------------ optimizer step
     def optimizer_step(self):
         lr = warmup_decay_lr(self.opt_steps, self.lr, self.warmup, self.total)
-        scale = 1.0 / self.accum
+        scale = 1.0 / (self.accum * self.fused)
         if self.arena is not None:
             ss = self._reduce_and_sumsq()
             if self.dist_on:

@@ -223,12 +223,18 @@ class TrainableMixin:
         self.__dict__["_dropout_rank"] = int(rank)
         self.set_dropout_seed(self.__dict__["_dropout_base"], off)
 
-    def advance_dropout(self):
-        self.dropout_state()[1:].add_(1)
+    def advance_dropout(self, n=1):
+        if n:
+            self.dropout_state()[1:].add_(int(n))
 
     # ------------------------------------------------------------------------------------------------ batch plan
-    def make_plan(self, input_ids, labels, attention_masks, offset, sam_segs_list=None, inference=False, **_):
-        """Host-side index plumbing of a batch -> BatchPlan (the only place that synchronises with the device)."""
+    def make_plan(self, input_ids, labels, attention_masks, offset, sam_segs_list=None, inference=False, micro_batches=1, **_):
+        """Host-side index plumbing of a batch -> BatchPlan (the only place that synchronises with the device).
+        micro_batches = k > 1: the batch is the concatenation of the k micro-batches of ONE gradient-accumulation window
+        (`merge_micro_batches`; reference: `gradient_accumulation_steps` micro-steps per optimizer step, training.py:79-82,532-547) run as a single
+        pass so that every GEMM sees k x the rows.  The loss of the pass is the SUM of the k micro-batch losses as the reference forms each of them
+        -- CE averaged over the micro-batch's OWN labelled tokens, align / IoP losses averaged over its own images -- so the gradient equals the
+        one k micro-steps accumulate; the LoRA dropout of micro-batch j draws the mask its own step would draw (`llmseg_dropout.seg_rows`)."""
         c = self.config
         dev = self.device_
         ids = input_ids.detach().cpu()
@@ -255,13 +261,30 @@ class TrainableMixin:
             new_labels = torch.where((ar >= pos[:, None]) & (ar < pos[:, None] + Pn), torch.full_like(new_labels, IGNORE_INDEX), new_labels)
         # CE rows: only hidden rows whose NEXT token carries a label reach the loss (shifted CE, llava_llama.py:108-118), so lm_head and the
         # CE run on those rows only -- same loss, same gradients (the other rows' dlogits are zero), ~10 x fewer lm_head rows in training
+        k = int(micro_batches)
+        assert k >= 1 and B % k == 0 and N % k == 0 and not (inference and k > 1), (k, B, N)
+        Bm, Nm = B // k, N // k
+        if k > 1:
+            assert all(off[(j + 1) * Bm] - off[j * Bm] == Nm for j in range(k)), "fused accumulation: every micro-batch must hold the same number of sequences"
         ce_rows = ce_labels = None
+        ce_segs = []
         if new_labels is not None:
             valid = new_labels[:, 1:] != IGNORE_INDEX                                    # [N, T-1]: row t predicts label t + 1
-            flat = (torch.arange(N)[:, None] * T + torch.arange(T - 1)[None, :])[valid]
-            if flat.numel() > 0:
-                ce_rows = torch.cat([flat, flat[:1]])                                    # + one trailing row: the shifted CE never uses the last position as a predictor
-                ce_labels = torch.cat([torch.tensor([IGNORE_INDEX]), new_labels[:, 1:][valid]])[None, :]     # [1, R + 1]
+            grid = torch.arange(N)[:, None] * T + torch.arange(T - 1)[None, :]
+            rows_l, labs_l, pos = [], [], 0
+            for j in range(k):                                                           # one CE segment per micro-batch (its own mean)
+                sl = slice(j * Nm, (j + 1) * Nm)
+                flat = grid[sl][valid[sl]]
+                if flat.numel() > 0:
+                    rows_l.append(torch.cat([flat, flat[:1]]))                           # + one trailing row: the shifted CE never uses the last position as a predictor
+                    labs_l.append(torch.cat([torch.tensor([IGNORE_INDEX]), new_labels[sl, 1:][valid[sl]]]))
+                    ce_segs.append((pos, pos + int(flat.numel()) + 1))
+                    pos += int(flat.numel()) + 1
+                else:
+                    assert k == 1, "fused accumulation: a micro-batch without a labelled token has no CE term (its own step would produce nan)"
+            if rows_l:
+                ce_rows = torch.cat(rows_l)
+                ce_labels = torch.cat(labs_l)[None, :]                                   # [1, sum (R_j + 1)]
         tok = ag.embed_token_index(ids, Pn)
         # [SEG] rows: mask shifted by one and by the P-1 extra image tokens (LISA.py:254-266)
         segm = torch.zeros((N, T), dtype=torch.bool)
@@ -272,8 +295,12 @@ class TrainableMixin:
         rounds = [seg_off[b + 1] - seg_off[b] for b in range(B)]
         plan = BatchPlan()
         segs_shapes = tuple(tuple(s.shape) for s in sam_segs_list) if sam_segs_list is not None else None
-        plan.sig = (N, L, T, B, tuple(off), tuple(seg_off), bool(inference), labels is not None, segs_shapes, None if ce_rows is None else int(ce_rows.numel()))
+        plan.sig = (N, L, T, B, tuple(off), tuple(seg_off), bool(inference), labels is not None, segs_shapes, None if ce_rows is None else int(ce_rows.numel()),
+                    k, tuple(ce_segs) if k > 1 else None)
         plan.N, plan.L, plan.T, plan.B, plan.off, plan.seg_off, plan.rounds = N, L, T, B, off, seg_off, rounds
+        plan.micro, plan.ce_segs = k, ce_segs
+        plan.drop_seg_rows = Nm * T if k > 1 else 0                                       # rows of one micro-batch in the Llama activations
+        plan.loss_div = float(B) if k == 1 else 1.0                                      # k > 1: 1 / (images per micro-batch) is folded into the item weights
         # groups of images with the same proposal count (the head runs once per group), and the loss weights 1 / (R + 1e-8) of
         # every (image, round) item in group order (LISA.py:452-455)
         plan.groups, loss_w = {}, {}
@@ -283,7 +310,7 @@ class TrainableMixin:
                     plan.groups.setdefault(int(sam_segs_list[b].shape[0]), []).append(b)
             plan.groups = {K: plan.groups[K] for K in sorted(plan.groups)}
             for K, members in plan.groups.items():
-                loss_w[K] = torch.tensor([1.0 / (rounds[b] + 1e-8) for b in members for _ in range(rounds[b])], dtype=torch.float32)
+                loss_w[K] = torch.tensor([1.0 / (rounds[b] + 1e-8) / (Bm if k > 1 else 1.0) for b in members for _ in range(rounds[b])], dtype=torch.float32)
         # pinned staging + non-blocking copies: a pageable host->device copy makes the host wait until the stream has drained, i.e. until the
         # previous micro-step's graph has finished -- with a loader in the loop that idles the GPU for the whole host side of a step
         up = lambda t: None if t is None else t.contiguous().pin_memory().to(dev, non_blocking=True)
@@ -294,7 +321,7 @@ class TrainableMixin:
         return plan
 
     # ------------------------------------------------------------------------------------------------ language
-    def _llama(self, embeds, key_mask_u8, F, kv_out=None):
+    def _llama(self, embeds, key_mask_u8, F, kv_out=None, drop_seg_rows=0):
         """32 x [RMSNorm -> q|k|v GEMM (+LoRA) -> RoPE -> causal attention -> o_proj(+res) -> RMSNorm -> gate|up GEMM ->
         SwiGLU -> down(+res)], final RMSNorm (HF LlamaModel, transformers 4.29; call site llava_llama.py:93-102).
         Activations of every layer are kept for the backward pass (288 GB HBM: no recompute, unlike the reference's
@@ -314,7 +341,7 @@ class TrainableMixin:
                 qkv = F.lora_qkv(h, self._w(p + "qkv", F), self._w(lp + "q_proj.lora_A.default.weight", F),
                                  self._w(lp + "q_proj.lora_B.default.weight", F), self._w(lp + "v_proj.lora_A.default.weight", F),
                                  self._w(lp + "v_proj.lora_B.default.weight", F), s, self._wT(p + "qkv", F),
-                                 (rng, i, p_drop) if p_drop > 0 else None)
+                                 ((rng, i, p_drop, drop_seg_rows) if drop_seg_rows else (rng, i, p_drop)) if p_drop > 0 else None)
             else:
                 mem = [p + f"self_attn.{n}_proj.weight" for n in "qkv"]
                 qkv = F.linear(h, self._wcat(p + "qkv", mem, F), None, ops.ACT_NONE, None, self._wT(p + "qkv", F) if self._frozen(mem) else None)
@@ -339,15 +366,23 @@ class TrainableMixin:
             proj = self.encode_images(images_clip)                         # [N*(P+1), H]
         H = c.llama.hidden
         embeds = F.embed_splice(input_ids.contiguous(), self._w("model.embed_tokens.weight", F), proj[1:], Pn, (Pn + 1) * H, plan.tok_index)
-        hidden = self._llama(embeds, plan.key_mask, F)
+        hidden = self._llama(embeds, plan.key_mask, F, drop_seg_rows=plan.__dict__.get("drop_seg_rows", 0))
         logits, loss = None, None
         gathered = plan.new_labels is not None and not want_logits and plan.ce_rows is not None and self.ce_gather_first
         if want_logits or (plan.new_labels is not None and not gathered):
             logits = F.linear(hidden.view(N * T, H), self._w("lm_head.weight", F)).view(N, T, -1)
         if gathered:                                                       # lm_head + CE on the label-carrying rows only (see make_plan)
             rows = F.gather_rows(hidden.view(N * T, H), plan.ce_rows)
-            loss = F.ce(F.linear(rows, self._w("lm_head.weight", F)).view(1, rows.shape[0], -1), plan.ce_labels)
+            lg = F.linear(rows, self._w("lm_head.weight", F)).view(1, rows.shape[0], -1)
+            if plan.__dict__.get("micro", 1) > 1:                          # fused accumulation window: each micro-batch's own mean, summed
+                loss = None
+                for a, b in plan.ce_segs:
+                    part = F.ce(lg[:, a:b], plan.ce_labels[:, a:b])
+                    loss = part if loss is None else loss + part
+            else:
+                loss = F.ce(lg, plan.ce_labels)
         elif plan.new_labels is not None:
+            assert plan.__dict__.get("micro", 1) == 1, "fused accumulation needs ce_gather_first (per-micro-batch CE segments)"
             loss = F.ce(logits, plan.new_labels)
         return loss, logits, hidden
 
@@ -542,7 +577,8 @@ class TrainableMixin:
             w = plan.tensors[f"loss_w{K}"]
             align = align + (o[:, 0] * w).sum()
             reg = reg + (o[:, 1] * w).sum()
-        align, reg = align / B, reg / B
+        div = plan.__dict__.get("loss_div", float(B))
+        align, reg = align / div, reg / div
         ce = ce * c.ce_loss_weight
         align = align * c.align_loss_weight
         reg = reg * c.regression_loss_weight

@@ -34,9 +34,12 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
-def keep_mask(rows, cols, seed, offset, stream, p):
-    """bool [rows, cols]: True where the element of a dense [rows, cols] activation is kept (cols % 8 == 0)."""
+def keep_mask(rows, cols, seed, offset, stream, p, seg_rows=0):
+    """bool [rows, cols]: True where the element of a dense [rows, cols] activation is kept (cols % 8 == 0).
+    seg_rows > 0 (`llmseg_dropout.seg_rows`): consecutive segments of seg_rows rows, segment s with the mask of its own pass at offset + s."""
     assert cols % 8 == 0
+    if seg_rows and rows > seg_rows:
+        return torch.cat([keep_mask(min(seg_rows, rows - r0), cols, seed, offset + i, stream, p) for i, r0 in enumerate(range(0, rows, seg_rows))], 0)
     thr = int(round(p * 65536))
     n8 = rows * cols // 8
     idx = np.arange(n8, dtype=np.uint64)
@@ -51,9 +54,9 @@ def drop_scale(p):
     return 65536.0 / (65536.0 - thr)
 
 
-def apply(x2d, seed, offset, stream, p):
+def apply(x2d, seed, offset, stream, p, seg_rows=0):
     """x2d [rows, cols] -> x * mask * scale (the HIP kernels' drop(x))."""
     if p <= 0:
         return x2d
-    m = keep_mask(x2d.shape[0], x2d.shape[1], seed, offset, stream, p).to(x2d.device)
+    m = keep_mask(x2d.shape[0], x2d.shape[1], seed, offset, stream, p, seg_rows).to(x2d.device)
     return x2d * m.to(x2d.dtype) * drop_scale(p)

@@ -284,6 +284,26 @@ def check_lora_paths():
     b_sel[:, 0] = 1
     colcnt = ops.lora_outer(a_ones.to(DEV), b_sel.to(DEV), drop=(rng, 9, p_drop))[:, 0].cpu()
     out.append(("dropout mask column counts (lora_outer)", (colcnt - keep.float().sum(0) * odrop.drop_scale(p_drop)).abs().max().item(), 1e-3))
+    # segments (llmseg_dropout.seg_rows, ABI 5): rows [j seg, (j + 1) seg) draw the mask of their own pass at offset + j -- positions through
+    # lora_apply, per-row counts through both lora_down kernels (per-row and MFMA), column counts through lora_outer, on a ragged last segment
+    seg = 16
+    keep_s = odrop.keep_mask(Mm, Hh, st[0], st[1], 9, p_drop, seg_rows=seg)
+    ref_rows = torch.cat([odrop.keep_mask(min(seg, Mm - r0), Hh, st[0], st[1] + j, 9, p_drop) for j, r0 in enumerate(range(0, Mm, seg))], 0)
+    assert torch.equal(keep_s, ref_rows) and not torch.equal(keep_s, keep)
+    yz = torch.zeros(Mm, Hh, device=DEV, dtype=BF)
+    ops.lora_apply_(yz, xa1.to(DEV), wn1.to(DEV), drop=(rng, 9, p_drop, seg))
+    out.append(("segmented dropout mask positions (lora_apply) vs the oracle: mismatching elements", float(((yz.cpu() != 0) != keep_s).sum()), 0.0))
+    ref_s = keep_s.float().sum(1) * odrop.drop_scale(p_drop)
+    got = ops.lora_down(ones.to(DEV), wsel.to(DEV), drop=(rng, 9, p_drop, seg))[:, 0].float().cpu()
+    out.append(("segmented dropout: kept count per row (lora_down)", (got - ref_s).abs().max().item(), 2.0 ** -8 * ref_s.max().item()))
+    colcnt = ops.lora_outer(a_ones.to(DEV), b_sel.to(DEV), drop=(rng, 9, p_drop, seg))[:, 0].cpu()
+    out.append(("segmented dropout: column counts (lora_outer)", (colcnt - keep_s.float().sum(0) * odrop.drop_scale(p_drop)).abs().max().item(), 1e-3))
+    # a tall activation takes the other lora_down route (RW = 4 rows per wave / MFMA tile without K-slices): same rule
+    Mt = 2100
+    ones_t = torch.ones(Mt, Hh).to(BF)
+    got = ops.lora_down(ones_t.to(DEV), wsel.to(DEV), drop=(rng, 9, p_drop, 700))[:, 0].float().cpu()
+    ref_t = odrop.keep_mask(Mt, Hh, st[0], st[1], 9, p_drop, seg_rows=700).float().sum(1) * odrop.drop_scale(p_drop)
+    out.append(("segmented dropout: kept count per row, tall activation (lora_down)", (got - ref_t).abs().max().item(), 2.0 ** -8 * ref_t.max().item()))
     return out
 
 
@@ -879,3 +899,87 @@ def check_checkpoint_resume(tmp_dir):
 
 
 ALL = [check_gemm_layouts, check_autograd_ops, check_lora_paths, check_arena_ops, check_adamw]
+
+
+def _variant_batches(batch, k):
+    """k micro-batches of the structure of `batch` with different data (text tokens, images, proposals rotated; specials and labels kept in place)."""
+    out = []
+    for j in range(k):
+        b = {key: ([t.clone() for t in v] if isinstance(v, list) else (v.clone() if torch.is_tensor(v) else v)) for key, v in batch.items()}
+        ids = b["input_ids"]
+        text = (ids >= 3) & (ids < 31999)
+        ids[text] = (ids[text] - 3 + 977 * j) % 31996 + 3
+        lab = b["labels"]
+        keep = lab >= 0
+        lab[keep] = ids[keep]
+        b["images"] = torch.roll(b["images"], shifts=37 * j, dims=-1)
+        b["images_clip"] = torch.roll(b["images_clip"], shifts=11 * j, dims=-2)
+        b["sam_segs_list"] = [torch.roll(t, shifts=j, dims=0) for t in b["sam_segs_list"]]
+        b["sam_ious_list"] = [torch.roll(t, shifts=3 * j, dims=-1) for t in b["sam_ious_list"]]
+        out.append(b)
+    return out
+
+
+def check_fused_accum(k=3):
+    """the k micro-batches of one accumulation window run as ONE pass (`Trainer(fused_accum=k)`, `make_plan(micro_batches=k)`,
+    `llmseg_dropout.seg_rows`) must leave in the fp32 arena what k micro-steps accumulate -- per-micro-batch CE means, per-micro-batch image
+    means of the align / IoP losses, micro-batch j under the dropout mask of ITS step.  Sequential (eager, accum = k) vs fused (eager, then
+    hipGraph) on the same weights (lr = 0 keeps them), same dropout seed; k DIFFERENT micro-batches.  What may differ is the fp32 summation
+    order (weight gradients summed over k x the rows in one GEMM instead of k accumulating GEMMs, split-K slice counts chosen for another M),
+    i.e. isolated bf16 roundings upstream: per tensor RMS difference <= 2 % of the tensor's RMS (a wrong normalisation is off by >= 33 %)."""
+    from llmseg_amd.train import Trainer, merge_micro_batches
+    from tests import model_checks as mc
+    cfg, m, sd, batch = _lora_case("sam")
+    names = [n for n, p in m.params.named_parameters() if p.requires_grad]
+    prm = dict(m.params.named_parameters())
+    batches = [mc._dev(b) for b in _variant_batches(batch, k)]
+    seed = 4242
+    grab = lambda store: (lambda t, ss: store.update(g={n: prm[n]._g32.detach().clone() for n in names}, ss=float(ss)))
+    # sequential: k micro-steps, one optimizer step (lr 0: the weights stay)
+    seq = {}
+    tr = Trainer(m, lr=0.0, grad_accum=k, warmup=1, total_steps=10)
+    tr.grad_hook = grab(seq)
+    m.set_dropout_seed(seed, 0)
+    seq_losses = [{kk: float(v.detach()) for kk, v in tr.micro_step(b, m.make_plan(**b)).items() if torch.is_tensor(v) and v.numel() == 1} for b in batches]
+    assert tr.opt_steps == 1 and "g" in seq
+    end_offset = int(m.dropout_state()[1])
+    tr.close()
+    merged = merge_micro_batches(batches)
+    plan = m.make_plan(**merged, micro_batches=k)
+    assert merged["offset"].tolist() == [0] + [int(batches[0]["offset"][-1]) * j + int(o) for j in range(k) for o in batches[0]["offset"][1:]]
+    res = []
+    outs = {}
+    for mode, use_graph in (("eager", False), ("hipGraph", True)):
+        fus = {}
+        tr = Trainer(m, lr=0.0, grad_accum=1, warmup=1, total_steps=10, fused_accum=k, use_graph=use_graph, graph_warmup=1)
+        tr.grad_hook = grab(fus)
+        reps = 3 if use_graph else 1                       # graph: eager warm-up, capture + replay, replay
+        for _ in range(reps):
+            m.set_dropout_seed(seed, 0)
+            out = tr.micro_step(merged, plan)
+        torch.cuda.synchronize()
+        if use_graph:
+            assert tr.graph_error is None, tr.graph_error
+            assert any(e["graph"] is not None for e in tr._graphs.values()), "the hipGraph path was never taken"
+        assert int(m.dropout_state()[1]) == end_offset, "the fused pass must leave the dropout offset where k micro-steps leave it"
+        outs[mode] = ({kk: float(v.detach()) for kk, v in out.items() if torch.is_tensor(v) and v.numel() == 1}, fus["g"], fus["ss"])
+        tr.close()
+    for kk in ("loss", "ce_loss", "align_loss", "regression_loss"):
+        s = sum(l[kk] for l in seq_losses)
+        res.append((f"fused accum k={k}: {kk} of the pass = sum of the {k} micro-step values ({s:.4f})", abs(outs["eager"][0][kk] - s), 2e-3 * max(1.0, abs(s))))
+    worst, worst_n, cos_min = 0.0, "", 1.0
+    for n in names:
+        a, b = seq["g"][n].double().flatten(), outs["eager"][1][n].double().flatten()
+        rms = float(a.pow(2).mean().sqrt())
+        if rms < 1e-6:
+            continue
+        d = float((a - b).pow(2).mean().sqrt()) / rms
+        if d > worst:
+            worst, worst_n = d, n
+        cos_min = min(cos_min, float((a @ b) / (a.norm() * b.norm() + 1e-30)))
+    res.append((f"fused accum k={k}: arena after ONE fused pass vs after {k} micro-steps, worst relative RMS difference over {len(names)} tensors ({worst_n})", worst, 2e-2))
+    res.append((f"fused accum k={k}: smallest cosine between the two gradients of a tensor; shown as 1 - cos", 1.0 - cos_min, 1e-3))
+    res.append((f"fused accum k={k}: squared gradient norm, fused vs sequential", abs(outs["eager"][2] - seq["ss"]) / max(seq["ss"], 1e-30), 1e-2))
+    same = all(torch.equal(outs["eager"][1][n], outs["hipGraph"][1][n]) for n in names) and outs["eager"][0] == outs["hipGraph"][0]
+    res.append((f"fused accum k={k}: the replayed hipGraph of the fused pass leaves the same bits as the eager pass", 0.0 if same else 1.0, 0.5))
+    return res

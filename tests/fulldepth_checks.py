@@ -122,3 +122,112 @@ def check_full_depth_inference(K=256, L=64, with_bf16_cpu=True, log=print, seed=
     del m
     torch.cuda.empty_cache()
     return res
+
+
+class _GradState(dict):
+    """bf16 host tensors widened to `dtype` on access; the trainable ones are persistent LEAVES (requires_grad) so that autograd through the
+    oracle leaves their gradients in `.leaves[name].grad`."""
+
+    def __init__(self, src, dtype, trainable):
+        super().__init__(src)
+        self.dtype = dtype
+        self.leaves = {n: dict.__getitem__(self, n).to(dtype).clone().requires_grad_(True) for n in trainable}
+
+    def __getitem__(self, k):
+        return self.leaves[k] if k in self.leaves else dict.__getitem__(self, k).to(self.dtype)
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+
+def check_full_depth_gradients(K=256, L=64, B=2, log=print, seed=0, table=None):
+    """BASELINE configs[2] at ITS OWN depth: 32-layer Llama-7B with LoRA r = 8 + dropout 0.05 on q / v, CLIP-L, 32-block SAM
+    ViT-H, B = 2 images of 1024 x 1024, 64-token prompts, K = 256 proposals -- ONE training micro-step into the fp32 gradient arena -- against
+    autograd through `oracle.lisa.model_forward` on the host with the same dropout masks (reference `model/LISA.py:225-474`, `training.py:546`).
+    Yardstick: the same oracle run in bf16 on the CPU (the reference's own arithmetic).  Policy: `tests/backward_checks.py::grad_err` (flipped
+    ReLU gates excluded row-wise, RMS / max <= max(3 %, 4 x bf16-CPU)) + the distribution bound over all compared tensors.
+    Compared: LoRA A / B (q and v) of layers 0 / 15 / 31, the touched rows of `embed_tokens` (all other rows must be exactly zero), `lm_head`
+    on the label rows + every 97th row, `text_hidden_fcs`, every trainable `lisa_*` tensor.  table: a list that receives markdown rows."""
+    from llmseg_amd.train import GradArena
+    from tests.backward_checks import GateTrace, grad_err, ratio_summary
+    dev = "cuda"
+    hcfg = hp.LisaConfig(backbone="sam", build_unused_towers=False)
+    hcfg.llama = hp.LlamaConfig(lora_r=8, lora_dropout=0.05)
+    m = hip_lisa.LISAForCausalLM(hcfg, device=dev).init_random(seed=11 + seed)
+    m.train()
+    m.set_trainable()
+    ocfg = olisa.LisaCfg(llama=ol.LlamaCfg(lora_r=8, lora_dropout=0.05), clip=ovit.VitCfg(eps=1e-5, img=224), sam=osam.SamCfg(), backbone="sam")
+    batch = synthetic.make_batch(B, img_size=1024, L=L, K=K, device=dev, seed=977 + seed, soft=True)
+    names = [n for n, p in m.params.named_parameters() if p.requires_grad]
+    host = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    drop = (0x5EED1234, 3)
+    gt = GateTrace()
+    cpu = lambda t, dt: t.detach().cpu().to(dt) if (torch.is_tensor(t) and t.is_floating_point()) else (t.cpu() if torch.is_tensor(t) else t)
+    keys = ("images", "images_clip", "input_ids", "labels", "attention_masks", "offset", "sam_segs_list", "sam_ious_list", "sam_iops_list")
+
+    def run(side, dt):
+        sd = _GradState(host, dt, names)
+        b = {k: ([cpu(t, dt if k == "sam_segs_list" else torch.float64 if t.dtype == torch.float64 else torch.float32) for t in batch[k]]
+                 if isinstance(batch[k], list) else cpu(batch[k], dt)) for k in keys}
+        t0 = time.perf_counter()
+
+        def fb():
+            o = olisa.model_forward(sd, ocfg, **b, inference=False, dropout_state=drop)
+            o["loss"].backward()
+            return o
+        out = gt.oracle(side, fb)
+        log(f"full depth gradients: {side} oracle ({dt}) forward + backward {time.perf_counter() - t0:.1f} s on {torch.get_num_threads()} threads")
+        return {k: float(out[k]) for k in ("loss", "ce_loss", "align_loss", "regression_loss")}, {n: sd.leaves[n].grad for n in names}
+
+    # the HIP micro-step first (its memory is released before the host holds two sets of gradients)
+    arena = GradArena(m)
+    m.set_dropout_seed(*drop)
+    plan = m.make_plan(**batch)
+    gt.hip_begin(m)
+    out = m.model_forward(**batch, inference=False, plan=plan)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    gt.hip_collect(m)
+    gt.hip_end(m)
+    prm = dict(m.params.named_parameters())
+    hip_loss = {k: float(out[k]) for k in ("loss", "ce_loss", "align_loss", "regression_loss")}
+    ids = batch["input_ids"].cpu()
+    touched = torch.unique(ids[ids >= 0])
+    lab = batch["labels"].cpu()
+    lm_rows = torch.unique(torch.cat([lab[lab >= 0], torch.arange(0, hcfg.llama.vocab, 97)]))
+    pick = [n for n in names if (".lora_" in n and any(f"layers.{i}." in n for i in (0, 15, 31))) or "text_hidden_fcs" in n or ".lisa_" in n]
+    hip_g = {n: prm[n]._g32.detach().float().cpu() for n in pick}
+    emb_g = prm["model.embed_tokens.weight"]._g32.detach()
+    untouched = torch.ones(emb_g.shape[0], dtype=torch.bool, device=emb_g.device)
+    untouched[touched.to(emb_g.device)] = False
+    emb_clean = float(emb_g[untouched].abs().max())
+    hip_g["model.embed_tokens.weight"] = emb_g[touched.to(emb_g.device)].float().cpu()
+    hip_g["lm_head.weight"] = prm["lm_head.weight"]._g32.detach()[lm_rows.to(emb_g.device)].float().cpu()
+    arena.detach()
+    del m, arena, prm, out, emb_g
+    torch.cuda.empty_cache()
+
+    ref_loss, ref_g = run("ref", torch.float32)
+    lo_loss, lo_g = run("lo", BF)
+    flips = gt.flipped_rows()
+    res = []
+    for k in ("ce_loss", "align_loss", "regression_loss", "loss"):
+        r = ref_loss[k]
+        res.append((f"full-depth train {k} (ref {r:.4f}, bf16-CPU err {abs(lo_loss[k] - r):.2e})", abs(hip_loss[k] - r), max(5e-3 * max(1.0, abs(r)), K_CPU * abs(lo_loss[k] - r))))
+    res.append(("full-depth embed_tokens gradient outside the touched rows (must be exactly 0)", emb_clean, 0.0))
+    sub = {"model.embed_tokens.weight": touched, "lm_head.weight": lm_rows}
+    stats = []
+    for n in pick + ["model.embed_tokens.weight", "lm_head.weight"]:
+        r, l = ref_g[n], lo_g[n].float()
+        if n in sub:
+            r, l = r[sub[n]], l[sub[n]]
+        st = []
+        ratio, desc = grad_err(hip_g[n], r, l, floor=3e-4, skip_rows=GateTrace.rows_for(n, flips), stats=st)
+        stats.append(st[0])
+        tag = f" ({len(sub[n])} rows)" if n in sub else ""
+        res.append((f"full-depth arena grad {n}{tag}: {desc}; shown as err / tol", ratio, 1.0))
+        if table is not None:
+            s = st[0]
+            table.append(f"| `{n}`{tag} | {s[4]:.2e} | {s[0]:.2e} | {s[1]:.2e} | {s[0] / max(s[1], 1e-30):.2f} | {s[2]:.2e} | {s[3]:.2e} | {s[2] / max(s[3], 1e-30):.2f} | {s[6]} | {ratio:.2f} |")
+    res += ratio_summary(stats, "full-depth arena grads")
+    return res

@@ -124,15 +124,35 @@ def test_amg_records_have_the_reference_fields():
 
 
 def test_device_table_cache_is_bounded():
-    """the per-(size, size) device tables of the target computation are an LRU of 64 entries, not an ever-growing dict."""
-    from llmseg_amd.targets import _LRU
-    d = _LRU(3)
+    """the device tables of the target computation are an LRU of 64 entries, not an ever-growing dict; one locked
+    lookup-or-build per call, keyed by device AND stream."""
+    import threading
+    from llmseg_amd import targets as ht
+    d = ht._LRU(3)
+    built = []
+    mk = lambda i: (lambda: built.append(i) or i * i)
     for i in range(5):
-        d[i] = i * i
-    assert list(d) == [2, 3, 4] and 0 not in d
-    assert d[2] == 4                      # a read refreshes the entry ...
-    d[9] = 81
-    assert list(d) == [4, 2, 9]           # ... so the oldest UNUSED one (3) was evicted
+        assert d.get(i, mk(i)) == i * i
+    assert list(d._d) == [2, 3, 4] and len(d) == 3
+    assert d.get(2, mk(2)) == 4 and built == [0, 1, 2, 3, 4]          # a hit builds nothing and refreshes the entry ...
+    d.get(9, mk(9))
+    assert list(d._d) == [4, 2, 9]                                     # ... so the oldest UNUSED one (3) was evicted
+    errs = []
+
+    def hammer(seed):
+        try:
+            for i in range(2000):
+                k = (i * 7 + seed) % 11
+                assert d.get(k, lambda k=k: k * k) == k * k
+        except Exception as e:                                         # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=hammer, args=(s,)) for s in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs and len(d) <= 3
+    assert ht._where("cpu") == ("cpu", 0)
+    a = ht._dev_nearest(7, 5, "cpu")
+    assert a is ht._dev_nearest(7, 5, "cpu") and a.tolist() == ht.nearest_index(7, 5).tolist()
 
 
 def test_oracle_equals_the_references_own_target_functions(golden):

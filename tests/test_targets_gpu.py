@@ -88,7 +88,10 @@ def test_dense_proposals_equal_the_rle_route():
     assert torch.equal(a["sam_segs"], b["sam_segs"][perm])
 
 
-@pytest.mark.parametrize("h,w,hg,wg,k,n_gt", [(97, 130, 194, 260, 9, 2), (300, 420, 150, 210, 20, 5), (256, 96, 256, 96, 6, 1), (64, 1024, 64, 1024, 5, 3)])
+# (1500, 2000): ~17 taps -> the scalar-weight branch (taps > 12) and the RING = 32 instantiation; (2100, 640): H > 2048 >= W -> the clamp of the
+# zero-padded square's columns beyond the image (both were compiled and shipped but never bit-checked); n_gt = 0: maps only
+@pytest.mark.parametrize("h,w,hg,wg,k,n_gt", [(97, 130, 194, 260, 9, 2), (300, 420, 150, 210, 20, 5), (256, 96, 256, 96, 6, 1), (64, 1024, 64, 1024, 5, 3),
+                                              (1500, 2000, 750, 1000, 4, 2), (2100, 640, 525, 160, 3, 1), (1030, 1700, 515, 850, 3, 6)])
 def test_one_pass_kernel_equals_the_three_kernel_route(h, w, hg, wg, k, n_gt):
     """llmseg_proposal_targets (one pass through the order index) against gather + llmseg_mask_targets + llmseg_resize_aa, bit for bit: widths that are
     not multiples of 16 (scalar staging path), tall / wide images (zero padding below / right of the image), several ground truths incl. an empty one and
