@@ -525,11 +525,12 @@ def grad_err(gh, gr, gl, floor=3e-4, skip_rows=None, stats=None):
     gh, gr, gl = gh.reshape(shp).double().cpu(), gr.double(), gl.double().reshape(shp)
     finite = bool(torch.isfinite(gh).all())
     n_skip = 0
-    d_skip = 0.0
+    d_skip = dl_skip = 0.0
     if skip_rows is not None and bool(skip_rows.any()):
         keep = ~skip_rows
         n_skip = int(skip_rows.sum())
         d_skip = float((gh[skip_rows] - gr[skip_rows]).abs().max())
+        dl_skip = float((gl[skip_rows] - gr[skip_rows]).abs().max())
         ref_max_all = float(gr.abs().max())
         gh, gr, gl = gh[keep], gr[keep], gl[keep]
     else:
@@ -538,13 +539,19 @@ def grad_err(gh, gr, gl, floor=3e-4, skip_rows=None, stats=None):
     rms = lambda x: float(x.pow(2).mean().sqrt()) if x.numel() else 0.0
     d, dl = (gh - gr).abs(), (gl - gr).abs()
     small = gh.numel() < 50                                   # a handful of entries (a bias of 1, a [1, 8] head): no statistics, one looser bound
+    # round 5 (full depth, K = 256): a tensor whose TRUE gradient vanishes (|ref|max below the noise floor: the head's q / k projections when the
+    # pooled mask features of all proposals nearly coincide -- softmax over identical keys) holds nothing but each pipeline's rounding noise;
+    # the comparison is noise against ONE draw of noise (measured ratio 4.1-4.5 at full depth): the same doubled multiplier as the small tensors
+    noise_only = ref_max_all < floor
+    loose = small or noise_only
     d_max, dl_max = (float(d.max()), float(dl.max())) if d.numel() else (0.0, 0.0)
     # small tensors: ONE bf16-CPU draw of one or a few numbers is no yardstick (the ratio of two such draws exceeds 9 in 7 % of cases): 10 % relative
-    t_rms = max((0.10 if small else 0.03) * rms(gr), (2 * K_RMS if small else K_RMS) * rms(dl), floor / 4)
-    t_max = max((0.10 if small else 0.03) * ref_max_all, (2 * K_MAX if small else K_MAX) * dl_max, floor)
+    t_rms = max((0.10 if small else 0.03) * rms(gr), (2 * K_RMS if loose else K_RMS) * rms(dl), floor / 4)
+    t_max = max((0.10 if small else 0.03) * ref_max_all, (2 * K_MAX if loose else K_MAX) * dl_max, floor)
     # the excluded rows: a flipped gate moves a row by one sample's whole contribution, which for a bias (a sum of cancelling terms) exceeds the
-    # row's own gradient (measured 6.9e-3 at |ref|max 1.8e-3) -- they only have to stay finite and within an order of magnitude of the tensor
-    t_skip = max(10.0 * ref_max_all, floor)
+    # row's own gradient (measured 6.9e-3 at |ref|max 1.8e-3; at full depth 1.2e-2 at |ref|max 1.4e-4, where the kept rows cancel almost completely) --
+    # they have to stay finite and within an order of magnitude of the tensor OR of what the bf16-CPU oracle's own flipped rows moved by (round 5)
+    t_skip = max(10.0 * ref_max_all, K_MAX * dl_skip, floor)
     if stats is not None:
         stats.append((rms(d), rms(dl), d_max, dl_max, rms(gr), ref_max_all, n_skip))
     r = max(rms(d) / t_rms, d_max / t_max, d_skip / t_skip, 0.0 if finite else 1e9)
@@ -922,64 +929,93 @@ def _variant_batches(batch, k):
 
 def check_fused_accum(k=3):
     """the k micro-batches of one accumulation window run as ONE pass (`Trainer(fused_accum=k)`, `make_plan(micro_batches=k)`,
-    `llmseg_dropout.seg_rows`) must leave in the fp32 arena what k micro-steps accumulate -- per-micro-batch CE means, per-micro-batch image
-    means of the align / IoP losses, micro-batch j under the dropout mask of ITS step.  Sequential (eager, accum = k) vs fused (eager, then
-    hipGraph) on the same weights (lr = 0 keeps them), same dropout seed; k DIFFERENT micro-batches.  What may differ is the fp32 summation
-    order (weight gradients summed over k x the rows in one GEMM instead of k accumulating GEMMs, split-K slice counts chosen for another M),
-    i.e. isolated bf16 roundings upstream: per tensor RMS difference <= 2 % of the tensor's RMS (a wrong normalisation is off by >= 33 %)."""
+    `llmseg_dropout.seg_rows`) must leave in the fp32 arena the gradient of  sum_j loss_j  with every loss_j formed as the reference forms it for
+    micro-batch j alone -- CE averaged over ITS labelled tokens, align / IoP losses over ITS images, LoRA dropout mask of ITS step (offset + j).
+    (a) against the ORACLE: autograd through `oracle.lisa.model_forward` on each of the k DIFFERENT micro-batches with dropout state (seed, j + 1),
+        summed -- `grad_err` policy with the bf16-CPU oracle as the yardstick, gates traced on both sides;
+    (b) against k sequential micro-steps of the HIP trainer on the same weights (lr = 0 keeps them): losses, the squared norm, `lm_head` (no ReLU /
+        softmax-temperature amplification downstream of it: 1 %), the whole gradient's direction.  Tensor by tensor the two HIP runs are two draws of
+        bf16 rounding noise (another M picks other split-K slice counts: activations differ in isolated ulps, measured 6.6e-3 relative on the head's
+        embeddings), which the tiny head's 1 / tau = 20 softmax amplifies to ~10 % of a head tensor's RMS -- the same spread HIP and the bf16-CPU
+        oracle show against fp32 here (tools/probes/fused_diag*.py), hence the oracle-based bound in (a) and the aggregate bounds in (b);
+    (c) the fused pass replayed from a hipGraph leaves the same BITS as the eager fused pass; the dropout offset ends where k micro-steps leave it."""
     from llmseg_amd.train import Trainer, merge_micro_batches
+    from oracle import lisa as olisa
     from tests import model_checks as mc
     cfg, m, sd, batch = _lora_case("sam")
     names = [n for n, p in m.params.named_parameters() if p.requires_grad]
     prm = dict(m.params.named_parameters())
-    batches = [mc._dev(b) for b in _variant_batches(batch, k)]
+    cpu_batches = _variant_batches(batch, k)
+    batches = [mc._dev(b) for b in cpu_batches]
     seed = 4242
     grab = lambda store: (lambda t, ss: store.update(g={n: prm[n]._g32.detach().clone() for n in names}, ss=float(ss)))
-    # sequential: k micro-steps, one optimizer step (lr 0: the weights stay)
+    scal = lambda out: {kk: float(v.detach()) for kk, v in out.items() if torch.is_tensor(v) and v.numel() == 1}
+    # (b) sequential: k micro-steps, one optimizer step (lr 0: the weights stay)
     seq = {}
     tr = Trainer(m, lr=0.0, grad_accum=k, warmup=1, total_steps=10)
     tr.grad_hook = grab(seq)
     m.set_dropout_seed(seed, 0)
-    seq_losses = [{kk: float(v.detach()) for kk, v in tr.micro_step(b, m.make_plan(**b)).items() if torch.is_tensor(v) and v.numel() == 1} for b in batches]
+    seq_losses = [scal(tr.micro_step(b, m.make_plan(**b))) for b in batches]
     assert tr.opt_steps == 1 and "g" in seq
     end_offset = int(m.dropout_state()[1])
     tr.close()
     merged = merge_micro_batches(batches)
     plan = m.make_plan(**merged, micro_batches=k)
     assert merged["offset"].tolist() == [0] + [int(batches[0]["offset"][-1]) * j + int(o) for j in range(k) for o in batches[0]["offset"][1:]]
-    res = []
-    outs = {}
+    res, outs = [], {}
+    gt = GateTrace()
     for mode, use_graph in (("eager", False), ("hipGraph", True)):
         fus = {}
         tr = Trainer(m, lr=0.0, grad_accum=1, warmup=1, total_steps=10, fused_accum=k, use_graph=use_graph, graph_warmup=1)
         tr.grad_hook = grab(fus)
-        reps = 3 if use_graph else 1                       # graph: eager warm-up, capture + replay, replay
-        for _ in range(reps):
+        if not use_graph:
+            gt.hip_begin(m)
+        for _ in range(3 if use_graph else 1):             # graph: eager warm-up, capture + replay, replay
             m.set_dropout_seed(seed, 0)
             out = tr.micro_step(merged, plan)
         torch.cuda.synchronize()
         if use_graph:
             assert tr.graph_error is None, tr.graph_error
             assert any(e["graph"] is not None for e in tr._graphs.values()), "the hipGraph path was never taken"
+        else:
+            gt.hip_collect(m)
+            gt.hip_end(m)
         assert int(m.dropout_state()[1]) == end_offset, "the fused pass must leave the dropout offset where k micro-steps leave it"
-        outs[mode] = ({kk: float(v.detach()) for kk, v in out.items() if torch.is_tensor(v) and v.numel() == 1}, fus["g"], fus["ss"])
+        outs[mode] = (scal(out), fus["g"], fus["ss"])
         tr.close()
+    # (a) the oracle: sum over the micro-batches of the reference's own per-micro-batch loss, each under its own dropout state
+    w = {n: sd[n].detach().clone().requires_grad_(True) for n in names}
+    wl = {n: sd[n].detach().to(BF).requires_grad_(True) for n in names}
+    sdw, sdl = {**sd, **w}, {**{kk: v.to(BF) for kk, v in sd.items()}, **wl}
+    ref_losses = []
+    for j, b in enumerate(cpu_batches):
+        def run_ref(b=b, j=j):
+            o = olisa.model_forward(sdw, cfg, **b, inference=False, dropout_state=(seed, j + 1))
+            o["loss"].backward()
+            return o
+        ref_losses.append(scal(gt.oracle("ref", run_ref)))
+        gt.oracle("lo", lambda b=b, j=j: olisa.model_forward(sdl, cfg, **mc._bf16_batch(b), inference=False, dropout_state=(seed, j + 1))["loss"].backward())
+    for side in ("ref", "lo"):                               # the fused pass is ONE forward whose head rows are the micro-batches' rows in order
+        gt.gates[side] = {n: [torch.cat(v, 0)] for n, v in gt.gates[side].items()}
+    flips = gt.flipped_rows()
     for kk in ("loss", "ce_loss", "align_loss", "regression_loss"):
-        s = sum(l[kk] for l in seq_losses)
-        res.append((f"fused accum k={k}: {kk} of the pass = sum of the {k} micro-step values ({s:.4f})", abs(outs["eager"][0][kk] - s), 2e-3 * max(1.0, abs(s))))
-    worst, worst_n, cos_min = 0.0, "", 1.0
+        r = sum(l[kk] for l in ref_losses)
+        res.append((f"fused accum k={k}: {kk} of the pass vs the oracle's sum over the {k} micro-batches ({r:.4f})", abs(outs["eager"][0][kk] - r), 5e-3 * max(1.0, abs(r))))
+        sq = sum(l[kk] for l in seq_losses)
+        res.append((f"fused accum k={k}: {kk} of the pass vs the sum of the {k} HIP micro-step values ({sq:.4f})", abs(outs["eager"][0][kk] - sq), 2e-3 * max(1.0, abs(sq))))
+    worst, stats = (0.0, ""), []
     for n in names:
-        a, b = seq["g"][n].double().flatten(), outs["eager"][1][n].double().flatten()
-        rms = float(a.pow(2).mean().sqrt())
-        if rms < 1e-6:
-            continue
-        d = float((a - b).pow(2).mean().sqrt()) / rms
-        if d > worst:
-            worst, worst_n = d, n
-        cos_min = min(cos_min, float((a @ b) / (a.norm() * b.norm() + 1e-30)))
-    res.append((f"fused accum k={k}: arena after ONE fused pass vs after {k} micro-steps, worst relative RMS difference over {len(names)} tensors ({worst_n})", worst, 2e-2))
-    res.append((f"fused accum k={k}: smallest cosine between the two gradients of a tensor; shown as 1 - cos", 1.0 - cos_min, 1e-3))
-    res.append((f"fused accum k={k}: squared gradient norm, fused vs sequential", abs(outs["eager"][2] - seq["ss"]) / max(seq["ss"], 1e-30), 1e-2))
+        ratio, desc = grad_err(outs["eager"][1][n], w[n].grad, wl[n].grad.float(), floor=3e-4 * k, skip_rows=GateTrace.rows_for(n, flips), stats=stats)
+        worst = max(worst, (ratio, f"{n}: {desc}"))
+    res.append((f"fused accum k={k}: arena after ONE fused pass vs autograd through the oracle on the {k} micro-batches, worst of {len(names)} tensors = {worst[1]}; "
+                "shown as err / tol", worst[0], 1.0))
+    res += ratio_summary(stats, f"fused accum k={k}")
+    flat = lambda g: torch.cat([g[n].double().flatten() for n in names])
+    a, b_ = flat(seq["g"]), flat(outs["eager"][1])
+    res.append((f"fused accum k={k}: direction of the whole gradient, fused pass vs {k} micro-steps; shown as 1 - cos", 1.0 - float((a @ b_) / (a.norm() * b_.norm())), 5e-3))
+    res.append((f"fused accum k={k}: squared gradient norm, fused vs sequential", abs(outs["eager"][2] - seq["ss"]) / max(seq["ss"], 1e-30), 5e-2))
+    la, lb = seq["g"]["lm_head.weight"].double().flatten(), outs["eager"][1]["lm_head.weight"].double().flatten()
+    res.append((f"fused accum k={k}: lm_head gradient (per-micro-batch CE means), relative RMS difference fused vs sequential", float((la - lb).norm() / la.norm()), 1e-2))
     same = all(torch.equal(outs["eager"][1][n], outs["hipGraph"][1][n]) for n in names) and outs["eager"][0] == outs["hipGraph"][0]
     res.append((f"fused accum k={k}: the replayed hipGraph of the fused pass leaves the same bits as the eager pass", 0.0 if same else 1.0, 0.5))
     return res

@@ -177,7 +177,7 @@ def check_full_depth_gradients(K=256, L=64, B=2, log=print, seed=0, table=None):
             return o
         out = gt.oracle(side, fb)
         log(f"full depth gradients: {side} oracle ({dt}) forward + backward {time.perf_counter() - t0:.1f} s on {torch.get_num_threads()} threads")
-        return {k: float(out[k]) for k in ("loss", "ce_loss", "align_loss", "regression_loss")}, {n: sd.leaves[n].grad for n in names}
+        return {k: float(out[k].detach()) for k in ("loss", "ce_loss", "align_loss", "regression_loss")}, {n: sd.leaves[n].grad for n in names}
 
     # the HIP micro-step first (its memory is released before the host holds two sets of gradients)
     arena = GradArena(m)
@@ -190,7 +190,7 @@ def check_full_depth_gradients(K=256, L=64, B=2, log=print, seed=0, table=None):
     gt.hip_collect(m)
     gt.hip_end(m)
     prm = dict(m.params.named_parameters())
-    hip_loss = {k: float(out[k]) for k in ("loss", "ce_loss", "align_loss", "regression_loss")}
+    hip_loss = {k: float(out[k].detach()) for k in ("loss", "ce_loss", "align_loss", "regression_loss")}
     ids = batch["input_ids"].cpu()
     touched = torch.unique(ids[ids >= 0])
     lab = batch["labels"].cpu()
