@@ -208,23 +208,50 @@ __global__ __launch_bounds__(256) void align_reg_kernel(const bf16_t* __restrict
     const float pr = bf2f(pred[k]), g = gt_iop[k];
     const float w = __expf(g - 1.f);
     rg += (pr - g) * (pr - g) * w;
-    if (d_pred) d_pred[k] = 2.f * (pr - g) * w * 50.f / (float)K;
+    if (d_pred && blockIdx.y == 0) d_pred[k] = 2.f * (pr - g) * w * 50.f / (float)K;
   }
   kl = block_sum(kl, red); rg = block_sum(rg, red);
-  if (threadIdx.x == 0) { out[0] = kl; out[1] = rg / (float)K * 50.f; }
+  if (threadIdx.x == 0 && blockIdx.y == 0) { out[0] = kl; out[1] = rg / (float)K * 50.f; }
   if (d_e || d_t) {
     // dKL/dcos_k = (softmax_s[k] - softmax_g[k]) / tau;  cos_k = <e_k, t> / (|e_k||t|)
+    // round 5: the per-key factors are formed ONCE (gs[k] <- dKL/dcos_k, en[k] <- 1 / |e_k|): the column loop below used to evaluate an exp and
+    // three divisions per (k, d) inside a serial chain of K iterations per thread (164 us for two items of K = 256 -- as long as two Llama
+    // GEMMs); same arithmetic per element otherwise (gk, then the two products), so the values are unchanged up to the reciprocal's rounding
     __syncthreads();
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+      gs[k] = (__expf(cs[k] / tau - lse_s) - gs[k]) / tau;
+      en[k] = 1.f / en[k];
+    }
+    __syncthreads();
+    // gridDim.y workgroups share an item's columns (each has formed the item's statistics itself: K x D bf16 out of L2); inside a workgroup
+    // the 4 waves take every 4th key of a 64-column block, the four partial d_t sums meet in LDS in wave order (fixed: no atomics)
+    const float itn = 1.f / tn;
+    const int cols = (D + (int)gridDim.y - 1) / (int)gridDim.y, d_lo = (int)blockIdx.y * cols, d_hi = min(D, d_lo + cols);
+    for (int d0 = d_lo; d0 < d_hi; d0 += 64) {
+      const int d = d0 + lane;
+      const bool on = d < d_hi;
       float acc_t = 0.f;
-      const float td = bf2f(t[d]);
-      for (int k = 0; k < K; ++k) {
-        const float gk = (__expf(cs[k] / tau - lse_s) - gs[k]) / tau;
-        const float ed = bf2f(e[(long)k * D + d]);
-        if (d_e) d_e[(long)k * D + d] = gk * (td / (en[k] * tn) - cs[k] * ed / (en[k] * en[k]));
-        acc_t += gk * (ed / (en[k] * tn) - cs[k] * td / (tn * tn));
+      const float td = on ? bf2f(t[d]) : 0.f;
+      if (on) {
+#pragma unroll 4
+        for (int k = wv; k < K; k += nw) {
+          const float gk = gs[k], ie = en[k], c = cs[k];
+          const float ed = bf2f(e[(long)k * D + d]);
+          if (d_e) d_e[(long)k * D + d] = gk * (td * ie * itn - c * ed * ie * ie);
+          acc_t += gk * (ed * ie * itn - c * td * itn * itn);
+        }
       }
-      if (d_t) d_t[d] = acc_t;
+      __syncthreads();                               // (red is reused per 64-column block)
+      if (d_t) {
+        float* part = sm + 3 * K + 16;               // [nw][64] behind red[16]
+        part[wv * 64 + lane] = acc_t;
+        __syncthreads();
+        if (wv == 0 && on) {
+          float sum = 0.f;
+          for (int w2 = 0; w2 < nw; ++w2) sum += part[w2 * 64 + lane];
+          d_t[d] = sum;
+        }
+      }
     }
   }
 }
@@ -577,9 +604,10 @@ extern "C" int llmseg_cosine_scores(const void* t, const void* e, float* sim, in
 extern "C" int llmseg_align_reg_loss(const void* e, const void* t, const float* gt_iou, const void* pred_iou, const float* gt_iop, float* out,
                                      float* d_e, float* d_t, float* d_pred, int32_t K, int32_t D, float tau, int32_t items, void* stream) {
   LL_CHECK(e && t && gt_iou && pred_iou && gt_iop && out && K > 0 && D > 0 && tau > 0.f && items > 0, "align_reg_loss: bad arguments");
-  const size_t lds = ((size_t)3 * K + 16) * sizeof(float);
+  const size_t lds = ((size_t)3 * K + 16 + 4 * 64) * sizeof(float);
   LL_CHECK(lds <= 64 * 1024, "align_reg_loss: K=%d too large", K);
-  LL_LAUNCH_KERNEL(align_reg_kernel, dim3(items), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)e, (const bf16_t*)t, gt_iou,
+  const unsigned ny = (d_e || d_t) ? (unsigned)std::max(1, std::min(8, D / 64)) : 1u;      // column chunks of an item's gradient pass
+  LL_LAUNCH_KERNEL(align_reg_kernel, dim3(items, ny), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)e, (const bf16_t*)t, gt_iou,
                      (const bf16_t*)pred_iou, gt_iop, out, d_e, d_t, d_pred, K, D, tau);
   LL_LAUNCH_CHECK("align_reg_loss");
   return LLMSEG_OK;
