@@ -112,7 +112,7 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
     T = args.prompt_len - 1 + cfg.n_img_tokens
     if args.mode == "train":
         trainer = trainer_cls(model, lr=3e-4, grad_accum=args.accum, device_ids=[local], use_graph=use_graph, ddp_wrapper=args.ddp_wrapper,
-                              force_ddp=args.force_ddp, leaf_stream=args.leaf_stream)
+                              force_ddp=args.force_ddp, leaf_stream=args.leaf_stream, time_comm=dist is not None)
         # warm-up covers the eager warm-up calls of the graph path + the capture itself
         def first_optimizer_step():
             # the warm-up micro-steps never reach the optimizer (one step per --accum micro-steps): run it once untimed -- on a cold box its
@@ -127,6 +127,31 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
                    graph=bool(use_graph and trainer.graph_error is None and any(e["graph"] is not None for e in trainer._graphs.values())))
         if trainer.graph_error:
             res["graph_error"] = trainer.graph_error[:200]
+        if dist is not None and trainer.arena is not None:
+            # what the data-parallel exchange costs: `exposed_ms` = compute-stream time per optimizer step from issuing the collectives to holding the
+            # reduced arena + its norm (inside the timed region: nothing overlaps it); `allreduce_ms` = the same buffers exchanged alone
+            # after the timed region (barrier + sync on both sides, max over ranks), dense and as shipped (embedding block as touched rows)
+            exp_ms = trainer.comm_times_ms()
+            flat = trainer.arena.flat
+            def alone(fn, reps=3):
+                fn(); _sync(dev); dist.barrier(); _sync(dev)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                _sync(dev); dist.barrier(); _sync(dev)
+                t = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return float(t.item())
+            scratch = torch.zeros_like(flat)
+            dense_ms = alone(lambda: dist.all_reduce(scratch))
+            del scratch
+            eo, en = trainer.arena.block_of.get(trainer._embed_key, (0, 0))
+            res["grad_exchange"] = {"optimizer_steps_timed": len(exp_ms), "exposed_ms_per_optimizer_step": (sum(exp_ms) / len(exp_ms)) if exp_ms else None,
+                                    "allreduce_ms_dense_fp32_arena_alone": dense_ms, "arena_bytes": int(flat.numel() * 4), "embedding_block_bytes": int(en * 4),
+                                    "sparse_embedding_rows": bool(trainer.sparse_embed), "world": world,
+                                    "micro_steps_per_optimizer_step": args.accum, "share_of_optimizer_step": ((sum(exp_ms) / len(exp_ms)) / (dt / args.steps * 1e3 * args.accum)) if exp_ms else None,
+                                    "note": "one exchange per optimizer step, issued after the last micro-step's backward (not overlapped with it); the embedding table's block "
+                                            "travels as an all-gather of the rows the window touched, the rest as asynchronous 128 MB all-reduce pieces"}
         # per-kernel timing: events cannot be recorded inside a replayed hipGraph, so the same micro-step runs eagerly (identical launches)
         # for a few steps right after the timed region, with an event pair around every GEMM launch on its stream
         trainer.use_graph = False
@@ -175,9 +200,18 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
     ach_all = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     model_flops = gemm_flops / n_prof + attention_flops(cfg, B, T)
     traffic, traffic_src = pmc_traffic(prof["dominant_kernel"], B)
-    res["roofline"] = {"bound": "mfma", "kernel": prof["dominant_kernel"], "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+    di = prof.get("dominant_info", {})
+    per = lambda key: di.get(key, 0) / n_prof
+    composition = ("the class = every llmseg_gemm_bf16 CALL the dispatch sends to this tile kernel with bf16 output (a timed record spans the whole call): "
+                   "%.0f calls per step, of which %.0f ran as K-slices (%.1f slices on average: ONE launch of the tile kernel's fp32-slab form -- rocprofv3 row "
+                   "`...<true, ...>` -- with the slices as its batch index, + one `splitk_reduce_kernel` launch that applies the epilogue) and %.0f as a single "
+                   "launch of the bf16-out form (row `...<false, false>`) or its LoRA extension-tile form (`...<false, true>`); %.0f kernel launches per step in all"
+                   % (per("calls"), per("calls_as_k_slices"), di.get("k_slices", 0) / max(1, di.get("calls_as_k_slices", 0)),
+                      per("calls") - per("calls_as_k_slices"), per("kernel_launches"))) if di else None
+    res["roofline"] = {"bound": "mfma", "kernel": prof["dominant_kernel"], "class_composition": composition, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                        "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                        "algorithmic_bytes_per_launch": prof["dominant_alg_bytes"] / max(1, dom_launches), "launches_per_step": dom_launches / n_prof,
+                       "launches_are": "user-level GEMM calls of the class (see class_composition); kernel launches per step: %.0f" % per("kernel_launches") if di else None,
                        "avg_launch_us": dom_ms * 1e3 / max(1, dom_launches), "time_share_of_step": dom_ms / n_prof / res["ms_per_step"],
                        "timing": "HIP events around every GEMM launch, %d eager single-stream steps of the same micro-step after the timed region" % n_prof,
                        "all_gemm_kernels": {"achieved": ach_all, "launches_per_step": gemm_launches / n_prof,
@@ -217,6 +251,42 @@ def accum_fused(model, cfg, args, B, dev, dist, rank, world, local, trainer_cls)
                    "same gradient as %d micro-steps (per-micro-batch CE / image means, per-micro-batch dropout masks)" % (k, B * k, B * k * (args.prompt_len - 1 + cfg.n_img_tokens), k)}
     if trainer.graph_error:
         res["graph_error"] = trainer.graph_error[:200]
+    trainer.close()
+    return res
+
+
+def mix_9_3_1(model, cfg, args, dev, dist, rank, world, local, trainer_cls):
+    """BASELINE configs[3]'s per-GPU workload on synthetic data: batch_size = 1 image per micro-step, the source of every sample drawn 9:3:1 from
+    sem_seg / refer_seg / reason_seg as `HybridDataset` draws it (utils/dataset.py:499-502), i.e. 1-3 conversations on the image (N = 1..3 sequences
+    through CLIP + Llama, one SAM forward).  One hipGraph per batch structure (3 of them), grad-accum 10, AdamW inside the timed region."""
+    from llmseg_amd import synthetic
+    img = 1024 if args.backbone == "sam" else 896
+    sampler = synthetic.HybridSampler((9, 3, 1), seed=2024 + rank)
+    n = 3 * args.accum                                                        # three optimizer steps
+    draws = [sampler.draw() for _ in range(n)]
+    pool = {c: synthetic.make_batch(1, img_size=img, L=args.prompt_len, K=args.masks, device=dev, seed=555 + c + rank, convs=[c]) for c in (1, 2, 3)}
+    plans = {c: model.make_plan(**b) for c, b in pool.items()}
+    trainer = trainer_cls(model, lr=3e-4, grad_accum=args.accum, device_ids=[local], use_graph=True)
+    for c in (1, 2, 3):                                                       # eager warm-ups + capture of every structure, outside the timed region
+        for _ in range(4):
+            trainer.micro_step(pool[c], plans[c])
+    it = [0]
+
+    def step():
+        c = draws[it[0] % n][1]
+        it[0] += 1
+        return trainer.micro_step(pool[c], plans[c])
+
+    def restart():
+        trainer.optimizer_step()
+        trainer.micro = 0
+    dt, out = timed(step, n, 0, dist, dev, restart)
+    counts = {s: sum(1 for d in draws if d[0] == s) for s in synthetic.HybridSampler.SOURCES}
+    res = {"value": world * n / dt, "unit": "images/s", "ms_per_step": dt / n * 1e3, "timed_micro_steps": n, "batch_size_per_gpu": 1,
+           "sources_drawn": counts, "conversations_drawn": {str(c): sum(1 for d in draws if d[1] == c) for c in (1, 2, 3)},
+           "graphs": sum(1 for e in trainer._graphs.values() if e["graph"] is not None), "loss": float(out["loss"].detach()),
+           "what": "BASELINE.json configs[3] per-GPU workload, synthetic: 1 image per micro-step, source drawn 9:3:1 (sem_seg / refer_seg / reason_seg) -> 1-3 "
+                   "conversations per image, grad-accum %d, one hipGraph per batch structure" % args.accum}
     trainer.close()
     return res
 
@@ -372,6 +442,7 @@ def main():
     ap.add_argument("--accum", type=int, default=10, help="gradient-accumulation micro-steps per optimizer step (reference: 10)")
     ap.add_argument("--no-k512", action="store_true", help="skip the BASELINE configs[4] side measurement (512 candidate masks, grad-accum 8) reported under batch_<B>_k512")
     ap.add_argument("--no-accum-fused", action="store_true", help="skip the fused-accumulation-window side measurement (the --accum micro-batches of an optimizer step as one pass)")
+    ap.add_argument("--no-mix", action="store_true", help="skip the BASELINE configs[3] side measurement (batch 1, sources drawn 9:3:1 -> 1-3 conversations per image)")
     ap.add_argument("--no-loader", action="store_true", help="skip the loader-in-the-loop side measurement (a different batch + device-side targets + a fresh plan every micro-step)")
     args = ap.parse_args()
 
@@ -443,6 +514,9 @@ def main():
     fused = None
     if train and use_graph and not args.no_accum_fused and args.accum > 1:
         fused = accum_fused(model, cfg, args, args.batch, dev, dist, rank, world, local, Trainer)
+    mix = None
+    if train and use_graph and not args.no_mix and not args.small:
+        mix = mix_9_3_1(model, cfg, args, dev, dist, rank, world, local, Trainer)
     loader = None
     if train and use_graph and not args.no_loader and not args.small:
         loader = loader_in_loop(model, cfg, args, args.batch, dev, dist, rank, world, local, Trainer, main_res["ms_per_step"])
@@ -471,6 +545,7 @@ def main():
             "model_mfma_frac": main_res["model_mfma_frac"],
             "loss": main_res["loss"],
             "launches_per_micro_step": main_res.get("launches_per_micro_step"),
+            "grad_exchange": main_res.get("grad_exchange"),
             "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
         }
         if "graph_error" in main_res:
@@ -483,6 +558,8 @@ def main():
             res[f"batch_{args.batch}_k512"] = k512
         if fused is not None:
             res["accum_fused"] = fused
+        if mix is not None:
+            res["mix_9_3_1_batch_1"] = mix
         if loader is not None:
             res["loader_in_loop"] = loader
         if world == 1 and not args.no_neighbours and not args.small and args.backbone == "sam":

@@ -435,6 +435,9 @@ int llmseg_prof_enable(int on);                 /* 1 = record events around GEMM
 const char* llmseg_prof_dominant_kernel(void);
 /* algorithmic bytes (A + W + C read / written once, bf16) summed over that class's launches in the last collected window */
 double llmseg_prof_dominant_bytes(void);
+/* composition of that class in the last collected window (a timed record is one user-level llmseg_gemm_bf16 CALL): out4 = {calls, calls that ran
+ * as K-slices, K-slices summed over those calls, kernel launches = calls + one splitk_reduce_kernel per K-sliced call} */
+int llmseg_prof_dominant_info(int64_t* out4);
 int llmseg_prof_collect(double* total_ms, double* total_flops, int64_t* launches, double* dom_ms, double* dom_flops, int64_t* dom_launches);
 
 #ifdef __cplusplus

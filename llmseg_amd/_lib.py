@@ -130,6 +130,7 @@ SIGNATURES = {
     "llmseg_prof_enable": [C.c_int],
     "llmseg_prof_dominant_kernel": [],
     "llmseg_prof_dominant_bytes": [],
+    "llmseg_prof_dominant_info": [C.POINTER(C.c_int64)],
     "llmseg_prof_collect": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double),
                             C.POINTER(C.c_int64)],
 }

@@ -47,6 +47,7 @@ std::vector<ProfRec> g_pool;
 hipEvent_t g_cur = nullptr;
 char g_dom_name[128] = "";
 double g_dom_bytes = 0;          // algorithmic bytes (A + W + C once, bf16) of the dominant class in the last collected window
+int64_t g_dom_info[4] = {0, 0, 0, 0};   // of that class: user-level GEMM calls, calls run as K-slices, K-slices summed over those, kernel launches
 }  // namespace
 
 void llmseg_prof_begin(hipStream_t s) {
@@ -83,12 +84,18 @@ extern "C" int llmseg_prof_enable(int on) {
 
 extern "C" const char* llmseg_prof_dominant_kernel(void) { return g_dom_name; }
 extern "C" double llmseg_prof_dominant_bytes(void) { return g_dom_bytes; }
+extern "C" int llmseg_prof_dominant_info(int64_t* out4) {
+  if (!out4) return LLMSEG_EINVAL;
+  for (int i = 0; i < 4; ++i) out4[i] = g_dom_info[i];
+  return LLMSEG_OK;
+}
 
 extern "C" int llmseg_prof_collect(double* total_ms, double* total_flops, int64_t* launches, double* dom_ms, double* dom_flops, int64_t* dom_launches) {
   std::lock_guard<std::mutex> lk(g_mu);
   double ms = 0, fl = 0;
   std::map<long, std::array<double, 4>> by_class;                      // kernel class (staging variant, fp32-out) -> {ms, flops, count, bytes}
   std::map<std::array<long, 4>, std::array<double, 3>> by_shape;      // (M,N,K,variant) -> {ms, flops, count}
+  std::map<long, std::array<int64_t, 3>> split_by_class;              // class -> {calls run as K-slices, their slices summed, calls with the extension K-tile}
   for (auto& r : g_recs) {
     (void)hipEventSynchronize(r.b);
     float t = 0;
@@ -97,6 +104,11 @@ extern "C" int llmseg_prof_collect(double* total_ms, double* total_flops, int64_
     fl += r.flops;
     auto& c = by_class[((r.tag[3] % 10000) / 1000) * 2 + (r.tag[3] & 1)];    // tag = split * 10000 + variant * 1000 + flags
     c[0] += t; c[1] += r.flops; c[2] += 1;
+    {
+      const long S = r.tag[3] / 10000;                                      // K-slices of this call (0 / 1 = none)
+      auto& sp = split_by_class[((r.tag[3] % 10000) / 1000) * 2 + (r.tag[3] & 1)];
+      if (S > 1) { sp[0] += 1; sp[1] += S; }
+    }
     c[3] += 2.0 * ((double)r.tag[0] * r.tag[2] + (double)r.tag[1] * r.tag[2] + (double)r.tag[0] * r.tag[1]);      // M K + N K + M N elements, 2 bytes each
     auto& e = by_shape[{r.tag[0], r.tag[1], r.tag[2], r.tag[3]}];
     e[0] += t; e[1] += r.flops; e[2] += 1;
@@ -133,6 +145,12 @@ extern "C" int llmseg_prof_collect(double* total_ms, double* total_flops, int64_
   if (dom_flops) *dom_flops = dom >= 0 ? by_class[dom][1] : 0;
   if (dom_launches) *dom_launches = dom >= 0 ? (int64_t)by_class[dom][2] : 0;
   g_dom_bytes = dom >= 0 ? by_class[dom][3] : 0;
+  if (dom >= 0) {
+    // a record is one user-level GEMM CALL: one launch of the tile kernel (the K-slices are its batch index), plus one splitk_reduce_kernel
+    // launch when it ran as K-slices -- what rocprofv3 lists as separate kernel rows
+    const auto& sp = split_by_class[dom];
+    g_dom_info[0] = (int64_t)by_class[dom][2]; g_dom_info[1] = sp[0]; g_dom_info[2] = sp[1]; g_dom_info[3] = (int64_t)by_class[dom][2] + sp[0];
+  } else g_dom_info[0] = g_dom_info[1] = g_dom_info[2] = g_dom_info[3] = 0;
   g_recs.clear();
   return LLMSEG_OK;
 }

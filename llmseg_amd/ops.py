@@ -652,5 +652,8 @@ def prof_collect():
     ms, fl, n, dms, dfl, dn = C.c_double(), C.c_double(), C.c_int64(), C.c_double(), C.c_double(), C.c_int64()
     _lib.load().llmseg_prof_collect(C.byref(ms), C.byref(fl), C.byref(n), C.byref(dms), C.byref(dfl), C.byref(dn))
     name = _lib.load().llmseg_prof_dominant_kernel()
+    info = (C.c_int64 * 4)()
+    _lib.load().llmseg_prof_dominant_info(info)
     return {"all": (ms.value, fl.value, n.value), "dominant": (dms.value, dfl.value, dn.value), "dominant_kernel": (name or b"").decode(),
-            "dominant_alg_bytes": _lib.load().llmseg_prof_dominant_bytes()}
+            "dominant_alg_bytes": _lib.load().llmseg_prof_dominant_bytes(),
+            "dominant_info": {"calls": int(info[0]), "calls_as_k_slices": int(info[1]), "k_slices": int(info[2]), "kernel_launches": int(info[3])}}

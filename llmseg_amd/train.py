@@ -95,6 +95,7 @@ class GradArena:
                     self._attach(w2d, p._g32.view(p.shape[0], p.shape[1]), make_leaf=True)
                     views["model.lisa_dino_conv.weight2d"] = w2d
         model.__dict__["_arena_views"] = views
+        self.block_of = {key: (off, n) for key, off, n in blocks}       # name (or fused-group name) -> (offset, elements) inside `flat`
 
 
     def _attach(self, t, view, make_leaf=False):
@@ -241,7 +242,7 @@ class Trainer:
 
     def __init__(self, module, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.0, clip=1.0, grad_accum=10, warmup=100, total_steps=5000,
                  optimizer=None, device_ids=None, force_ddp=False, ddp_wrapper=False, use_graph=False, graph_warmup=2, use_arena=None,
-                 reduce_chunk_mb=128, sync_init=True, check_every=100, leaf_stream=False, fused_accum=1):
+                 reduce_chunk_mb=128, sync_init=True, check_every=100, leaf_stream=False, fused_accum=1, sparse_embed=None, time_comm=False):
         """optimizer: None = HipAdamW; or a factory `params -> optimizer` / an optimizer object (CPU tests).  use_arena: None = automatic
         (the HIP model with the built-in optimizer), True = force the fp32 gradient arena (the module's autograd Functions must honour `_g32`)."""
         self.module = module
@@ -272,6 +273,19 @@ class Trainer:
         # `grad_accum` such passes (normally grad_accum = 1) and averages over grad_accum * k micro-batches.
         self.fused = int(fused_accum)
         assert self.fused >= 1
+        # sparse_embed (default: on whenever a process group and an `embed_tokens` block exist): the embedding table's gradient block (0.52 GB of the
+        # 1.16 GB arena at Llama-7B) has non-zero rows only for the tokens the ranks saw in this accumulation window (<= accum x N x L of 32004 rows:
+        # 98 % zeros at the benchmark's batch), so it is exchanged as an all-gather of (row index, row) lists instead of a dense all-reduce --
+        # `_exchange_embed_rows`.  The reference reduces it densely (DeepSpeed ZeRO-2 buckets, training.py:321-329).
+        self._embed_key = "model.embed_tokens.weight"
+        has_embed = self.arena is not None and self._embed_key in getattr(self.arena, "block_of", {})
+        self.sparse_embed = (self.dist_on and has_embed) if sparse_embed is None else (bool(sparse_embed) and has_embed)
+        if self.sparse_embed:
+            self._embed_cols = int(next(p for p in self.params if getattr(p, "_g32", None) is not None and p.dim() == 2 and
+                                        p._g32.data_ptr() == self.arena.flat[self.arena.block_of[self._embed_key][0]:].data_ptr()).shape[1])
+        self._window_ids = []
+        self.time_comm = bool(time_comm)                                 # bench / tests: event pair around the exchange of every optimizer step
+        self.comm_ms = []
         self.micro = 0
         self.opt_steps = 0
         self.is_hip_model = is_hip_model
@@ -374,6 +388,8 @@ class Trainer:
                 out["loss"].backward()
         if drop_on and self.fused > 1:
             self.module.advance_dropout(self.fused - 1)  # segment j of the fused pass used offset + j: the next pass starts after the window
+        if self.sparse_embed:
+            self._window_ids.append(batch["input_ids"].detach().reshape(-1).clone())     # which embedding rows this micro-step touched (device, no sync)
         self.micro += 1
         if last:
             self.optimizer_step()
@@ -474,16 +490,67 @@ class Trainer:
         sumsq = self.opt.sumsq_flat if hasattr(self.opt, "sumsq_flat") else None
         ss = torch.zeros(1, device=flat.device, dtype=torch.float32)
         if not self.dist_on:
+            self._window_ids = []
             return sumsq(flat) if sumsq is not None else (self.opt.ops.sumsq(flat, ss), ss)[1]
-        pieces = [flat[o:o + self.reduce_chunk] for o in range(0, flat.numel(), self.reduce_chunk)]
+        ev = None
+        if self.time_comm and flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        # dense part: everything but the embedding block when that one travels as rows
+        spans = [(0, flat.numel())]
+        if self.sparse_embed:
+            eo, en = self.arena.block_of[self._embed_key]
+            spans = [(a, b) for a, b in ((0, eo), (eo + en, flat.numel())) if b > a]
+        pieces = [flat[o:min(o + self.reduce_chunk, b)] for a, b in spans for o in range(a, b, self.reduce_chunk)]
         works = [dist.all_reduce(pc, async_op=True) for pc in pieces]
+        if self.sparse_embed:
+            self._exchange_embed_rows()                  # queued behind the dense pieces on the collective stream; its host-side size exchange overlaps them
         for pc, w in zip(pieces, works):
             w.wait()                                     # stream-level wait on a device backend: the host runs ahead
-            if sumsq is not None:
-                ss = ss + sumsq(pc)
-            else:
-                self.opt.ops.sumsq(pc, ss)
+        # the squared norm over the WHOLE arena in one fixed order (identical on every rank: the clip coefficient needs no collective)
+        if sumsq is not None:
+            ss = sumsq(flat)
+        else:
+            self.opt.ops.sumsq(flat, ss)
+        if ev is not None:
+            ev[1].record()
+            self._comm_events = getattr(self, "_comm_events", []) + [ev]
         return ss
+
+    def _exchange_embed_rows(self):
+        """Data-parallel sum of the embedding table's gradient block as ROWS.  Every rank: the distinct token ids of its window (device `unique`),
+        their count exchanged (one 8-byte all-gather + the ONLY host synchronisation of an optimizer step), index lists padded to the largest count,
+        all-gather of indices [world, n] and rows [world, n, H]; then the block is rebuilt as the sum over ranks IN RANK ORDER (`index_add_` with
+        indices that are distinct within a rank: no two additions race on an element, padding adds +0.0), so every rank holds the same bits."""
+        eo, en = self.arena.block_of[self._embed_key]
+        ids = torch.cat(self._window_ids) if self._window_ids else torch.zeros(0, dtype=torch.int64, device=self.arena.flat.device)
+        self._window_ids = []
+        H = self._embed_cols
+        block = self.arena.flat[eo:eo + en].view(-1, H)
+        rows = torch.unique(ids[(ids >= 0) & (ids < block.shape[0])])
+        cnt = torch.tensor([rows.numel()], device=block.device, dtype=torch.int64)
+        cnts = [torch.zeros_like(cnt) for _ in range(self.world)]
+        dist.all_gather(cnts, cnt)
+        n = max(1, int(torch.stack(cnts).max()))         # host sync: the gather below needs one size on every rank
+        idx = torch.full((n,), -1, device=block.device, dtype=torch.int64)
+        idx[: rows.numel()] = rows
+        vals = torch.zeros((n, H), device=block.device, dtype=block.dtype)
+        vals[: rows.numel()] = block[rows]
+        all_idx = [torch.empty_like(idx) for _ in range(self.world)]
+        all_val = [torch.empty_like(vals) for _ in range(self.world)]
+        dist.all_gather(all_idx, idx)
+        dist.all_gather(all_val, vals)
+        block.zero_()
+        for i_r, v_r in zip(all_idx, all_val):           # rank order: the same sum on every rank
+            block.index_add_(0, i_r.clamp(min=0), v_r * (i_r >= 0).to(v_r.dtype)[:, None])
+
+    def comm_times_ms(self):
+        """`time_comm`: milliseconds the compute stream spent per optimizer step from issuing the gradient exchange to holding the reduced arena
+        and its norm (nothing else runs on it meanwhile: this IS the exposed time of the exchange); clears the record."""
+        evs, self._comm_events = getattr(self, "_comm_events", []), []
+        if evs:
+            torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in evs]
 
     # ------------------------------------------------------------------------------------------------ checkpoint (reference: training.py:404-421, 460-477)
     def state_dict(self):

@@ -198,6 +198,81 @@ def test_ddp_gloo_matches_single_process():
     assert torch.allclose(ret[0][1], ref, atol=1e-6), (ret[0][1] - ref).abs().max()
 
 
+class ArenaEmbedFn(torch.autograd.Function):
+    """rows = W[ids] whose gradient is scatter-ACCUMULATED into W's `_g32` arena view (what `llmseg_scatter_add_rows` does kernel-side)."""
+
+    @staticmethod
+    def forward(ctx, ids, w):
+        ctx.ids, ctx.g = ids, w._g32
+        return w[ids]
+
+    @staticmethod
+    def backward(ctx, dy):
+        ctx.g.index_add_(0, ctx.ids.reshape(-1), dy.reshape(-1, dy.shape[-1]))
+        return None, None
+
+
+class _Inner(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.embed_tokens = nn.Embedding(50, 6)
+
+
+class ArenaEmbedToy(nn.Module):
+    """`model.embed_tokens.weight` (a table whose gradient touches few rows) + a dense head: the two kinds of arena blocks the exchange treats apart."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.model = _Inner()
+        self.head = nn.Linear(6, 1)
+
+    def forward(self, input_ids, y):
+        e = ArenaEmbedFn.apply(input_ids, self.model.embed_tokens.weight).mean(1)
+        return {"loss": ((ArenaLinearFn.apply(torch.tanh(e), self.head.weight, self.head.bias) - y) ** 2).mean()}
+
+
+def _embed_data(rank, step):
+    g = torch.Generator().manual_seed(1000 * step + rank)
+    return torch.randint(0, 50, (3, 4), generator=g), torch.randn(3, 1, generator=g)
+
+
+def _embed_worker(rank, world, port, ret, sparse):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = ArenaEmbedToy()
+    tr = Trainer(m, lr=1e-2, clip=1.0, grad_accum=2, warmup=2, total_steps=10, optimizer=lambda ps: CpuArenaAdamW(ps), use_arena=True,
+                 reduce_chunk_mb=64 / (1 << 20), check_every=1, sparse_embed=sparse)
+    assert tr.sparse_embed == sparse and (not sparse or tr._embed_cols == 6)
+    seen = {}
+    tr.grad_hook = lambda t, ss: seen.update(flat=t.arena.flat.clone(), ss=float(ss))
+    for s_ in range(4):
+        ids, y = _embed_data(rank, s_)
+        tr.micro_step(dict(input_ids=ids, y=y))
+    ret[(sparse, rank)] = (tr.opt_steps, torch.cat([p.detach().flatten() for p in m.parameters()]).clone(), seen["flat"], seen["ss"])
+    dist.destroy_process_group()
+
+
+def test_sparse_embedding_row_exchange_equals_dense_all_reduce():
+    """The embedding block travels as an all-gather of (row, values) lists (`Trainer._exchange_embed_rows`): the reduced arena equals the dense
+    all-reduce's (fp32 summation order over two ranks: exact), replicas stay bit-identical, rows no rank touched stay exactly zero."""
+    world = 2
+    ret = mp.Manager().dict()
+    for sparse, port in ((True, 29617), (False, 29619)):
+        mp.spawn(_embed_worker, args=(world, port, ret, sparse), nprocs=world, join=True)
+    for sparse in (True, False):
+        assert ret[(sparse, 0)][0] == 2 and torch.equal(ret[(sparse, 0)][1], ret[(sparse, 1)][1]) and torch.equal(ret[(sparse, 0)][2], ret[(sparse, 1)][2])
+    assert torch.allclose(ret[(True, 0)][2], ret[(False, 0)][2], atol=1e-7) and torch.allclose(ret[(True, 0)][1], ret[(False, 0)][1], atol=1e-7)
+    assert abs(ret[(True, 0)][3] - ret[(False, 0)][3]) <= 1e-6 * abs(ret[(False, 0)][3])
+    touched = set()
+    for r in range(world):
+        for s_ in (2, 3):                                            # the second accumulation window (what the hook saw last)
+            touched |= set(_embed_data(r, s_)[0].reshape(-1).tolist())
+    emb = ret[(True, 0)][2][: 50 * 6].view(50, 6)
+    rows_nz = set(torch.nonzero(emb.abs().sum(1)).flatten().tolist())
+    assert rows_nz <= touched and len(rows_nz) >= len(touched) - 2
+
+
 def test_warmup_decay_lr():
     assert warmup_decay_lr(0, 1.0, 100, 5000) == 0.0
     assert abs(warmup_decay_lr(50, 1.0, 100, 5000) - 0.5) < 1e-12
