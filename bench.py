@@ -120,6 +120,7 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
             # accumulation window so that the timed region contains exactly steps / accum optimizer steps
             trainer.optimizer_step()
             trainer.micro = 0
+            trainer.comm_times_ms()                                    # (drop the untimed step's exchange record)
         dt, out = timed(lambda: trainer.micro_step(batch, plan), args.steps, args.warmup + (3 if use_graph else 0), dist, dev, first_optimizer_step)
         loss = float(out["loss"].detach())
         assert loss == loss, "NaN loss"
