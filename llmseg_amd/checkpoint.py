@@ -15,7 +15,8 @@ was built with `LisaConfig(sam_decoder=True)` (`evaluate()` reads them) and repo
 
 Written by this package: the same directory layout and the same `module` key names, so the reference's loader (and ours) can read the
 weights; the optimizer state is ONE file in this package's own format (`llmseg_optim_states.pt`: fp32 master weights, Adam moments, step
-counters) -- DeepSpeed's rank-partitioned flat buffers are not reproduced (PARITY UNPINNED: deepspeed==0.10.0 is absent).
+counters) -- DeepSpeed's rank-partitioned flat buffers are not WRITTEN; they are READ (`load_zero2_optimizer_states`, round 5; PARITY UNPINNED:
+deepspeed==0.10.0 is absent, the layout is restated from its published zero_to_fp32 logic).
 """
 import os
 import re
@@ -105,6 +106,62 @@ def save_checkpoint(save_dir, model, trainer=None, global_step=0, trainable_only
     return d
 
 
+def load_zero2_optimizer_states(tag_dir, model, trainer):
+    """Adam state of a DeepSpeed ZeRO-2 bf16 checkpoint (`bf16_zero_pp_rank_<r>_mp_rank_00_optim_states.pt`, one file per data-parallel rank,
+    next to `mp_rank_00_model_states.pt`) -> this trainer's fp32 masters / moments / step, so that a resume from an authors' TRAINING checkpoint
+    (`training.py:404-421`) continues Adam instead of restarting it.  PARITY UNPINNED: deepspeed==0.10.0 is absent; the layout is restated from its
+    published `zero_to_fp32.py` / `stage_1_and_2.py`:
+      * the model-states file holds `param_shapes`: a list (one entry per optimizer param group) of {parameter name: shape} in the order the group was
+        flattened (the engine's trainable parameters in `named_parameters()` order);
+      * every rank file holds `optimizer_state_dict` with `single_partition_of_fp32_groups[g]` (that rank's slice of group g's flat fp32 master vector) and
+        `base_optimizer_state["state"][g]` = {"step", "exp_avg", "exp_avg_sq"} (the same slice of the moments);
+      * the flat vector of a group = its parameters concatenated, zero-padded to a multiple of 2 x world, cut into `world` equal partitions.
+    Raises when the files do not have that shape; -> dict(restored=[names], skipped=[names of the file the model does not train], step=int)."""
+    import glob
+    ms = torch.load(os.path.join(tag_dir, "mp_rank_00_model_states.pt"), map_location="cpu", weights_only=False)
+    shapes = ms.get("param_shapes")
+    if not shapes:
+        raise ValueError("the model-states file carries no `param_shapes` (not a DeepSpeed ZeRO checkpoint)")
+    shapes = shapes if isinstance(shapes, (list, tuple)) else [shapes]
+    files = sorted(glob.glob(os.path.join(tag_dir, "*zero_pp_rank_*_mp_rank_00_optim_states.pt")),
+                   key=lambda f: int(re.search(r"zero_pp_rank_(\d+)_", os.path.basename(f)).group(1)))
+    if not files:
+        raise FileNotFoundError(f"no *zero_pp_rank_<r>_mp_rank_00_optim_states.pt under {tag_dir}")
+    parts = [torch.load(f, map_location="cpu", weights_only=False)["optimizer_state_dict"] for f in files]
+    world = len(parts)
+    if any(int(p.get("zero_stage", 2)) > 2 for p in parts):
+        raise ValueError("ZeRO-3 checkpoints partition every parameter separately: not read here (the reference trains with stage 2, training.py:321)")
+    names = [n for n, p in model.params.named_parameters() if p.requires_grad]
+    slot = {n: i for i, n in enumerate(names)}
+    restored, skipped, step = [], [], 0
+    for g, group in enumerate(shapes):
+        flat = {"master": torch.cat([p["single_partition_of_fp32_groups"][g].float().reshape(-1) for p in parts])}
+        st = [p["base_optimizer_state"]["state"][g] for p in parts]
+        flat["m"] = torch.cat([s_["exp_avg"].float().reshape(-1) for s_ in st])
+        flat["v"] = torch.cat([s_["exp_avg_sq"].float().reshape(-1) for s_ in st])
+        step = max(step, int(st[0].get("step", 0)))
+        need = sum(int(torch.Size(shp).numel()) for shp in group.values())
+        align = 2 * world
+        if not (need <= flat["master"].numel() <= (need + align - 1) // align * align + align):
+            raise ValueError(f"group {g}: {need} parameter elements do not fit {flat['master'].numel()} partitioned elements over {world} ranks")
+        off = 0
+        for name, shp in group.items():
+            n = int(torch.Size(shp).numel())
+            key = reference_key(name)
+            if key in slot:
+                i = slot[key]
+                for dst, src in ((trainer.opt.master[i], flat["master"]), (trainer.opt.m[i], flat["m"]), (trainer.opt.v[i], flat["v"])):
+                    if tuple(dst.shape) != tuple(torch.Size(shp)):
+                        raise ValueError(f"{name}: optimizer state of shape {tuple(shp)} for a parameter of shape {tuple(dst.shape)}")
+                    dst.copy_(src[off:off + n].view(dst.shape))
+                restored.append(key)
+            else:
+                skipped.append(name)
+            off += n
+    trainer.opt.t = step
+    return {"restored": restored, "skipped": skipped, "step": step, "not_in_file": [n for n in names if n not in set(restored)]}
+
+
 def load_checkpoint(load_dir, model, trainer=None, steps_per_epoch=500):
     """Resume (`--auto_resume`, training.py:404-421): weights, then -- when this package wrote the checkpoint -- the optimizer state.
     -> dict(tag, global_steps, start_epoch, optimizer_restored)."""
@@ -122,8 +179,12 @@ def load_checkpoint(load_dir, model, trainer=None, steps_per_epoch=500):
                 seed, off = (int(v) for v in st["dropout_state"].tolist())      # the base seed; every rank's module derives its own key
                 model.set_dropout_seed(seed, off)
             restored = True
+        elif hasattr(trainer.opt, "master") and [x for x in os.listdir(os.path.dirname(f)) if "zero_pp_rank_" in x and x.endswith("_optim_states.pt")]:
+            z = load_zero2_optimizer_states(os.path.dirname(f), model, trainer)      # a reference TRAINING checkpoint: its ZeRO-2 Adam partitions
+            restored = not z["not_in_file"]
+            trainer.opt_steps = z["step"]
         elif hasattr(trainer.opt, "resync_master"):
-            trainer.opt.resync_master()                 # a reference checkpoint: fresh Adam moments on the loaded weights
+            trainer.opt.resync_master()                 # weights only (a released checkpoint): fresh Adam moments on the loaded weights
     m = re.search(r"(\d+)$", tag or "")
     steps = int(m.group(1)) if m else (info.get("global_steps") or 0)
     return {"tag": tag, "global_steps": steps, "start_epoch": steps // max(1, steps_per_epoch), "optimizer_restored": restored,

@@ -76,3 +76,42 @@ def test_decoder_keys_follow_the_model(tmp_path):
     assert info["missing"] == [base[1]]
     with pytest.raises(KeyError):
         ck.load_reference_checkpoint(_Fake(base), path2, strict=True)
+
+
+def test_zero2_optimizer_partitions_are_read(tmp_path):
+    """N4: the Adam state of a DeepSpeed ZeRO-2 bf16 TRAINING checkpoint -- flat fp32 groups cut into equal per-rank partitions, padded to
+    2 x world, `param_shapes` in the model-states file -- lands in the trainer's masters / moments.  The writer below follows the published layout
+    (deepspeed absent: unpinned); 3 ranks, a parameter the model does not train in the file, padding at the end."""
+    import types
+    names = ["model.embed_tokens.weight", "model.layers.0.self_attn.q_proj.lora_A.default.weight", "model.text_hidden_fcs.0.0.bias"]
+    shapes = {"base_model.model." + names[0]: torch.Size([5, 4]), "base_model.model." + names[1]: torch.Size([2, 4]),
+              "base_model.model.model.gone.weight": torch.Size([3]), "base_model.model." + names[2]: torch.Size([7])}
+    g = torch.Generator().manual_seed(0)
+    full = {k: {n: torch.randn(shp, generator=g) for n, shp in shapes.items()} for k in ("master", "m", "v")}
+    world = 3
+    flat = {k: torch.cat([t.reshape(-1) for t in full[k].values()]) for k in full}
+    total = (flat["master"].numel() + 2 * world - 1) // (2 * world) * (2 * world)
+    flat = {k: torch.cat([v, torch.zeros(total - v.numel())]) for k, v in flat.items()}
+    per = total // world
+    d = tmp_path / "global_step40"
+    d.mkdir()
+    torch.save({"module": {}, "param_shapes": [shapes], "global_steps": 40}, str(d / "mp_rank_00_model_states.pt"))
+    for r in range(world):
+        sl = slice(r * per, (r + 1) * per)
+        torch.save({"optimizer_state_dict": {"zero_stage": 2, "partition_count": [world], "single_partition_of_fp32_groups": [flat["master"][sl].clone()],
+                                              "base_optimizer_state": {"state": {0: {"step": 40, "exp_avg": flat["m"][sl].clone(), "exp_avg_sq": flat["v"][sl].clone()}}}}},
+                   str(d / f"bf16_zero_pp_rank_{r}_mp_rank_00_optim_states.pt"))
+    prm = {n: torch.nn.Parameter(torch.zeros(shapes["base_model.model." + n])) for n in names}
+    model = types.SimpleNamespace(params=types.SimpleNamespace(named_parameters=lambda: list(prm.items())))
+    opt = types.SimpleNamespace(master=[torch.zeros_like(p) for p in prm.values()], m=[torch.zeros_like(p) for p in prm.values()],
+                                v=[torch.zeros_like(p) for p in prm.values()], t=0)
+    tr = types.SimpleNamespace(opt=opt)
+    rep = ck.load_zero2_optimizer_states(str(d), model, tr)
+    assert rep["restored"] == names and rep["skipped"] == ["base_model.model.model.gone.weight"] and rep["step"] == 40 and not rep["not_in_file"] and opt.t == 40
+    for i, n in enumerate(names):
+        for dst, k in ((opt.master, "master"), (opt.m, "m"), (opt.v, "v")):
+            assert torch.equal(dst[i], full[k]["base_model.model." + n]), (n, k)
+    import pytest
+    torch.save({"module": {}}, str(d / "mp_rank_00_model_states.pt"))
+    with pytest.raises(ValueError, match="param_shapes"):
+        ck.load_zero2_optimizer_states(str(d), model, tr)
