@@ -215,7 +215,7 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
                        "launches_are": "user-level GEMM calls of the class (see class_composition); kernel launches per step: %.0f" % per("kernel_launches") if di else None,
                        "avg_launch_us": dom_ms * 1e3 / max(1, dom_launches), "time_share_of_step": dom_ms / n_prof / res["ms_per_step"],
                        "timing": "HIP events around every GEMM launch, %d eager single-stream steps of the same micro-step after the timed region" % n_prof,
-                       "all_gemm_kernels": {"achieved": ach_all, "launches_per_step": gemm_launches / n_prof,
+                       "all_gemm_kernels": {"achieved": ach_all, "frac": ach_all / PEAK_BF16_TFLOPS, "launches_per_step": gemm_launches / n_prof,
                                             "avg_launch_us": gemm_ms * 1e3 / max(1, gemm_launches),
                                             "time_share_of_step": gemm_ms / n_prof / res["ms_per_step"]}}
     res["model_tflop_per_image"] = model_flops / B / 1e12

@@ -1065,7 +1065,16 @@ inline double pp_cost(long M, long N, int nt, int mi, int S, long ncu, bool f32o
   const long rounds = (tiles * S + ncu - 1) / ncu;
   const int q = (nt + S - 1) / S;
   const double it = mi == 4 ? 1.7 : 1.0, fix = (mi == 4 ? 7.0 : 4.5) + ((S > 1 || f32out) ? 1.0 : 0.0);
-  double us = (double)rounds * (q * it + fix);
+  // Round 5: without K-slices a partially filled last round is priced at 0.5 + 0.5 x its fill instead of a whole round -- a CU that shares the
+  // fabric with fewer neighbours fetches its operands faster (measured, tools/gemm_bench.py at the 2-image shapes: 8192 x 1280 x 1280 on 160
+  // workgroups of 256 x 256 takes 35 us, not 41; the whole-round price made the 128 x 256 tile win SAM proj / lin1 / q|k|v-windows, where the
+  // 256 x 256 tile measures +9 / +6 / +5 %).  K-sliced plans keep the whole-round price their slice counts were tuned with.
+  double eff_rounds = (double)rounds;
+  if (S == 1) {
+    const long full = tiles / ncu, rem = tiles - full * ncu;
+    eff_rounds = (double)full + (rem ? 0.5 + 0.5 * (double)rem / (double)ncu : 0.0);
+  }
+  double us = eff_rounds * (q * it + fix);
   if (S > 1) us += 2.5 + ((double)(S + 1) * M * N * 4.0) / 4.0e6;     // reduce launch: slabs read once (mostly from the Infinity Cache)
   return us;
 }
