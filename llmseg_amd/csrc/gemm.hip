@@ -1064,6 +1064,8 @@ inline double pp_cost(long M, long N, int nt, int mi, int S, long ncu, bool f32o
   const long tiles = ((M + 64 * mi - 1) / (64 * mi)) * ((N + 255) / 256);
   const long rounds = (tiles * S + ncu - 1) / ncu;
   const int q = (nt + S - 1) / S;
+  // (round 5: re-fitting these constants to the two-phase kernel from two isolated shapes -- 0.8 + 6.4 / 1.64 + 4.5 -- moved the K-slice plans of
+  // the Llama N = 4096 shapes and cost 4 % at 2 images, 6 % at 24: measured and reverted, profiles/r05g_gemm_dispatch.md)
   const double it = mi == 4 ? 1.7 : 1.0, fix = (mi == 4 ? 7.0 : 4.5) + ((S > 1 || f32out) ? 1.0 : 0.0);
   // Round 5: without K-slices a partially filled last round is priced at 0.5 + 0.5 x its fill instead of a whole round -- a CU that shares the
   // fabric with fewer neighbours fetches its operands faster (measured, tools/gemm_bench.py at the 2-image shapes: 8192 x 1280 x 1280 on 160
