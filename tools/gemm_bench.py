@@ -26,6 +26,10 @@ if os.environ.get("GEMM_SET") == "clip":  # CLIP-L at two sequences per step (M 
 if os.environ.get("GEMM_SET") == "dec":  # decode steps of generation (one token per sequence): weight streams
     SHAPES = [(m, n, k, f"dec {t}") for m in (1, 4) for n, k, t in ((12288, 4096, "qkv"), (4096, 4096, "o"), (22016, 4096, "gate_up"), (4096, 11008, "down"),
                                                                      (32004, 4096, "lm_head"))]
+if os.environ.get("GEMM_SET") == "fused":  # the fused accumulation window: 10 micro-batches of 2 images in one pass (Llama M = 20 x 319)
+    SHAPES = [(6380, 12288, 4096, "llama qkv"), (6380, 4096, 4096, "llama o"), (6380, 22016, 4096, "llama gate_up"), (6380, 4096, 11008, "llama down"),
+              (6380, 4096, 12288, "llama dx(qkv)"), (6380, 4096, 22016, "llama dx(gate_up)"), (6380, 11008, 4096, "llama dx(down)"),
+              (81920, 1280, 1280, "sam proj"), (81920, 5120, 1280, "sam lin1")]
 RACE_REPEATS = int(os.environ.get("RACE_REPEATS", "0"))
 if os.environ.get("GEMM_SHAPES"):
     SHAPES = [SHAPES[int(i)] for i in os.environ["GEMM_SHAPES"].split(",")]
