@@ -34,10 +34,14 @@ def cpu_baseline(threads=None, budget_s=45.0):
 
 
 def pmc_traffic(kernel, B):
-    """HBM bytes per launch of `kernel` from the fabric counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x 2 on
-    gfx950; tools/pmc_traffic.sh -> profiles/traffic.json, collected on an MI355X with this same bench command at the same batch).  The
-    counters cannot be read from inside this process: (None, provenance) when no record for this kernel and batch is committed.
-    -> (bytes per launch | None, {"file", "sha1", "collected"}): which committed file the number comes from and what tree it was collected on."""
+    """HBM bytes per user-level GEMM CALL of the dominant class from the fabric counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+    FETCH_SIZE x 2 on gfx950; tools/pmc_traffic.sh -> profiles/traffic.json, collected on an MI355X with this same bench command at the same batch).
+    The roofline's class is "every call the dispatch sends to one tile kernel" (see `class_composition`): its traffic is the launch-weighted sum over that
+    kernel's three forms -- `<false, ..>` bf16 output, `<true, ..>` fp32 K-slice slabs, `<false, true, ..>` with the LoRA extension tile -- plus the
+    `splitk_reduce_kernel` launches (attributed to the class that owns most K-sliced launches), divided by the number of calls (= launches of the three
+    forms), i.e. the same population `algorithmic_bytes_per_launch` is averaged over (round 4 divided one form's bytes by the whole class's calls).
+    The counters cannot be read from inside this process: (None, provenance) when no record for this batch is committed.
+    -> (bytes per call | None, {"file", "sha1", "collected", "definition"})."""
     import hashlib
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
@@ -46,9 +50,22 @@ def pmc_traffic(kernel, B):
     except (OSError, ValueError):
         return None, None
     rec = doc.get(f"batch_{B}", {})
-    prov = {"file": "profiles/traffic.json", "sha1": hashlib.sha1(raw).hexdigest()[:16], "collected": rec.get("source")}
-    hit = rec.get("kernels", {}).get(kernel.replace("<*", "<false"))
-    return (None if hit is None else hit["hbm_bytes_per_launch"]), prov
+    ks = rec.get("kernels", {})
+    base = kernel.split("<")[0] + "<"
+    forms = {k: v for k, v in ks.items() if k.startswith(base)}
+    prov = {"file": "profiles/traffic.json", "sha1": hashlib.sha1(raw).hexdigest()[:16], "collected": rec.get("source"),
+            "definition": "sum over the class's kernel forms (+ split-K reduce launches) of bytes x launches, / calls of the class"}
+    if not forms:
+        return None, prov
+    calls = sum(v["launches"] for v in forms.values())
+    total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in forms.values())
+    sliced = lambda b: sum(v["launches"] for k, v in ks.items() if k.startswith(b) and k[len(b):].startswith("true"))
+    others = [k.split("<")[0] + "<" for k in ks if k.startswith("gemm_bf16_tn_pp") and not k.startswith(base)]
+    red = ks.get("splitk_reduce_kernel")
+    if red is not None and sliced(base) >= max([sliced(o) for o in set(others)] + [0]):
+        total += red["hbm_bytes_per_launch"] * red["launches"]
+    prov["forms"] = {k: {"launches": v["launches"], "hbm_bytes_per_launch": v["hbm_bytes_per_launch"]} for k, v in forms.items()}
+    return total / max(1, calls), prov
 
 
 def attention_flops(cfg, B, T):
