@@ -2,6 +2,7 @@
 // LLaVA embedding splice, row gather.  All are streaming kernels: 16-byte (8 x bf16) accesses per lane, wave64
 // shuffles for row statistics, fp32 math, one rounding to bf16 on store (see include/llmseg_hip.h for the
 // reference ops each one replaces).
+#include <cstdlib>
 #include "common.h"
 #include "llmseg_hip.h"
 
@@ -350,7 +351,8 @@ extern "C" int llmseg_norm(const void* x, const void* w, const void* b, void* y,
   LL_CHECK((cols & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0, "norm: cols/ld must be multiples of 8");
   LL_CHECK(AL16(x) && AL16(w) && AL16(y) && (b == nullptr || AL16(b)), "norm: pointers must be 16-byte aligned");
   const int cpl = (int)(((cols >> 3) + 63) / 64);
-  if (rows >= 64 && rows < 2048 && cols >= 2048 && cols <= 8192) {          // short and wide: a workgroup per row (rows < 64: the decode path keeps its kernel)
+  static const long wg_max_rows = getenv("LLMSEG_NORM_WG_MAX") ? atol(getenv("LLMSEG_NORM_WG_MAX")) : 2048;      // A/B switch (tools/hbm_kernels.py)
+  if (rows >= 64 && rows < wg_max_rows && cols >= 2048 && cols <= 8192) {    // short and wide: a workgroup per row (rows < 64: the decode path keeps its kernel)
     const int cpt = (int)(((cols >> 3) + 255) / 256);
 #define LL_NORMW(C)                                                                                                                             \
   LL_LAUNCH_KERNEL(norm_wg_kernel<C>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, \
