@@ -242,7 +242,7 @@ class Trainer:
 
     def __init__(self, module, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.0, clip=1.0, grad_accum=10, warmup=100, total_steps=5000,
                  optimizer=None, device_ids=None, force_ddp=False, ddp_wrapper=False, use_graph=False, graph_warmup=2, use_arena=None,
-                 reduce_chunk_mb=128, sync_init=True, check_every=100, leaf_stream=False, fused_accum=1, sparse_embed=None, time_comm=False):
+                 reduce_chunk_mb=128, sync_init=True, check_every=100, leaf_stream=False, fused_accum=1, sparse_embed=None, time_comm=False, wire_dtype=None):
         """optimizer: None = HipAdamW; or a factory `params -> optimizer` / an optimizer object (CPU tests).  use_arena: None = automatic
         (the HIP model with the built-in optimizer), True = force the fp32 gradient arena (the module's autograd Functions must honour `_g32`)."""
         self.module = module
@@ -284,6 +284,9 @@ class Trainer:
             self._embed_cols = int(next(p for p in self.params if getattr(p, "_g32", None) is not None and p.dim() == 2 and
                                         p._g32.data_ptr() == self.arena.flat[self.arena.block_of[self._embed_key][0]:].data_ptr()).shape[1])
         self._window_ids = []
+        # wire_dtype=torch.bfloat16: the dense pieces cross the fabric in bf16 (half the bytes), as the reference's DeepSpeed bf16 engine reduces its gradients
+        # (training.py:314-329); accumulation over micro-steps, the embedding rows and everything after the exchange stay fp32.  Default: fp32 on the wire.
+        self.wire_dtype = wire_dtype
         self.time_comm = bool(time_comm)                                 # bench / tests: event pair around the exchange of every optimizer step
         self.comm_ms = []
         self.micro = 0
@@ -502,11 +505,14 @@ class Trainer:
             eo, en = self.arena.block_of[self._embed_key]
             spans = [(a, b) for a, b in ((0, eo), (eo + en, flat.numel())) if b > a]
         pieces = [flat[o:min(o + self.reduce_chunk, b)] for a, b in spans for o in range(a, b, self.reduce_chunk)]
-        works = [dist.all_reduce(pc, async_op=True) for pc in pieces]
+        wire = [pc if self.wire_dtype in (None, pc.dtype) else pc.to(self.wire_dtype) for pc in pieces]
+        works = [dist.all_reduce(wb, async_op=True) for wb in wire]
         if self.sparse_embed:
             self._exchange_embed_rows()                  # queued behind the dense pieces on the collective stream; its host-side size exchange overlaps them
-        for pc, w in zip(pieces, works):
+        for pc, wb, w in zip(pieces, wire, works):
             w.wait()                                     # stream-level wait on a device backend: the host runs ahead
+            if wb is not pc:
+                pc.copy_(wb)                             # back to the fp32 arena (every rank widens the same bf16 sums: replicas stay identical)
         # the squared norm over the WHOLE arena in one fixed order (identical on every rank: the clip coefficient needs no collective)
         if sumsq is not None:
             ss = sumsq(flat)

@@ -237,19 +237,19 @@ def _embed_data(rank, step):
     return torch.randint(0, 50, (3, 4), generator=g), torch.randn(3, 1, generator=g)
 
 
-def _embed_worker(rank, world, port, ret, sparse):
+def _embed_worker(rank, world, port, ret, sparse, wire=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     m = ArenaEmbedToy()
     tr = Trainer(m, lr=1e-2, clip=1.0, grad_accum=2, warmup=2, total_steps=10, optimizer=lambda ps: CpuArenaAdamW(ps), use_arena=True,
-                 reduce_chunk_mb=64 / (1 << 20), check_every=1, sparse_embed=sparse)
+                 reduce_chunk_mb=64 / (1 << 20), check_every=1, sparse_embed=sparse, wire_dtype=wire)
     assert tr.sparse_embed == sparse and (not sparse or tr._embed_cols == 6)
     seen = {}
     tr.grad_hook = lambda t, ss: seen.update(flat=t.arena.flat.clone(), ss=float(ss))
     for s_ in range(4):
         ids, y = _embed_data(rank, s_)
         tr.micro_step(dict(input_ids=ids, y=y))
-    ret[(sparse, rank)] = (tr.opt_steps, torch.cat([p.detach().flatten() for p in m.parameters()]).clone(), seen["flat"], seen["ss"])
+    ret[(sparse if wire is None else "bf16", rank)] = (tr.opt_steps, torch.cat([p.detach().flatten() for p in m.parameters()]).clone(), seen["flat"], seen["ss"])
     dist.destroy_process_group()
 
 
@@ -271,6 +271,21 @@ def test_sparse_embedding_row_exchange_equals_dense_all_reduce():
     emb = ret[(True, 0)][2][: 50 * 6].view(50, 6)
     rows_nz = set(torch.nonzero(emb.abs().sum(1)).flatten().tolist())
     assert rows_nz <= touched and len(rows_nz) >= len(touched) - 2
+
+
+def test_bf16_wire_option():
+    """`Trainer(wire_dtype=torch.bfloat16)`: the dense pieces are exchanged in bf16 (the reference's DeepSpeed engine reduces bf16 gradients), the embedding
+    rows and the arena stay fp32: replicas bit-identical, the reduced dense part within bf16 rounding of the fp32 exchange, the embedding block equal to it."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_embed_worker, args=(world, 29621, ret, True, torch.bfloat16), nprocs=world, join=True)
+    mp.spawn(_embed_worker, args=(world, 29623, ret, True), nprocs=world, join=True)
+    a, b = ret[("bf16", 0)], ret[(True, 0)]
+    assert torch.equal(a[1], ret[("bf16", 1)][1]) and torch.equal(a[2], ret[("bf16", 1)][2])
+    emb = slice(0, 50 * 6)
+    assert torch.equal(a[2][emb], b[2][emb])                                                     # rows: fp32 on the wire either way
+    dense_a, dense_b = a[2][50 * 6:], b[2][50 * 6:]
+    assert not torch.equal(dense_a, dense_b) and torch.allclose(dense_a, dense_b, rtol=2 ** -7, atol=1e-6)
 
 
 def test_warmup_decay_lr():
