@@ -314,3 +314,49 @@ def test_graph_inputs_and_rank_dropout_seed():
     assert float(a["images"].min()) == 1.0 and float(a["sam_segs_list"][1].min()) == 2.0 and a["masks_list"][0].shape[-1] == 7
     seeds = {T.rank_dropout_seed(0x5EED, r) for r in range(8)}
     assert len(seeds) == 8 and T.rank_dropout_seed(0x5EED, 0) == 0x5EED and all(0 <= v < 2 ** 63 for v in seeds)
+
+
+def test_fused_window_plan_and_merge(monkeypatch):
+    """Host logic of the fused accumulation window (`merge_micro_batches` + `make_plan(micro_batches=k)`): offsets re-based, one CE segment per
+    micro-batch with its own trailing row, item weights 1 / (rounds x images of the micro-batch), dropout segment = rows of one micro-batch, a plan
+    signature that differs from the unfused one; misuse fails loudly.  (`make_plan` pins its uploads: patched out, there is no device here.)"""
+    import types
+    from llmseg_amd import trainable
+    from llmseg_amd.train import merge_micro_batches
+    from oracle import cases
+    monkeypatch.setattr(torch.Tensor, "pin_memory", lambda self: self)
+    base = cases.tiny_lisa_batch(img_size=32)
+    batches = []
+    for j in range(3):
+        b = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in base.items()}
+        b["labels"][:, :10 + j] = -100                                    # different label counts per micro-batch: different CE denominators
+        batches.append(b)
+    merged = merge_micro_batches(batches)
+    assert merged["offset"].tolist() == [0, 2, 3, 5, 6, 8, 9] and merged["input_ids"].shape[0] == 9 and len(merged["sam_segs_list"]) == 6
+
+    class Fake(trainable.TrainableMixin):
+        pass
+    f = Fake()
+    f.config, f.device_, f.seg_token_idx = types.SimpleNamespace(n_img_tokens=256), torch.device("cpu"), cases.SEG
+    p1 = [f.make_plan(**b) for b in batches]
+    pk = f.make_plan(**merged, micro_batches=3)
+    assert pk.micro == 3 and pk.loss_div == 1.0 and p1[0].loss_div == 2.0 and pk.sig != f.make_plan(**merged).sig
+    T = 24 - 1 + 256
+    assert pk.drop_seg_rows == 3 * T and p1[0].drop_seg_rows == 0
+    sizes = [int(p.ce_rows.numel()) for p in p1]
+    assert pk.ce_segs == [(0, sizes[0]), (sizes[0], sizes[0] + sizes[1]), (sizes[0] + sizes[1], sum(sizes))] and len(set(sizes)) == 3
+    off = 0
+    for j, p in enumerate(p1):                                          # segment j = micro-batch j's own rows (shifted by its sequences) and labels
+        a, b_ = pk.ce_segs[j]
+        assert torch.equal(pk.ce_rows[a:b_], p.ce_rows + j * 3 * T) and torch.equal(pk.ce_labels[0, a:b_], p.ce_labels[0])
+        assert int(pk.ce_labels[0, a]) == -100                           # every segment starts with its own ignored trailing-row label
+    assert torch.allclose(pk.tensors["loss_w16"], torch.cat([p.tensors["loss_w16"] / 2.0 for p in p1]))       # 1 / rounds, / 2 images per micro-batch
+    import pytest
+    with pytest.raises(AssertionError):
+        f.make_plan(**merged, micro_batches=2)                           # 9 sequences / 6 images do not split into 2 equal micro-batches
+    # two micro-batches of 2 images whose sequence counts differ (4 and 2): N = 6 splits evenly, the micro-batches do not
+    ids4 = torch.cat([base["input_ids"], base["input_ids"][:1]])
+    big = dict(input_ids=torch.cat([ids4, base["input_ids"][:2]]), labels=torch.cat([ids4, base["input_ids"][:2]]), attention_masks=torch.ones(6, 24, dtype=torch.bool),
+               offset=torch.tensor([0, 2, 4, 5, 6]), sam_segs_list=base["sam_segs_list"] * 2)
+    with pytest.raises(AssertionError, match="same number of sequences"):
+        f.make_plan(**big, micro_batches=2)
