@@ -32,8 +32,8 @@ enum { LLMSEG_ACT_NONE = 0, LLMSEG_ACT_RELU = 1, LLMSEG_ACT_GELU = 2, LLMSEG_ACT
  * past the caller's struct.  llmseg_struct_size(which) returns the library's sizeof (0 = llmseg_gemm_args, 1 = llmseg_attn_args,
  * 2 = llmseg_attn_bwd_args, 3 = llmseg_dropout; -1 for an unknown index) so a binding can assert at load time;
  * llmseg_version() is bumped whenever a struct or a signature changes (4: the reduction entry points take a workspace; 5 = this header:
- * llmseg_dropout.seg_rows). */
-#define LLMSEG_ABI_VERSION 5
+ * llmseg_dropout.seg_rows; 6: llmseg_gemm_args.norm_w / norm_eps / norm_out / ldn). */
+#define LLMSEG_ABI_VERSION 6
 
 /* Determinism (round 4).  No kernel adds floating-point numbers with atomics: every sum whose terms come from several workgroups is
  * written as per-workgroup partials into CALLER-OWNED scratch (`workspace`, `workspace_bytes`; any device memory, 256-byte aligned, not
@@ -90,6 +90,12 @@ typedef struct {
    *   a_swiglu            : A rows are [gate | up] of width 2K (lda >= 2K), A := silu(gate) * up on load (HF LlamaMLP).
    * Same bits as llmseg_norm / llmseg_swiglu followed by the GEMM. */
   const void* a_norm_w; float a_norm_eps; int a_swiglu;
+  /* optional second output (ABI 6): norm_out[m][:] = RMSNorm(C[m][:]) * norm_w, bf16 [M][ldn], with exactly the arithmetic of llmseg_norm(rms = 1) applied to
+   * the bf16 C this call writes (HF LlamaRMSNorm: fp32 statistics, rounding before the weight multiply) -- the residual stream's next pre-norm
+   * (llava_llama.py:93-102: o_proj / down_proj + residual, then the following LlamaRMSNorm).  bf16 output, batch 1, N % 8 == 0, ldn % 8 == 0.  When the product runs
+   * as K-slices (Llama o / down at M = 2 x 319) the reduce launch computes it on the row it has just summed (one launch and one pass over the row instead of
+   * two); otherwise the library runs llmseg_norm behind the GEMM.  Same bits either way.  NULL = off. */
+  const void* norm_w; float norm_eps; int reserved1; void* norm_out; int64_t ldn;
 } llmseg_gemm_args;
 int llmseg_gemm_bf16(const llmseg_gemm_args* args, void* stream);
 /* tuning knob (results are identical up to fp32 summation order of split-K; only speed differs):

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LLMSEG_LIB") or os.path.join(_HERE, "libllmseg_hip.so")     # LLMSEG_LIB: side builds of the same ABI (tools/ experiments)
 
-ABI_VERSION = 5          # == LLMSEG_ABI_VERSION of include/llmseg_hip.h
+ABI_VERSION = 6          # == LLMSEG_ABI_VERSION of include/llmseg_hip.h
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SILU, ACT_SIGMOID = range(6)
 
@@ -33,7 +33,8 @@ class GemmArgs(_Sized):
                 ("batch2", C.c_int64), ("strideA2", C.c_int64), ("strideW2", C.c_int64), ("strideC2", C.c_int64),
                 ("A2", C.c_void_p), ("W2", C.c_void_p), ("lda2", C.c_int64), ("ldw2", C.c_int64),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("accumulate", C.c_int),
-                ("a_norm_w", C.c_void_p), ("a_norm_eps", C.c_float), ("a_swiglu", C.c_int)]
+                ("a_norm_w", C.c_void_p), ("a_norm_eps", C.c_float), ("a_swiglu", C.c_int),
+                ("norm_w", C.c_void_p), ("norm_eps", C.c_float), ("reserved1", C.c_int), ("norm_out", C.c_void_p), ("ldn", C.c_int64)]
 
 
 class AttnArgs(_Sized):

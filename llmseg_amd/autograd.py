@@ -155,6 +155,32 @@ def linear(x, w, b=None, act=ops.ACT_NONE, residual=None, wt=None):
     return LinearFn.apply(x, w, b, act, residual, wt)
 
 
+class LinearNormFn(Function):
+    """(y, h) = (x @ w^T + residual, RMSNorm(y) * norm_w): a residual-stream projection together with the stream's NEXT pre-norm
+    (`llmseg_gemm_args.norm_out`: when the product runs as K-slices its reduce launch writes both).  h is a forward-only by-product: it is handed
+    to `norm_pass(..., pre=h)`, whose node owns the norm's backward; this node's backward is `LinearFn`'s."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, residual, wt, norm_w, eps):
+        assert b is None and act == ops.ACT_NONE and residual is not None
+        h = torch.empty((x.shape[0], w.shape[0]), device=x.device, dtype=BF16)
+        y = ops.gemm(x, w, residual=residual, norm_w=norm_w, norm_eps=eps, norm_out=h)
+        ctx.wt, ctx.act, ctx.has_res = wt, act, True
+        ctx.gw, ctx.gb, ctx.b_needs = g32_of(w), None, False
+        ctx.save_for_backward(x, w, None)
+        ctx.mark_non_differentiable(h)
+        ctx.set_materialize_grads(False)        # no zero-fill for h's absent gradient
+        return y, h
+
+    @staticmethod
+    def backward(ctx, dy, _dh):
+        return LinearFn.backward(ctx, dy) + (None, None)
+
+
+def linear_norm(x, w, residual, wt, norm_w, eps):
+    return LinearNormFn.apply(x, w, None, ops.ACT_NONE, residual, wt, norm_w, eps)
+
+
 def lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, drop=None, want_bt=False):
     """qkv = x Wqkv^T + s (drop_q(x) Aq^T) Bq^T on the q block + s (drop_v(x) Av^T) Bv^T on the v block, rank 8.  The two updates
     ride in the qkv GEMM as one extra 64-wide K-tile: A2 = [x Aq^T | x Av^T | 0], W2 rows of the q block = [s Bq | 0], rows of the
@@ -288,31 +314,32 @@ class NormPassFn(Function):
     (64 of them per Llama micro-step)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, eps, rms):
+    def forward(ctx, x, w, b, eps, rms, pre=None):
+        """pre: norm(x) already computed by the producer of x (`LinearNormFn`): used as the output instead of a launch."""
         x = x.contiguous()
         ctx.eps, ctx.rms, ctx.has_b = eps, rms, b is not None
         ctx.gw, ctx.gb = g32_of(w), (g32_of(b) if b is not None else None)
         ctx.save_for_backward(x, w)
         ctx.set_materialize_grads(False)
-        return ops.norm(x, w, b, eps=eps, rms=rms), x.view_as(x)
+        return (ops.norm(x, w, b, eps=eps, rms=rms) if pre is None else pre.view_as(pre)), x.view_as(x)
 
     @staticmethod
     def backward(ctx, dy, dpass):
         x, w = ctx.saved_tensors
         if dy is None:
-            return dpass, None, None, None, None
+            return dpass, None, None, None, None, None
         dres = None if dpass is None else dpass.contiguous()
         if ctx.gw is not None:
-            return ops.norm_bwd(dy.contiguous(), x, w, ctx.eps, ctx.rms, ctx.gw, ctx.gb, dres=dres), None, None, None, None
+            return ops.norm_bwd(dy.contiguous(), x, w, ctx.eps, ctx.rms, ctx.gw, ctx.gb, dres=dres), None, None, None, None, None
         need_w = ctx.needs_input_grad[1]
         dw = torch.zeros(w.shape, device=w.device, dtype=torch.float32) if need_w else None
         db = torch.zeros(w.shape, device=w.device, dtype=torch.float32) if (need_w and ctx.has_b) else None
         dx = ops.norm_bwd(dy.contiguous(), x, w, ctx.eps, ctx.rms, dw, db, dres=dres)
-        return dx, (dw.to(BF16) if need_w else None), (db.to(BF16) if db is not None else None), None, None
+        return dx, (dw.to(BF16) if need_w else None), (db.to(BF16) if db is not None else None), None, None, None
 
 
-def norm_pass(x, w, b=None, eps=1e-5, rms=False):
-    return NormPassFn.apply(x, w, b, eps, rms)
+def norm_pass(x, w, b=None, eps=1e-5, rms=False, pre=None):
+    return NormPassFn.apply(x, w, b, eps, rms, pre)
 
 
 def attention_backward(q, k, v, do, dq, dk, dv, *, batch, heads, Nq, Nk, hd, qs, ks, vs, dos, dqs, dks, dvs, scale, causal=False,

@@ -1026,6 +1026,72 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float
   }
 }
 
+// Split-K tail of a residual-stream product WITH the stream's next pre-norm (llmseg_gemm_args.norm_out, round 5): a workgroup per output row sums the row's S
+// slab rows, adds the residual, stores the bf16 row x -- splitk_reduce_kernel's arithmetic for alpha = 1, no bias / activation / LayerScale -- and, holding that
+// row in registers, writes RMSNorm(x) * w with norm_wg_kernel<CPT>'s arithmetic and the SAME thread -> column mapping (chunk c = thread + 256 i: identical partial
+// sums, identical block reduction), so both outputs carry the bits the two-launch route produces.  One launch and one pass over the row instead of two.
+template <int CPT>
+__global__ __launch_bounds__(256) void splitk_reduce_rmsnorm_kernel(GemmP p, const float* __restrict__ slab, int S, const bf16_t* __restrict__ nw, float eps,
+                                                                   bf16_t* __restrict__ nout, long ldn) {
+  __shared__ float red[16];
+  const long m = blockIdx.x;
+  const int nch = p.N >> 3;
+  const long slab_sz = (long)p.M * p.N;
+  uint4 xc[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    xc[i] = make_uint4(0, 0, 0, 0);
+    if (c < nch) {
+      const int n = c * 8;
+      const float* sp = slab + m * p.N + n;
+      float4 a0 = *reinterpret_cast<const float4*>(sp), a1 = *reinterpret_cast<const float4*>(sp + 4);
+      for (int s2 = 1; s2 < S; ++s2) {
+        const float4 b0 = *reinterpret_cast<const float4*>(sp + s2 * slab_sz), b1 = *reinterpret_cast<const float4*>(sp + s2 * slab_sz + 4);
+        a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+        a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+      }
+      float v[8] = {a0.x * p.alpha, a0.y * p.alpha, a0.z * p.alpha, a0.w * p.alpha, a1.x * p.alpha, a1.y * p.alpha, a1.z * p.alpha, a1.w * p.alpha};
+      if (p.res) {
+        float r[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.res + m * p.ldr + n), r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+      }
+      xc[i] = pack8(v);
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n) = xc[i];
+    }
+  }
+  float f[8], v2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    if (threadIdx.x + 256 * i < nch) {
+      unpack8(xc[i], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = f[e] - 0.f; v2 += d * d; }
+    }
+  }
+  v2 = block_sum(v2, red);
+  const float rstd = rsqrtf(v2 / (float)p.N + eps);
+  bf16_t* yr = nout + m * ldn;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    if (c < nch) {
+      float g[8], o[8];
+      unpack8(xc[i], f);
+      unpack8(*reinterpret_cast<const uint4*>(nw + c * 8), g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = g[e] * bf2f(f2bf(f[e] * rstd));      // HF LlamaRMSNorm: round before the weight multiply
+      *reinterpret_cast<uint4*>(yr + c * 8) = pack8(o);
+    }
+  }
+}
+
+// a pending second output of the call being dispatched on this thread (llmseg_gemm_args.norm_out): the K-sliced ping-pong route consumes it in its reduce launch
+struct NormReq { const bf16_t* w; bf16_t* out; long ldn; float eps; bool active, done; };
+static thread_local NormReq g_norm_req = {nullptr, nullptr, 0, 0.f, false, false};
+
 template <bool OUT_F32, int MI, int NBUF>
 void launch_glds(const GemmP& p, dim3 grid, hipStream_t s) {
   LL_LAUNCH_KERNEL((gemm_bf16_tn_glds_kernel<OUT_F32, MI, NBUF>), grid, dim3(NT), 0, s, p);
@@ -1096,7 +1162,22 @@ inline bool split_ok(int nt, int S) {       // every slice needs >= 2 K-tiles (t
 
 static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_variant);
 
-extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) { return gemm_dispatch(a, stream, -1); }
+extern "C" int llmseg_norm(const void* x, const void* w, const void* b, void* y, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy, float eps, int rms,
+                           const int32_t* row_map, void* stream);
+
+extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
+  if (!(a && a->struct_size == sizeof(*a) && a->norm_out)) return gemm_dispatch(a, stream, -1);
+  // second output RMSNorm(C) * norm_w: the K-sliced route folds it into its reduce launch, every other route gets llmseg_norm behind the product
+  LL_CHECK(a->norm_w && !a->out_f32 && a->batch <= 1 && a->batch2 <= 1 && (a->N & 7) == 0 && (a->ldn & 7) == 0 && a->ldn >= a->N && (a->ldc & 7) == 0 &&
+               ((((uintptr_t)a->norm_w) | ((uintptr_t)a->norm_out) | ((uintptr_t)a->C)) & 15) == 0 && !a->accumulate,
+           "gemm: norm_out needs norm_w, bf16 output, batch 1, N, ldc and ldn multiples of 8, 16-byte aligned pointers");
+  g_norm_req = NormReq{(const bf16_t*)a->norm_w, (bf16_t*)a->norm_out, (long)a->ldn, a->norm_eps, true, false};
+  const int rc = gemm_dispatch(a, stream, -1);
+  const bool done = g_norm_req.done;
+  g_norm_req.active = false;
+  if (rc != LLMSEG_OK || done) return rc;
+  return llmseg_norm(a->C, a->norm_w, nullptr, a->norm_out, a->M, a->N, a->ldc, a->ldn, a->norm_eps, 1, nullptr, stream);
+}
 
 // force_variant >= 0: an internal caller fixes the kernel (8 / 9, one K-slice)
 static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_variant) {
@@ -1175,12 +1256,18 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
       g2.A = a->A2; g2.W = a->W2; g2.lda = a->lda2; g2.ldw = a->ldw2; g2.K = 64; g2.A2 = g2.W2 = nullptr;
       g2.bias = g2.gamma = g2.residual = nullptr; g2.alpha = 1.f; g2.act = LLMSEG_ACT_NONE; g2.out_f32 = 1; g2.accumulate = 0;
       g2.C = (float*)a->workspace + (long)split * p.M * p.N; g2.ldc = p.N; g2.workspace = nullptr; g2.workspace_bytes = 0;
+      g2.norm_w = nullptr; g2.norm_out = nullptr;              // (the caller's second output belongs to the whole product, not to this slab)
+      const bool pend = g_norm_req.active;
+      g_norm_req.active = false;
       const int rc = llmseg_gemm_bf16(&g2, stream);
+      g_norm_req.active = pend;
       if (rc != LLMSEG_OK) return rc;
     } else if (variant != 8 && variant != 9) {
       LL_CHECK(a->act == LLMSEG_ACT_NONE && !a->gamma, "gemm: extension operands on this shape need a linear epilogue");
       llmseg_gemm_args g1 = *a, g2 = *a;
       g1.A2 = g1.W2 = nullptr;
+      g1.norm_w = g2.norm_w = nullptr; g1.norm_out = g2.norm_out = nullptr;      // second output: after BOTH launches (the entry point's llmseg_norm)
+      g_norm_req.active = false;
       int rc = llmseg_gemm_bf16(&g1, stream);
       if (rc != LLMSEG_OK) return rc;
       g2.A = a->A2; g2.W = a->W2; g2.lda = a->lda2; g2.ldw = a->ldw2; g2.K = 64; g2.bias = nullptr; g2.residual = a->C; g2.ldr = a->ldc;
@@ -1288,6 +1375,20 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
     else LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<true, false, 2>), grid, dim3(NTB), 0, s, ps);
     const long total4 = (long)p.M * (p.N >> 2);
     const unsigned rg = (unsigned)std::min<long>((total4 + 255) / 256, 4096);
+    // the row kernel only where llmseg_norm would run its workgroup-per-row kernel on this shape (same arithmetic, same bits) and the epilogue is the plain residual add
+    static const long wg_max_rows = getenv("LLMSEG_NORM_WG_MAX") ? atol(getenv("LLMSEG_NORM_WG_MAX")) : 2048;
+    static const bool no_fuse = getenv("LLMSEG_GEMM_NO_NORM_FUSE") != nullptr;      // A/B switch: always the two-launch route
+    const bool fuse_norm = g_norm_req.active && !no_fuse && !f && p.alpha == 1.f && !p.bias && !p.gamma && p.act == LLMSEG_ACT_NONE && p.M >= 64 && p.M < wg_max_rows &&
+                           p.N >= 2048 && p.N <= 8192 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.res || (p.ldr & 7) == 0) && (g_norm_req.ldn & 7) == 0 &&
+                           ((((uintptr_t)p.C) | ((uintptr_t)p.res) | ((uintptr_t)g_norm_req.w) | ((uintptr_t)g_norm_req.out)) & 15) == 0;
+    if (fuse_norm) {
+      const int S2 = split + (p.A2 ? 1 : 0);
+      const int cpt = ((p.N >> 3) + 255) / 256;
+      if (cpt <= 1) LL_LAUNCH_KERNEL(splitk_reduce_rmsnorm_kernel<1>, dim3((unsigned)p.M), dim3(256), 0, s, p, (const float*)a->workspace, S2, g_norm_req.w, g_norm_req.eps, g_norm_req.out, g_norm_req.ldn);
+      else if (cpt <= 2) LL_LAUNCH_KERNEL(splitk_reduce_rmsnorm_kernel<2>, dim3((unsigned)p.M), dim3(256), 0, s, p, (const float*)a->workspace, S2, g_norm_req.w, g_norm_req.eps, g_norm_req.out, g_norm_req.ldn);
+      else LL_LAUNCH_KERNEL(splitk_reduce_rmsnorm_kernel<4>, dim3((unsigned)p.M), dim3(256), 0, s, p, (const float*)a->workspace, S2, g_norm_req.w, g_norm_req.eps, g_norm_req.out, g_norm_req.ldn);
+      g_norm_req.done = true;
+    } else
     LL_LAUNCH_KERNEL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, s, p, (const float*)a->workspace, split + (p.A2 ? 1 : 0), f ? 1 : 0);
   } else {
     dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);

@@ -55,7 +55,7 @@ def _reduce_ws(dev):
 
 
 def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alpha=1.0, out_f32=False, trans_a=False, trans_w=False,
-         a2=None, w2=None, accumulate=False, a_norm_w=None, a_norm_eps=1e-6, a_swiglu=False):
+         a2=None, w2=None, accumulate=False, a_norm_w=None, a_norm_eps=1e-6, a_swiglu=False, norm_w=None, norm_eps=1e-6, norm_out=None):
     """out[M,N] = residual + gamma * act(alpha * A @ W^T + bias) with A = a [M,K] (or a^T when trans_a: a stored [K,M]) and
     W = w [N,K] (or w^T when trans_w: w stored [K,N]).  2-D bf16 operands, last dim contiguous.  a2 [M,64] / w2 [N,64]: optional
     extension of the contraction (A @ W^T + a2 @ w2^T), e.g. zero-padded low-rank updates.  accumulate (fp32 `out` only):
@@ -83,6 +83,9 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alp
                  ldr=0 if residual is None else residual.stride(0),
                  batch=1, strideA=0, strideW=0, strideC=0, alpha=alpha, act=act, out_f32=1 if out_f32 else 0,
                  trans_a=1 if trans_a else 0, trans_w=1 if trans_w else 0, accumulate=1 if accumulate else 0)
+    if norm_out is not None:                                            # second output: RMSNorm(out) * norm_w (llmseg_gemm_args.norm_out, ABI 6)
+        assert norm_w is not None and not out_f32 and norm_out.shape == out.shape and norm_out.stride(1) == 1 and norm_out.dtype == BF16
+        g.norm_w, g.norm_eps, g.norm_out, g.ldn = _req(norm_w).data_ptr(), norm_eps, _req(norm_out).data_ptr(), norm_out.stride(0)
     if a_norm_w is not None:
         g.a_norm_w, g.a_norm_eps = _req(a_norm_w).data_ptr(), a_norm_eps
     if a_swiglu:

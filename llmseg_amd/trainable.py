@@ -25,7 +25,13 @@ class _Direct:
     grad = False
     linear = staticmethod(lambda x, w, b=None, act=ops.ACT_NONE, residual=None, wt=None: ops.gemm(x, w, bias=b, act=act, residual=residual))
     norm = staticmethod(lambda x, w, b=None, eps=1e-5, rms=False: ops.norm(x, w, b, eps=eps, rms=rms))
-    norm_pass = staticmethod(lambda x, w, b=None, eps=1e-5, rms=False: (ops.norm(x, w, b, eps=eps, rms=rms), x))
+    norm_pass = staticmethod(lambda x, w, b=None, eps=1e-5, rms=False, pre=None: ((ops.norm(x, w, b, eps=eps, rms=rms) if pre is None else pre), x))
+
+    @staticmethod
+    def linear_norm(x, w, residual, wt, norm_w, eps):
+        """(x @ w^T + residual, RMSNorm of that * norm_w) in one GEMM call (`llmseg_gemm_args.norm_out`)."""
+        h = torch.empty((x.shape[0], w.shape[0]), device=x.device, dtype=BF16)
+        return ops.gemm(x, w, residual=residual, norm_w=norm_w, norm_eps=eps, norm_out=h), h
     attn_packed = staticmethod(lambda qkv, batch, n, heads, hd, causal=False, key_mask=None:
                                ops.attention_packed(qkv, batch, n, heads, hd, causal=causal, key_mask=key_mask))
     swiglu = staticmethod(lambda gu, inter: ops.swiglu(gu, inter))
@@ -78,6 +84,7 @@ class _Auto:
     linear = staticmethod(ag.linear)
     norm = staticmethod(ag.norm)
     norm_pass = staticmethod(ag.norm_pass)
+    linear_norm = staticmethod(ag.linear_norm)
     attn_packed = staticmethod(lambda qkv, batch, n, heads, hd, causal=False, key_mask=None:
                                ag.PackedAttnFn.apply(qkv, batch, n, heads, hd, causal, key_mask, None))
     rope_attn = staticmethod(ag.rope_attention)
@@ -333,9 +340,11 @@ class TrainableMixin:
         s = c.lora_alpha / c.lora_r if c.lora_r > 0 else 0.0
         p_drop = c.lora_dropout if (F.grad and self.training) else 0.0
         rng = self.dropout_state() if p_drop > 0 else None
+        pre = None           # RMSNorm of x under the NEXT pre-norm's weight, when the GEMM that produced x wrote it as its second output
+        fuse = self.fuse_residual_norm
         for i in range(c.layers):
             p = f"model.layers.{i}."
-            h, x = F.norm_pass(x, self._w(p + "input_layernorm.weight", F), None, c.eps, True)      # x: the residual branch of the same node
+            h, x = F.norm_pass(x, self._w(p + "input_layernorm.weight", F), None, c.eps, True, pre)      # x: the residual branch of the same node
             if c.lora_r > 0:
                 lp = p + "self_attn."
                 qkv = F.lora_qkv(h, self._w(p + "qkv", F), self._w(lp + "q_proj.lora_A.default.weight", F),
@@ -348,11 +357,21 @@ class TrainableMixin:
             a = F.rope_attn(qkv, rope, N, T, c.heads, c.head_dim, True, key_mask_u8)
             if kv_out is not None:                     # generation prefill (no-grad path): qkv now holds the rotated K and V
                 kv_out(i, qkv)
-            x = F.linear(a, self._w(p + "self_attn.o_proj.weight", F), None, ops.ACT_NONE, x, self._wT(p + "self_attn.o_proj.weight", F))
-            h, x = F.norm_pass(x, self._w(p + "post_attention_layernorm.weight", F), None, c.eps, True)
+            pre = None
+            if fuse:         # o_proj + residual and the post-attention norm of the sum: one GEMM call (its K-slice reduce launch writes both)
+                x, pre = F.linear_norm(a, self._w(p + "self_attn.o_proj.weight", F), x, self._wT(p + "self_attn.o_proj.weight", F),
+                                       self._w(p + "post_attention_layernorm.weight", F), c.eps)
+            else:
+                x = F.linear(a, self._w(p + "self_attn.o_proj.weight", F), None, ops.ACT_NONE, x, self._wT(p + "self_attn.o_proj.weight", F))
+            h, x = F.norm_pass(x, self._w(p + "post_attention_layernorm.weight", F), None, c.eps, True, pre)
             mem = [p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"]
             gu = F.linear(h, self._wcat(p + "gate_up", mem, F), None, ops.ACT_NONE, None, self._wT(p + "gate_up", F) if self._frozen(mem) else None)
-            x = F.linear(F.swiglu(gu, c.inter), self._w(p + "mlp.down_proj.weight", F), None, ops.ACT_NONE, x, self._wT(p + "mlp.down_proj.weight", F))
+            pre = None
+            if fuse and i + 1 < c.layers:      # down_proj + residual and the NEXT layer's input norm
+                x, pre = F.linear_norm(F.swiglu(gu, c.inter), self._w(p + "mlp.down_proj.weight", F), x, self._wT(p + "mlp.down_proj.weight", F),
+                                       self._w(f"model.layers.{i + 1}.input_layernorm.weight", F), c.eps)
+            else:
+                x = F.linear(F.swiglu(gu, c.inter), self._w(p + "mlp.down_proj.weight", F), None, ops.ACT_NONE, x, self._wT(p + "mlp.down_proj.weight", F))
         return F.norm(x, self._w("model.norm.weight", F), None, c.eps, True).view(N, T, H)
 
     def llava_forward(self, images_clip, input_ids, plan, want_logits=True):
@@ -435,6 +454,7 @@ class TrainableMixin:
         return iou.view(Cn * K), emb
 
     # ------------------------------------------------------------------------------------------------ model_forward
+    fuse_residual_norm = True      # o_proj / down_proj + residual + the following RMSNorm as one GEMM call (class default; False = the separate norm launch)
     ce_gather_first = True         # lm_head + CE on the label-carrying rows only (class default; False = all N*T rows, as the reference computes them)
     overlap_towers = True          # issue the frozen segmentation backbone on its own HIP stream (class default; set False to serialise)
 

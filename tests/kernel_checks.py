@@ -228,6 +228,30 @@ def check_gemm_hot_shapes():
     return out
 
 
+def check_gemm_norm_out():
+    """`llmseg_gemm_args.norm_out` (the residual-stream projection with the stream's next RMSNorm as a second output) against the two-call
+    spelling gemm -> norm: same bits in both outputs, on the shapes whose K-slice reduce launch writes the norm (Llama o_proj / down_proj at
+    2 images per step) and on shapes that take the library's own gemm + norm route (one K slice, M past the workgroup-norm range, narrow N)."""
+    out = []
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for M, N, K, tag in [(638, 4096, 4096, "o_proj B=2"), (638, 4096, 11008, "down_proj B=2"), (319, 4096, 4096, "one image"),
+                         (77, 4096, 4096, "ragged M"), (7656, 4096, 4096, "B=24 (gemm + norm)"), (638, 1024, 4096, "narrow N (gemm + norm)"),
+                         (638, 4096, 128, "short K (gemm + norm)")]:
+        a = (torch.rand((M, K), device=DEV, generator=g) * 2 - 1).to(BF)
+        w = ((torch.rand((N, K), device=DEV, generator=g) * 2 - 1) * (3.0 / K) ** 0.5).to(BF)
+        r = torch.randn((M, N), device=DEV, generator=g).to(BF)
+        nw = (1.0 + 0.1 * torch.randn((N,), device=DEV, generator=g)).to(BF)
+        y0 = ops.gemm(a, w, residual=r)
+        h0 = ops.norm(y0, nw, None, eps=1e-6, rms=True)
+        h1 = torch.full((M, N), float("nan"), device=DEV, dtype=BF)
+        y1 = ops.gemm(a, w, residual=r, norm_w=nw, norm_eps=1e-6, norm_out=h1)
+        ref = (a.float() @ w.float().t() + r.float()).cpu()
+        out.append((f"gemm norm_out {tag}: C vs fp32", err(y1, ref), tol_bf16(ref, 1.5)))
+        out.append((f"gemm norm_out {tag}: C bits == gemm", float((y1.view(torch.int16) != y0.view(torch.int16)).sum().item()), 0.0))
+        out.append((f"gemm norm_out {tag}: norm bits == gemm -> norm", float((h1.view(torch.int16) != h0.view(torch.int16)).sum().item()), 0.0))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------- attention
 def _attn_ref(q, k, v, scale, bias=None):
     s = (q.float() @ k.float().transpose(-1, -2)) * scale

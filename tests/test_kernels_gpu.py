@@ -26,6 +26,11 @@ def test_gemm_hot_shapes():
     _run(kc.check_gemm_hot_shapes)
 
 
+def test_gemm_norm_out():
+    from tests import kernel_checks as kc
+    _run(kc.check_gemm_norm_out)
+
+
 def test_attention():
     from tests import kernel_checks as kc
     _run(kc.check_attention)
