@@ -224,7 +224,7 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
     per = lambda key: di.get(key, 0) / n_prof
     composition = ("the class = every llmseg_gemm_bf16 CALL the dispatch sends to this tile kernel with bf16 output (a timed record spans the whole call): "
                    "%.0f calls per step, of which %.0f ran as K-slices (%.1f slices on average: ONE launch of the tile kernel's fp32-slab form -- rocprofv3 row "
-                   "`...<true, ...>` -- with the slices as its batch index, + one `splitk_reduce_kernel` launch that applies the epilogue) and %.0f as a single "
+                   "`...<true, ...>` -- with the slices as its batch index, + one `splitk_reduce_kernel` launch that applies the epilogue -- `splitk_reduce_rmsnorm_kernel` where the call also asks for the next RMSNorm, `norm_out`: that row's time is inside the call) and %.0f as a single "
                    "launch of the bf16-out form (row `...<false, false>`) or its LoRA extension-tile form (`...<false, true>`); %.0f kernel launches per step in all"
                    % (per("calls"), per("calls_as_k_slices"), di.get("k_slices", 0) / max(1, di.get("calls_as_k_slices", 0)),
                       per("calls") - per("calls_as_k_slices"), per("kernel_launches"))) if di else None
