@@ -38,7 +38,7 @@ def pmc_traffic(kernel, B):
     FETCH_SIZE x 2 on gfx950; tools/pmc_traffic.sh -> profiles/traffic.json, collected on an MI355X with this same bench command at the same batch).
     The roofline's class is "every call the dispatch sends to one tile kernel" (see `class_composition`): its traffic is the launch-weighted sum over that
     kernel's three forms -- `<false, ..>` bf16 output, `<true, ..>` fp32 K-slice slabs, `<false, true, ..>` with the LoRA extension tile -- plus the
-    `splitk_reduce_kernel` launches (attributed to the class that owns most K-sliced launches), divided by the number of calls (= launches of the three
+    `splitk_reduce*` launches (attributed to the class that owns most K-sliced launches), divided by the number of calls (= launches of the three
     forms), i.e. the same population `algorithmic_bytes_per_launch` is averaged over (round 4 divided one form's bytes by the whole class's calls).
     The counters cannot be read from inside this process: (None, provenance) when no record for this batch is committed.
     -> (bytes per call | None, {"file", "sha1", "collected", "definition"})."""
@@ -61,9 +61,9 @@ def pmc_traffic(kernel, B):
     total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in forms.values())
     sliced = lambda b: sum(v["launches"] for k, v in ks.items() if k.startswith(b) and k[len(b):].startswith("true"))
     others = [k.split("<")[0] + "<" for k in ks if k.startswith("gemm_bf16_tn_pp") and not k.startswith(base)]
-    red = ks.get("splitk_reduce_kernel")
-    if red is not None and sliced(base) >= max([sliced(o) for o in set(others)] + [0]):
-        total += red["hbm_bytes_per_launch"] * red["launches"]
+    reds = [v for k, v in ks.items() if k.startswith("splitk_reduce")]          # the plain reduce and its reduce + RMSNorm form (`norm_out` calls)
+    if reds and sliced(base) >= max([sliced(o) for o in set(others)] + [0]):
+        total += sum(r["hbm_bytes_per_launch"] * r["launches"] for r in reds)
     prov["forms"] = {k: {"launches": v["launches"], "hbm_bytes_per_launch": v["hbm_bytes_per_launch"]} for k, v in forms.items()}
     return total / max(1, calls), prov
 
