@@ -1019,3 +1019,110 @@ def check_fused_accum(k=3):
     same = all(torch.equal(outs["eager"][1][n], outs["hipGraph"][1][n]) for n in names) and outs["eager"][0] == outs["hipGraph"][0]
     res.append((f"fused accum k={k}: the replayed hipGraph of the fused pass leaves the same bits as the eager pass", 0.0 if same else 1.0, 0.5))
     return res
+
+
+def _mix_batch(c, j, img, K=16, L=24):
+    """One image carrying c conversations (BASELINE configs[3]: batch_size = 1 per GPU; 1-3 conversations per sampled image depending on the
+    source the 9:3:1 draw picked, utils/dataset.py:499-502), every tensor seeded by the micro-step index j; one right-padded sequence when c > 1."""
+    from oracle import cases, seeded
+    ids = cases.prompt_ids(c, L, 500 + 7 * j)
+    labels = ids.clone()
+    labels[:, :10] = -100
+    am = torch.ones(c, L, dtype=torch.bool)
+    if c > 1:
+        am[c - 1, L - 2:] = False
+    return dict(images=seeded.uniform((1, 3, img, img), 600 + j, -2, 2), images_clip=seeded.uniform((1, 3, 224, 224), 700 + j, -2, 2),
+                input_ids=ids, labels=labels, attention_masks=am, offset=torch.tensor([0, c]),
+                sam_segs_list=[(seeded.uniform((K, 256, 256), 800 + j) > 0.4).float()],
+                sam_ious_list=[seeded.uniform((c, K), 900 + j, 0, 1).double()], sam_iops_list=[seeded.uniform((c, K), 1000 + j, 0, 1).double()])
+
+
+def check_mix_window(accum=10, sampler_seed=1):
+    """BASELINE configs[3]'s per-GPU workload through the Trainer: batch_size = 1, the source of every sample drawn 9:3:1 by
+    `synthetic.HybridSampler` (reference `HybridDataset.__getitem__`, utils/dataset.py:499-502; `--sample_rates 9,3,1`, training.py:66-70), hence a
+    window of `grad_accumulation_steps` = 10 micro-batches (training.py:532-547) whose STRUCTURE changes from micro-step to micro-step: 1, 2 or 3
+    conversations on the image = N = 1..3 sequences through CLIP + Llama, `offset` = [0, c], the head over c x K rows -- three kernel sequences,
+    three hipGraphs.  One accumulation window:
+      (a) eager Trainer: every micro-step's losses and the fp32 arena the optimizer consumes, against autograd through `oracle.lisa.model_forward`
+          over the same ten batches, each under its own dropout state (seed, j + 1) -- `grad_err` policy, gates traced per pass;
+      (b) hipGraph Trainer (one graph per structure, captured on first reuse): the SECOND pass over the window -- mostly replays, the plan tensors
+          re-uploaded whenever the structure repeats with other data -- leaves the same BITS in the arena and the same losses as (a)."""
+    from llmseg_amd import synthetic
+    from llmseg_amd.train import Trainer
+    from oracle import lisa as olisa
+    from tests import model_checks as mc
+    cfg, m, sd, _ = _lora_case("sam")
+    names = [n for n, p in m.params.named_parameters() if p.requires_grad]
+    prm = dict(m.params.named_parameters())
+    sampler = synthetic.HybridSampler((9, 3, 1), seed=sampler_seed)
+    draws = [sampler.draw() for _ in range(accum)]
+    convs = [c for _, c in draws]
+    assert set(convs) == {1, 2, 3}, f"the window must hold all three batch structures, drew {draws}"
+    cpu_batches = [mc._round_batch(_mix_batch(c, j, cfg.sam.img)) for j, c in enumerate(convs)]
+    batches = [mc._dev(b) for b in cpu_batches]
+    plans = [m.make_plan(**b) for b in batches]
+    assert len({p.sig for p in plans}) == 3
+    seed = 777
+    scal = lambda out: {kk: float(v.detach()) for kk, v in out.items() if torch.is_tensor(v) and v.numel() == 1}
+    grab = lambda store: (lambda t, ss: store.update(g={n: prm[n]._g32.detach().clone() for n in names}, ss=float(ss)))
+
+    def window(tr, gt=None):
+        m.set_dropout_seed(seed, 0)
+        out = []
+        for b, p in zip(batches, plans):
+            out.append(scal(tr.micro_step(b, p)))
+            if gt is not None:
+                gt.hip_collect(m)
+        return out
+    # (a) eager
+    gt = GateTrace()
+    eag = {}
+    tr = Trainer(m, lr=0.0, grad_accum=accum, warmup=1, total_steps=10)
+    tr.grad_hook = grab(eag)
+    gt.hip_begin(m)
+    eager_losses = window(tr, gt)
+    gt.hip_end(m)
+    assert tr.opt_steps == 1 and "g" in eag
+    tr.close()
+    # (b) hipGraph: window 1 = eager warm-up of each structure + captures, window 2 = replays
+    gra = {}
+    tr = Trainer(m, lr=0.0, grad_accum=accum, warmup=1, total_steps=10, use_graph=True, graph_warmup=1)
+    tr.grad_hook = grab(gra)
+    window(tr)
+    graph_losses = window(tr)
+    torch.cuda.synchronize()
+    assert tr.graph_error is None, tr.graph_error
+    n_graphs = sum(1 for e in tr._graphs.values() if e["graph"] is not None)
+    tr.close()
+    # the oracle over the same ten batches
+    w = {n: sd[n].detach().clone().requires_grad_(True) for n in names}
+    wl = {n: sd[n].detach().to(BF).requires_grad_(True) for n in names}
+    sdw, sdl = {**sd, **w}, {**{kk: v.to(BF) for kk, v in sd.items()}, **wl}
+    ref_losses = []
+    for j, b in enumerate(cpu_batches):
+        def run_ref(b=b, j=j):
+            o = olisa.model_forward(sdw, cfg, **b, inference=False, dropout_state=(seed, j + 1))
+            o["loss"].backward()
+            return o
+        ref_losses.append(scal(gt.oracle("ref", run_ref)))
+        gt.oracle("lo", lambda b=b, j=j: olisa.model_forward(sdl, cfg, **mc._bf16_batch(b), inference=False, dropout_state=(seed, j + 1))["loss"].backward())
+    flips = gt.flipped_rows()
+    res = [(f"mix 9:3:1 window: conversations per micro-step {convs} (sources {[s for s, _ in draws]}): three structures", 0.0, 0.5),
+           (f"mix 9:3:1 window: one hipGraph per batch structure ({n_graphs} captured)", 0.0 if n_graphs == 3 else 1.0, 0.5)]
+    for kk in ("loss", "ce_loss", "align_loss", "regression_loss"):
+        worst = max(abs(h[kk] - r[kk]) / (5e-3 * max(1.0, abs(r[kk]))) for h, r in zip(eager_losses, ref_losses))
+        res.append((f"mix 9:3:1 window: {kk} of every micro-step vs the oracle on the same batch (ref {[round(r[kk], 4) for r in ref_losses]}); shown as err / tol", worst, 1.0))
+    worst, stats = (0.0, ""), []
+    for n in names:
+        ratio, desc = grad_err(eag["g"][n], w[n].grad, wl[n].grad.float(), floor=3e-4 * accum, skip_rows=GateTrace.rows_for(n, flips), stats=stats)
+        worst = max(worst, (ratio, f"{n}: {desc}"))
+    res.append((f"mix 9:3:1 window: arena after the {accum} micro-steps vs autograd through the oracle over the same batches, worst of {len(names)} tensors = {worst[1]}; "
+                "shown as err / tol", worst[0], 1.0))
+    res += ratio_summary(stats, "mix 9:3:1 window")
+    g64 = [w[n].grad.double().reshape(-1) for n in names]
+    ss_ref = float(sum((x * x).sum() for x in g64))
+    res.append(("mix 9:3:1 window: squared norm of the accumulated gradient vs the oracle's", abs(eag["ss"] - ss_ref) / max(ss_ref, 1e-30), 5e-2))
+    same = all(torch.equal(eag["g"][n], gra["g"][n]) for n in names)
+    res.append(("mix 9:3:1 window: the hipGraph trainer's second pass leaves the same bits in the arena as the eager trainer", 0.0 if same else 1.0, 0.5))
+    res.append((f"mix 9:3:1 window: losses of every micro-step identical, graph vs eager", 0.0 if graph_losses == eager_losses else 1.0, 0.5))
+    return res

@@ -89,6 +89,13 @@ def test_fused_accumulation_window_equals_micro_steps():
     _assert(bc.check_fused_accum(3))
 
 
+def test_trainer_configs3_mix_9_3_1_batch1_window():
+    """BASELINE configs[3]'s per-GPU workload: batch 1, source drawn 9:3:1 -> 1-3 conversations per image (three batch structures, three
+    hipGraphs), one accumulation window of 10 micro-steps against the oracle; graph == eager bit for bit."""
+    from tests import backward_checks as bc
+    _assert(bc.check_mix_window())
+
+
 def test_graph_trainer_with_rotating_batches():
     from tests import backward_checks as bc
     _assert(bc.check_graph_rotating_batches())
