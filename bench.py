@@ -280,6 +280,45 @@ def accum_fused(model, cfg, args, B, dev, dist, rank, world, local, trainer_cls)
     return res
 
 
+def window_towers(model, cfg, args, B, dev, dist, rank, world, local, trainer_cls, convs=None):
+    """The headline's optimizer step -- `--accum` micro-batches of B images, fwd+bwd each, AdamW on the accumulated gradient -- with the two FROZEN
+    towers (SAM ViT-H, CLIP-L + projector) run ONCE per accumulation window over all accum x B images (`Trainer.window_step`): their GEMMs see
+    M = accum x B x 4096 rows, the micro-steps (hipGraph replays) run CLIP-less / SAM-less with the tower outputs as inputs, and the towers of
+    window w + 1 are issued on the side stream beside the micro-steps of window w.  Same gradient as the headline's micro-steps (features are
+    inputs: tests/backward_checks.py::check_window_towers).  Timed: whole windows (tower pass + accum micro-steps + optimizer step).
+    convs: conversations per image drawn per micro-batch (BASELINE configs[3]: batch 1, 1-3 conversations) instead of one per image."""
+    from llmseg_amd import synthetic
+    img = 1024 if args.backbone == "sam" else 896
+    k = args.accum
+    if convs is None:
+        batches = [synthetic.make_batch(B, img_size=img, L=args.prompt_len, K=args.masks, device=dev, seed=1234 + rank + 101 * j) for j in range(k)]
+    else:
+        batches = [synthetic.make_batch(B, img_size=img, L=args.prompt_len, K=args.masks, device=dev, seed=555 + rank + 101 * j, convs=[c] * B) for j, c in enumerate(convs)]
+    plans = [model.make_plan(**b) for b in batches]
+    trainer = trainer_cls(model, lr=3e-4, grad_accum=k, device_ids=[local], use_graph=True)
+    pending = [trainer.encode_window(batches, prefetch=True)]
+
+    def window():
+        tw = pending.pop()
+        pending.append(trainer.encode_window(batches, prefetch=True))     # the next window's towers: beside this window's micro-steps
+        return trainer.window_step(batches, plans, towers=tw)[-1]
+    windows = max(2, args.steps // k)
+    dt, out = timed(window, windows, 3, dist, dev)
+    n_img = B * k
+    res = {"value": n_img * world * windows / dt, "unit": "images/s", "ms_per_micro_step": dt / windows / k * 1e3, "ms_per_window": dt / windows * 1e3,
+           "micro_batches_per_window": k, "images_per_tower_pass_per_gpu": n_img, "timed_windows": windows, "loss": float(out["loss"].detach()),
+           "graphs": sum(1 for e in trainer._graphs.values() if e["graph"] is not None),
+           "graph": bool(trainer.graph_error is None and any(e["graph"] is not None for e in trainer._graphs.values())),
+           "what": "the same optimizer step as the headline (%d micro-batches of %d image(s), fwd+bwd + AdamW), frozen SAM-H / CLIP-L towers run once per window on "
+                   "all %d images (prefetched on a side stream one window ahead), micro-steps replayed from hipGraphs with the tower outputs as inputs" % (k, B, n_img)}
+    if convs is not None:
+        res["conversations_per_micro_batch"] = list(convs)
+    if trainer.graph_error:
+        res["graph_error"] = trainer.graph_error[:200]
+    trainer.close()
+    return res
+
+
 def mix_9_3_1(model, cfg, args, dev, dist, rank, world, local, trainer_cls):
     """BASELINE configs[3]'s per-GPU workload on synthetic data: batch_size = 1 image per micro-step, the source of every sample drawn 9:3:1 from
     sem_seg / refer_seg / reason_seg as `HybridDataset` draws it (utils/dataset.py:499-502), i.e. 1-3 conversations on the image (N = 1..3 sequences
@@ -467,6 +506,7 @@ def main():
     ap.add_argument("--accum", type=int, default=10, help="gradient-accumulation micro-steps per optimizer step (reference: 10)")
     ap.add_argument("--no-k512", action="store_true", help="skip the BASELINE configs[4] side measurement (512 candidate masks, grad-accum 8) reported under batch_<B>_k512")
     ap.add_argument("--no-accum-fused", action="store_true", help="skip the fused-accumulation-window side measurement (the --accum micro-batches of an optimizer step as one pass)")
+    ap.add_argument("--no-window-towers", action="store_true", help="skip the side measurement with the frozen towers batched over the accumulation window (Trainer.window_step)")
     ap.add_argument("--no-mix", action="store_true", help="skip the BASELINE configs[3] side measurement (batch 1, sources drawn 9:3:1 -> 1-3 conversations per image)")
     ap.add_argument("--no-loader", action="store_true", help="skip the loader-in-the-loop side measurement (a different batch + device-side targets + a fresh plan every micro-step)")
     args = ap.parse_args()
@@ -539,9 +579,16 @@ def main():
     fused = None
     if train and use_graph and not args.no_accum_fused and args.accum > 1:
         fused = accum_fused(model, cfg, args, args.batch, dev, dist, rank, world, local, Trainer)
+    wtow = None
+    if train and use_graph and not args.no_window_towers and args.accum > 1:
+        wtow = window_towers(model, cfg, args, args.batch, dev, dist, rank, world, local, Trainer)
     mix = None
     if train and use_graph and not args.no_mix and not args.small:
         mix = mix_9_3_1(model, cfg, args, dev, dist, rank, world, local, Trainer)
+        if not args.no_window_towers:
+            from llmseg_amd import synthetic
+            sampler = synthetic.HybridSampler((9, 3, 1), seed=2024 + rank)
+            mix["window_towers"] = window_towers(model, cfg, args, 1, dev, dist, rank, world, local, Trainer, convs=[sampler.draw()[1] for _ in range(args.accum)])
     loader = None
     if train and use_graph and not args.no_loader and not args.small:
         loader = loader_in_loop(model, cfg, args, args.batch, dev, dist, rank, world, local, Trainer, main_res["ms_per_step"])
@@ -583,6 +630,8 @@ def main():
             res[f"batch_{args.batch}_k512"] = k512
         if fused is not None:
             res["accum_fused"] = fused
+        if wtow is not None:
+            res["window_towers"] = wtow
         if mix is not None:
             res["mix_9_3_1_batch_1"] = mix
         if loader is not None:

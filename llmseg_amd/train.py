@@ -181,7 +181,7 @@ class HipAdamW:
 # What a captured fwd+bwd micro-step reads from the batch (`TrainableMixin._model_forward`): everything else of the collate dict
 # (labels, attention masks, offset -> consumed on the host by `make_plan`; masks_list / label_list / resize_list -> pass-through)
 # never reaches a kernel, so it is neither copied into the graph's buffers nor part of the graph key.
-GRAPH_INPUTS = ("images", "images_clip", "input_ids", "sam_segs_list", "sam_ious_list", "sam_iops_list")
+GRAPH_INPUTS = ("images", "images_clip", "tower_visual", "tower_clip", "input_ids", "sam_segs_list", "sam_ious_list", "sam_iops_list")
 
 
 def _graph_inputs(batch):
@@ -234,6 +234,24 @@ def merge_micro_batches(batches):
     return out
 
 
+class WindowTowers:
+    """Outputs of the frozen towers for the images of one accumulation window (`Trainer.encode_window`): `parts[j]` = (tower_visual, tower_clip)
+    of micro-batch j, views into two tensors kept alive here."""
+
+    def __init__(self, parts, event, keep, stream):
+        self.parts, self.event, self.keep, self.stream = parts, event, keep, stream
+
+    def wait(self):
+        """The current stream waits for the pass (no host synchronisation)."""
+        if self.event is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self.event)
+            if self.stream is not None:
+                for t in self.keep:
+                    t.record_stream(cur)
+            self.event = None
+
+
 class Trainer:
     """One process per GPU.  `module(**batch)` must return a dict with a scalar "loss".
 
@@ -242,7 +260,7 @@ class Trainer:
 
     def __init__(self, module, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.0, clip=1.0, grad_accum=10, warmup=100, total_steps=5000,
                  optimizer=None, device_ids=None, force_ddp=False, ddp_wrapper=False, use_graph=False, graph_warmup=2, use_arena=None,
-                 reduce_chunk_mb=128, sync_init=True, check_every=100, leaf_stream=False, fused_accum=1, sparse_embed=None, time_comm=False, wire_dtype=None):
+                 reduce_chunk_mb=128, sync_init=True, check_every=100, leaf_stream=False, fused_accum=1, sparse_embed=None, time_comm=False, wire_dtype="auto"):
         """optimizer: None = HipAdamW; or a factory `params -> optimizer` / an optimizer object (CPU tests).  use_arena: None = automatic
         (the HIP model with the built-in optimizer), True = force the fp32 gradient arena (the module's autograd Functions must honour `_g32`)."""
         self.module = module
@@ -276,16 +294,22 @@ class Trainer:
         # sparse_embed (default: on whenever a process group and an `embed_tokens` block exist): the embedding table's gradient block (0.52 GB of the
         # 1.16 GB arena at Llama-7B) has non-zero rows only for the tokens the ranks saw in this accumulation window (<= accum x N x L of 32004 rows:
         # 98 % zeros at the benchmark's batch), so it is exchanged as an all-gather of (row index, row) lists instead of a dense all-reduce --
-        # `_exchange_embed_rows`.  The reference reduces it densely (DeepSpeed ZeRO-2 buckets, training.py:321-329).
+        # `_exchange_embed_rows`.  The row set is read from the BLOCK ITSELF (rows with a non-zero entry; two row reductions over 0.52 GB, ~0.2 ms), not
+        # from a record of the ids the micro-steps saw: whatever wrote into the block -- a direct `_eager_step`, another Function, a batch dict
+        # without `input_ids` -- is exchanged.  The reference reduces it densely (DeepSpeed ZeRO-2 buckets, training.py:321-329).
         self._embed_key = "model.embed_tokens.weight"
         has_embed = self.arena is not None and self._embed_key in getattr(self.arena, "block_of", {})
         self.sparse_embed = (self.dist_on and self.world > 1 and has_embed) if sparse_embed is None else (bool(sparse_embed) and has_embed)     # (world 1: measured 1.4 ms of pure overhead)
         if self.sparse_embed:
             self._embed_cols = int(next(p for p in self.params if getattr(p, "_g32", None) is not None and p.dim() == 2 and
                                         p._g32.data_ptr() == self.arena.flat[self.arena.block_of[self._embed_key][0]:].data_ptr()).shape[1])
-        self._window_ids = []
-        # wire_dtype=torch.bfloat16: the dense pieces cross the fabric in bf16 (half the bytes), as the reference's DeepSpeed bf16 engine reduces its gradients
-        # (training.py:314-329); accumulation over micro-steps, the embedding rows and everything after the exchange stay fp32.  Default: fp32 on the wire.
+        # wire_dtype: what the DENSE pieces cross the fabric in.  "auto" (default) = bf16 for the HIP model under a process group of more than one rank --
+        # the reference's DeepSpeed bf16 engine reduces bf16 gradients (training.py:314-329): half the bytes of an fp32 exchange -- and fp32 otherwise;
+        # None / torch.float32 = fp32.  Accumulation over micro-steps, the embedding rows and everything after the exchange stay fp32 either way, and
+        # every rank widens the same bf16 sums, so replicas stay bit-identical.
+        if isinstance(wire_dtype, str):
+            assert wire_dtype == "auto", wire_dtype
+            wire_dtype = torch.bfloat16 if (self.dist_on and self.world > 1 and is_hip_model and self.arena is not None) else None
         self.wire_dtype = wire_dtype
         self.time_comm = bool(time_comm)                                 # bench / tests: event pair around the exchange of every optimizer step
         self.comm_ms = []
@@ -391,12 +415,59 @@ class Trainer:
                 out["loss"].backward()
         if drop_on and self.fused > 1:
             self.module.advance_dropout(self.fused - 1)  # segment j of the fused pass used offset + j: the next pass starts after the window
-        if self.sparse_embed:
-            self._window_ids.append(batch["input_ids"].detach().reshape(-1).clone())     # which embedding rows this micro-step touched (device, no sync)
         self.micro += 1
         if last:
             self.optimizer_step()
         return out
+
+    # ------------------------------------------------------------------------------------------------ accumulation window with batched towers
+    def encode_window(self, batches, prefetch=False):
+        """The two FROZEN towers (SAM ViT-H / DINOv2, CLIP-L + mm_projector: no gradient, LISA.py:173-199, clip_encoder.py:41-60) for ALL images of
+        one accumulation window in ONE pass: their GEMMs run at accum x B x 4096 rows instead of B x 4096 (SAM at two images per micro-step:
+        M = 8192 -> 81 920, where the same kernels reach 1.1-1.35 instead of 0.74-1.04 PFLOP/s), the window attention fills the chip at batch 1.
+        -> `WindowTowers`: per micro-batch views (tower_visual_j, tower_clip_j) into the two result tensors -- inputs of the micro-steps
+        (`window_step`), which then run CLIP -> Llama -> head without either tower.
+        prefetch=True: issued on the model's side stream (after everything already queued on the current stream), so the pass for window w + 1
+        can run beside the micro-steps of window w; `WindowTowers.wait()` makes the current stream wait for it."""
+        imgs = torch.cat([b["images"] for b in batches], 0)
+        clips = torch.cat([b["images_clip"] for b in batches], 0)
+        cur = torch.cuda.current_stream()
+        side = self.module._tower_stream() if prefetch else None
+        if side is not None:
+            side.wait_stream(cur)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            vis, clip = self.module.encode_towers(imgs, clips)
+            ev = torch.cuda.Event()
+            ev.record()
+        if side is not None:
+            imgs.record_stream(side)
+            clips.record_stream(side)
+        n_img = imgs.shape[0]
+        rv, rc = vis.shape[0] // n_img, clip.shape[0] // n_img
+        parts, o = [], 0
+        for b in batches:
+            n = b["images"].shape[0]
+            parts.append((vis[o * rv:(o + n) * rv], clip[o * rc:(o + n) * rc]))
+            o += n
+        return WindowTowers(parts, ev, (vis, clip), side)
+
+    def window_step(self, batches, plans=None, towers=None):
+        """One whole accumulation window (`grad_accum` micro-batches -> one optimizer step; reference loop training.py:532-547) with the frozen
+        towers batched over the window: `encode_window` once, then the micro-steps with the tower outputs as inputs.  The trainable part sees
+        exactly the tensors it would have computed itself from `images` / `images_clip`, so the arena holds the same gradient (bit for bit whenever
+        the towers' kernels pick the same summation order at both row counts -- tests/backward_checks.py::check_window_towers).
+        `towers`: a `WindowTowers` issued earlier (`encode_window(batches, prefetch=True)`).  -> list of the micro-steps' loss dicts."""
+        assert len(batches) == self.accum and self.micro % self.accum == 0, "window_step: one call = one accumulation window"
+        assert self.is_hip_model and self.arena is not None
+        if towers is None:
+            towers = self.encode_window(batches)
+        towers.wait()
+        outs = []
+        for j, (b, (tv, tc)) in enumerate(zip(batches, towers.parts)):
+            mb = {k: v for k, v in b.items() if k not in ("images", "images_clip")}
+            mb.update(images=None, images_clip=None, tower_visual=tv, tower_clip=tc)
+            outs.append(self.micro_step(mb, None if plans is None else plans[j]))
+        return outs
 
     def _backward(self, loss):
         """loss.backward() with the arena's weight-gradient kernels on the side stream (`autograd.Leaves`), joined before returning."""
@@ -423,6 +494,9 @@ class Trainer:
                 self._capture(ent, batch, plan)
             except Exception as e:                       # noqa: BLE001 -- fall back to eager launches, keep training
                 self.graph_error = repr(e)
+                import warnings
+                warnings.warn(f"llmseg_amd.Trainer: hipGraph capture of the micro-step failed ({self.graph_error}); training continues with eager "
+                              "launches at roughly half the speed", RuntimeWarning, stacklevel=3)
                 torch.cuda.synchronize()
                 ent["graph"] = None
                 return self._eager_step(batch, plan)
@@ -448,6 +522,8 @@ class Trainer:
         sb = {k: ([x.clone() for x in v] if isinstance(v, (list, tuple)) else v.clone()) for k, v in _graph_inputs(batch).items()}
         for k in ("labels", "attention_masks", "offset"):          # positional arguments of model_forward that a planned forward never reads
             sb[k] = batch.get(k)
+        for k in ("images", "images_clip"):                        # absent when the frozen towers' outputs are the inputs (`window_step`)
+            sb.setdefault(k, None)
         torch.cuda.synchronize()
         gplan = plan.clone()
         g = torch.cuda.CUDAGraph()
@@ -485,20 +561,23 @@ class Trainer:
         return float(lr)
 
     def _reduce_and_sumsq(self):
-        """The data-parallel exchange + the global gradient norm.  The flat fp32 arena is all-reduced in `reduce_chunk`-element pieces,
-        ALL issued asynchronously up front (RCCL runs them back to back on its own stream: per-link ring traffic is the same as one
-        call); the squared-norm reduction of piece i runs on the compute stream as soon as piece i has arrived, i.e. under the transfer
-        of pieces i+1...  Also issued at world size 1, where the collective is the identity.  -> device fp32 [1] sum of squares."""
+        """The data-parallel exchange + the global gradient norm.  Order of issue: (1) the embedding block's row set and the 8-byte all-gather of its
+        size -- the one host synchronisation of an optimizer step, taken BEFORE anything large is queued, so the host does not sit behind the dense
+        pieces; (2) the dense part of the flat fp32 arena as `reduce_chunk`-element all-reduce pieces, ALL issued asynchronously (RCCL runs them back
+        to back on its own stream: per-link ring traffic is the same as one call); (3) the all-gather of the embedding rows, queued behind them;
+        (4) stream-level waits, bf16 wire pieces widened back into the arena; (5) ONE squared-norm reduction over the finished arena in a fixed
+        order (identical on every rank: the clip coefficient needs no collective).  Also issued at world size 1, where the collectives are the
+        identity.  -> device fp32 [1] sum of squares."""
         flat = self.arena.flat
         sumsq = self.opt.sumsq_flat if hasattr(self.opt, "sumsq_flat") else None
         ss = torch.zeros(1, device=flat.device, dtype=torch.float32)
         if not self.dist_on:
-            self._window_ids = []
             return sumsq(flat) if sumsq is not None else (self.opt.ops.sumsq(flat, ss), ss)[1]
         ev = None
         if self.time_comm and flat.is_cuda:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
+        rows_plan = self._embed_rows_plan() if self.sparse_embed else None
         # dense part: everything but the embedding block when that one travels as rows
         spans = [(0, flat.numel())]
         if self.sparse_embed:
@@ -507,13 +586,12 @@ class Trainer:
         pieces = [flat[o:min(o + self.reduce_chunk, b)] for a, b in spans for o in range(a, b, self.reduce_chunk)]
         wire = [pc if self.wire_dtype in (None, pc.dtype) else pc.to(self.wire_dtype) for pc in pieces]
         works = [dist.all_reduce(wb, async_op=True) for wb in wire]
-        if self.sparse_embed:
-            self._exchange_embed_rows()                  # queued behind the dense pieces on the collective stream; its host-side size exchange overlaps them
+        if rows_plan is not None:
+            self._exchange_embed_rows(*rows_plan)        # queued behind the dense pieces on the collective stream
         for pc, wb, w in zip(pieces, wire, works):
             w.wait()                                     # stream-level wait on a device backend: the host runs ahead
             if wb is not pc:
                 pc.copy_(wb)                             # back to the fp32 arena (every rank widens the same bf16 sums: replicas stay identical)
-        # the squared norm over the WHOLE arena in one fixed order (identical on every rank: the clip coefficient needs no collective)
         if sumsq is not None:
             ss = sumsq(flat)
         else:
@@ -523,21 +601,24 @@ class Trainer:
             self._comm_events = getattr(self, "_comm_events", []) + [ev]
         return ss
 
-    def _exchange_embed_rows(self):
-        """Data-parallel sum of the embedding table's gradient block as ROWS.  Every rank: the distinct token ids of its window (device `unique`),
-        their count exchanged (one 8-byte all-gather + the ONLY host synchronisation of an optimizer step), index lists padded to the largest count,
-        all-gather of indices [world, n] and rows [world, n, H]; then the block is rebuilt as the sum over ranks IN RANK ORDER (`index_add_` with
-        indices that are distinct within a rank: no two additions race on an element, padding adds +0.0), so every rank holds the same bits."""
+    def _embed_rows_plan(self):
+        """-> (rows, n): this rank's non-zero rows of the embedding block (ascending, distinct: `nonzero` of a row mask) and the largest count over
+        the ranks (one 8-byte all-gather + the ONLY host synchronisation of an optimizer step)."""
         eo, en = self.arena.block_of[self._embed_key]
-        ids = torch.cat(self._window_ids) if self._window_ids else torch.zeros(0, dtype=torch.int64, device=self.arena.flat.device)
-        self._window_ids = []
-        H = self._embed_cols
-        block = self.arena.flat[eo:eo + en].view(-1, H)
-        rows = torch.unique(ids[(ids >= 0) & (ids < block.shape[0])])
-        cnt = torch.tensor([rows.numel()], device=block.device, dtype=torch.int64)
+        block = self.arena.flat[eo:eo + en].view(-1, self._embed_cols)
+        rows = ((torch.amax(block, 1) != 0) | (torch.amin(block, 1) != 0)).nonzero().flatten()      # (a NaN row compares != 0: it travels and shows up in the norm)
+        cnt = torch.tensor([rows.numel()], device=block.device, dtype=torch.int64)      # (`nonzero` already synchronised with the host)
         cnts = [torch.zeros_like(cnt) for _ in range(self.world)]
         dist.all_gather(cnts, cnt)
-        n = max(1, int(torch.stack(cnts).max()))         # host sync: the gather below needs one size on every rank
+        return rows, max(1, int(torch.stack(cnts).max()))
+
+    def _exchange_embed_rows(self, rows, n):
+        """Data-parallel sum of the embedding table's gradient block as ROWS: index lists padded to the largest count `n`, all-gather of indices
+        [world, n] and rows [world, n, H]; then the block is rebuilt as the sum over ranks IN RANK ORDER (`index_add_` with indices that are distinct
+        within a rank -- `rows` comes from `nonzero` -- so no two additions race on an element; padding adds +0.0 to row 0): every rank holds the same bits."""
+        eo, en = self.arena.block_of[self._embed_key]
+        H = self._embed_cols
+        block = self.arena.flat[eo:eo + en].view(-1, H)
         idx = torch.full((n,), -1, device=block.device, dtype=torch.int64)
         idx[: rows.numel()] = rows
         vals = torch.zeros((n, H), device=block.device, dtype=block.dtype)

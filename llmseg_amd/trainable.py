@@ -306,6 +306,7 @@ class TrainableMixin:
                     k, tuple(ce_segs) if k > 1 else None)
         plan.N, plan.L, plan.T, plan.B, plan.off, plan.seg_off, plan.rounds = N, L, T, B, off, seg_off, rounds
         plan.micro, plan.ce_segs = k, ce_segs
+        plan.clip_identity = N == (1 if inference else B) and clip_index.tolist() == list(range(N))     # sequence i reads image i: no expansion copy
         plan.drop_seg_rows = Nm * T if k > 1 else 0                                       # rows of one micro-batch in the Llama activations
         plan.loss_div = float(B) if k == 1 else 1.0                                      # k > 1: 1 / (images per micro-batch) is folded into the item weights
         # groups of images with the same proposal count (the head runs once per group), and the loss weights 1 / (R + 1e-8) of
@@ -374,16 +375,21 @@ class TrainableMixin:
                 x = F.linear(F.swiglu(gu, c.inter), self._w(p + "mlp.down_proj.weight", F), None, ops.ACT_NONE, x, self._wT(p + "mlp.down_proj.weight", F))
         return F.norm(x, self._w("model.norm.weight", F), None, c.eps, True).view(N, T, H)
 
-    def llava_forward(self, images_clip, input_ids, plan, want_logits=True):
+    def llava_forward(self, images_clip, input_ids, plan, want_logits=True, clip_proj=None):
         """LlavaLlamaForCausalLM.forward (llava_llama.py:55-135): splice, decoder stack, lm_head, shifted CE.
-        `images_clip` already holds one image per sequence.  -> (ce_loss | None, logits | None, final-norm hidden [N,T,H])."""
+        `images_clip`: one CLIP input per IMAGE of the batch (the reference expands it to one per conversation before the tower, LISA.py:293-303:
+        the same rows C times; here the frozen tower runs once per image and its projected tokens are expanded through `plan.clip_index`).
+        `clip_proj`: the projected tokens [B*(P+1), H] when they were computed elsewhere (`encode_towers`).
+        -> (ce_loss | None, logits | None, final-norm hidden [N,T,H])."""
         c = self.config
         F = self._F()
         N, T = plan.N, plan.T
         Pn = c.n_img_tokens
-        with torch.no_grad():                                              # CLIP + mm_projector are frozen
-            proj = self.encode_images(images_clip)                         # [N*(P+1), H]
         H = c.llama.hidden
+        with torch.no_grad():                                              # CLIP + mm_projector are frozen
+            proj = self.encode_images(images_clip) if clip_proj is None else clip_proj      # [B*(P+1), H]
+            if not plan.__dict__.get("clip_identity", False):              # one block of P+1 rows per SEQUENCE
+                proj = proj.view(-1, (Pn + 1) * H).index_select(0, plan.clip_index).view(N * (Pn + 1), H)
         embeds = F.embed_splice(input_ids.contiguous(), self._w("model.embed_tokens.weight", F), proj[1:], Pn, (Pn + 1) * H, plan.tok_index)
         hidden = self._llama(embeds, plan.key_mask, F, drop_seg_rows=plan.__dict__.get("drop_seg_rows", 0))
         logits, loss = None, None
@@ -464,13 +470,20 @@ class TrainableMixin:
             st = self.__dict__["_side_stream"] = torch.cuda.Stream(device=self.device_)
         return st
 
-    def visual_features_cl(self, images, F):
-        """-> (channels-last feature rows bf16, rows per image, row offset of the first patch, grid)."""
+    def visual_features_cl(self, images, F, tower_visual=None, n_images=None):
+        """-> (channels-last feature rows bf16, rows per image, row offset of the first patch, grid).
+        tower_visual: the frozen backbone's rows for these images when they were computed elsewhere (`encode_towers`)."""
         c = self.config
         with torch.no_grad():                                              # both backbones are frozen
             if c.backbone == "sam":
-                return self._sam_encoder_cl(images), c.sam.grid ** 2, 0, c.sam.grid
-            x, n_tok, (gh, gw) = self._dinov2_tokens(images)
+                return (self._sam_encoder_cl(images) if tower_visual is None else tower_visual), c.sam.grid ** 2, 0, c.sam.grid
+            if tower_visual is None:
+                x, n_tok, (gh, gw) = self._dinov2_tokens(images)
+            else:
+                x = tower_visual
+                n_tok = x.shape[0] // n_images
+                gh = gw = int(round((n_tok - 1) ** 0.5))
+                assert gh * gw + 1 == n_tok, "tower_visual of the DINOv2 backbone: square token grids only"
         assert gh == gw
         d = self.prepare()
         views = self.__dict__.get("_arena_views", {})
@@ -487,29 +500,57 @@ class TrainableMixin:
 
     def model_forward(self, images, images_clip, input_ids, labels, attention_masks, offset, masks_list=None, label_list=None,
                       resize_list=None, sam_segs_list=None, sam_ious_list=None, sam_iops_list=None, inference=False,
-                      return_aux=False, plan=None, **kwargs):
+                      return_aux=False, plan=None, tower_visual=None, tower_clip=None, **kwargs):
         """Same arguments and return keys as the reference (model/LISA.py:225-474).  `plan` (optional): the BatchPlan of this batch
-        (`make_plan`); without it the plan is built here, which synchronises with the device once."""
+        (`make_plan`); without it the plan is built here, which synchronises with the device once.
+        `tower_visual` / `tower_clip` (optional, not in the reference): the outputs of the two FROZEN towers for this batch's images, computed
+        elsewhere by `encode_towers` (e.g. once per accumulation window over all of its images, `Trainer.window_step`); `images` /
+        `images_clip` are then not read and may be None."""
         if plan is None:
             plan = self.make_plan(input_ids, None if inference else labels, attention_masks, offset, sam_segs_list, inference)
+        towers = None if tower_visual is None else (tower_visual, tower_clip)
         if inference:
             with torch.no_grad():
                 return self._model_forward(images, images_clip, input_ids, masks_list, sam_segs_list, sam_ious_list, sam_iops_list, True,
-                                           return_aux, plan)
-        return self._model_forward(images, images_clip, input_ids, masks_list, sam_segs_list, sam_ious_list, sam_iops_list, False, return_aux, plan)
+                                           return_aux, plan, towers)
+        return self._model_forward(images, images_clip, input_ids, masks_list, sam_segs_list, sam_ious_list, sam_iops_list, False, return_aux, plan, towers)
 
-    def _model_forward(self, images, images_clip, input_ids, masks_list, sam_segs_list, sam_ious_list, sam_iops_list, inference, return_aux, plan):
+    @torch.no_grad()
+    def encode_towers(self, images, images_clip):
+        """The two frozen towers of the path on a batch of images: -> (tower_visual, tower_clip) for `model_forward(..., tower_visual=, tower_clip=)`.
+        tower_visual: the segmentation backbone's token rows [B * rows_per_img, C] -- SAM ViT-H's neck output (LISA.py:173-184) or DINOv2's
+        x_norm tokens BEFORE the trainable 1x1 conv (LISA.py:186-199,242-245); tower_clip: CLIP-L -> mm_projector rows [B * (P+1), H]
+        (clip_encoder.py:41-60, llava_arch.py:93-96).  Neither has a gradient, so they are INPUTS of the trainable part: B may be the images of a
+        whole accumulation window (every GEMM of the towers then runs at accum x the rows), and slices of the results feed the micro-steps."""
+        images, images_clip = images.to(BF16).contiguous(), images_clip.to(BF16).contiguous()
+        c = self.config
+        if c.backbone == "sam":
+            vis = self._sam_encoder_cl(images)
+        else:
+            vis = self._dinov2_tokens(images)[0]
+        return vis, self.encode_images(images_clip)
+
+    def tower_rows_per_image(self, img_hw=None):
+        """(rows of tower_visual, rows of tower_clip) per image."""
+        c = self.config
+        if c.backbone == "sam":
+            return c.sam.grid ** 2, c.n_img_tokens + 1
+        hh, ww = img_hw
+        return (hh // c.dino.patch) * (ww // c.dino.patch) + 1, c.n_img_tokens + 1
+
+    def _model_forward(self, images, images_clip, input_ids, masks_list, sam_segs_list, sam_ious_list, sam_iops_list, inference, return_aux, plan, towers=None):
         c = self.config
         F = self._F()
-        images, images_clip = images.to(BF16).contiguous(), images_clip.to(BF16)
-        B = images.shape[0]
-        assert B == plan.B
-        if inference:
+        B = plan.B
+        if towers is None:
+            images, images_clip = images.to(BF16).contiguous(), images_clip.to(BF16).contiguous()
+            assert B == images.shape[0]
+        if inference and towers is None:
             assert images_clip.shape[0] == 1                                             # LISA.py:271
         # The frozen segmentation backbone (SAM ViT-H / DINOv2) and the CLIP -> Llama chain do not depend on each other until the mask
         # pooling: they are issued on two HIP streams, so the short-matrix Llama GEMMs (M = N_seq x 319 rows leaves CUs idle) and the
         # backbone's kernels share the chip.  Inside a captured micro-step the two streams become parallel branches of the hipGraph.
-        side = self._tower_stream() if (self.overlap_towers and (c.backbone == "sam" or not F.grad)) else None   # (DINOv2's 1x1 conv trains: keep autograd on one stream)
+        side = self._tower_stream() if (towers is None and self.overlap_towers and (c.backbone == "sam" or not F.grad)) else None   # (DINOv2's 1x1 conv trains: keep autograd on one stream)
         if side is not None:
             cur = torch.cuda.current_stream()
             side.wait_stream(cur)
@@ -517,9 +558,9 @@ class TrainableMixin:
                 feat, rows_per_img, row0, g = self.visual_features_cl(images, F)
             images.record_stream(side)
         else:
-            feat, rows_per_img, row0, g = self.visual_features_cl(images, F)
-        clip_in = images_clip.index_select(0, plan.clip_index)                          # one CLIP image per sequence (LISA.py:271-303)
-        ce, logits, hidden = self.llava_forward(clip_in.contiguous(), input_ids, plan, want_logits=return_aux or (not inference and plan.new_labels is None))
+            feat, rows_per_img, row0, g = self.visual_features_cl(images, F, None if towers is None else towers[0], B)
+        ce, logits, hidden = self.llava_forward(images_clip, input_ids, plan, want_logits=return_aux or (not inference and plan.new_labels is None),
+                                                clip_proj=None if towers is None else towers[1])
         if side is not None:
             cur.wait_stream(side)
             feat.record_stream(cur)

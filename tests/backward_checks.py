@@ -1126,3 +1126,102 @@ def check_mix_window(accum=10, sampler_seed=1):
     res.append(("mix 9:3:1 window: the hipGraph trainer's second pass leaves the same bits in the arena as the eager trainer", 0.0 if same else 1.0, 0.5))
     res.append((f"mix 9:3:1 window: losses of every micro-step identical, graph vs eager", 0.0 if graph_losses == eager_losses else 1.0, 0.5))
     return res
+
+
+def check_window_towers(k=3):
+    """the frozen towers (SAM ViT-H, CLIP-L + mm_projector) batched over the accumulation window -- `Trainer.window_step` /
+    `encode_window` / `model_forward(tower_visual=, tower_clip=)` (reference: the towers carry no gradient, LISA.py:173-184,242-245;
+    clip_encoder.py:41-60 runs under no_grad).
+      (1) the plumbing is EXACT: micro-steps fed the tower outputs computed per micro-batch (`encode_towers` at the micro-batch's own row count)
+          leave the same BITS in the arena and the same losses as micro-steps that run the towers themselves -- features are inputs;
+      (2) one `window_step` over the k micro-batches (towers at k x the rows): the tower outputs against the per-micro-batch ones (bit-equal
+          wherever the kernels keep their summation order across row counts -- reported; bounded by 2 bf16 ulps of the feature scale otherwise),
+          the arena against (1) in aggregate (direction, norm, lm_head) and bit for bit when the features are;
+      (3) `window_step` replayed from hipGraphs with the next window's towers PREFETCHED on the side stream == the eager window, bit for bit;
+      (4) at the real width (SAM ViT-H dim 1280, one windowed + one global block + neck; 1024 x 1024): images encoded 3 at a time == encoded
+          one by one, bit for bit -- the shapes the benchmark's window pass runs."""
+    from llmseg_amd.train import Trainer
+    from tests import model_checks as mc
+    cfg, m, sd, batch = _lora_case("sam")
+    names = [n for n, p in m.params.named_parameters() if p.requires_grad]
+    prm = dict(m.params.named_parameters())
+    batches = [mc._dev(b) for b in _variant_batches(batch, k)]
+    plans = [m.make_plan(**b) for b in batches]
+    seed = 515
+    scal = lambda out: {kk: float(v.detach()) for kk, v in out.items() if torch.is_tensor(v) and v.numel() == 1}
+    grab = lambda store: (lambda t, ss: store.update(g={n: prm[n]._g32.detach().clone() for n in names}, ss=float(ss)))
+    flat = lambda g: torch.cat([g[n].double().flatten() for n in names])
+
+    def run(mode, use_graph=False):
+        st = {}
+        tr = Trainer(m, lr=0.0, grad_accum=k, warmup=1, total_steps=10, use_graph=use_graph, graph_warmup=1)
+        tr.grad_hook = grab(st)
+        losses = None
+        for rep in range(3 if use_graph else 1):
+            m.set_dropout_seed(seed, 0)
+            if mode == "own":
+                losses = [scal(tr.micro_step(b, p)) for b, p in zip(batches, plans)]
+            elif mode == "per_micro_batch":
+                losses = []
+                for b, p in zip(batches, plans):
+                    tv, tc = m.encode_towers(b["images"], b["images_clip"])
+                    mb = {kk: v for kk, v in b.items() if kk not in ("images", "images_clip")}
+                    losses.append(scal(tr.micro_step(dict(mb, images=None, images_clip=None, tower_visual=tv, tower_clip=tc), p)))
+            elif mode == "window":
+                losses = [scal(o) for o in tr.window_step(batches, plans)]
+            else:                                         # the next window's towers issued on the side stream before this window's micro-steps
+                tw = st.pop("next", None) or tr.encode_window(batches, prefetch=True)
+                st["next"] = tr.encode_window(batches, prefetch=True)
+                losses = [scal(o) for o in tr.window_step(batches, plans, towers=tw)]
+        torch.cuda.synchronize()
+        if use_graph:
+            assert tr.graph_error is None, tr.graph_error
+            assert any(e["graph"] is not None for e in tr._graphs.values()), "the hipGraph path was never taken"
+        tr.close()
+        return losses, st["g"], st["ss"]
+    l_own, g_own, ss_own = run("own")
+    l_pmb, g_pmb, _ = run("per_micro_batch")
+    l_win, g_win, ss_win = run("window")
+    l_gra, g_gra, _ = run("window_prefetch", use_graph=True)
+    res = [("window towers (1): tower outputs as INPUTS, computed per micro-batch: arena elements that differ from the self-computing micro-steps",
+            float(sum((g_own[n] != g_pmb[n]).sum() for n in names)), 0.0),
+           (f"window towers (1): losses identical ({l_own[0]['loss']:.5f} ..)", 0.0 if l_own == l_pmb else 1.0, 0.5)]
+    with torch.no_grad():
+        imgs = torch.cat([b["images"] for b in batches]); clips = torch.cat([b["images_clip"] for b in batches])
+        vw, cw = m.encode_towers(imgs, clips)
+        per = [m.encode_towers(b["images"], b["images_clip"]) for b in batches]
+        vp, cp = torch.cat([p[0] for p in per]), torch.cat([p[1] for p in per])
+    ulp = lambda t: 2.0 ** -7 * float(t.float().abs().max())
+    feq = bool(torch.equal(vw, vp) and torch.equal(cw, cp))
+    res.append((f"window towers (2): SAM rows at {k} x the batch vs per micro-batch (bit-equal: {bool(torch.equal(vw, vp))}); max diff", float((vw.float() - vp.float()).abs().max()), 2 * ulp(vp)))
+    res.append((f"window towers (2): CLIP -> projector rows (bit-equal: {bool(torch.equal(cw, cp))}); max diff", float((cw.float() - cp.float()).abs().max()), 2 * ulp(cp)))
+    if feq:
+        res.append(("window towers (2): same tower bits => same arena bits: differing elements", float(sum((g_own[n] != g_win[n]).sum() for n in names)), 0.0))
+    a, b_ = flat(g_own), flat(g_win)
+    res.append(("window towers (2): direction of the whole gradient, window pass vs self-computing micro-steps; shown as 1 - cos", 1.0 - float((a @ b_) / (a.norm() * b_.norm())), 5e-3))
+    res.append(("window towers (2): squared gradient norm", abs(ss_win - ss_own) / max(ss_own, 1e-30), 5e-2))
+    la, lb = g_own["lm_head.weight"].double().flatten(), g_win["lm_head.weight"].double().flatten()
+    res.append(("window towers (2): lm_head gradient, relative RMS difference", float((la - lb).norm() / la.norm()), 1e-2))
+    res.append(("window towers (2): losses of the micro-steps", max(abs(x["loss"] - y["loss"]) for x, y in zip(l_own, l_win)), 2e-3 * max(1.0, abs(l_own[0]["loss"]))))
+    res.append(("window towers (3): hipGraph micro-steps + prefetched towers vs the eager window: differing arena elements", float(sum((g_win[n] != g_gra[n]).sum() for n in names)), 0.0))
+    res.append(("window towers (3): losses identical", 0.0 if l_win == l_gra else 1.0, 0.5))
+    del m
+    # (4) full width
+    from oracle import cases, sam_encoder as osam, seeded
+    scfg = osam.SamCfg(depth=2, global_idx=(1,))
+    fcfg = cases.tiny_lisa_cfg("sam")
+    fcfg.sam = scfg
+    from llmseg_amd import lisa as hip_lisa
+    mf = hip_lisa.LISAForCausalLM(mc.to_hip_cfg(fcfg), device=mc.DEV)
+    mf.load_state_dict({kk: v.to(BF).float() for kk, v in seeded.fill_state_dict(seeded.lisa_shapes(fcfg), 5).items()}, strict=False)
+    img = seeded.uniform((3, 3, 1024, 1024), 19, -2, 2).to(BF).to(mc.DEV)
+    clip = seeded.uniform((3, 3, 224, 224), 20, -2, 2).to(BF).to(mc.DEV)
+    with torch.no_grad():
+        v3, c3 = mf.encode_towers(img, clip)
+        one = [mf.encode_towers(img[i:i + 1], clip[i:i + 1]) for i in range(3)]
+    v1, c1 = torch.cat([o[0] for o in one]), torch.cat([o[1] for o in one])
+    res.append((f"window towers (4): full-width SAM-H blocks + neck, 3 images at once vs one by one: differing elements of {v3.numel()}", float((v3 != v1).sum()), 0.0))
+    res.append(("window towers (4): max difference", float((v3.float() - v1.float()).abs().max()), 0.0))
+    res.append(("window towers (4): tiny CLIP + projector, 3 at once vs one by one: max difference (informative: small-shape K-slice plans depend on the row count)",
+                float((c3.float() - c1.float()).abs().max()), 2 * ulp(c1)))
+    return res

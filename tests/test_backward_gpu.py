@@ -96,6 +96,12 @@ def test_trainer_configs3_mix_9_3_1_batch1_window():
     _assert(bc.check_mix_window())
 
 
+def test_window_step_with_batched_frozen_towers():
+    """The frozen towers once per accumulation window (`Trainer.window_step`): exact plumbing, window pass vs micro-steps, graph + prefetch."""
+    from tests import backward_checks as bc
+    _assert(bc.check_window_towers(3))
+
+
 def test_graph_trainer_with_rotating_batches():
     from tests import backward_checks as bc
     _assert(bc.check_graph_rotating_batches())

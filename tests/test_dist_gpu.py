@@ -89,7 +89,7 @@ def _rank_batch(batch, r):
     return b
 
 
-def _two_rank_worker(rank, world, port, ret, tmp):
+def _two_rank_worker(rank, world, port, ret, tmp, wire):
     import sys
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -104,8 +104,11 @@ def _two_rank_worker(rank, world, port, ret, tmp):
                 for p in m.trainable_parameters():
                     p.add_(0.03)
         m.set_dropout_seed(SEED, 0)
-        tr = Trainer(m, lr=LR, grad_accum=ACCUM, warmup=0, total_steps=20, reduce_chunk_mb=8)
+        tr = Trainer(m, lr=LR, grad_accum=ACCUM, warmup=0, total_steps=20, reduce_chunk_mb=8, **({} if wire == "default" else {"wire_dtype": None}))
         assert tr.arena is not None and tr.dist_on and tr.arena.flat.numel() > 2 * tr.reduce_chunk, (tr.arena.flat.numel(), tr.reduce_chunk)
+        assert tr.sparse_embed and tr.wire_dtype == (torch.bfloat16 if wire == "default" else None), (tr.sparse_embed, tr.wire_dtype)
+        if rank == 0:
+            torch.save(torch.tensor(tr.arena.block_of[tr._embed_key]), os.path.join(tmp, "embed_block.pt"))
         assert int(m.dropout_state()[0]) == rank_dropout_seed(SEED, rank)
         tr.check_replicas()
         first = {}
@@ -121,13 +124,16 @@ def _two_rank_worker(rank, world, port, ret, tmp):
         dist.destroy_process_group()
 
 
-def test_two_ranks_share_one_gpu_gloo(tmp_path):
+@pytest.mark.parametrize("wire", ["fp32", "default"])
+def test_two_ranks_share_one_gpu_gloo(tmp_path, wire):
+    """wire = "default": what a multi-rank Trainer does unless told otherwise -- dense pieces in bf16 on the wire (the reference's DeepSpeed bf16 engine,
+    training.py:314-329), the embedding block as fp32 rows; "fp32": `wire_dtype=None`."""
     import torch.multiprocessing as mp
     from llmseg_amd.train import Trainer, rank_dropout_seed
     from tests import backward_checks as bc, model_checks as mc
     world = 2
     ret = mp.Manager().dict()
-    mp.spawn(_two_rank_worker, args=(world, 29581, ret, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_two_rank_worker, args=(world, 29581 if wire == "fp32" else 29583, ret, str(tmp_path), wire), nprocs=world, join=True)
     (l0, p0, n0, ss0), (l1, p1, n1, ss1) = ret[0], ret[1]
     assert n0 == n1 == OPT_STEPS and ss0 == ss1
     assert torch.equal(p0, p1), (p0 - p1).abs().max().item()           # replicas bit-identical after the exchanges
@@ -153,5 +159,13 @@ def test_two_ranks_share_one_gpu_gloo(tmp_path):
     g_dist, g_union = torch.load(os.path.join(str(tmp_path), "arena0.pt")), first["g"][0]
     # identical up to the fp32 association of the two accumulation orders: (a + b) + (c + d) across ranks vs ((a + b) + c) + d in one process
     scale = g_union.abs().max().item()
-    assert scale > 1e-3 and (g_dist - g_union).abs().max().item() <= 2e-5 * scale + 1e-7, ((g_dist - g_union).abs().max().item(), scale)
-    assert abs(ss0 - first["g"][1]) <= 1e-4 * first["g"][1]
+    eo, en = [int(v) for v in torch.load(os.path.join(str(tmp_path), "embed_block.pt"))]
+    d = (g_dist - g_union).abs()
+    assert scale > 1e-3 and d[eo:eo + en].max().item() <= 2e-5 * scale + 1e-7, (d[eo:eo + en].max().item(), scale)      # the embedding rows: fp32 on the wire either way
+    d[eo:eo + en] = 0
+    if wire == "fp32":
+        assert d.max().item() <= 2e-5 * scale + 1e-7, (d.max().item(), scale)
+        assert abs(ss0 - first["g"][1]) <= 1e-4 * first["g"][1]
+    else:                                                    # every dense element: its two per-rank sums rounded to bf16, added in bf16
+        assert bool((d <= 2.0 ** -7 * g_union.abs() + 2.0 ** -7 * 1e-3 * scale).all()), (d.max().item(), scale)
+        assert d.max().item() > 0 and abs(ss0 - first["g"][1]) <= 2e-2 * first["g"][1]
