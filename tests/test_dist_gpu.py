@@ -167,5 +167,5 @@ def test_two_ranks_share_one_gpu_gloo(tmp_path, wire):
         assert d.max().item() <= 2e-5 * scale + 1e-7, (d.max().item(), scale)
         assert abs(ss0 - first["g"][1]) <= 1e-4 * first["g"][1]
     else:                                                    # every dense element: its two per-rank sums rounded to bf16, added in bf16
-        assert bool((d <= 2.0 ** -7 * g_union.abs() + 2.0 ** -7 * 1e-3 * scale).all()), (d.max().item(), scale)
+        assert d.max().item() <= 2.0 ** -7 * scale and d.norm().item() <= 2.0 ** -7 * g_union.norm().item(), (d.max().item(), scale, d.norm().item(), g_union.norm().item())
         assert d.max().item() > 0 and abs(ss0 - first["g"][1]) <= 2e-2 * first["g"][1]
