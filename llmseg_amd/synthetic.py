@@ -82,3 +82,43 @@ class HybridSampler:
         src = self.SOURCES[i]
         c = 3 if src == "sem_seg" else int(self.rng.integers(1, 4)) if src == "refer_seg" else int(self.rng.integers(1, 3))
         return src, c
+
+
+class SyntheticSegDataset:
+    """A dataset in the reference datasets' own item format (what `collate_fn_new` consumes; utils/reason_seg_dataset.py:127-282 for training items,
+    utils/dataset.py:561-656 for validation items), made of seeded noise: item i is a pure function of (seed, i).  For the driver's plumbing
+    (`python -m llmseg_amd.run --dataset_module synthetic`) and its tests -- images / proposals / ground truths carry no meaning.
+    Every item goes through the real sample builder `collate.reason_seg_sample`: proposal records as COCO RLE + area (the reference's file format,
+    prepare_datasets/*), decoded, area-sorted, resampled to 256 x 256 and scored against the ground truths on the device (llmseg_amd/targets.py)."""
+
+    ANSWERS = ("It is [SEG].", "Sure, [SEG].", "Sure, it is [SEG].", "Sure, the segmentation result is [SEG].", "[SEG].")      # utils/utils.py:38-45
+    WORDS = ("the", "thing", "that", "matters", "most", "left", "of", "object", "person", "holding", "red", "cup", "near", "window")
+
+    def __init__(self, n, device, img_size=1024, inference=False, seed=0, proposals=12, hw=(96, 128), max_sentences=3):
+        self.n, self.device, self.img, self.inference, self.seed, self.K, self.hw, self.max_s = int(n), device, img_size, inference, int(seed), proposals, hw, max_sentences
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        from . import collate, targets
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        g = torch.Generator().manual_seed(self.seed * 7919 + int(i))
+        H, W = self.hw
+        thr = torch.rand((self.K, 1, 1), generator=g) * 0.7 + 0.2
+        masks = (torch.rand((self.K, H, W), generator=g) > thr).to(torch.uint8)
+        recs = [{"segmentation": r, "area": int(mk.sum()), "bbox": [0, 0, 1, k]} for k, (r, mk) in enumerate(zip(targets.rle_encode_masks(masks), masks))]
+        n_s = 1 if self.inference else int(torch.randint(1, self.max_s + 1, (1,), generator=g))
+        words = lambda: " ".join(self.WORDS[int(j)] for j in torch.randint(0, len(self.WORDS), (5,), generator=g))
+        image = torch.randn((3, self.img, self.img), generator=g)
+        image_clip = torch.randn((3, 224, 224), generator=g)
+        if self.inference:
+            gt = (torch.rand((1, H + 3, W + 5), generator=g) > 0.5).to(torch.uint8)
+            return collate.reason_seg_sample(image, image_clip, [words() + " "], gt, recs, self.device, inference=True, image_path=f"synthetic_val_{i}.jpg",
+                                             resize=(self.img, self.img), top=self.K)
+        gt = (torch.rand((n_s, H, W), generator=g) > 0.5).to(torch.uint8)
+        qs = [collate.DEFAULT_IMAGE_TOKEN + "\n " + words() + " Please output segmentation mask." for _ in range(n_s)]
+        ans = [self.ANSWERS[int(torch.randint(0, len(self.ANSWERS), (1,), generator=g))] for _ in range(n_s)]
+        return collate.reason_seg_sample(image, image_clip, qs, gt, recs, self.device, inference=False, answers=ans, image_path=f"synthetic_train_{i}.jpg",
+                                         resize=(self.img, self.img), top=self.K)

@@ -260,7 +260,8 @@ class Trainer:
 
     def __init__(self, module, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.0, clip=1.0, grad_accum=10, warmup=100, total_steps=5000,
                  optimizer=None, device_ids=None, force_ddp=False, ddp_wrapper=False, use_graph=False, graph_warmup=2, use_arena=None,
-                 reduce_chunk_mb=128, sync_init=True, check_every=100, leaf_stream=False, fused_accum=1, sparse_embed=None, time_comm=False, wire_dtype="auto"):
+                 reduce_chunk_mb=128, sync_init=True, check_every=100, leaf_stream=False, fused_accum=1, sparse_embed=None, time_comm=False, wire_dtype="auto",
+                 max_graphs=None):
         """optimizer: None = HipAdamW; or a factory `params -> optimizer` / an optimizer object (CPU tests).  use_arena: None = automatic
         (the HIP model with the built-in optimizer), True = force the fp32 gradient arena (the module's autograd Functions must honour `_g32`)."""
         self.module = module
@@ -319,6 +320,12 @@ class Trainer:
         self.use_graph = bool(use_graph) and self.arena is not None and is_hip_model
         self.graph_warmup = graph_warmup
         self._graphs = {}
+        # max_graphs: bound on the captured graphs kept alive (each owns the activations of a whole micro-step: ~15 GB at two images).  A benchmark sees
+        # one batch structure, BASELINE configs[3] three; a real loader produces a new (sequences, token length, labelled-token count, [SEG] positions)
+        # combination for most batches -- those run eagerly (`graph_warmup` calls before a capture), and when the cache is full the least recently
+        # replayed graph is dropped.  None = unbounded.
+        self.max_graphs = max_graphs
+        self._graph_clock = 0
         self.graph_error = None
         self.grad_hook = None
         self.reduce_chunk = max(1, int(reduce_chunk_mb * (1 << 20) // 4))       # fp32 elements per all-reduce chunk of the arena
@@ -466,7 +473,9 @@ class Trainer:
         for j, (b, (tv, tc)) in enumerate(zip(batches, towers.parts)):
             mb = {k: v for k, v in b.items() if k not in ("images", "images_clip")}
             mb.update(images=None, images_clip=None, tower_visual=tv, tower_clip=tc)
-            outs.append(self.micro_step(mb, None if plans is None else plans[j]))
+            out = self.micro_step(mb, None if plans is None else plans[j])
+            # (a replayed hipGraph returns ITS output buffers: the next replay of the same structure overwrites them -- hand out copies of the scalars)
+            outs.append({k: (v.detach().clone() if torch.is_tensor(v) and v.numel() == 1 else v) for k, v in out.items()})
         return outs
 
     def _backward(self, loss):
@@ -490,6 +499,12 @@ class Trainer:
             ent["calls"] += 1
             return self._eager_step(batch, plan)       # eager warm-up (lazy caches, workspace) -- also a real micro-step
         if ent["graph"] is None:
+            if self.max_graphs is not None:
+                live = [(e.get("used", 0), k) for k, e in self._graphs.items() if e.get("graph") is not None]
+                while len(live) >= max(1, int(self.max_graphs)):
+                    live.sort()
+                    _, victim = live.pop(0)
+                    del self._graphs[victim]                     # its graph, input buffers and memory pool go with it
             try:
                 self._capture(ent, batch, plan)
             except Exception as e:                       # noqa: BLE001 -- fall back to eager launches, keep training
@@ -500,6 +515,8 @@ class Trainer:
                 torch.cuda.synchronize()
                 ent["graph"] = None
                 return self._eager_step(batch, plan)
+        self._graph_clock += 1
+        ent["used"] = self._graph_clock
         _copy_batch(ent["batch"], batch)
         if plan is not ent["last_plan"]:                 # plans are immutable once built: the same object again needs no second upload
             ent["plan"].copy_tensors_from(plan)
