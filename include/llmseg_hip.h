@@ -31,9 +31,9 @@ enum { LLMSEG_ACT_NONE = 0, LLMSEG_ACT_RELU = 1, LLMSEG_ACT_GELU = 2, LLMSEG_ACT
  * so a binding written against an older header (fields were appended in every round) fails loudly instead of having the library read
  * past the caller's struct.  llmseg_struct_size(which) returns the library's sizeof (0 = llmseg_gemm_args, 1 = llmseg_attn_args,
  * 2 = llmseg_attn_bwd_args, 3 = llmseg_dropout; -1 for an unknown index) so a binding can assert at load time;
- * llmseg_version() is bumped whenever a struct or a signature changes (4: the reduction entry points take a workspace; 5 = this header:
+ * llmseg_version() is bumped whenever a struct or a signature changes (7: the fp32-activation head entry points; 4: the reduction entry points take a workspace; 5 = this header:
  * llmseg_dropout.seg_rows; 6: llmseg_gemm_args.norm_w / norm_eps / norm_out / ldn). */
-#define LLMSEG_ABI_VERSION 6
+#define LLMSEG_ABI_VERSION 7
 
 /* Determinism (round 4).  No kernel adds floating-point numbers with atomics: every sum whose terms come from several workgroups is
  * written as per-workgroup partials into CALLER-OWNED scratch (`workspace`, `workspace_bytes`; any device memory, 256-byte aligned, not
@@ -286,6 +286,22 @@ int llmseg_upsample_maskpool(const void* feat, const void* segs, void* pooled, v
 
 /* Cosine scoring (LISA.py:398-403): sim[k] = <t,e_k> / (|t||e_k|); t bf16 [D], e bf16 [K][D]; sim fp32 [K]. */
 int llmseg_cosine_scores(const void* t, const void* e, float* sim, int32_t K, int32_t D, void* stream);
+
+/* ---- ABI 7: the mask-selection head with fp32 ACTIVATIONS (inference scores; weights stay the model's bf16 tensors) ------------------------
+ * What these replace on the reference side: the nn.Linear / nn.LayerNorm / Attention modules of model/transformer.py:215-341 and the scoring of
+ * model/LISA.py:340-408 when the reference is run in fp32 on the CPU (its own "CPU path" of north_star).  Plain fp32 FMA chains, ascending k. */
+/* y[m][n] = act(alpha * sum_k x[m][k] * W(n,k) + bias[n]) + residual[m][n];  x fp32 [M][ldx], residual fp32 [M][ldr] or NULL, y fp32 [M][ldy];
+ * W bf16: w_kn = 0 -> stored [N][ldw] (nn.Linear weight, F.linear); w_kn = 1 -> stored [K][ldw] (right operand given K-major: the channels-last
+ * feature map of the mask pooling, LISA.py:201-218); bias bf16 [N] or NULL. */
+int llmseg_linear_f32(const float* x, int64_t ldx, const void* W, int64_t ldw, int32_t w_kn, const void* bias, const float* residual, int64_t ldr,
+                      float* y, int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, float alpha, void* stream);
+/* nn.LayerNorm over the last dimension (transformer.py:236-283 norm1..4): x, y fp32 [rows][D] contiguous; w, b bf16 [D] (b may be NULL). */
+int llmseg_layernorm_f32(const float* x, const void* w, const void* b, float* y, int64_t rows, int32_t D, float eps, void* stream);
+/* softmax(q k^T * scale) v (transformer.py:319-341), all fp32; strides[12] = {q, k, v, o} x {batch, head, row} in elements; head_dim 32 or 64. */
+int llmseg_attn_f32(const float* q, const float* k, const float* v, float* o, const int64_t* strides, int32_t batch, int32_t heads, int32_t Nq, int32_t Nk,
+                    int32_t head_dim, float scale, void* stream);
+/* llmseg_cosine_scores on fp32 operands: t fp32 [D], e fp32 [K][D] -> sim fp32 [K]. */
+int llmseg_cosine_f32(const float* t, const float* e, float* sim, int32_t K, int32_t D, void* stream);
 
 /* softmax_align_loss + iou_regression_loss (model/loss.py:50-94) for `items` (image, round) pairs with the same K, one workgroup
  * each, every operand contiguous over items (e [items][K][D], t [items][D], gt_iou / pred_iou / gt_iop [items][K]); fp32 results:

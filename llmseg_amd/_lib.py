@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LLMSEG_LIB") or os.path.join(_HERE, "libllmseg_hip.so")     # LLMSEG_LIB: side builds of the same ABI (tools/ experiments)
 
-ABI_VERSION = 6          # == LLMSEG_ABI_VERSION of include/llmseg_hip.h
+ABI_VERSION = 7          # == LLMSEG_ABI_VERSION of include/llmseg_hip.h
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SILU, ACT_SIGMOID = range(6)
 
@@ -99,6 +99,10 @@ SIGNATURES = {
     "llmseg_mask_pullback": [_p, _p, _p, _p, _i32, _i32, _i32, _p],
     "llmseg_upsample_maskpool": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p],
     "llmseg_cosine_scores": [_p, _p, _p, _i32, _i32, _p],
+    "llmseg_linear_f32": [_p, _i64, _p, _i64, _i32, _p, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _f32, _p],
+    "llmseg_layernorm_f32": [_p, _p, _p, _p, _i64, _i32, _f32, _p],
+    "llmseg_attn_f32": [_p, _p, _p, _p, C.POINTER(C.c_int64), _i32, _i32, _i32, _i32, _i32, _f32, _p],
+    "llmseg_cosine_f32": [_p, _p, _p, _i32, _i32, _p],
     "llmseg_align_reg_loss": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
     "llmseg_dice_bce": [_p, _p, _p, _i32, _i64, _f32, _p, _i64, _p],
     "llmseg_dice_bce_bwd": [_p, _p, _p, _p, _i32, _i64, _f32, _p],

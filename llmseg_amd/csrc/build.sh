@@ -6,7 +6,7 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
 OUT="${LLMSEG_OUT:-$ROOT/llmseg_amd/libllmseg_hip.so}"      # LLMSEG_OUT: side builds for experiments (tools/)
 OBJ="${LLMSEG_OBJ:-$ROOT/build/obj}"                          # build/ is git-ignored and gpurun-ignored
-SRCS="gemm.hip attention.hip attention_bwd.hip pointwise.hip head.hip backward.hip targets.hip image.hip capi.cpp"
+SRCS="gemm.hip attention.hip attention_bwd.hip pointwise.hip head.hip head_f32.hip backward.hip targets.hip image.hip capi.cpp"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE $*"
 mkdir -p "$OBJ"
 SIG="$(echo "$FLAGS" | md5sum | cut -c1-8)"

@@ -660,3 +660,64 @@ def prof_collect():
     return {"all": (ms.value, fl.value, n.value), "dominant": (dms.value, dfl.value, dn.value), "dominant_kernel": (name or b"").decode(),
             "dominant_alg_bytes": _lib.load().llmseg_prof_dominant_bytes(),
             "dominant_info": {"calls": int(info[0]), "calls_as_k_slices": int(info[1]), "k_slices": int(info[2]), "kernel_launches": int(info[3])}}
+
+
+# ---- fp32-activation head (inference scores): csrc/head_f32.hip ------------------------------------------------------------------------------
+F32 = torch.float32
+
+
+def linear_f32(x, w, bias=None, act=ACT_NONE, residual=None, w_kn=False, alpha=1.0):
+    """act(alpha * x @ W^T + bias) + residual with fp32 activations: x fp32 [M, K] (last dim contiguous), w bf16 [N, K] (or [K, N] when w_kn),
+    bias bf16 [N], residual fp32 [M, N] -> fp32 [M, N]."""
+    _req(x, F32); _req(w)
+    assert x.dim() == 2 and w.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1
+    M, K = x.shape
+    N = w.shape[1] if w_kn else w.shape[0]
+    assert (w.shape[0] if w_kn else w.shape[1]) == K, (x.shape, w.shape, w_kn)
+    if bias is not None:
+        _req(bias); assert bias.numel() == N and bias.is_contiguous()
+    if residual is not None:
+        _req(residual, F32); assert residual.shape == (M, N) and residual.stride(1) == 1
+    y = torch.empty((M, N), device=x.device, dtype=F32)
+    _lib.check(_lib.load().llmseg_linear_f32(_ptr(x), x.stride(0), _ptr(w), w.stride(0), 1 if w_kn else 0, _ptr(bias), _ptr(residual),
+                                             residual.stride(0) if residual is not None else 0, _ptr(y), N, M, N, K, act, float(alpha), _stream()), "linear_f32")
+    return y
+
+
+def layernorm_f32(x, w, b=None, eps=1e-5):
+    _req(x, F32); _req(w)
+    assert x.is_contiguous() and x.dim() == 2 and w.numel() == x.shape[1]
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().llmseg_layernorm_f32(_ptr(x), _ptr(w), _ptr(b), _ptr(y), x.shape[0], x.shape[1], float(eps), _stream()), "layernorm_f32")
+    return y
+
+
+def attention_f32(q, k, v, o, batch, heads, Nq, Nk, head_dim, q_strides, k_strides, v_strides, o_strides, scale=None):
+    """softmax(q k^T * scale) v, all operands fp32; *_strides = (batch, head, row) in elements."""
+    for t in (q, k, v, o):
+        _req(t, F32)
+    st = (C.c_int64 * 12)(*[int(s) for tup in (q_strides, k_strides, v_strides, o_strides) for s in tup])
+    _lib.check(_lib.load().llmseg_attn_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(o), st, batch, heads, Nq, Nk, head_dim,
+                                           float(scale if scale is not None else 1.0 / math.sqrt(head_dim)), _stream()), "attn_f32")
+    return o
+
+
+def cosine_f32(t, e):
+    _req(t, F32); _req(e, F32)
+    assert t.is_contiguous() and e.is_contiguous() and e.dim() == 2 and t.numel() == e.shape[1]
+    out = torch.empty((e.shape[0],), device=e.device, dtype=F32)
+    _lib.check(_lib.load().llmseg_cosine_f32(_ptr(t), _ptr(e), _ptr(out), e.shape[0], e.shape[1], _stream()), "cosine_f32")
+    return out
+
+
+def mask_pullback_f32(segs, g, S):
+    """segs bf16 [K, S, S] -> (pulled_back fp32 [K, g*g] = segs . U, the proposals pulled back through the adjoint of the bilinear upsampling;
+    wsum fp32 [K] = sum of each proposal's pixels): stage 1 of the mask pooling with its fp32 outputs, no GEMM."""
+    _req(segs)
+    assert segs.is_contiguous()
+    K = segs.shape[0]
+    pb = torch.empty((K, g * g), device=segs.device, dtype=F32)
+    ws = torch.empty((K,), device=segs.device, dtype=F32)
+    wn = torch.empty((K, g * g), device=segs.device, dtype=BF16)
+    _lib.check(_lib.load().llmseg_mask_pullback(_ptr(segs), _ptr(wn), _ptr(pb), _ptr(ws), K, g, S, _stream()), "mask_pullback")
+    return pb, ws

@@ -459,7 +459,74 @@ class TrainableMixin:
         emb = lin(lin(s, "model.lisa_embedding_head.0", ops.ACT_RELU), "model.lisa_embedding_head.2")
         return iou.view(Cn * K), emb
 
+    def _mask_head_f32(self, pooled, text):
+        """`_mask_head` with fp32 ACTIVATIONS (inference only; LISA.py:363-391, transformer.py:215-341): pooled fp32 [K, D] of one image, text fp32 [C, D]
+        -> (pred_iou fp32 [C*K], emb fp32 [C*K, D]).  Same weights (the model's bf16 tensors), same wiring; every intermediate stays fp32."""
+        P = self.params
+        Cn, (K, D) = text.shape[0], pooled.shape
+        nh, hd = 8, D // 8
+        s = pooled.repeat(Cn, 1) if Cn > 1 else pooled                                      # row = c*K + k (LISA.py:372)
+        t = text.contiguous()
+        lin = lambda x, p, act=ops.ACT_NONE, res=None: ops.linear_f32(x, P[p + ".weight"], P[p + ".bias"], act, res)
+        ln = lambda x, p: ops.layernorm_f32(x, P[p + ".weight"], P[p + ".bias"], 1e-5)
+        one_key = lambda p, tt: lin(lin(tt, p + "v_proj"), p + "out_proj")                  # softmax over a single key == 1 (see `_head_attn_1key`)
+        bcast = lambda ss, add: (ss.view(Cn, K, D) + add[:, None, :]).view(Cn * K, D)       # (glue: a broadcast add of [C, D] rows)
+        for i in range(2):
+            p = f"model.lisa_attention_layers.{i}."
+            qkv = ops.linear_f32(s, P[p + "self_attn.qkv.weight"], P[p + "self_attn.qkv.bias"])            # [C*K, 3D] = q | k | v
+            a = torch.empty((Cn * K, D), device=s.device, dtype=torch.float32)
+            st = (K * 3 * D, hd, 3 * D)
+            ops.attention_f32(qkv, qkv[:, D:], qkv[:, 2 * D:], a, Cn, nh, K, K, hd, st, st, st, (K * D, hd, D))
+            s = ln(lin(a, p + "self_attn.out_proj", res=s), p + "norm1")
+            s = ln(bcast(s, one_key(p + "cross_attn_token_to_image.", t)), p + "norm2")
+            s = ln(lin(lin(s, p + "mlp.lin1", ops.ACT_RELU), p + "mlp.lin2", res=s), p + "norm3")
+            pc = p + "cross_attn_image_to_token."
+            q = lin(t, pc + "q_proj")
+            kv = ops.linear_f32(s, P[pc + "qkv.weight"][D:], P[pc + "qkv.bias"][D:])                       # [C*K, 2D] = k | v
+            o = torch.empty((Cn, D), device=s.device, dtype=torch.float32)
+            ops.attention_f32(q, kv, kv[:, D:], o, Cn, nh, 1, K, hd, (D, hd, D), (K * 2 * D, hd, 2 * D), (K * 2 * D, hd, 2 * D), (D, hd, D))
+            t = ln(lin(o, pc + "out_proj", res=t), p + "norm4")
+        s = ln(bcast(s, one_key("model.lisa_final_attn.", t)), "model.lisa_norm_final_attn")
+        iou = lin(lin(s, "model.lisa_iou_head.0", ops.ACT_RELU), "model.lisa_iou_head.2", ops.ACT_SIGMOID)
+        emb = lin(lin(s, "model.lisa_embedding_head.0", ops.ACT_RELU), "model.lisa_embedding_head.2")
+        return iou.view(Cn * K), emb
+
+    def _inference_scores_f32(self, feat, rows_per_img, row0, g, hidden, plan, sam_segs_list, masks_list, return_aux, logits):
+        """The inference tail of `model_forward` (LISA.py:318-408) with fp32 activations from the two bf16 trunk outputs on: [SEG] rows of the
+        final-norm hidden states -> text_hidden_fcs; proposals x upsampled features -> mask pooling as (segs . U) . feat / (sum segs + 1e-8) with the
+        pulled-back masks kept in fp32; the head; cosine scores.  ~1 GFLOP per image: plain fp32 kernels (csrc/head_f32.hip)."""
+        P, c = self.params, self.config
+        N, T, H = hidden.shape
+        B = plan.B
+        if plan.seg_idx.numel():
+            hs = ops.gather_rows(hidden.view(N * T, H), plan.seg_idx).float()
+            hs = ops.linear_f32(hs, P["model.text_hidden_fcs.0.0.weight"], P["model.text_hidden_fcs.0.0.bias"], ops.ACT_RELU)
+            pred = ops.linear_f32(hs, P["model.text_hidden_fcs.0.2.weight"], P["model.text_hidden_fcs.0.2.bias"])
+        else:
+            pred = torch.empty((0, c.out_dim), device=hidden.device, dtype=torch.float32)
+        pred_embeddings = [pred[plan.seg_off[b]:plan.seg_off[b + 1]] for b in range(B)]
+        sims, ious = [], []
+        for b in range(B):
+            if plan.rounds[b] == 0:
+                sims.append(None); ious.append(None)
+                continue
+            segs = sam_segs_list[b].to(BF16).contiguous()
+            K, S = segs.shape[0], segs.shape[1]
+            fb = feat[b * rows_per_img + row0: b * rows_per_img + row0 + g * g]
+            pb, ws = ops.mask_pullback_f32(segs, g, S)                                      # pb fp32 [K, g*g] = segs . U, ws fp32 [K] = sum of segs
+            pooled = ops.linear_f32(pb, fb, w_kn=True) / (ws[:, None] + 1e-8)
+            iou, emb = self._mask_head_f32(pooled, pred_embeddings[b])
+            Cn = plan.rounds[b]
+            e0 = emb.view(Cn, K, -1)[0].contiguous()
+            sims.append(torch.stack([ops.cosine_f32(pred_embeddings[b][ci].contiguous(), e0) for ci in range(Cn)]))
+            ious.append(iou.view(Cn, K)[:1])
+        out = {"pred_similarity": sims, "gt_masks": masks_list, "pred_iou": ious}
+        if return_aux:
+            out.update(logits=logits, hidden=hidden, feats=feat, pred_embeddings=pred_embeddings)
+        return out
+
     # ------------------------------------------------------------------------------------------------ model_forward
+    fp32_head = True               # inference: mask pooling, text_hidden_fcs, the head and the cosine scores with fp32 activations (class default; False = the bf16 MFMA route the training pass uses)
     fuse_residual_norm = True      # o_proj / down_proj + residual + the following RMSNorm as one GEMM call (class default; False = the separate norm launch)
     ce_gather_first = True         # lm_head + CE on the label-carrying rows only (class default; False = all N*T rows, as the reference computes them)
     overlap_towers = True          # issue the frozen segmentation backbone on its own HIP stream (class default; set False to serialise)
@@ -564,6 +631,9 @@ class TrainableMixin:
         if side is not None:
             cur.wait_stream(side)
             feat.record_stream(cur)
+
+        if inference and self.fp32_head:
+            return self._inference_scores_f32(feat, rows_per_img, row0, g, hidden, plan, sam_segs_list, masks_list, return_aux, logits)
 
         # [SEG] rows: gather first, then the MLP (identical to the reference's MLP-on-everything + boolean gather, LISA.py:318-323)
         N, T, H = hidden.shape

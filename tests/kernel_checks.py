@@ -583,3 +583,56 @@ def check_validate_body():
 
 
 ALL = [check_gemm, check_attention, check_pointwise, check_head, check_metric, check_validate_body]
+
+
+def check_head_f32():
+    """The fp32-activation head kernels (csrc/head_f32.hip; ABI 7) against float64 torch on the host: an fp32 FMA chain differs from the exact
+    result by ~sqrt(K) ulps, so the bounds are a few 1e-6 relative to the output scale -- three orders below the bf16 route's."""
+    import torch.nn.functional as F
+    from llmseg_amd import ops
+    res = []
+    f64 = lambda t: t.detach().double().cpu()
+    for (M, N, K, w_kn, act, use_b, use_r) in ((70, 130, 50, False, ops.ACT_NONE, True, True), (256, 256, 256, False, ops.ACT_RELU, True, False),
+                                               (512, 2048, 256, False, ops.ACT_SIGMOID, True, False), (3, 256, 4096, False, ops.ACT_RELU, True, False),
+                                               (256, 256, 4096, True, ops.ACT_NONE, False, False), (33, 65, 17, True, ops.ACT_NONE, True, True)):
+        x = rnd(M, K, seed=M + N).float().to(DEV)
+        w = rnd(*((K, N) if w_kn else (N, K)), seed=K + 1, scale=1.0 / K ** 0.5).to(BF).to(DEV)
+        b = rnd(N, seed=5).to(BF).to(DEV) if use_b else None
+        r = rnd(M, N, seed=6).float().to(DEV) if use_r else None
+        got = ops.linear_f32(x, w, b, act, r, w_kn=w_kn, alpha=0.5 if use_r else 1.0)
+        wm = f64(w) if w_kn else f64(w).t()
+        ref = (0.5 if use_r else 1.0) * (f64(x) @ wm) + (f64(b) if use_b else 0.0)
+        ref = torch.relu(ref) if act == ops.ACT_RELU else torch.sigmoid(ref) if act == ops.ACT_SIGMOID else ref
+        ref = ref + (f64(r) if use_r else 0.0)
+        res.append((f"linear_f32 {M}x{N}x{K} w_kn={w_kn} act={act}", (f64(got) - ref).abs().max().item(), 4e-6 * max(1.0, ref.abs().max().item())))
+    # strided input rows (a column block of a wider matrix, as the head slices q | k | v)
+    xw = rnd(40, 96, seed=9).float().to(DEV)
+    w = rnd(24, 32, seed=10).to(BF).to(DEV)
+    got = ops.linear_f32(xw[:, 32:64], w)
+    res.append(("linear_f32 on a strided column block", (f64(got) - f64(xw[:, 32:64]) @ f64(w).t()).abs().max().item(), 4e-6 * 8))
+    for rows, D in ((5, 256), (513, 256), (7, 100)):
+        x = (rnd(rows, D, seed=rows) * 3 + 1).float().to(DEV)
+        w, b = (rnd(D, seed=2) + 1).to(BF).to(DEV), rnd(D, seed=3).to(BF).to(DEV)
+        ref = F.layer_norm(f64(x), (D,), f64(w), f64(b), 1e-5)
+        res.append((f"layernorm_f32 {rows}x{D}", (f64(ops.layernorm_f32(x, w, b, 1e-5)) - ref).abs().max().item(), 4e-6 * max(1.0, ref.abs().max().item())))
+    for (Bn, H, Nq, Nk, hd) in ((2, 8, 256, 256, 32), (3, 8, 1, 300, 32), (1, 4, 130, 70, 64), (2, 8, 512, 512, 32)):
+        D = H * hd
+        qkv = rnd(Bn * max(Nq, Nk), 3 * D, seed=Nq + Nk).float().to(DEV)
+        q = qkv[: Bn * Nq, :D]; k = qkv[: Bn * Nk, D:2 * D]; v = qkv[: Bn * Nk, 2 * D:]
+        o = torch.empty((Bn * Nq, D), device=DEV, dtype=torch.float32)
+        ops.attention_f32(q, k, v, o, Bn, H, Nq, Nk, hd, (Nq * 3 * D, hd, 3 * D), (Nk * 3 * D, hd, 3 * D), (Nk * 3 * D, hd, 3 * D), (Nq * D, hd, D))
+        sp = lambda t, n: f64(t).reshape(Bn, n, H, hd).transpose(1, 2)
+        ref = (torch.softmax(sp(q, Nq) @ sp(k, Nk).transpose(-1, -2) / hd ** 0.5, -1) @ sp(v, Nk)).transpose(1, 2).reshape(Bn * Nq, D)
+        res.append((f"attention_f32 B={Bn} heads={H} Nq={Nq} Nk={Nk} hd={hd}", (f64(o) - ref).abs().max().item(), 4e-6 * max(1.0, ref.abs().max().item())))
+    t, e = rnd(256, seed=1).float().to(DEV), rnd(300, 256, seed=2).float().to(DEV)
+    ref = (f64(e) / f64(e).norm(dim=-1, keepdim=True)) @ (f64(t) / f64(t).norm())
+    res.append(("cosine_f32 300x256", (f64(ops.cosine_f32(t, e)) - ref).abs().max().item(), 2e-6))
+    segs = (rnd(20, 256, 256, seed=3) > 0.2).to(BF).to(DEV)
+    feat = rnd(64 * 64, 256, seed=4).to(BF).to(DEV)
+    pb, ws = ops.mask_pullback_f32(segs, 64, 256)
+    up = F.interpolate(f64(feat).t().reshape(1, 256, 64, 64), size=(256, 256), mode="bilinear", align_corners=False)[0].flatten(1)      # [C, S*S]
+    wf = f64(segs).flatten(1)
+    ref = (wf @ up.t()) / (wf.sum(-1, keepdim=True) + 1e-8)
+    got = ops.linear_f32(pb, feat, w_kn=True) / (ws[:, None] + 1e-8)
+    res.append(("fp32 mask pooling (pull-back . features / sum) vs upsample-then-pool in float64", (f64(got) - ref).abs().max().item(), 2e-5 * max(1.0, ref.abs().max().item())))
+    return res

@@ -74,6 +74,9 @@ def check_tiny_inference(backbone="dinov2", with_bf16_cpu=True):
     with torch.no_grad():
         ref = olisa.model_forward(sd, cfg, **batch, inference=True, return_aux=True)
         got = m.model_forward(**_dev(batch), inference=True, return_aux=True)
+        m.fp32_head = False                                    # A/B: the bf16 MFMA head of rounds 1-5 on the same trunk outputs
+        got16 = m.model_forward(**_dev(batch), inference=True, return_aux=True)
+        m.fp32_head = True
         if with_bf16_cpu:
             lo = olisa.model_forward(_bf16_sd(sd), cfg, **_bf16_batch(batch), inference=True, return_aux=True)
     B, C, g, _ = ref["feats"].shape
@@ -84,6 +87,8 @@ def check_tiny_inference(backbone="dinov2", with_bf16_cpu=True):
         scale = max(1.0, r_.abs().max().item())
         lo_e = _e(l_, r_) if with_bf16_cpu else 0.0
         flat = f", flat-1e-3 {'met' if _e(g_, r_) <= 1e-3 else 'NOT met'}" if name in ("pred_similarity", "pred_iou") else ""     # north_star's flat bound, kept visible
+        if name in ("pred_similarity", "pred_iou"):
+            flat += f", bf16 head on the same trunk {_e(got16[name][0], r_):.2e}"
         res.append((f"{backbone} {name} (bf16-CPU err {lo_e:.2e}{flat})", _e(g_, r_), max(floor * scale, 1.5 * lo_e)))
 
     rows_per = got["feats"].shape[0] // B
@@ -237,6 +242,11 @@ def check_head_golden(golden_loader):
         iou = iou.view(C, K, 1).float().cpu()
         emb = emb.view(C, K, -1).float().cpu()
         res.append((f"head K={K} pred_iou vs oracle (rounded weights; bf16-CPU err {e_cpu:.2e})", (iou - ref_iou).abs().max().item(), max(4e-3, 1.5 * e_cpu)))
+        # the fp32-activation head (what inference runs, round 6): the same fp32 arithmetic as the oracle up to summation order
+        with torch.no_grad():
+            iou32, emb32 = m._mask_head_f32(pooled.to(BF).float().to(DEV), text.to(BF).float().to(DEV))
+        res.append((f"fp32 head K={K} pred_iou vs oracle (rounded weights)", (iou32.view(C, K, 1).cpu() - ref_iou).abs().max().item(), 2e-5))
+        res.append((f"fp32 head K={K} embedding vs oracle (rounded weights)", (emb32.view(C, K, -1).cpu() - ref_emb).abs().max().item(), 2e-5 * max(1.0, ref_emb.abs().max().item())))
         res.append((f"head K={K} embedding vs oracle (rounded weights)", (emb - ref_emb).abs().max().item(), 2e-2 * max(1.0, ref_emb.abs().max().item())))
         # against the reference fixture itself (fp32, un-rounded weights): adds the bf16 rounding of the weights
         res.append((f"head K={K} pred_iou vs reference fixture", (iou - g[key_iou]).abs().max().item(), 8e-3))

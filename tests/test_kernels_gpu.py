@@ -36,6 +36,11 @@ def test_attention():
     _run(kc.check_attention)
 
 
+def test_head_f32_kernels():
+    from tests import kernel_checks as kc
+    _run(kc.check_head_f32)
+
+
 def test_decode_attn():
     from tests import kernel_checks as kc
     _run(kc.check_decode_attn)
