@@ -89,7 +89,8 @@ def check_tiny_inference(backbone="dinov2", with_bf16_cpu=True):
         flat = f", flat-1e-3 {'met' if _e(g_, r_) <= 1e-3 else 'NOT met'}" if name in ("pred_similarity", "pred_iou") else ""     # north_star's flat bound, kept visible
         if name in ("pred_similarity", "pred_iou"):
             flat += f", bf16 head on the same trunk {_e(got16[name][0], r_):.2e}"
-        res.append((f"{backbone} {name} (bf16-CPU err {lo_e:.2e}{flat})", _e(g_, r_), max(floor * scale, 1.5 * lo_e)))
+        # round 6: the scores come from the fp32 head -- their multiplier is 1.0 (the HIP path must beat ONE draw of the reference's own bf16 arithmetic), was 1.5
+        res.append((f"{backbone} {name} (bf16-CPU err {lo_e:.2e}{flat})", _e(g_, r_), max(floor * scale, (1.0 if name in ("pred_similarity", "pred_iou") else 1.5) * lo_e)))
 
     rows_per = got["feats"].shape[0] // B
     gf = got["feats"].view(B, rows_per, C)[:, rows_per - g * g:].reshape(B * g * g, C)
