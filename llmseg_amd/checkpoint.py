@@ -118,6 +118,8 @@ def load_zero2_optimizer_states(tag_dir, model, trainer):
       * the flat vector of a group = its parameters concatenated, zero-padded to a multiple of 2 x world, cut into `world` equal partitions.
     Raises when the files do not have that shape; -> dict(restored=[names], skipped=[names of the file the model does not train], step=int)."""
     import glob
+    # TRUST ASSUMPTION (here and in `load_reference_checkpoint`): DeepSpeed's rank files pickle more than tensors, so they are unpickled in full --
+    # load only checkpoints you would hand to the reference's own `model_engine.load_checkpoint` (training.py:404-421).
     ms = torch.load(os.path.join(tag_dir, "mp_rank_00_model_states.pt"), map_location="cpu", weights_only=False)
     shapes = ms.get("param_shapes")
     if not shapes:
@@ -139,7 +141,13 @@ def load_zero2_optimizer_states(tag_dir, model, trainer):
         st = [p["base_optimizer_state"]["state"][g] for p in parts]
         flat["m"] = torch.cat([s_["exp_avg"].float().reshape(-1) for s_ in st])
         flat["v"] = torch.cat([s_["exp_avg_sq"].float().reshape(-1) for s_ in st])
-        step = max(step, int(st[0].get("step", 0)))
+        g_step = st[0].get("step")
+        if g_step is None:                                   # some optimizers keep `step` in the param group, not in the per-parameter state
+            pgs = parts[0]["base_optimizer_state"].get("param_groups", [])
+            g_step = pgs[g].get("step") if g < len(pgs) and isinstance(pgs[g], dict) else None
+        if g_step is None:
+            g_step = ms.get("global_steps")
+        step = max(step, int(g_step or 0))
         need = sum(int(torch.Size(shp).numel()) for shp in group.values())
         align = 2 * world
         if not (need <= flat["master"].numel() <= (need + align - 1) // align * align + align):
@@ -158,6 +166,10 @@ def load_zero2_optimizer_states(tag_dir, model, trainer):
             else:
                 skipped.append(name)
             off += n
+    if step == 0 and restored and any(float(m_.abs().max()) > 0 for m_ in trainer.opt.m):
+        import warnings
+        warnings.warn("ZeRO-2 optimizer partitions carry warm Adam moments but no step count (state, param_groups and global_steps all lack it): bias correction "
+                      "and the LR warm-up would restart at 0 -- set trainer.opt.t / trainer.opt_steps yourself", RuntimeWarning, stacklevel=2)
     trainer.opt.t = step
     return {"restored": restored, "skipped": skipped, "step": step, "not_in_file": [n for n in names if n not in set(restored)]}
 

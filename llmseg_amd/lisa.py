@@ -141,6 +141,10 @@ class LISAForCausalLM(TrainableMixin, GenerateMixin, SamDecoderMixin, AmgMixin, 
         assert torch_dtype == BF16, "the HIP path computes in bf16 (training.py:151-156 `--precision bf16`)"
         cfg = pretrained.config_from_hf(version, backbone=backbone, sam_decoder=sam_decoder, **(towers or {}))     # towers: {"clip" / "sam" / "dino": config} when not ViT-L / ViT-H / ViT-L
         file_vocab = cfg.llama.vocab
+        if vocab_size is None:
+            import warnings
+            warnings.warn(f"from_pretrained: vocab_size not given -- assuming len(tokenizer) = the file's {file_vocab} + 1 ([SEG] added, training.py:130-135).  A checkpoint "
+                          "that already holds [SEG] (a LISA / LLM-Seg export) needs vocab_size = its own row count and the matching seg_token_idx.", RuntimeWarning, stacklevel=2)
         cfg.llama.vocab = int(vocab_size) if vocab_size is not None else file_vocab + 1          # pass len(tokenizer); default: the file's + [SEG]
         cfg.llama.lora_r, cfg.llama.lora_alpha, cfg.llama.lora_dropout = lora_r, lora_alpha, lora_dropout
         m = cls(cfg, device=device, **model_args)

@@ -39,6 +39,8 @@ def _read_file(path):
     try:
         sd = torch.load(path, map_location="cpu", weights_only=True)
     except Exception:                                  # noqa: BLE001 -- old checkpoints pickle more than tensors
+        # TRUST ASSUMPTION: a full unpickle executes code from the file.  Only reached for files the tensors-only reader rejects (the authors' 2023
+        # `.bin` / `.pth` exports); point the loaders at files you would also hand to the reference's own `torch.load` (build_sam.py:105, HF `from_pretrained`).
         sd = torch.load(path, map_location="cpu", weights_only=False)
     for k in ("state_dict", "model", "module"):        # common wrappers
         if isinstance(sd, dict) and k in sd and isinstance(sd[k], dict) and not torch.is_tensor(sd[k]):
@@ -99,10 +101,11 @@ def _own(model):
 
 
 @torch.no_grad()
-def _copy_in(model, items, rename, what, allow_extra_rows=()):
+def _copy_in(model, items, rename, what, allow_extra_rows=(), skip_mismatched=()):
     """Copy (name, tensor) pairs into the model.  `rename(name) -> key | None`.  -> dict(loaded, ignored, mismatched).
     `allow_extra_rows`: parameters that may have MORE rows than the file (vocabulary grown by added tokens): the file's rows are copied,
-    the remaining row indices are returned under `short` for `resize_token_embeddings`."""
+    the remaining row indices are returned under `short` for `resize_token_embeddings`.  `skip_mismatched`: key prefixes whose tensors are
+    optional extras of the file -- a shape mismatch there is recorded under `ignored` (with a warning) instead of raising."""
     own = _own(model)
     loaded, ignored, short = [], [], {}
     for name, t in items:
@@ -116,6 +119,11 @@ def _copy_in(model, items, rename, what, allow_extra_rows=()):
                 p[: t.shape[0]].copy_(t.to(device=p.device, dtype=p.dtype))
                 short[key] = int(t.shape[0])
                 loaded.append(key)
+                continue
+            if any(key.startswith(pre) for pre in skip_mismatched):
+                import warnings
+                warnings.warn(f"{what}: {name} has shape {tuple(t.shape)}, the model's {key} is {tuple(p.shape)}: skipped (optional tensor of the file)", RuntimeWarning, stacklevel=3)
+                ignored.append(name)
                 continue
             raise ValueError(f"{what}: {name} has shape {tuple(t.shape)}, the model's {key} is {tuple(p.shape)}")
         p.copy_(t.to(device=p.device, dtype=p.dtype))
@@ -141,7 +149,8 @@ def load_llava(model, llava_dir):
     (`model.vision_tower.*`, present in some exports) are loaded too when the shapes fit."""
     def rename(n):
         return None if any(p.search(n) for p in _SKIP) else n
-    res = _copy_in(model, iter_weights(llava_dir), rename, "LLaVA checkpoint", allow_extra_rows=("model.embed_tokens.weight", "lm_head.weight"))
+    res = _copy_in(model, iter_weights(llava_dir), rename, "LLaVA checkpoint", allow_extra_rows=("model.embed_tokens.weight", "lm_head.weight"),
+                   skip_mismatched=("model.vision_tower.",))
     return _finish(model, res, ("model.layers.", "model.embed_tokens.", "model.norm.", "lm_head.", "model.mm_projector."), "LLaVA checkpoint",
                    allow_missing=(".lora_",))
 

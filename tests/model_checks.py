@@ -356,7 +356,8 @@ def check_collate_batch(golden_loader, backbone="sam"):
     # floors: ONE bf16-CPU draw is no yardstick for a bounded score of this tiny model (its error on this batch was 7.5e-4 for pred_iou, 2.0e-3 on the
     # tiny-inference batch; HIP 1.1e-3 ... 3.5e-3 across two GEMM-dispatch revisions of identical arithmetic) -- the head-fixture test's floor for
     # pred_iou (4e-3: check_head_golden), half of it for the similarity; the flat 1e-3 of north_star stays visible in the line
-    for k, floor in (("pred_similarity", 2e-3), ("pred_iou", 4e-3)):
+    # round 6: the scores come from the fp32 head; pred_iou's floor is back from 4e-3 to 1.5e-3 (the 4e-3 floor had been set after a dispatch change moved the bf16 head's error to 3.5e-3)
+    for k, floor in (("pred_similarity", 2e-3), ("pred_iou", 1.5e-3)):
         lo_e, e = _e(lo[k][0], ref[k][0]), _e(got[k][0], ref[k][0])
         res.append((f"{backbone} collated val batch {k} (bf16-CPU err {lo_e:.2e}, flat-1e-3 {'met' if e <= 1e-3 else 'NOT met'})", e, max(floor, 1.5 * lo_e)))
     return res

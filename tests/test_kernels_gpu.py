@@ -12,6 +12,8 @@ def _need_gpu():
 
 def _run(fn):
     res = fn()
+    from tests._lines import record
+    record(res)
     bad = [(n, e, t) for n, e, t in res if not (e <= t)]
     assert not bad, "kernel parity failures: " + "; ".join(f"{n}: err {e:.3e} > tol {t:.3e}" for n, e, t in bad)
 

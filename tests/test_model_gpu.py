@@ -6,6 +6,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _assert(res):
+    from tests._lines import record
+    record(res)
     bad = [(n, e, t) for n, e, t in res if not (e <= t)]
     assert not bad, "; ".join(f"{n}: err {e:.3e} > tol {t:.3e}" for n, e, t in bad)
 

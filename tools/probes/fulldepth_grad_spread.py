@@ -1,16 +1,17 @@
 """Spread of the full-depth gradient comparison over seeds (weights, batch, dropout): tests/fulldepth_checks.py::check_full_depth_gradients for seeds 1..n,
 the distribution of RMS err HIP / RMS err bf16-CPU and max ratios per seed -> markdown on stdout (profiles/r05_spread_fulldepth_grads.md).
-    python tools/probes/fulldepth_grad_spread.py [n_seeds=2]        (~3 min of GPU box time per seed: two oracle forward+backward passes on the host)"""
+    python tools/probes/fulldepth_grad_spread.py [n_seeds=2] [first_seed=1]        (~3 min of GPU box time per seed: two oracle forward+backward passes on the host)"""
 import sys
 
 sys.path.insert(0, ".")
 from tests import fulldepth_checks as fc      # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 print("# Full-depth fwd+bwd gradient parity over seeds (BASELINE configs[2] shape; seed 0 is the suite's test: profiles/r05_fulldepth_grads.md)\n")
 print("| seed | tensors | median RMS ratio HIP / bf16-CPU | 90 % | max RMS ratio | max of max-error ratio | worst err / tol | failed | loss err (ref) | embed rows outside touched |")
 print("|---|---|---|---|---|---|---|---|---|---|")
-for seed in range(1, n + 1):
+for seed in range(first, first + n):
     table, logs = [], []
     res = fc.check_full_depth_gradients(seed=seed, table=table, log=logs.append)
     rr, mm, et = [], [], []
