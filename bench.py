@@ -129,7 +129,7 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
     T = args.prompt_len - 1 + cfg.n_img_tokens
     if args.mode == "train":
         trainer = trainer_cls(model, lr=3e-4, grad_accum=args.accum, device_ids=[local], use_graph=use_graph, ddp_wrapper=args.ddp_wrapper,
-                              force_ddp=args.force_ddp, leaf_stream=args.leaf_stream, time_comm=dist is not None)
+                              force_ddp=args.force_ddp, leaf_stream=args.leaf_stream, time_comm=dist is not None, overlap_exchange=args.overlap_exchange)
         # warm-up covers the eager warm-up calls of the graph path + the capture itself
         def first_optimizer_step():
             # the warm-up micro-steps never reach the optimizer (one step per --accum micro-steps): run it once untimed -- on a cold box its
@@ -166,10 +166,12 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
             eo, en = trainer.arena.block_of.get(trainer._embed_key, (0, 0))
             res["grad_exchange"] = {"optimizer_steps_timed": len(exp_ms), "exposed_ms_per_optimizer_step": (sum(exp_ms) / len(exp_ms)) if exp_ms else None,
                                     "allreduce_ms_dense_fp32_arena_alone": dense_ms, "arena_bytes": int(flat.numel() * 4), "embedding_block_bytes": int(en * 4),
-                                    "sparse_embedding_rows": bool(trainer.sparse_embed), "world": world,
+                                    "sparse_embedding_rows": bool(trainer.sparse_embed), "world": world, "overlap_exchange": bool(trainer.overlap_exchange),
+                                    "wire_dtype": str(trainer.wire_dtype).replace("torch.", "") if trainer.wire_dtype is not None else "float32",
                                     "micro_steps_per_optimizer_step": args.accum, "share_of_optimizer_step": ((sum(exp_ms) / len(exp_ms)) / (dt / args.steps * 1e3 * args.accum)) if exp_ms else None,
-                                    "note": "one exchange per optimizer step, issued after the last micro-step's backward (not overlapped with it); the embedding table's block "
-                                            "travels as an all-gather of the rows the window touched, the rest as asynchronous 128 MB all-reduce pieces"}
+                                    "note": "one exchange per optimizer step; without --overlap-exchange everything is issued after the last micro-step's backward, with it the arena's tail "
+                                            "(lm_head, text_hidden_fcs, lisa_*: ~half of the arena) leaves between the two halves of that backward and `exposed_ms` covers the rest; the embedding "
+                                            "table's block travels as an all-gather of its non-zero rows, the rest as asynchronous 128 MB all-reduce pieces"}
         # per-kernel timing: events cannot be recorded inside a replayed hipGraph, so the same micro-step runs eagerly (identical launches)
         # for a few steps right after the timed region, with an event pair around every GEMM launch on its stream
         trainer.use_graph = False
@@ -497,6 +499,7 @@ def main():
     ap.add_argument("--no-fwd-only", action="store_true", help="skip the forward-only measurement (profiling runs)")
     ap.add_argument("--no-overlap", action="store_true", help="issue the frozen backbone on the main stream instead of its own HIP stream")
     ap.add_argument("--leaf-stream", action="store_true", help="issue the arena's weight-gradient kernels on a side stream (A/B of autograd.Leaves; measured slower)")
+    ap.add_argument("--overlap-exchange", action="store_true", help="cut every backward at the Llama output and issue the arena tail's all-reduce between the halves of a window's last micro-step (Trainer(overlap_exchange=True))")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--ddp-wrapper", action="store_true", help="torch DDP wrapper + bf16 .grad instead of the fp32 gradient arena")
     ap.add_argument("--force-ddp", "--force-dist", dest="force_ddp", action="store_true",

@@ -261,7 +261,7 @@ class Trainer:
     def __init__(self, module, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.0, clip=1.0, grad_accum=10, warmup=100, total_steps=5000,
                  optimizer=None, device_ids=None, force_ddp=False, ddp_wrapper=False, use_graph=False, graph_warmup=2, use_arena=None,
                  reduce_chunk_mb=128, sync_init=True, check_every=100, leaf_stream=False, fused_accum=1, sparse_embed=None, time_comm=False, wire_dtype="auto",
-                 max_graphs=None):
+                 max_graphs=None, overlap_exchange=False):
         """optimizer: None = HipAdamW; or a factory `params -> optimizer` / an optimizer object (CPU tests).  use_arena: None = automatic
         (the HIP model with the built-in optimizer), True = force the fp32 gradient arena (the module's autograd Functions must honour `_g32`)."""
         self.module = module
@@ -313,6 +313,22 @@ class Trainer:
             wire_dtype = torch.bfloat16 if (self.dist_on and self.world > 1 and is_hip_model and self.arena is not None) else None
         self.wire_dtype = wire_dtype
         self.time_comm = bool(time_comm)                                 # bench / tests: event pair around the exchange of every optimizer step
+        # overlap_exchange (the reference's DeepSpeed `overlap_comm`, training.py:321-329): every micro-step's backward runs in two halves cut at
+        # the Llama output -- A: loss -> lm_head / CE, text_hidden_fcs, the mask-selection head (their gradients are the TAIL of the arena: blocks
+        # `model.text_hidden_fcs*`, `model.lisa_*`, `lm_head` follow the decoder layers in parameter order); B: the decoder stack (LoRA blocks) and the
+        # embedding rows.  On the LAST micro-step of a window the tail's all-reduce pieces are issued between A and B and travel while B (~19 ms at two
+        # images) computes; after B only the head of the arena (LoRA: 16 MB, + the embedding rows) is left to exchange.  Same kernels in the same order
+        # on the same data: the arena holds the same bits as without the cut.  With hipGraphs a micro-step is TWO graphs (A, B) replayed back to back.
+        self.overlap_exchange = bool(overlap_exchange) and self.arena is not None and is_hip_model
+        self._tail_start = None
+        self._pending = None
+        if self.overlap_exchange:
+            tail = lambda k: k.startswith("model.text_hidden_fcs") or k.startswith("model.lisa_") or k.startswith("lm_head")
+            blocks = sorted(self.arena.block_of.items(), key=lambda kv: kv[1][0])
+            first = next((i for i, (k, _) in enumerate(blocks) if tail(k)), None)
+            ok = first is not None and all(tail(k) for k, _ in blocks[first:]) and not any(tail(k) for k, _ in blocks[:first])
+            assert ok, "overlap_exchange: the arena's tail is not exactly {text_hidden_fcs, lisa_*, lm_head} (parameter order changed?)"
+            self._tail_start = blocks[first][1][0]
         self.comm_ms = []
         self.micro = 0
         self.opt_steps = 0
@@ -410,7 +426,7 @@ class Trainer:
         if self.arena is not None and self.is_hip_model:
             if plan is None:
                 plan = self.module.make_plan(**batch)
-            out = self._graph_step(batch, plan) if self.use_graph else self._eager_step(batch, plan)
+            out = self._graph_step(batch, plan, last) if self.use_graph else self._eager_step(batch, plan, last)
         elif self.arena is not None:
             out = self.module(**batch)
             out["loss"].backward()
@@ -488,16 +504,40 @@ class Trainer:
             Leaves.join()
             Leaves.on = False
 
-    def _eager_step(self, batch, plan):
-        out = self.module.model_forward(**batch, plan=plan)
-        self._backward(out["loss"])
+    def _eager_step(self, batch, plan, last=False):
+        if not self.overlap_exchange:
+            out = self.module.model_forward(**batch, plan=plan)
+            self._backward(out["loss"])
+            return out
+        self.module.__dict__["_split_backward"] = True
+        try:
+            out = self.module.model_forward(**batch, plan=plan)
+            root, leaf = self.module.__dict__.pop("_split_pair")
+        finally:
+            self.module.__dict__.pop("_split_backward", None)
+        self._backward(out["loss"])                      # half A: everything downstream of the Llama output
+        if last:
+            self._issue_tail_exchange()
+        root.backward(leaf.grad)                         # half B: the decoder stack, LoRA blocks, embedding rows
         return out
 
-    def _graph_step(self, batch, plan):
+    def _issue_tail_exchange(self):
+        """Between the two halves of the window's last backward: the arena's tail is final -- its all-reduce pieces leave now and travel beside half B."""
+        if self.dist_on and self._pending is None:
+            self._pending = self._issue_dense([(self._tail_start, self.arena.flat.numel())])
+
+    def _issue_dense(self, spans):
+        """Asynchronous all-reduce of arena spans in `reduce_chunk`-element pieces (bf16 copies when `wire_dtype` says so) -> [(piece, wire buffer, work)]."""
+        flat = self.arena.flat
+        pieces = [flat[o:min(o + self.reduce_chunk, b)] for a, b in spans for o in range(a, b, self.reduce_chunk)]
+        wire = [pc if self.wire_dtype in (None, pc.dtype) else pc.to(self.wire_dtype) for pc in pieces]
+        return [(pc, wb, dist.all_reduce(wb, async_op=True)) for pc, wb in zip(pieces, wire)]
+
+    def _graph_step(self, batch, plan, last=False):
         ent = self._graphs.setdefault((plan.sig, _input_sig(batch)), {"calls": 0, "graph": None})
         if ent["graph"] is None and (ent["calls"] < self.graph_warmup or self.graph_error is not None):
             ent["calls"] += 1
-            return self._eager_step(batch, plan)       # eager warm-up (lazy caches, workspace) -- also a real micro-step
+            return self._eager_step(batch, plan, last)       # eager warm-up (lazy caches, workspace) -- also a real micro-step
         if ent["graph"] is None:
             if self.max_graphs is not None:
                 live = [(e.get("used", 0), k) for k, e in self._graphs.items() if e.get("graph") is not None]
@@ -514,7 +554,7 @@ class Trainer:
                               "launches at roughly half the speed", RuntimeWarning, stacklevel=3)
                 torch.cuda.synchronize()
                 ent["graph"] = None
-                return self._eager_step(batch, plan)
+                return self._eager_step(batch, plan, last)
         self._graph_clock += 1
         ent["used"] = self._graph_clock
         _copy_batch(ent["batch"], batch)
@@ -522,6 +562,10 @@ class Trainer:
             ent["plan"].copy_tensors_from(plan)
             ent["last_plan"] = plan
         ent["graph"].replay()
+        if ent.get("graph_b") is not None:               # overlap_exchange: the micro-step is two graphs, the tail's exchange leaves between them
+            if last:
+                self._issue_tail_exchange()
+            ent["graph_b"].replay()
         return ent["out"]
 
     def graph_buffers(self, batch, plan):
@@ -544,10 +588,26 @@ class Trainer:
         torch.cuda.synchronize()
         gplan = plan.clone()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            out = self.module.model_forward(**sb, plan=gplan)
-            self._backward(out["loss"])
-        ent.update(graph=g, batch=sb, plan=gplan, last_plan=plan, out={k: v.detach() for k, v in out.items() if torch.is_tensor(v)})
+        gb = keep = None
+        if not self.overlap_exchange:
+            with torch.cuda.graph(g):
+                out = self.module.model_forward(**sb, plan=gplan)
+                self._backward(out["loss"])
+        else:
+            self.module.__dict__["_split_backward"] = True
+            try:
+                with torch.cuda.graph(g):                # graph A: forward + the backward of everything downstream of the Llama output
+                    out = self.module.model_forward(**sb, plan=gplan)
+                    root, leaf = self.module.__dict__.pop("_split_pair")
+                    self._backward(out["loss"])
+            finally:
+                self.module.__dict__.pop("_split_backward", None)
+                self.module.__dict__.pop("_split_pair", None)
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb, pool=g.pool()):    # graph B: the decoder stack's backward from the gradient graph A left in `leaf.grad`
+                root.backward(leaf.grad)
+            keep = (leaf, leaf.grad)                     # (graph B reads this buffer on every replay)
+        ent.update(graph=g, graph_b=gb, keep=keep, batch=sb, plan=gplan, last_plan=plan, out={k: v.detach() for k, v in out.items() if torch.is_tensor(v)})
 
     # ------------------------------------------------------------------------------------------------ optimizer step
     def optimizer_step(self):
@@ -600,12 +660,13 @@ class Trainer:
         if self.sparse_embed:
             eo, en = self.arena.block_of[self._embed_key]
             spans = [(a, b) for a, b in ((0, eo), (eo + en, flat.numel())) if b > a]
-        pieces = [flat[o:min(o + self.reduce_chunk, b)] for a, b in spans for o in range(a, b, self.reduce_chunk)]
-        wire = [pc if self.wire_dtype in (None, pc.dtype) else pc.to(self.wire_dtype) for pc in pieces]
-        works = [dist.all_reduce(wb, async_op=True) for wb in wire]
+        issued, self._pending = (self._pending or []), None
+        if issued:                                       # overlap_exchange: the tail left between the two halves of the last backward
+            spans = [(a, min(b, self._tail_start)) for a, b in spans if a < self._tail_start]
+        issued = issued + self._issue_dense(spans)
         if rows_plan is not None:
             self._exchange_embed_rows(*rows_plan)        # queued behind the dense pieces on the collective stream
-        for pc, wb, w in zip(pieces, wire, works):
+        for pc, wb, w in issued:
             w.wait()                                     # stream-level wait on a device backend: the host runs ahead
             if wb is not pc:
                 pc.copy_(wb)                             # back to the fp32 arena (every rank widens the same bf16 sums: replicas stay identical)

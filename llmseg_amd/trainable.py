@@ -392,6 +392,12 @@ class TrainableMixin:
                 proj = proj.view(-1, (Pn + 1) * H).index_select(0, plan.clip_index).view(N * (Pn + 1), H)
         embeds = F.embed_splice(input_ids.contiguous(), self._w("model.embed_tokens.weight", F), proj[1:], Pn, (Pn + 1) * H, plan.tok_index)
         hidden = self._llama(embeds, plan.key_mask, F, drop_seg_rows=plan.__dict__.get("drop_seg_rows", 0))
+        if F.grad and self.__dict__.get("_split_backward"):
+            # `Trainer(overlap_exchange=True)`: cut the autograd graph at the Llama output.  backward(loss) then stops at `leaf` with everything
+            # downstream of the decoder stack (lm_head, text_hidden_fcs, the mask-selection head: the tail of the gradient arena) final, and
+            # `root.backward(leaf.grad)` runs the decoder stack's backward -- the trainer issues the tail's all-reduce between the two.
+            root, hidden = hidden, hidden.detach().requires_grad_(True)
+            self.__dict__["_split_pair"] = (root, hidden)
         logits, loss = None, None
         gathered = plan.new_labels is not None and not want_logits and plan.ce_rows is not None and self.ce_gather_first
         if want_logits or (plan.new_labels is not None and not gathered):

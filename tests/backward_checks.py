@@ -1232,3 +1232,53 @@ def check_window_towers(k=3):
     res.append((f"window towers (4): ... vs one at a time (configs[3]'s micro-batch, M = 4096 / 4900: K-sliced plans): {nd} elements differ; max difference",
                 float((v6.float() - v1.float()).abs().max()), 2 * ulp(v6)))
     return res
+
+
+def check_overlap_exchange():
+    """`Trainer(overlap_exchange=True)` (the reference's DeepSpeed `overlap_comm`, training.py:321-329): every micro-step's backward
+    cut at the Llama output -- half A (lm_head / CE, text_hidden_fcs, the mask-selection head), [the arena tail's all-reduce leaves here on the last
+    micro-step of a window], half B (decoder stack, LoRA, embedding rows).  Without a process group nothing is exchanged, so this checks the cut itself:
+    the same kernels in the same order on the same data -> the SAME BITS in the arena, the same losses and master weights as the uncut trainer, eagerly and
+    as the two-graph replay; and that the arena's tail is exactly what half A finishes (the head of the arena is still zero between the halves)."""
+    from llmseg_amd.train import Trainer
+    from tests import model_checks as mc
+    res = []
+    runs = {}
+    for mode, kw in (("plain eager", dict()), ("cut eager", dict(overlap_exchange=True)), ("plain graph", dict(use_graph=True, graph_warmup=1)),
+                     ("cut graph", dict(use_graph=True, graph_warmup=1, overlap_exchange=True))):
+        cfg, m, sd, batch = _lora_case("sam")
+        m.set_dropout_seed(21, 0)
+        tr = Trainer(m, lr=2e-3, grad_accum=2, warmup=0, total_steps=20, **kw)
+        seen = []
+        tr.grad_hook = lambda t, ss: seen.append((t.arena.flat.detach().clone(), float(ss)))
+        db = mc._dev(batch)
+        plan = m.make_plan(**db)
+        losses = [float(tr.micro_step(db, plan)["loss"]) for _ in range(6)]
+        torch.cuda.synchronize()
+        if kw.get("use_graph"):
+            assert tr.graph_error is None, tr.graph_error
+            ents = [e for e in tr._graphs.values() if e["graph"] is not None]
+            assert ents and all((e.get("graph_b") is not None) == bool(kw.get("overlap_exchange")) for e in ents)
+        if kw.get("overlap_exchange"):
+            # the tail boundary: between the halves of an eager micro-step the arena's head (embedding, LoRA) must still be untouched
+            tr.arena.zero_()
+            m.__dict__["_split_backward"] = True
+            out = m.model_forward(**db, plan=plan)
+            root, leaf = m.__dict__.pop("_split_pair"); m.__dict__.pop("_split_backward")
+            out["loss"].backward()
+            head_nz = float((tr.arena.flat[: tr._tail_start] != 0).sum())
+            tail_nz = float((tr.arena.flat[tr._tail_start:] != 0).float().mean())
+            root.backward(leaf.grad)
+            head_after = float((tr.arena.flat[: tr._tail_start] != 0).sum())
+            res.append((f"overlap exchange [{mode}]: after half A the arena's head (embedding + LoRA blocks, {tr._tail_start} elements) is still zero; non-zero elements", head_nz, 0.0))
+            res.append((f"overlap exchange [{mode}]: half A filled the tail (non-zero fraction {tail_nz:.3f}) and half B the head ({int(head_after)} elements)",
+                        0.0 if (tail_nz > 0.3 and head_after > 0) else 1.0, 0.5))
+        runs[mode] = (losses, [a for a, _ in seen], [s_ for _, s_ in seen], torch.cat([w.flatten() for w in tr.opt.master]).clone())
+        tr.close()
+    ref = runs["plain eager"]
+    for mode in ("cut eager", "plain graph", "cut graph"):
+        l, arenas, sss, w = runs[mode]
+        res.append((f"overlap exchange: [{mode}] losses identical to the uncut eager trainer", 0.0 if l == ref[0] else 1.0, 0.5))
+        res.append((f"overlap exchange: [{mode}] arena elements that differ over 3 optimizer steps", float(sum((a != b).sum() for a, b in zip(arenas, ref[1]))), 0.0))
+        res.append((f"overlap exchange: [{mode}] master weights that differ after 3 optimizer steps", float((w != ref[3]).sum()), 0.0))
+    return res

@@ -104,6 +104,11 @@ def test_window_step_with_batched_frozen_towers():
     _assert(bc.check_window_towers(3))
 
 
+def test_backward_cut_at_the_llama_output_for_the_exchange_overlap():
+    from tests import backward_checks as bc
+    _assert(bc.check_overlap_exchange())
+
+
 def test_graph_trainer_with_rotating_batches():
     from tests import backward_checks as bc
     _assert(bc.check_graph_rotating_batches())

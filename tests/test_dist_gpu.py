@@ -24,8 +24,8 @@ def _run_window(mode, steps=4, accum=2):
         tr = Trainer(m, ddp_wrapper=True, force_ddp=(mode == "ddp"), device_ids=[0], **kw)
         assert (tr.ddp is not None) == (mode == "ddp") and tr.arena is None
     else:
-        tr = Trainer(m, **kw)
-        assert tr.arena is not None and tr.dist_on == (mode == "arena_dist")
+        tr = Trainer(m, overlap_exchange=(mode == "arena_dist_overlap"), time_comm=(mode == "arena_dist_overlap"), **kw)
+        assert tr.arena is not None and tr.dist_on == mode.startswith("arena_dist")
     db = mc._dev(batch)
     losses = []
     for _ in range(steps):
@@ -43,6 +43,7 @@ def test_world1_process_group_paths():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         l1, p1, n1 = _run_window("arena_dist")
+        l2, p2, n2 = _run_window("arena_dist_overlap")      # the tail's all-reduce issued between the two halves of the window's last backward
         g1, q1, _ = _run_window("ddp")
     finally:
         dist.destroy_process_group()
@@ -50,6 +51,7 @@ def test_world1_process_group_paths():
     # the all-reduce over one rank is the identity and no kernel sums with atomics: the same losses and parameters, bit for bit
     assert l0 == l1, (l0, l1)
     assert torch.equal(p0, p1), (p0 - p1).abs().max().item()
+    assert l0 == l2 and n2 == 2 and torch.equal(p0, p2), ((p0 - p2).abs().max().item(), l0, l2)
     assert g0 == g1, (g0, g1)
     assert torch.equal(q0, q1), (q0 - q1).abs().max().item()
     # arena (fp32 accumulation) vs bf16 .grad accumulation: the same training trajectory up to bf16 gradient rounding
@@ -104,9 +106,9 @@ def _two_rank_worker(rank, world, port, ret, tmp, wire):
                 for p in m.trainable_parameters():
                     p.add_(0.03)
         m.set_dropout_seed(SEED, 0)
-        tr = Trainer(m, lr=LR, grad_accum=ACCUM, warmup=0, total_steps=20, reduce_chunk_mb=8, **({} if wire == "default" else {"wire_dtype": None}))
+        tr = Trainer(m, lr=LR, grad_accum=ACCUM, warmup=0, total_steps=20, reduce_chunk_mb=8, **({"wire_dtype": None} if wire == "fp32" else {}), overlap_exchange=(wire == "overlap"))
         assert tr.arena is not None and tr.dist_on and tr.arena.flat.numel() > 2 * tr.reduce_chunk, (tr.arena.flat.numel(), tr.reduce_chunk)
-        assert tr.sparse_embed and tr.wire_dtype == (torch.bfloat16 if wire == "default" else None), (tr.sparse_embed, tr.wire_dtype)
+        assert tr.sparse_embed and tr.wire_dtype == (None if wire == "fp32" else torch.bfloat16) and tr.overlap_exchange == (wire == "overlap"), (tr.sparse_embed, tr.wire_dtype)
         if rank == 0:
             torch.save(torch.tensor(tr.arena.block_of[tr._embed_key]), os.path.join(tmp, "embed_block.pt"))
         assert int(m.dropout_state()[0]) == rank_dropout_seed(SEED, rank)
@@ -124,16 +126,17 @@ def _two_rank_worker(rank, world, port, ret, tmp, wire):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("wire", ["fp32", "default"])
+@pytest.mark.parametrize("wire", ["fp32", "default", "overlap"])
 def test_two_ranks_share_one_gpu_gloo(tmp_path, wire):
     """wire = "default": what a multi-rank Trainer does unless told otherwise -- dense pieces in bf16 on the wire (the reference's DeepSpeed bf16 engine,
-    training.py:314-329), the embedding block as fp32 rows; "fp32": `wire_dtype=None`."""
+    training.py:314-329), the embedding block as fp32 rows; "fp32": `wire_dtype=None`; "overlap": the default wire + `overlap_exchange=True` (the arena's tail
+    leaves between the two halves of the window's last backward, DeepSpeed's `overlap_comm`)."""
     import torch.multiprocessing as mp
     from llmseg_amd.train import Trainer, rank_dropout_seed
     from tests import backward_checks as bc, model_checks as mc
     world = 2
     ret = mp.Manager().dict()
-    mp.spawn(_two_rank_worker, args=(world, 29581 if wire == "fp32" else 29583, ret, str(tmp_path), wire), nprocs=world, join=True)
+    mp.spawn(_two_rank_worker, args=(world, {"fp32": 29581, "default": 29583, "overlap": 29585}[wire], ret, str(tmp_path), wire), nprocs=world, join=True)
     (l0, p0, n0, ss0), (l1, p1, n1, ss1) = ret[0], ret[1]
     assert n0 == n1 == OPT_STEPS and ss0 == ss1
     assert torch.equal(p0, p1), (p0 - p1).abs().max().item()           # replicas bit-identical after the exchanges
