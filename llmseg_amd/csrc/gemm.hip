@@ -508,6 +508,69 @@ __global__ __launch_bounds__(NT, NBUF == 2 ? (MI == 4 ? 1 : 2) : (MI == 4 ? 2 : 
 }
 
 
+// ---- variant G4 (round 6): 128 x 128 tile, 4 waves, FOUR-stage LDS-DMA ring with counted waits ---------------------------------------------
+// For the products that put at most one workgroup on a CU (CLIP at two sequences: M = 514; the mask-selection head: M = C K = 512, N = 256 ... 2048):
+// there the 128 x 128 kernel above has nothing to hide its fetch latency with (its one or two buffers wait for every K-tile: 16.6-17.3 us on
+// 514 x 3072 x 1024 whichever kernel ran it, profiles/r04g_small_gemm_variants.txt).  Here THREE K-tiles (96 KiB) are in flight while the fourth
+// stage is computed: iteration t = { s_waitcnt vmcnt(stages still allowed in flight) | s_barrier | issue K-tile t + 3 into the buffer iteration
+// t - 1 read (every wave has passed the barrier, so every wave has finished reading it) | 16 MFMAs on stage t }.  Same lane -> (row, chunk) DMA
+// mapping, swizzle and MFMA order as the kernel above: identical bits.  K % 64 == 0; 128 KiB of LDS, one workgroup per CU.
+#define G4_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+template <bool OUT_F32>
+__global__ __launch_bounds__(NT, 1) void gemm_bf16_tn_g4_kernel(GemmP p) {
+  constexpr int MI = 2, BM = 128, NS = 4;
+  constexpr int A_BYTES = BM * BK * 2, BUF = A_BYTES + BN * BK * 2;          // 16 KiB + 16 KiB per stage
+  __shared__ __attribute__((aligned(16))) char smem[NS * BUF];
+  const TileXY tc = tile_of<BM>(p, blockIdx.x);
+  const int m0 = tc.m0, n0 = tc.n0;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const long b1 = blockIdx.y % p.batch1, b2 = blockIdx.y / p.batch1;
+  const long bz = b1 * p.sC + b2 * p.sC2;
+  const bf16_t* __restrict__ Ag = p.A + b1 * p.sA + b2 * p.sA2;
+  const bf16_t* __restrict__ Wg = p.W + b1 * p.sW + b2 * p.sW2;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ag + (long)m0 * p.lda), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Wg + (long)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
+  // DMA instruction i of this wave fills LDS rows (i*4 + wave)*8 .. +7 of an operand tile (1 KiB); per-lane byte offsets relative to the tile's first row
+  int a_off[4], w_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 4 + wave) * 8 + (lane >> 3);
+    const int sw = ((lane & 7) ^ ((row >> 1) & 7)) << 3;
+    a_off[i] = (int)(((long)min(row, p.M - 1 - m0) * p.lda + sw) * 2);
+    w_off[i] = (int)(((long)min(row, p.N - 1 - n0) * p.ldw + sw) * 2);
+  }
+  const int nt = p.K / BK;
+  auto issue = [&](int t, int st) {
+    char* base = smem + st * BUF;
+    const int koff = t * (BK * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(base + A_BYTES + (i * 4 + wave) * 1024), 16, w_off[i], koff, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(base + (i * 4 + wave) * 1024), 16, a_off[i], koff, 0, 0);
+  };
+  f32x16_t acc[2][MI];
+  zero_acc<MI>(acc);
+  const int frow = lane & 31, fhalf = lane >> 5;
+  issue(0, 0);
+  if (nt > 1) issue(1, 1);
+  if (nt > 2) issue(2, 2);
+  for (int t = 0; t < nt; ++t) {
+    const int ahead = min(nt - 1 - t, 2);            // K-tiles issued beyond t: 8 DMA instructions of this wave each
+    if (ahead == 2) G4_VM(16); else if (ahead == 1) G4_VM(8); else G4_VM(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 3 < nt) issue(t + 3, (t + 3) & 3);
+    const char* abase = smem + (t & 3) * BUF;
+    mma_slab<MI>(abase, abase + A_BYTES, wm, wn, frow, fhalf, acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();                                   // the epilogue's slabs alias stage 0
+  epilogue_lds<OUT_F32, MI>(p, Acc32<MI>{acc}, smem, wave, m0, n0, wm, wn, lane, bz);
+}
+
 // ---- variant Q: (64 MI) x 256 tile, 8 waves in two groups that run ONE BARRIER APART ("ping-pong") -------------------------
 // MI = 4: 256 x 256 (waves 2 x 4, each 128 x 64); MI = 2: 128 x 256 (each wave 64 x 64) for short matrices (Llama at 2 images per
 // micro-step has M = 638 rows: five 128-row tiles waste 0.3 % of the rows, three 256-row tiles 17 %).
@@ -1104,7 +1167,7 @@ void llmseg_prof_begin(hipStream_t s);
 void llmseg_prof_end(hipStream_t s, double flops);
 void llmseg_prof_tag(long a, long b, long c, long d);
 
-// tuning knob (tools/gemm_bench.py): bits 0-3 kernel (0 = register staging 128x128; 2 = LDS-DMA 128x128; 8 / 9 = LDS-DMA ping-pong
+// tuning knob (tools/gemm_bench.py): bits 0-3 kernel (0 = register staging 128x128; 2 = LDS-DMA 128x128; 3 = four-stage LDS-DMA 128x128; 8 / 9 = LDS-DMA ping-pong
 // 256x256 / 128x256; 5 (default) = cost model), bits 4-7 = XCD skew + 1, bits 8-12 = forced split-K slice count for 8 / 9.
 static int g_gemm_variant = 5, g_gemm_skew = 13, g_gemm_split = 0, g_gemm_pp2 = getenv("LLMSEG_GEMM_PP2") ? atoi(getenv("LLMSEG_GEMM_PP2")) : 1;
 static const int g_gemm_rsplit = getenv("LLMSEG_GEMM_NO_RSPLIT") ? 0 : 1;      // K-slices for the register-staging kernel (A/B switch)
@@ -1219,7 +1282,7 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
   const int nt = p.K / BK;
   const long ncu = num_cus();
   int variant = (p.K % BK == 0 && !ta && !tw) ? (force_variant >= 0 ? force_variant : g_gemm_variant) : 0;
-  if (variant != 0 && variant != 2 && variant != 8 && variant != 9) variant = 5;
+  if (variant != 0 && variant != 2 && variant != 3 && variant != 8 && variant != 9) variant = 5;
   if ((variant == 8 || variant == 9) && nt < (a->A2 ? 1 : 2)) variant = 2;
   // split-K needs a dense-enough problem for the slab layout [S][M][N], 4-column alignment and room in the caller's workspace
   const bool can_split = batch == 1 && (p.N & 3) == 0 && (p.ldc & 3) == 0 && a->workspace != nullptr &&
@@ -1237,6 +1300,16 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
           const double us = pp_cost(p.M, p.N, nt, mi, S, ncu, a->out_f32 != 0) * (double)batch;
           if (us < best.us * 0.97 || (us < best.us && S == 1)) best = GemmPlan{mi == 4 ? 8 : 9, S, us};
         }
+      }
+    }
+    // round 6: the four-stage 128 x 128 kernel for products that fit ONE round of the CUs (at most one workgroup per CU: nothing else hides the
+    // fetch latency there): ~0.55 us per K-tile behind a three-tile-deep DMA queue + ~4 us of first-tile latency and epilogue (tools/gemm_bench.py, GEMM_SET=clip)
+    static const int g4_env = getenv("LLMSEG_GEMM_G4") ? atoi(getenv("LLMSEG_GEMM_G4")) : 0;      // A/B switch: 1 = let the cost model pick it
+    if (g4_env && !a->A2 && nt >= 2) {
+      const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
+      if (t128 <= ncu) {
+        const double us = nt * 0.55 + 4.0;
+        if (us < best.us) best = GemmPlan{3, 1, us};
       }
     }
     variant = best.variant; split = best.split;
@@ -1394,6 +1467,10 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
     dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);
     switch (variant) {
       case 2: f ? launch_glds<true, 2, 1>(p, grid, s) : launch_glds<false, 2, 1>(p, grid, s); break;
+      case 3:
+        if (f) LL_LAUNCH_KERNEL((gemm_bf16_tn_g4_kernel<true>), grid, dim3(NT), 0, s, p);
+        else LL_LAUNCH_KERNEL((gemm_bf16_tn_g4_kernel<false>), grid, dim3(NT), 0, s, p);
+        break;
       case 8:
         if (p.A2) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<false, true, 4>), grid, dim3(NTB), 0, s, p);      // bf16 out only (checked above)
         else if (f) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<true, false, 4>), grid, dim3(NTB), 0, s, p);

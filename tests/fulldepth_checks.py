@@ -147,7 +147,7 @@ class _GradState(dict):
         return self[k] if k in self else default
 
 
-def check_full_depth_gradients(K=256, L=64, B=2, log=print, seed=0, table=None):
+def check_full_depth_gradients(K=256, L=64, B=2, log=print, seed=0, table=None, dump=None, hip_only=False):
     """BASELINE configs[2] at ITS OWN depth: 32-layer Llama-7B with LoRA r = 8 + dropout 0.05 on q / v, CLIP-L, 32-block SAM
     ViT-H, B = 2 images of 1024 x 1024, 64-token prompts, K = 256 proposals -- ONE training micro-step into the fp32 gradient arena -- against
     autograd through `oracle.lisa.model_forward` on the host with the same dropout masks (reference `model/LISA.py:225-474`, `training.py:546`).
@@ -213,10 +213,20 @@ def check_full_depth_gradients(K=256, L=64, B=2, log=print, seed=0, table=None):
     arena.detach()
     del m, arena, prm, out, emb_g
     torch.cuda.empty_cache()
+    if dump is not None:                               # (tools/probes/fd_seed_diag.py: the tensors themselves, for cross-comparisons between runs)
+        dump["hip"] = {n: hip_g[n].clone() for n in pick}
+        dump["hip_loss"] = hip_loss
+    if hip_only:
+        return []
 
     ref_loss, ref_g = run("ref", torch.float32)
     lo_loss, lo_g = run("lo", BF)
     flips = gt.flipped_rows()
+    if dump is not None:
+        dump["ref"] = {n: ref_g[n].detach().float().clone() for n in pick}
+        dump["lo"] = {n: lo_g[n].detach().float().clone() for n in pick}
+        dump["ref_loss"], dump["lo_loss"] = ref_loss, lo_loss
+        dump["flips"] = {k: v.clone() for k, v in flips.items()}
     res = []
     for k in ("ce_loss", "align_loss", "regression_loss", "loss"):
         r = ref_loss[k]
