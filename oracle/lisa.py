@@ -137,7 +137,12 @@ def model_forward(sd, cfg: LisaCfg, images, images_clip, input_ids, labels, atte
         clip_in = torch.cat([images_clip[i:i + 1].expand(r, -1, -1, -1) for i, r in enumerate(reps)], 0)
         ce, logits, hidden = llava_forward(sd, cfg, clip_in, attention_masks, input_ids, labels, dropout_state)
 
-    h = F.relu(F.linear(hidden, sd["model.text_hidden_fcs.0.0.weight"], sd["model.text_hidden_fcs.0.0.bias"]))
+    pre = F.linear(hidden, sd["model.text_hidden_fcs.0.0.weight"], sd["model.text_hidden_fcs.0.0.bias"])
+    h = F.relu(pre)
+    g_forced = mask_head.forced("model.text_hidden_fcs.0.0", pre[segmask])         # test hook: gates imposed on the [SEG] rows (the only rows read below)
+    if g_forced is not None:
+        h = h.clone()
+        h[segmask] = pre[segmask] * g_forced
     if mask_head.TRACE is not None:                                                # test hook: gates of the rows that are gathered below
         mask_head.TRACE.setdefault("model.text_hidden_fcs.0.0", []).append(h.detach()[segmask])
     h = F.linear(h, sd["model.text_hidden_fcs.0.2.weight"], sd["model.text_hidden_fcs.0.2.bias"])

@@ -17,8 +17,36 @@ import torch.nn.functional as F
 TRACE = None
 
 
+# Test hook (round 6): gates imposed from outside.  {name of the feeding Linear: bool / float [samples, units]} (all calls of a forward pass stacked
+# in call order, as TRACE records them): where set, ReLU(x) is evaluated as x * gate -- the SAME piecewise-linear branch another evaluation of the
+# model took -- so that a gradient comparison measures arithmetic and not which side of a kink a pre-activation within rounding noise of zero fell
+# on.  At full depth the 256 proposal rows of an image are nearly identical (their spread is below one bf16 step), so a unit near zero flips for ALL
+# rows at once: one coherent flip moves every head gradient by several per cent (tests/fulldepth_checks.py, profiles/r06_head_bwd_diag_seed4.md).
+FORCE = None
+_FORCE_POS = {}
+
+
+def force_gates(gates):
+    """gates: None (off) or {name: tensor [samples, units]}; resets the per-name cursors."""
+    global FORCE
+    FORCE = gates
+    _FORCE_POS.clear()
+
+
+def forced(name, x2d):
+    """-> gate rows for the next x2d.shape[0] samples of `name`, or None."""
+    if FORCE is None or name not in FORCE:
+        return None
+    pos = _FORCE_POS.get(name, 0)
+    g = FORCE[name][pos:pos + x2d.shape[0]]
+    assert g.shape == x2d.shape, (name, tuple(g.shape), tuple(x2d.shape), pos)
+    _FORCE_POS[name] = pos + x2d.shape[0]
+    return g.to(x2d.dtype)
+
+
 def _relu(name, x):
-    y = F.relu(x)
+    g = forced(name, x.reshape(-1, x.shape[-1]))
+    y = F.relu(x) if g is None else x * g.reshape(x.shape)
     if TRACE is not None:
         TRACE.setdefault(name, []).append(y.detach().reshape(-1, y.shape[-1]))
     return y

@@ -147,7 +147,7 @@ class _GradState(dict):
         return self[k] if k in self else default
 
 
-def check_full_depth_gradients(K=256, L=64, B=2, log=print, seed=0, table=None, dump=None, hip_only=False):
+def check_full_depth_gradients(K=256, L=64, B=2, log=print, seed=0, table=None, dump=None, hip_only=False, force_gates=True):
     """BASELINE configs[2] at ITS OWN depth: 32-layer Llama-7B with LoRA r = 8 + dropout 0.05 on q / v, CLIP-L, 32-block SAM
     ViT-H, B = 2 images of 1024 x 1024, 64-token prompts, K = 256 proposals -- ONE training micro-step into the fp32 gradient arena -- against
     autograd through `oracle.lisa.model_forward` on the host with the same dropout masks (reference `model/LISA.py:225-474`, `training.py:546`).
@@ -219,8 +219,23 @@ def check_full_depth_gradients(K=256, L=64, B=2, log=print, seed=0, table=None, 
     if hip_only:
         return []
 
-    ref_loss, ref_g = run("ref", torch.float32)
-    lo_loss, lo_g = run("lo", BF)
+    # Round 6: both oracle runs differentiate the piecewise-linear branch the HIP forward took (its recorded ReLU gates are imposed: `oracle.mask_head.force_gates`).
+    # Why: at this size the 256 proposal rows of an image differ by less than one bf16 step (row spread 1.6e-3 of their magnitude), so a head unit whose
+    # pre-activation is within rounding noise of zero flips for ALL rows of the image at once; every such coherent flip moves all upstream head gradients
+    # by several per cent.  Seeds 3 and 4 of the spread (profiles/r06_spread_fulldepth_grads_seeds3-5.md) failed that way at 10 x the bf16-CPU draw, while
+    # the head backward ALONE -- HIP vs fp32 autograd on the HIP path's own head inputs and upstream gradients -- is within 1.2-5 % and TWICE as close as
+    # torch's bf16 autograd on the same inputs, and the loss kernel's gradients match float64 to 1e-6 (profiles/r06_head_bwd_diag_seed{0,4}.md).  Either
+    # subgradient at a kink is valid; what the comparison has to pin is the arithmetic on the branch taken.  force_gates=False restores the round-5 form.
+    from oracle import mask_head as omh_
+    if force_gates:
+        omh_.force_gates({n: torch.cat(v, 0) for n, v in gt.gates["hip"].items()})
+    try:
+        ref_loss, ref_g = run("ref", torch.float32)
+        if force_gates:
+            omh_.force_gates({n: torch.cat(v, 0) for n, v in gt.gates["hip"].items()})
+        lo_loss, lo_g = run("lo", BF)
+    finally:
+        omh_.force_gates(None)
     flips = gt.flipped_rows()
     if dump is not None:
         dump["ref"] = {n: ref_g[n].detach().float().clone() for n in pick}
