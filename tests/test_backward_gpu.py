@@ -49,7 +49,7 @@ def test_model_grads_lora_arena():
 def test_full_depth_configs2_gradients():
     """BASELINE configs[2] at its own depth: 32-layer Llama-7B (LoRA r 8 + dropout) + CLIP-L + 32-block SAM ViT-H, B = 2, K = 256, one
     micro-step into the fp32 arena vs autograd through the oracle on the host.  Writes the per-tensor ratio table to
-    gpurun_out/r05_fulldepth_grads.md (copied to profiles/)."""
+    gpurun_out/fulldepth_grads.md (copied to profiles/)."""
     import os
     free_gb = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2 ** 30
     if free_gb < 128:
@@ -61,7 +61,7 @@ def test_full_depth_configs2_gradients():
         print(f"{n}: err {e:.3e} tol {t:.3e}")
     try:
         os.makedirs("gpurun_out", exist_ok=True)
-        with open(os.path.join("gpurun_out", "r05_fulldepth_grads.md"), "w") as fh:
+        with open(os.path.join("gpurun_out", "fulldepth_grads.md"), "w") as fh:
             fh.write("# Full-depth fwd+bwd gradient parity (BASELINE configs[2]: 32-layer Llama-7B + LoRA r 8 + dropout 0.05, CLIP-L, SAM ViT-H, B = 2, K = 256)\n\n"
                      "HIP fp32 arena after ONE micro-step vs autograd through the fp32 oracle on the host; yardstick = the same oracle in bf16 on the CPU.\n\n"
                      + "\n".join(f"- {s}" for s in logs) + "\n\n"
