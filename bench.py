@@ -230,7 +230,12 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
                    "launch of the bf16-out form (row `...<false, false>`) or its LoRA extension-tile form (`...<false, true>`); %.0f kernel launches per step in all"
                    % (per("calls"), per("calls_as_k_slices"), di.get("k_slices", 0) / max(1, di.get("calls_as_k_slices", 0)),
                       per("calls") - per("calls_as_k_slices"), per("kernel_launches"))) if di else None
-    res["roofline"] = {"bound": "mfma", "kernel": prof["dominant_kernel"], "class_composition": composition, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+    res["roofline"] = {"bound": "mfma", "kernel": prof["dominant_kernel"], "class_composition": composition,
+                       "hottest_symbol": "by rocprofv3's per-symbol table (profiles/r06_b2_1stream_kernel_stats.md) the single hottest SYMBOL at 2 images is "
+                                         "gemm_bf16_tn_pp_kernel<false, false, 4> (the 256 x 256 tile: SAM products at M = 8192 / 9800; ~0.30 of peak): its calls are "
+                                         "counted under `other_gemm_classes` below.  `kernel` above names the dominant CLASS by total time = the 128 x 256 tile's three "
+                                         "symbols (bf16-out, fp32 K-slice slabs, LoRA extension tile) + their reduce launches (the Llama products at M = 638)",
+                       "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                        "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                        "algorithmic_bytes_per_launch": prof["dominant_alg_bytes"] / max(1, dom_launches), "launches_per_step": dom_launches / n_prof,
                        "launches_are": "user-level GEMM calls of the class (see class_composition); kernel launches per step: %.0f" % per("kernel_launches") if di else None,
@@ -509,6 +514,7 @@ def main():
     ap.add_argument("--accum", type=int, default=10, help="gradient-accumulation micro-steps per optimizer step (reference: 10)")
     ap.add_argument("--no-k512", action="store_true", help="skip the BASELINE configs[4] side measurement (512 candidate masks, grad-accum 8) reported under batch_<B>_k512")
     ap.add_argument("--no-accum-fused", action="store_true", help="skip the fused-accumulation-window side measurement (the --accum micro-batches of an optimizer step as one pass)")
+    ap.add_argument("--window-towers-only", action="store_true", help="profiling aid: measure only the window-towers side line")
     ap.add_argument("--no-window-towers", action="store_true", help="skip the side measurement with the frozen towers batched over the accumulation window (Trainer.window_step)")
     ap.add_argument("--no-mix", action="store_true", help="skip the BASELINE configs[3] side measurement (batch 1, sources drawn 9:3:1 -> 1-3 conversations per image)")
     ap.add_argument("--no-loader", action="store_true", help="skip the loader-in-the-loop side measurement (a different batch + device-side targets + a fresh plan every micro-step)")
@@ -567,6 +573,14 @@ def main():
         model.set_trainable()
     use_graph = train and not args.no_graph and not args.ddp_wrapper
 
+    if args.window_towers_only:                # profiling aid (tools/r06_final.sh): ONLY the window-towers side line, printed as its own small JSON line
+        r = window_towers(model, cfg, args, args.batch, dev, dist, rank, world, local, Trainer)
+        if rank == 0:
+            print(json.dumps({"metric": "images/sec (1024x1024, 64-tok prompt) model_forward fwd+bwd, frozen towers once per accumulation window (side line)", "value": r["value"],
+                              "unit": "images/s", "n_gpus": world, "side_line": True, "window_towers": r}), flush=True)
+        if dist:
+            dist.barrier(); dist.destroy_process_group()
+        return
     main_res = measure(model, cfg, args, args.batch, dev, dist, rank, world, local, use_graph, Trainer)
     extra = None
     if args.extra_batch and args.extra_batch != args.batch:
