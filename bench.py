@@ -129,7 +129,8 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
     T = args.prompt_len - 1 + cfg.n_img_tokens
     if args.mode == "train":
         trainer = trainer_cls(model, lr=3e-4, grad_accum=args.accum, device_ids=[local], use_graph=use_graph, ddp_wrapper=args.ddp_wrapper,
-                              force_ddp=args.force_ddp, leaf_stream=args.leaf_stream, time_comm=dist is not None, overlap_exchange=args.overlap_exchange)
+                              force_ddp=args.force_ddp, leaf_stream=args.leaf_stream, time_comm=dist is not None,
+                              overlap_exchange=(True if args.overlap_exchange else False if args.no_overlap_exchange else None))
         # warm-up covers the eager warm-up calls of the graph path + the capture itself
         def first_optimizer_step():
             # the warm-up micro-steps never reach the optimizer (one step per --accum micro-steps): run it once untimed -- on a cold box its
@@ -505,6 +506,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="issue the frozen backbone on the main stream instead of its own HIP stream")
     ap.add_argument("--leaf-stream", action="store_true", help="issue the arena's weight-gradient kernels on a side stream (A/B of autograd.Leaves; measured slower)")
     ap.add_argument("--overlap-exchange", action="store_true", help="cut every backward at the Llama output and issue the arena tail's all-reduce between the halves of a window's last micro-step (Trainer(overlap_exchange=True))")
+    ap.add_argument("--no-overlap-exchange", action="store_true", help="exchange everything after the window's last backward (the default under > 1 rank is to overlap the arena's tail with it)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--ddp-wrapper", action="store_true", help="torch DDP wrapper + bf16 .grad instead of the fp32 gradient arena")
     ap.add_argument("--force-ddp", "--force-dist", dest="force_ddp", action="store_true",

@@ -261,7 +261,7 @@ class Trainer:
     def __init__(self, module, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.0, clip=1.0, grad_accum=10, warmup=100, total_steps=5000,
                  optimizer=None, device_ids=None, force_ddp=False, ddp_wrapper=False, use_graph=False, graph_warmup=2, use_arena=None,
                  reduce_chunk_mb=128, sync_init=True, check_every=100, leaf_stream=False, fused_accum=1, sparse_embed=None, time_comm=False, wire_dtype="auto",
-                 max_graphs=None, overlap_exchange=False):
+                 max_graphs=None, overlap_exchange=None):
         """optimizer: None = HipAdamW; or a factory `params -> optimizer` / an optimizer object (CPU tests).  use_arena: None = automatic
         (the HIP model with the built-in optimizer), True = force the fp32 gradient arena (the module's autograd Functions must honour `_g32`)."""
         self.module = module
@@ -319,6 +319,10 @@ class Trainer:
         # embedding rows.  On the LAST micro-step of a window the tail's all-reduce pieces are issued between A and B and travel while B (~19 ms at two
         # images) computes; after B only the head of the arena (LoRA: 16 MB, + the embedding rows) is left to exchange.  Same kernels in the same order
         # on the same data: the arena holds the same bits as without the cut.  With hipGraphs a micro-step is TWO graphs (A, B) replayed back to back.
+        # Default (None): ON under a process group of more than one rank, off otherwise.  Measured at world 1 over RCCL (profiles/r06_world1_exchange.md): the
+        # two-graph micro-step costs nothing (41.98 vs 42.04 ms per micro-step).
+        if overlap_exchange is None:
+            overlap_exchange = self.dist_on and self.world > 1
         self.overlap_exchange = bool(overlap_exchange) and self.arena is not None and is_hip_model
         self._tail_start = None
         self._pending = None

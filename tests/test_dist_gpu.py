@@ -106,9 +106,10 @@ def _two_rank_worker(rank, world, port, ret, tmp, wire):
                 for p in m.trainable_parameters():
                     p.add_(0.03)
         m.set_dropout_seed(SEED, 0)
-        tr = Trainer(m, lr=LR, grad_accum=ACCUM, warmup=0, total_steps=20, reduce_chunk_mb=8, **({"wire_dtype": None} if wire == "fp32" else {}), overlap_exchange=(wire == "overlap"))
+        tr = Trainer(m, lr=LR, grad_accum=ACCUM, warmup=0, total_steps=20, reduce_chunk_mb=8, **({"wire_dtype": None, "overlap_exchange": False} if wire == "fp32" else
+                                                                                                  {"overlap_exchange": False} if wire == "no_overlap" else {}))
         assert tr.arena is not None and tr.dist_on and tr.arena.flat.numel() > 2 * tr.reduce_chunk, (tr.arena.flat.numel(), tr.reduce_chunk)
-        assert tr.sparse_embed and tr.wire_dtype == (None if wire == "fp32" else torch.bfloat16) and tr.overlap_exchange == (wire == "overlap"), (tr.sparse_embed, tr.wire_dtype)
+        assert tr.sparse_embed and tr.wire_dtype == (None if wire == "fp32" else torch.bfloat16) and tr.overlap_exchange == (wire == "default"), (tr.sparse_embed, tr.wire_dtype)
         if rank == 0:
             torch.save(torch.tensor(tr.arena.block_of[tr._embed_key]), os.path.join(tmp, "embed_block.pt"))
         assert int(m.dropout_state()[0]) == rank_dropout_seed(SEED, rank)
@@ -126,17 +127,17 @@ def _two_rank_worker(rank, world, port, ret, tmp, wire):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("wire", ["fp32", "default", "overlap"])
+@pytest.mark.parametrize("wire", ["fp32", "no_overlap", "default"])
 def test_two_ranks_share_one_gpu_gloo(tmp_path, wire):
     """wire = "default": what a multi-rank Trainer does unless told otherwise -- dense pieces in bf16 on the wire (the reference's DeepSpeed bf16 engine,
-    training.py:314-329), the embedding block as fp32 rows; "fp32": `wire_dtype=None`; "overlap": the default wire + `overlap_exchange=True` (the arena's tail
-    leaves between the two halves of the window's last backward, DeepSpeed's `overlap_comm`)."""
+    training.py:314-329), the embedding block as fp32 rows, the arena's tail leaving between the two halves of the window's last backward (DeepSpeed's
+    `overlap_comm`); "no_overlap": the same wire, everything exchanged after the backward; "fp32": `wire_dtype=None`, no overlap."""
     import torch.multiprocessing as mp
     from llmseg_amd.train import Trainer, rank_dropout_seed
     from tests import backward_checks as bc, model_checks as mc
     world = 2
     ret = mp.Manager().dict()
-    mp.spawn(_two_rank_worker, args=(world, {"fp32": 29581, "default": 29583, "overlap": 29585}[wire], ret, str(tmp_path), wire), nprocs=world, join=True)
+    mp.spawn(_two_rank_worker, args=(world, {"fp32": 29581, "no_overlap": 29583, "default": 29585}[wire], ret, str(tmp_path), wire), nprocs=world, join=True)
     (l0, p0, n0, ss0), (l1, p1, n1, ss1) = ret[0], ret[1]
     assert n0 == n1 == OPT_STEPS and ss0 == ss1
     assert torch.equal(p0, p1), (p0 - p1).abs().max().item()           # replicas bit-identical after the exchanges
