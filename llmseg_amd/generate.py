@@ -155,7 +155,7 @@ class GenerateMixin:
                 st.warm = True
                 return self._decode_body(st)                    # first step of this state: eager (also warms every allocation)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):      # (another thread -- an RCCL watchdog -- may query events meanwhile: train.py::_capture)
                 self._decode_body(st)
             st.graph = g                                        # capture records, it does not execute: fall through to the replay
         st.graph.replay()

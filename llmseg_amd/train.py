@@ -591,16 +591,21 @@ class Trainer:
             sb.setdefault(k, None)
         torch.cuda.synchronize()
         gplan = plan.clone()
+        # capture_error_mode="thread_local": with a process group the RCCL watchdog thread polls its work items with hipEventQuery; under the default "global" mode
+        # that call, made by ANOTHER thread while this one captures, is an error ("operation not permitted when stream is capturing") that aborts the process --
+        # seen in round 6 when a capture followed a collective within the watchdog's polling interval (bench.py under torchrun, --small).  Only this thread's own
+        # unsafe calls need to be errors.
+        mode = dict(capture_error_mode="thread_local")
         g = torch.cuda.CUDAGraph()
         gb = keep = None
         if not self.overlap_exchange:
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, **mode):
                 out = self.module.model_forward(**sb, plan=gplan)
                 self._backward(out["loss"])
         else:
             self.module.__dict__["_split_backward"] = True
             try:
-                with torch.cuda.graph(g):                # graph A: forward + the backward of everything downstream of the Llama output
+                with torch.cuda.graph(g, **mode):        # graph A: forward + the backward of everything downstream of the Llama output
                     out = self.module.model_forward(**sb, plan=gplan)
                     root, leaf = self.module.__dict__.pop("_split_pair")
                     self._backward(out["loss"])
@@ -608,7 +613,7 @@ class Trainer:
                 self.module.__dict__.pop("_split_backward", None)
                 self.module.__dict__.pop("_split_pair", None)
             gb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gb, pool=g.pool()):    # graph B: the decoder stack's backward from the gradient graph A left in `leaf.grad`
+            with torch.cuda.graph(gb, pool=g.pool(), **mode):    # graph B: the decoder stack's backward from the gradient graph A left in `leaf.grad`
                 root.backward(leaf.grad)
             keep = (leaf, leaf.grad)                     # (graph B reads this buffer on every replay)
         ent.update(graph=g, graph_b=gb, keep=keep, batch=sb, plan=gplan, last_plan=plan, out={k: v.detach() for k, v in out.items() if torch.is_tensor(v)})
