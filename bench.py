@@ -506,6 +506,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="issue the frozen backbone on the main stream instead of its own HIP stream")
     ap.add_argument("--leaf-stream", action="store_true", help="issue the arena's weight-gradient kernels on a side stream (A/B of autograd.Leaves; measured slower)")
     ap.add_argument("--overlap-exchange", action="store_true", help="cut every backward at the Llama output and issue the arena tail's all-reduce between the halves of a window's last micro-step (Trainer(overlap_exchange=True))")
+    ap.add_argument("--multirank-defaults", action="store_true", help="(with --force-dist on one GPU) build every Trainer with the defaults of a > 1-rank run: embedding rows, bf16 wire, overlapped exchange")
     ap.add_argument("--no-overlap-exchange", action="store_true", help="exchange everything after the window's last backward (the default under > 1 rank is to overlap the arena's tail with it)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--ddp-wrapper", action="store_true", help="torch DDP wrapper + bf16 .grad instead of the fp32 gradient arena")
@@ -556,7 +557,19 @@ def main():
 
     from llmseg_amd.lisa import LISAForCausalLM
     from llmseg_amd.params import LisaConfig, LlamaConfig, SamConfig, VitConfig
-    from llmseg_amd.train import Trainer
+    from llmseg_amd.train import Trainer as _Trainer
+    if args.multirank_defaults:
+        # one GPU, world-1 RCCL group, but every Trainer of this run is built with what a Trainer under > 1 rank defaults to (embedding block as rows, bf16 on the
+        # wire, the exchange overlapped with the backward): the code path the driver's N > 1 runs take, with identity collectives
+        assert dist is not None, "--multirank-defaults needs --force-dist"
+
+        def Trainer(*a, **kw):
+            for k, v in (("sparse_embed", True), ("wire_dtype", torch.bfloat16), ("overlap_exchange", True)):
+                if kw.get(k) is None:
+                    kw[k] = v
+            return _Trainer(*a, **kw)
+    else:
+        Trainer = _Trainer
 
     cfg = LisaConfig(backbone=args.backbone, build_unused_towers=False, sam_decoder=(args.backbone == "sam"))
     train = args.mode == "train"
