@@ -571,6 +571,115 @@ __global__ __launch_bounds__(NT, 1) void gemm_bf16_tn_g4_kernel(GemmP p) {
   epilogue_lds<OUT_F32, MI>(p, Acc32<MI>{acc}, smem, wave, m0, n0, wm, wn, lane, bz);
 }
 
+// ---- variant Q-LW (round 6 experiment): the 128 x 256 tile with DEDICATED LOADER WAVES --------------------------------------------------------------
+// Hypothesis: at M = 638 the 128 x 256 tile is bound neither by the fabric (operands mostly L2 hits: a W tile is shared by the five row tiles of
+// an XCD) nor by the vector-memory path (48 KiB per K-tile = 0.75 of its 64 B/clk at full MFMA rate) but by the ISSUE cost of the LDS-DMA instructions inside
+// the waves that also issue the MFMAs: a `buffer_load ... lds` piece stalls its wave for 60-185 cycles (MI355X_MICROARCH.md), six of them per wave and K-tile
+// against 32 MFMAs (~512 cycles).  Here 8 consumer waves (2 per SIMD; the wave tiling, fragment reads, MFMA order and epilogue of the ping-pong kernels: same
+// bits) never touch global memory; 4 loader waves (one per SIMD) issue all 48 pieces of a K-tile, two K-tiles ahead, into a three-stage LDS ring.
+// ONE workgroup barrier per K-tile:  loader: s_waitcnt vmcnt(tile t landed) | barrier | issue tile t + 2 (into the stage tile t - 1 was read from: every
+// consumer has passed this barrier, so it has finished tile t - 1);  consumer: barrier | 16 fragment reads + 32 MFMAs on tile t.
+constexpr int NTL = 768;
+template <bool OUT_F32>
+__global__ __launch_bounds__(NTL, 1) void gemm_bf16_tn_lw_kernel(GemmP p) {
+  constexpr int MI = 2, BMB = 128, BNB = 256, NS = 3;
+  constexpr int A_BYTES = BMB * BK * 2, W_BYTES = BNB * BK * 2, BUF = A_BYTES + W_BYTES;      // 16 + 32 KiB per stage, 144 KiB in all
+  __shared__ __attribute__((aligned(16))) char smem[NS * BUF];
+  int bid = blockIdx.x;
+  const int nwg = p.tiles_m * p.tiles_n;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int len = q + (xcd < r ? 1 : 0);
+    const int idx = ((bid >> 3) + xcd * p.skew) % len;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int per_group = p.group_m * p.tiles_n;
+  const int first_m = (bid / per_group) * p.group_m;
+  const int gsz = min(p.tiles_m - first_m, p.group_m);
+  const int m0 = (first_m + (bid % per_group) % gsz) * BMB;
+  const int n0 = ((bid % per_group) / gsz) * BNB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long b1 = blockIdx.y % p.batch1, b2 = blockIdx.y / p.batch1;
+  const long bz = b1 * p.sC + b2 * p.sC2;
+  int nt = p.K / BK;
+  if (p.kt_total > 0) nt = min(nt, p.kt_total - (int)b1 * nt);                                 // split-K: the last slice may be shorter
+
+  if (wave >= 8) {
+    // ------------------------------------------------------------------ loader wave l: A pieces l, l + 4, .. (4 of 16), W pieces l, l + 4, .. (8 of 32)
+    const int l = wave - 8;
+    const bf16_t* __restrict__ Ag = p.A + b1 * p.sA + b2 * p.sA2;
+    const bf16_t* __restrict__ Wg = p.W + b1 * p.sW + b2 * p.sW2;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ag + (long)m0 * p.lda), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Wg + (long)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
+    int a_off[4], w_off[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (l + 4 * j) * 8 + (lane >> 3);
+      a_off[j] = (int)(((long)min(row, p.M - 1 - m0) * p.lda + (((lane & 7) ^ ((row >> 1) & 7)) << 3)) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = (l + 4 * j) * 8 + (lane >> 3);
+      w_off[j] = (int)(((long)min(row, p.N - 1 - n0) * p.ldw + (((lane & 7) ^ ((row >> 1) & 7)) << 3)) * 2);
+    }
+    auto issue = [&](int t, int st) {
+      char* base = smem + st * BUF + l * 1024;
+      const int koff = t * (BK * 2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(base + A_BYTES + j * 4096), 16, w_off[j], koff, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(base + j * 4096), 16, a_off[j], koff, 0, 0);
+    };
+    issue(0, 0);
+    if (nt > 1) issue(1, 1);
+    int st2 = 2;                                           // stage of tile t + 2
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt) G4_VM(12); else G4_VM(0);            // tile t has landed (tile t + 1 may still be in flight)
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 2 < nt) issue(t + 2, st2);
+      st2 = st2 == NS - 1 ? 0 : st2 + 1;
+    }
+    __builtin_amdgcn_s_barrier();                          // (the consumers' barrier ahead of the epilogue)
+    return;
+  }
+
+  // ---------------------------------------------------------------------- consumer waves: 2 x 4, each 64 x 64 of the tile
+  const int wm = wave >> 2, wn = wave & 3;
+  f32x4_t acc[4][2 * MI];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < 2 * MI; ++mb) acc[nb][mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fq = lane >> 4;
+  int st = 0;
+  for (int t = 0; t < nt; ++t) {
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const char* base = smem + st * BUF;
+    bf16x8_t wf[4][2], af[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) wf[nb][ks] = *reinterpret_cast<const bf16x8_t*>(base + A_BYTES + lds_off(wn * 64 + nb * 16 + frow, ks * 4 + fq));
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) af[mb][ks] = *reinterpret_cast<const bf16x8_t*>(base + lds_off(wm * 64 + mb * 16 + frow, ks * 4 + fq));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], af[mb][ks], acc[nb][mb], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    st = st == NS - 1 ? 0 : st + 1;
+  }
+  __builtin_amdgcn_s_barrier();                            // every consumer has finished reading LDS: the epilogue's slabs alias the stages
+  epilogue_lds<OUT_F32, MI>(p, Acc16<MI>{acc}, smem, wave, m0, n0, wm, wn, lane, bz);
+}
+
 // ---- variant Q: (64 MI) x 256 tile, 8 waves in two groups that run ONE BARRIER APART ("ping-pong") -------------------------
 // MI = 4: 256 x 256 (waves 2 x 4, each 128 x 64); MI = 2: 128 x 256 (each wave 64 x 64) for short matrices (Llama at 2 images per
 // micro-step has M = 638 rows: five 128-row tiles waste 0.3 % of the rows, three 256-row tiles 17 %).
@@ -1179,7 +1288,7 @@ extern "C" int llmseg_gemm_set_variant(int v) {
   g_gemm_variant = v & 15;
   if ((v >> 4) & 15) g_gemm_skew = ((v >> 4) & 15) - 1;
   g_gemm_split = (v >> 8) & 31;
-  g_gemm_pp2 = (v >> 13) & 3 ? ((v >> 13) & 3) - 1 : g_gemm_pp2;     // bits 13-14: 128 x 256 kernel form + 1 (1 = four phases / two buffers, 2 = two phases / three buffers)
+  g_gemm_pp2 = (v >> 13) & 3 ? ((v >> 13) & 3) - 1 : g_gemm_pp2;     // bits 13-14: 128 x 256 kernel form + 1 (1 = four phases / two buffers, 2 = two phases / three buffers, 3 = loader waves)
   return LLMSEG_OK;
 }
 
@@ -1444,6 +1553,7 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
     ps.c_vec = 1; ps.r_vec = 0; ps.b_vec = 1; ps.A2 = ps.W2 = nullptr;
     dim3 grid(p.tiles_m * p.tiles_n, (unsigned)split);
     if (variant == 8) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<true, false, 4>), grid, dim3(NTB), 0, s, ps);
+    else if (g_gemm_pp2 == 2) LL_LAUNCH_KERNEL((gemm_bf16_tn_lw_kernel<true>), grid, dim3(NTL), 0, s, ps);      // loader-wave form (experiment)
     else if (g_gemm_pp2) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp2_kernel<true, false>), grid, dim3(NTB), 0, s, ps);
     else LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<true, false, 2>), grid, dim3(NTB), 0, s, ps);
     const long total4 = (long)p.M * (p.N >> 2);
@@ -1477,6 +1587,11 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
         else LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<false, false, 4>), grid, dim3(NTB), 0, s, p);
         break;
       case 9:
+        if (g_gemm_pp2 == 2 && !p.A2) {                     // loader-wave form (experiment; the LoRA extension tile keeps the two-phase kernel)
+          if (f) LL_LAUNCH_KERNEL((gemm_bf16_tn_lw_kernel<true>), grid, dim3(NTL), 0, s, p);
+          else LL_LAUNCH_KERNEL((gemm_bf16_tn_lw_kernel<false>), grid, dim3(NTL), 0, s, p);
+          break;
+        }
         if (g_gemm_pp2) {
           if (p.A2) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp2_kernel<false, true>), grid, dim3(NTB), 0, s, p);
           else if (f) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp2_kernel<true, false>), grid, dim3(NTB), 0, s, p);
