@@ -45,6 +45,7 @@ struct GemmP {
   int accum;                 // fp32 output only: C += result (gradient accumulation into an fp32 arena)
   int k_split_total;         // register-staging kernel as K-slices: total K (elements); blockIdx.y % batch1 = slice, p.K = elements per slice; 0 = off
   const bf16_t* a_norm_w; float a_norm_eps; int a_swiglu;     // skinny route: transform of the A rows while they are loaded (decode-step fusions)
+  int ablate;                // loader-wave experiment only (LLMSEG_LW_ABLATE; results are garbage): bit 0 = no MFMAs, bit 1 = no fragment reads, bit 2 = no DMA after the prologue
 };
 
 // exact-erf GELU on a pair (packed fp32 VALU: v_pk_fma / v_pk_mul).  Same Abramowitz-Stegun 7.1.26 erf as apply_act, rearranged:
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(NTL, 1) void gemm_bf16_tn_lw_kernel(GemmP p) {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if (t + 2 < nt) issue(t + 2, st2);
+      if (t + 2 < nt && !(p.ablate & 4)) issue(t + 2, st2);
       st2 = st2 == NS - 1 ? 0 : st2 + 1;
     }
     __builtin_amdgcn_s_barrier();                          // (the consumers' barrier ahead of the epilogue)
@@ -658,21 +659,28 @@ __global__ __launch_bounds__(NTL, 1) void gemm_bf16_tn_lw_kernel(GemmP p) {
   for (int t = 0; t < nt; ++t) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    const char* base = smem + st * BUF;
+    const char* base = smem + ((p.ablate & 2) ? 0 : st) * BUF;
     bf16x8_t wf[4][2], af[4][2];
+    if (!(p.ablate & 2) || t == 0) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) wf[nb][ks] = *reinterpret_cast<const bf16x8_t*>(base + A_BYTES + lds_off(wn * 64 + nb * 16 + frow, ks * 4 + fq));
+        for (int nb = 0; nb < 4; ++nb) wf[nb][ks] = *reinterpret_cast<const bf16x8_t*>(base + A_BYTES + lds_off(wn * 64 + nb * 16 + frow, ks * 4 + fq));
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) af[mb][ks] = *reinterpret_cast<const bf16x8_t*>(base + lds_off(wm * 64 + mb * 16 + frow, ks * 4 + fq));
+        for (int mb = 0; mb < 4; ++mb) af[mb][ks] = *reinterpret_cast<const bf16x8_t*>(base + lds_off(wm * 64 + mb * 16 + frow, ks * 4 + fq));
+      }
     }
+    if (!(p.ablate & 1)) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
+        for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], af[mb][ks], acc[nb][mb], 0, 0, 0);
+          for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], af[mb][ks], acc[nb][mb], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) acc[nb][0][0] += __builtin_bit_cast(f32x4_t, wf[nb][0])[0] + __builtin_bit_cast(f32x4_t, af[nb][1])[1] + __builtin_bit_cast(f32x4_t, wf[nb][1])[2] + __builtin_bit_cast(f32x4_t, af[nb][0])[3];
+    }
     __builtin_amdgcn_sched_barrier(0);
     st = st == NS - 1 ? 0 : st + 1;
   }
@@ -1380,6 +1388,7 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
   p.sA2 = a->strideA2; p.sW2 = a->strideW2; p.sC2 = a->strideC2;
   p.alpha = a->alpha; p.act = a->act;
   p.kt_total = 0; p.k_split_total = 0; p.accum = a->accumulate ? 1 : 0;
+  { static const int abl = getenv("LLMSEG_LW_ABLATE") ? atoi(getenv("LLMSEG_LW_ABLATE")) : 0; p.ablate = abl; }
   // vector stores/loads need 4-element alignment of every row start; otherwise the kernel goes element-wise
   p.c_vec = ((((uintptr_t)a->C) % (4 * esz)) == 0 && (a->ldc & 3) == 0 && ((a->strideC | a->strideC2) & 3) == 0) ? 1 : 0;
   p.r_vec = (p.res && (((uintptr_t)p.res) & 7) == 0 && (p.ldr & 3) == 0 && ((a->strideC | a->strideC2) & 3) == 0) ? 1 : 0;
