@@ -76,3 +76,34 @@ def test_validation_save_if_better_and_eval_only(tmp_path):
     m.eval()
     direct = V.validate_threshold(m, run.val_samples(val, partial(collate_fn_new, tokenizer=tok), torch.device("cuda", 0)), threshold=0.5)
     assert e["eval"]["images"] == 3 and e["eval"]["giou"] == direct["giou"] and e["eval"]["ciou"] == direct["ciou"]
+
+
+def _two_rank_driver(rank, world, port, ret, tmp):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from llmseg_amd import run
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, tok, train, val = _setup()
+        logs = []
+        s = run.main(_argv(tmp, "ddp", "--epochs", "1"), model=m, tokenizer=tok, train_dataset=train, val_dataset=val, log=logs.append)
+        ret[rank] = (s["opt_steps"], s["epochs"][0]["giou"], s["epochs"][0]["ciou"], s["epochs"][0]["train"], _masters(m), len(logs), s["saved"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_driver_under_two_ranks_sharing_the_gpu(tmp_path):
+    """The driver with a process group of two (gloo; both ranks on cuda:0 -- no 2-GPU box is available to the build): each rank draws its own slice of the data stream, the gradient
+    exchange keeps the replicas bit-identical, the loss meters and the gIoU / cIoU sums are reduced over the ranks (same numbers on both), only rank 0 logs and writes the checkpoint."""
+    import torch.multiprocessing as mp
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_two_rank_driver, args=(world, 29611, ret, str(tmp_path)), nprocs=world, join=True)
+    a, b = ret[0], ret[1]
+    assert a[0] == b[0] == 2 and torch.equal(a[4], b[4]), (a[4] - b[4]).abs().max().item()      # replicas identical after two optimizer steps
+    assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3], (a[1:4], b[1:4])                     # reduced validation metrics and train meters agree
+    assert a[5] > 0 and b[5] == 0                                                                # rank 0 logs
+    if a[6]:
+        assert sorted(os.listdir(os.path.join(tmp_path, "ddp", "ckpt_model"))) == ["global_step2", "latest"]
