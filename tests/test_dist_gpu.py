@@ -127,7 +127,7 @@ def _two_rank_worker(rank, world, port, ret, tmp, wire):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("wire", ["fp32", "no_overlap", "default"])
+@pytest.mark.parametrize("wire", ["fp32", "default"])      # ("no_overlap" -- bf16 wire, everything after the backward -- is a valid third value: dropped from the suite for time)
 def test_two_ranks_share_one_gpu_gloo(tmp_path, wire):
     """wire = "default": what a multi-rank Trainer does unless told otherwise -- dense pieces in bf16 on the wire (the reference's DeepSpeed bf16 engine,
     training.py:314-329), the embedding block as fp32 rows, the arena's tail leaving between the two halves of the window's last backward (DeepSpeed's
