@@ -33,7 +33,7 @@ enum { LLMSEG_ACT_NONE = 0, LLMSEG_ACT_RELU = 1, LLMSEG_ACT_GELU = 2, LLMSEG_ACT
  * 2 = llmseg_attn_bwd_args, 3 = llmseg_dropout; -1 for an unknown index) so a binding can assert at load time;
  * llmseg_version() is bumped whenever a struct or a signature changes (7: the fp32-activation head entry points; 4: the reduction entry points take a workspace; 5 = this header:
  * llmseg_dropout.seg_rows; 6: llmseg_gemm_args.norm_w / norm_eps / norm_out / ldn). */
-#define LLMSEG_ABI_VERSION 7
+#define LLMSEG_ABI_VERSION 8
 
 /* Determinism (round 4).  No kernel adds floating-point numbers with atomics: every sum whose terms come from several workgroups is
  * written as per-workgroup partials into CALLER-OWNED scratch (`workspace`, `workspace_bytes`; any device memory, 256-byte aligned, not
@@ -169,6 +169,11 @@ typedef struct {
   const uint8_t* key_mask;   /* [batch][Nk] 1 = attend, or NULL */
   const float* lse;
   float* delta;
+  /* optional (ABI 8): fp32 [Nq][head_dim / 2] tables of a rotate-half rotation applied to every dQ and dK row (position = row index,
+   * Nq == Nk) before it is stored, with llmseg_rope's arithmetic on the bf16-rounded gradient -- bit for bit what llmseg_rope over the
+   * stored dQ | dK gives.  The Llama layer passes (cos, -sin): the inverse rotation of HF apply_rotary_pos_emb's backward
+   * (modeling_llama.py, transformers 4.29), which used to be a launch of its own per layer.  head_dim 64 or 128. */
+  const float* rope_cos; const float* rope_sin;
 } llmseg_attn_bwd_args;
 int llmseg_attn_bwd(const llmseg_attn_bwd_args* args, void* stream);
 

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LLMSEG_LIB") or os.path.join(_HERE, "libllmseg_hip.so")     # LLMSEG_LIB: side builds of the same ABI (tools/ experiments)
 
-ABI_VERSION = 7          # == LLMSEG_ABI_VERSION of include/llmseg_hip.h
+ABI_VERSION = 8          # == LLMSEG_ABI_VERSION of include/llmseg_hip.h
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SILU, ACT_SIGMOID = range(6)
 
@@ -54,7 +54,8 @@ class AttnBwdArgs(_Sized):
     _fields_ = ([("struct_size", C.c_uint32), ("reserved0", C.c_uint32)] + [(n, C.c_void_p) for n in ("Q", "K", "V", "O", "dO", "dQ", "dK", "dV")] +
                 [(f"{t}_stride_{s}", C.c_int64) for t in ("q", "k", "v", "o", "do", "dq", "dk", "dv") for s in ("b", "h", "row")] +
                 [("batch", C.c_int32), ("heads", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("head_dim", C.c_int32),
-                 ("scale", C.c_float), ("causal", C.c_int32), ("key_mask", C.c_void_p), ("lse", C.c_void_p), ("delta", C.c_void_p)])
+                 ("scale", C.c_float), ("causal", C.c_int32), ("key_mask", C.c_void_p), ("lse", C.c_void_p), ("delta", C.c_void_p),
+                 ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p)])
 
 
 class Dropout(C.Structure):

@@ -12,6 +12,7 @@ Parameter gradients have two destinations:
   * plain autograd: without `_g32` the Function returns a bf16 gradient and autograd fills `.grad` as usual (parity tests).
 """
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -23,6 +24,8 @@ BF16 = torch.bfloat16
 
 BIG_LINEAR = 1 << 34          # M*N*K above which LinearFn.backward transposes/pads its operands for the LDS-DMA GEMM kernels
 BIG_WEIGHT = 1 << 26          # N * K of a Linear whose dX / dW always take the transposed-operand route below (lm_head: 131 M)
+# A/B switches of the round-6 Llama-layer fusions (tests compare each fused route with the unfused one bit for bit)
+FUSE_ROPE_BWD = os.environ.get("LLMSEG_NO_FUSE_ROPE_BWD") is None      # inverse RoPE inside the attention backward's dq / dk store
 
 
 class Leaves:
@@ -405,17 +408,20 @@ class PackedAttnFn(Function):
         ld = qkv.stride(0)
         st = (n * ld, hd, ld)
         dst = (n * D, hd, D)
+        rope_in_bwd = ctx.rope is not None and lse is not None and hd in (64, 128) and FUSE_ROPE_BWD
         if lse is not None:
             ops.attention_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], out, do, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], lse, batch=batch, heads=heads,
                               Nq=n, Nk=n, head_dim=hd, q_strides=st, k_strides=st, v_strides=st, o_strides=(n * out.stride(0), hd, out.stride(0)),
-                              do_strides=dst, dq_strides=st, dk_strides=st, dv_strides=st, causal=causal, key_mask=key_mask)
+                              do_strides=dst, dq_strides=st, dk_strides=st, dv_strides=st, causal=causal, key_mask=key_mask,
+                              rope=(ctx.rope[0], ctx.rope[2]) if rope_in_bwd else None)      # the inverse rotation rides in the dq / dk store
         else:
             attention_backward(qkv, qkv[:, D:], qkv[:, 2 * D:], do, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], batch=batch, heads=heads, Nq=n, Nk=n,
                                hd=hd, qs=st, ks=st, vs=st, dos=dst, dqs=st, dks=st, dvs=st, scale=1.0 / math.sqrt(hd), causal=causal,
                                key_mask=key_mask)
         if ctx.rope is not None:
             assert grads[0] is None, "the rotated qkv buffer must not be consumed outside this node"
-            ops.rope_(dqkv, ctx.rope[0], ctx.rope[2], batch * n, n, 2 * heads, hd, ld)
+            if not rope_in_bwd:
+                ops.rope_(dqkv, ctx.rope[0], ctx.rope[2], batch * n, n, 2 * heads, hd, ld)
         return dqkv, None, None, None, None, None, None, None
 
 

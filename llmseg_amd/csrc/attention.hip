@@ -188,7 +188,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnP p) {
   uint4 kreg0 = make_uint4(0, 0, 0, 0), kreg1 = kreg0, kreg2 = kreg0, kreg3 = kreg0;
   uint4 vreg0 = kreg0, vreg1 = kreg0, vreg2 = kreg0, vreg3 = kreg0;
   const int v_kq = tid & 15, v_c = tid >> 4;
-  const bool v_on = tid < 16 * CH;
+  const bool v_on = (16 * CH >= NT) || tid < 16 * CH;     // head_dim 128 with 4 waves: every thread stages V (no branch around the prefetch)
 
 #define LL_K_LOAD(IT, REG)                                                                          \
   if constexpr (KIT > IT) {                                                                         \
@@ -247,8 +247,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnP p) {
     for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
   float m_run = NEG, l_run = 0.f;
 
+  // key-padding byte of this lane's key in tile T.  The double-buffered loop fetches it one tile AHEAD, in front of that tile's staging loads: a
+  // load inside the tile body would sit behind them in the in-order vmcnt queue, and its wait would expose the whole prefetch (22 -> see profiles).
+#define LL_PIN_V asm volatile("" : "+v"(vreg0.x), "+v"(vreg0.y), "+v"(vreg0.z), "+v"(vreg0.w), "+v"(vreg1.x), "+v"(vreg1.y), "+v"(vreg1.z), "+v"(vreg1.w), \
+                                  "+v"(vreg2.x), "+v"(vreg2.y), "+v"(vreg2.z), "+v"(vreg2.w), "+v"(vreg3.x), "+v"(vreg3.y), "+v"(vreg3.z), "+v"(vreg3.w));
+#define LL_KM_LOAD(T) (p.key_mask ? (unsigned)p.key_mask[(long)b * p.Nk + min((T) * BKV + lane, p.Nk - 1)] : 1u)
+  unsigned km_cur = 1u, km_nxt = 1u;
+  if constexpr (DB) km_cur = LL_KM_LOAD(0);
   LL_STAGE_LOAD(0)
   LL_STAGE_STORE(0)
+  // the Q fragments must have LANDED before the tile loop: hipcc sinks their loads behind tile 0's staging loads, and a fragment still pending at
+  // the loop header becomes a vmcnt wait inside EVERY iteration -- which then drains that iteration's prefetch in front of the softmax
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+  asm volatile("" : "+v"(km_cur));
   __syncthreads();
 
   // One K/V tile.  TT = tile index expression, TC = the same as a LITERAL when the tile loop is unrolled (REL == 3), else 0.
@@ -310,12 +322,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnP p) {
       }                                                                                                             \
     }                                                                                                               \
     float mx = NEG;                                                                                                 \
-    const bool need_mask = p.causal || p.key_mask != nullptr || (k0 + BKV > p.Nk);                                  \
     uint32_t km_lo = 0xffffffffu, km_hi = 0xffffffffu;                                                              \
-    if (p.key_mask) {       /* ONE byte load per lane per tile + a ballot instead of 32 broadcast byte loads per lane */ \
-      const unsigned long long kb = __ballot(p.key_mask[(long)b * p.Nk + min(k0 + lane, p.Nk - 1)] != 0) >> (4 * half); \
+    unsigned long long kb_all = ~0ull;                                                                              \
+    if (p.key_mask) {       /* ONE byte load per lane per tile (km_cur: fetched a tile ahead, LL_KM_LOAD) + a ballot instead of 32 broadcast byte loads per lane */ \
+      kb_all = __ballot(km_cur != 0);                                                                               \
+      const unsigned long long kb = kb_all >> (4 * half);                                                           \
       km_lo = (uint32_t)kb; km_hi = (uint32_t)(kb >> 32);                                                           \
     }                                                                                                               \
+    /* wave-uniform: the tile needs no masking when it ends inside Nk, no key of it is padded, and (causal) its last key is not after */ \
+    /* the wave's FIRST query -- the interior of the causal triangle skips the per-element mask arithmetic */                          \
+    const bool need_mask = (k0 + BKV > p.Nk) || kb_all != ~0ull || (p.causal && k0 + BKV - 1 > q0 + wave * 32);     \
     if (need_mask) { LL_SCORE_LOOP(true) } else { LL_SCORE_LOOP(false) }                                            \
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                         \
     const float m_new = fmaxf(m_run, mx);                                                                           \
@@ -369,14 +385,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnP p) {
 #else
       Ks = smem + (t & 1) * TILE_BYTES; Vt = Ks + BKV * PK;
       Ks_w = smem + ((t + 1) & 1) * TILE_BYTES; Vt_w = Ks_w + BKV * PK;
-      if (t + 1 < ntiles) LL_STAGE_LOAD(t + 1)
-      LL_TILE_BODY(t, 0)
+      if (t + 1 < ntiles) { km_nxt = LL_KM_LOAD(t + 1); LL_STAGE_LOAD(t + 1) }
+      if (!(p.causal && t * BKV > q0 + wave * 32 + 31)) LL_TILE_BODY(t, 0)      // causal: a tile wholly after this wave's last query contributes exact zeros
+      LL_PIN_V        // hipcc otherwise hoists the V transposes (and with them the wait for ALL of the prefetch) in front of the tile's MFMAs
       if (t + 1 < ntiles) LL_STAGE_STORE(t + 1)      // the other buffer: its last readers passed the barrier of iteration t-1
+      km_cur = km_nxt;
       __syncthreads();
 #endif
     }
   } else {
     for (int t = 0; t < ntiles; ++t) {
+      km_cur = LL_KM_LOAD(t);
       if (t + 1 < ntiles) LL_STAGE_LOAD(t + 1)
       LL_TILE_BODY(t, 0)
       __syncthreads();
@@ -1179,7 +1198,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecP p) {
       const bf16_t* src = row + (tid < 64 ? 0 : D);
       const float a = bf2f(src[i]), b = bf2f(src[i + 64]);
       const float cv = p.cs[(long)pos * 64 + i], sv = p.sn[(long)pos * 64 + i];
-      const bf16_t o1 = f2bf(a * cv - b * sv), o2 = f2bf(b * cv + a * sv);
+      const bf16_t o1 = f2bf(rope_lo(a, b, cv, sv)), o2 = f2bf(rope_hi(a, b, cv, sv));
       if (tid < 64) { qs[i] = bf2f(o1); qs[i + 64] = bf2f(o2); }
       else {
         knew[i] = o1; knew[i + 64] = o2;

@@ -20,6 +20,7 @@
 // per-lane scalars in mode dQ and come from a 64-entry LDS table in the key-owner modes.  dQ also writes D for the dK pass.
 // 8 tile-GEMMs instead of the minimal 5 buy three simple passes at 2 waves/SIMD without a dQ atomic-add pass; the three passes share ONE
 // launch (attn_bwd_all_kernel), D = rowsum(dO * O) comes from a small launch ahead of it.
+#include <algorithm>
 #include <cstdlib>
 #include "common.h"
 #include "llmseg_hip.h"
@@ -27,6 +28,9 @@
 namespace {
 
 constexpr int BO = 128, BT = 64, NT = 256;
+#ifndef BWD_ABLATE
+#define BWD_ABLATE 0           // side builds (tools): 1 = no tile compute, 2 = no dq/dk/dv stores, 3 = tiles staged once, 4 = no P / dS element pass, 5 = no owner-fragment loads
+#endif
 constexpr float LOG2E = 1.4426950408889634f;
 enum { MODE_DQ = 0, MODE_DK = 1, MODE_DV = 2 };
 
@@ -39,6 +43,7 @@ struct BwdP {
   float scale, scale_log2;
   int causal;
   const uint8_t* key_mask;
+  const float* rope_cos; const float* rope_sin;      // optional: rotation of the dQ / dK rows at the store (fp32 [Nq][HD / 2])
 };
 
 __device__ __forceinline__ uint32_t bperm_lo(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }
@@ -49,7 +54,7 @@ constexpr int bwd_smem_bytes(bool has2) { return BT * ((HD + 8) * 2) * (has2 ? 2
 
 // One owner block (128 owner rows) of one mode.  `smem`: bwd_smem_bytes<HD>(MODE != MODE_DV) bytes of LDS, 16-byte aligned.
 template <int HD, int MODE>
-__device__ __forceinline__ void attn_bwd_body(const BwdP& p, const int own_block, char* smem) {
+__device__ __forceinline__ void attn_bwd_body(const BwdP& p, const int own_block, const int b, const int h, char* smem) {
   constexpr int KS = HD / 16, DT = HD / 32, CH = HD / 8;
   constexpr int PK = (HD + 8) * 2;            // natural tile row pitch (bytes): CH + 1 chunks -> conflict-free ds_read_b128
   constexpr int PV = (BT + 4) * 2;            // transposed tile row pitch (bytes)
@@ -64,7 +69,6 @@ __device__ __forceinline__ void attn_bwd_body(const BwdP& p, const int own_block
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, half = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
   const int own0 = own_block * BO;
   const int Nown = OWNER_Q ? p.Nq : p.Nk, Nst = OWNER_Q ? p.Nk : p.Nq;
   const int wo0 = own0 + wave * 32;
@@ -83,11 +87,11 @@ __device__ __forceinline__ void attn_bwd_body(const BwdP& p, const int own_block
   bf16x8_t xf1[KS], xf2[HAS2 ? KS : 1];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    xf1[ks] = *reinterpret_cast<const bf16x8_t*>(x1 + ks * 16 + half * 8);
-    if (HAS2) xf2[ks] = *reinterpret_cast<const bf16x8_t*>(x2 + ks * 16 + half * 8);
+    xf1[ks] = *reinterpret_cast<const bf16x8_t*>((BWD_ABLATE == 5 ? (OWNER_Q ? Qg : Kg) : x1) + ks * 16 + half * 8);
+    if (HAS2) xf2[ks] = *reinterpret_cast<const bf16x8_t*>((BWD_ABLATE == 5 ? (OWNER_Q ? dOg : Vg) : x2) + ks * 16 + half * 8);
   }
   bool own_ok = ow < Nown;
-  float lse_o = 0.f, d_o = 0.f;
+  float lse_o = 0.f, d_o = 0.f, d_os = 0.f;
   if (OWNER_Q) {
     lse_o = p.lse[stat0 + owc];
     const bf16_t* orow = p.O + (long)b * p.os[0] + (long)h * p.os[1] + (long)owc * p.os[2];
@@ -101,6 +105,7 @@ __device__ __forceinline__ void attn_bwd_body(const BwdP& p, const int own_block
       for (int e = 0; e < 8; ++e) part = fmaf(of[e], df[e], part);
     }
     d_o = part + __shfl_xor(part, 32, 64);              // = delta[ow] (attn_delta_kernel writes the table the dK blocks read)
+    d_os = d_o * p.scale;
   } else if (p.key_mask) {
     own_ok = own_ok && (p.key_mask[(long)b * p.Nk + owc] != 0);
   }
@@ -117,7 +122,7 @@ __device__ __forceinline__ void attn_bwd_body(const BwdP& p, const int own_block
   const bf16_t* sb = OWNER_Q ? Vg : dOg;                  // staged tensor B: natural -> Y2 (modes dQ, dK) / transposed -> Yt (mode dV)
   const long sb_r = OWNER_Q ? p.vs[2] : p.dos[2];
   const int kq = tid & 15, cc = tid >> 4;
-  const bool st_on = tid < 16 * CH;
+  const bool st_on = (16 * CH >= NT) || tid < 16 * CH;    // head_dim 128: every thread stages (no branch around the prefetch)
 
   f32x16_t acc[DT];
 #pragma unroll
@@ -125,124 +130,217 @@ __device__ __forceinline__ void attn_bwd_body(const BwdP& p, const int own_block
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
 
+  // Staging registers of the NEXT tile (round 6): its rows are fetched while the current tile is computed and written to LDS at the top of
+  // the next iteration -- the chain of <= 5 tiles per workgroup used to pay one exposed global round trip per tile (51 -> see profiles).
+  uint4 ra0 = make_uint4(0, 0, 0, 0), ra1 = ra0, ra2 = ra0, ra3 = ra0, rb0 = ra0, rb1 = ra0, rb2 = ra0, rb3 = ra0;
+  float r_lse = 0.f, r_dl = 0.f;
+  unsigned km_nxt = 1u, km_cur = 1u;
+#define BW_LOAD(T)                                                                                              \
+  {                                                                                                             \
+    const int t0_ = (T) * BT;                                                                                   \
+    if (OWNER_Q && p.key_mask) km_nxt = p.key_mask[(long)b * p.Nk + min(t0_ + lane, p.Nk - 1)];               \
+    if (!OWNER_Q && tid < BT) {                                                                                 \
+      const long qi_ = stat0 + min(t0_ + tid, p.Nq - 1);                                                        \
+      r_lse = p.lse[qi_];                                                                                       \
+      if (MODE == MODE_DK) r_dl = p.delta[qi_];                                                                 \
+    }                                                                                                           \
+    if (st_on) {                                                                                                \
+      const long w0_ = min(t0_ + 4 * kq + 0, Nst - 1), w1_ = min(t0_ + 4 * kq + 1, Nst - 1);                    \
+      const long w2_ = min(t0_ + 4 * kq + 2, Nst - 1), w3_ = min(t0_ + 4 * kq + 3, Nst - 1);                    \
+      ra0 = *reinterpret_cast<const uint4*>(sa + w0_ * sa_r + cc * 8); rb0 = *reinterpret_cast<const uint4*>(sb + w0_ * sb_r + cc * 8); \
+      ra1 = *reinterpret_cast<const uint4*>(sa + w1_ * sa_r + cc * 8); rb1 = *reinterpret_cast<const uint4*>(sb + w1_ * sb_r + cc * 8); \
+      ra2 = *reinterpret_cast<const uint4*>(sa + w2_ * sa_r + cc * 8); rb2 = *reinterpret_cast<const uint4*>(sb + w2_ * sb_r + cc * 8); \
+      ra3 = *reinterpret_cast<const uint4*>(sa + w3_ * sa_r + cc * 8); rb3 = *reinterpret_cast<const uint4*>(sb + w3_ * sb_r + cc * 8); \
+    }                                                                                                           \
+  }
+#define BW_PIN4(r) "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)
+  // hipcc otherwise hoists the register transposes of BW_STORE (and with them the wait for the whole prefetch) in front of the tile's MFMAs
+#define BW_PIN                                                                                                  \
+  {                                                                                                             \
+    asm volatile("" : BW_PIN4(ra0), BW_PIN4(ra1), BW_PIN4(ra2), BW_PIN4(ra3));                                  \
+    asm volatile("" : BW_PIN4(rb0), BW_PIN4(rb1), BW_PIN4(rb2), BW_PIN4(rb3), "+v"(r_lse), "+v"(r_dl), "+v"(km_nxt)); \
+  }
+#define BW_STORE                                                                                                \
+  {                                                                                                             \
+    if (st_on) {                                                                                                \
+      *reinterpret_cast<uint4*>(Y1 + (4 * kq + 0) * PK + cc * 16) = ra0;                                        \
+      *reinterpret_cast<uint4*>(Y1 + (4 * kq + 1) * PK + cc * 16) = ra1;                                        \
+      *reinterpret_cast<uint4*>(Y1 + (4 * kq + 2) * PK + cc * 16) = ra2;                                        \
+      *reinterpret_cast<uint4*>(Y1 + (4 * kq + 3) * PK + cc * 16) = ra3;                                        \
+      if (HAS2) {                                                                                               \
+        *reinterpret_cast<uint4*>(Y2 + (4 * kq + 0) * PK + cc * 16) = rb0;                                      \
+        *reinterpret_cast<uint4*>(Y2 + (4 * kq + 1) * PK + cc * 16) = rb1;                                      \
+        *reinterpret_cast<uint4*>(Y2 + (4 * kq + 2) * PK + cc * 16) = rb2;                                      \
+        *reinterpret_cast<uint4*>(Y2 + (4 * kq + 3) * PK + cc * 16) = rb3;                                      \
+      }                                                                                                         \
+      /* 4 rows x 8 d -> 8 d-rows of 4 consecutive staged rows (8 bytes each) */                                \
+      const uint4 r0 = HAS2 ? ra0 : rb0, r1 = HAS2 ? ra1 : rb1, r2 = HAS2 ? ra2 : rb2, r3 = HAS2 ? ra3 : rb3;   \
+      char* dst = Yt + (8 * cc) * PV + 8 * kq;                                                                  \
+      *reinterpret_cast<uint2*>(dst + 0 * PV) = make_uint2(bperm_lo(r0.x, r1.x), bperm_lo(r2.x, r3.x));         \
+      *reinterpret_cast<uint2*>(dst + 1 * PV) = make_uint2(bperm_hi(r0.x, r1.x), bperm_hi(r2.x, r3.x));         \
+      *reinterpret_cast<uint2*>(dst + 2 * PV) = make_uint2(bperm_lo(r0.y, r1.y), bperm_lo(r2.y, r3.y));         \
+      *reinterpret_cast<uint2*>(dst + 3 * PV) = make_uint2(bperm_hi(r0.y, r1.y), bperm_hi(r2.y, r3.y));         \
+      *reinterpret_cast<uint2*>(dst + 4 * PV) = make_uint2(bperm_lo(r0.z, r1.z), bperm_lo(r2.z, r3.z));         \
+      *reinterpret_cast<uint2*>(dst + 5 * PV) = make_uint2(bperm_hi(r0.z, r1.z), bperm_hi(r2.z, r3.z));         \
+      *reinterpret_cast<uint2*>(dst + 6 * PV) = make_uint2(bperm_lo(r0.w, r1.w), bperm_lo(r2.w, r3.w));         \
+      *reinterpret_cast<uint2*>(dst + 7 * PV) = make_uint2(bperm_hi(r0.w, r1.w), bperm_hi(r2.w, r3.w));         \
+    }                                                                                                           \
+    if (!OWNER_Q && tid < BT) {                                                                                 \
+      st_l[tid] = r_lse;                                                                                        \
+      if (MODE == MODE_DK) st_d[tid] = r_dl;                                                                    \
+    }                                                                                                           \
+    km_cur = km_nxt;                                                                                            \
+  }
+
+  if (t_begin < t_end) BW_LOAD(t_begin)
+  // the owner fragments (and the first tile) must have LANDED before the loop: a load still pending at the loop header becomes a vmcnt
+  // wait inside every iteration, which would drain that iteration's prefetch early
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    asm volatile("" : "+v"(xf1[ks]));
+    if (HAS2) asm volatile("" : "+v"(xf2[ks]));
+  }
+  BW_PIN
+
   for (int t = t_begin; t < t_end; ++t) {
     const int t0 = t * BT;
     __syncthreads();                                      // the previous tile's fragment reads are done
-    if (st_on) {
-      uint4 ra[4], rb[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const long row = min(t0 + 4 * kq + j, Nst - 1);
-        ra[j] = *reinterpret_cast<const uint4*>(sa + row * sa_r + cc * 8);
-        rb[j] = *reinterpret_cast<const uint4*>(sb + row * sb_r + cc * 8);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<uint4*>(Y1 + (4 * kq + j) * PK + cc * 16) = ra[j];
-        if (HAS2) *reinterpret_cast<uint4*>(Y2 + (4 * kq + j) * PK + cc * 16) = rb[j];
-      }
-      // 4 rows x 8 d -> 8 d-rows of 4 consecutive staged rows (8 bytes each)
-      const uint4 r0 = HAS2 ? ra[0] : rb[0], r1 = HAS2 ? ra[1] : rb[1], r2 = HAS2 ? ra[2] : rb[2], r3 = HAS2 ? ra[3] : rb[3];
-      char* dst = Yt + (8 * cc) * PV + 8 * kq;
-      *reinterpret_cast<uint2*>(dst + 0 * PV) = make_uint2(bperm_lo(r0.x, r1.x), bperm_lo(r2.x, r3.x));
-      *reinterpret_cast<uint2*>(dst + 1 * PV) = make_uint2(bperm_hi(r0.x, r1.x), bperm_hi(r2.x, r3.x));
-      *reinterpret_cast<uint2*>(dst + 2 * PV) = make_uint2(bperm_lo(r0.y, r1.y), bperm_lo(r2.y, r3.y));
-      *reinterpret_cast<uint2*>(dst + 3 * PV) = make_uint2(bperm_hi(r0.y, r1.y), bperm_hi(r2.y, r3.y));
-      *reinterpret_cast<uint2*>(dst + 4 * PV) = make_uint2(bperm_lo(r0.z, r1.z), bperm_lo(r2.z, r3.z));
-      *reinterpret_cast<uint2*>(dst + 5 * PV) = make_uint2(bperm_hi(r0.z, r1.z), bperm_hi(r2.z, r3.z));
-      *reinterpret_cast<uint2*>(dst + 6 * PV) = make_uint2(bperm_lo(r0.w, r1.w), bperm_lo(r2.w, r3.w));
-      *reinterpret_cast<uint2*>(dst + 7 * PV) = make_uint2(bperm_hi(r0.w, r1.w), bperm_hi(r2.w, r3.w));
-    }
-    if (!OWNER_Q && tid < BT) {
-      const long qi = stat0 + min(t0 + tid, p.Nq - 1);
-      st_l[tid] = p.lse[qi];
-      if (MODE == MODE_DK) st_d[tid] = p.delta[qi];
-    }
+    BW_STORE
     __syncthreads();
+    if (BWD_ABLATE != 3) BW_LOAD(min(t + 1, t_end - 1))      // unconditional (the last iteration re-fetches its own tile): a branch around the loads costs register copies that wait for them
 
     // wave-level skips: nothing owned, or (causal) this tile lies entirely on the masked side of this wave's rows
-    if (wo0 >= Nown) continue;
-    if (p.causal && (OWNER_Q ? t0 > wo0 + 31 : t0 + BT - 1 < wo0)) continue;
-
-    f32x16_t s[2], dp[2];
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { s[jb][e] = 0.f; dp[jb][e] = 0.f; }
-    // k-step outer: consecutive MFMAs cycle through the (up to four) accumulators
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
+    const bool skip = wo0 >= Nown || (p.causal && (OWNER_Q ? t0 > wo0 + 31 : t0 + BT - 1 < wo0));
+    if (!skip && BWD_ABLATE != 1) {
+      // key-padding mask of the staged keys (mode dQ): one byte per lane (fetched with the tile) + a ballot, pre-shifted by the lane half's 4
+      uint32_t km_lo = 0xffffffffu, km_hi = 0xffffffffu;
+      if (OWNER_Q && p.key_mask) {
+        const unsigned long long kb = __ballot(km_cur != 0) >> (4 * half);
+        km_lo = (uint32_t)kb; km_hi = (uint32_t)(kb >> 32);
+      }
+      // one 32-row block of the staged tile at a time (scores, then its share of the output product): 32 score registers live instead of 64,
+      // which is what makes room for the prefetch registers at 2 waves per SIMD
+#pragma unroll 1
       for (int jb = 0; jb < 2; ++jb) {
-        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(Y1 + (jb * 32 + ql) * PK + (2 * ks + half) * 16);
-        s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xf1[ks], s[jb], 0, 0, 0);
-        if (HAS2) {
-          const bf16x8_t a2 = *reinterpret_cast<const bf16x8_t*>(Y2 + (jb * 32 + ql) * PK + (2 * ks + half) * 16);
-          dp[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xf2[ks], dp[jb], 0, 0, 0);
+        f32x16_t s, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(Y1 + (jb * 32 + ql) * PK + (2 * ks + half) * 16);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xf1[ks], s, 0, 0, 0);
+          if (HAS2) {
+            const bf16x8_t a2 = *reinterpret_cast<const bf16x8_t*>(Y2 + (jb * 32 + ql) * PK + (2 * ks + half) * 16);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xf2[ks], dp, 0, 0, 0);
+          }
+        }
+        // P (mode dV) or dS (modes dQ, dK), in place.  Branch-free: the row statistics of the 16 staged rows this lane's registers run over are four
+        // 16-byte LDS reads per table, issued together (the per-element `ok ? ... : 0` with an LDS read inside compiled to 32 branches with a
+        // dependent ds_read_b32 each: 18 of the launch's 51 us), the exponential is computed for every element and the mask is a select.
+        if (BWD_ABLATE != 4) {
+          const uint32_t kmw = jb ? km_hi : km_lo;
+          const int sr0 = t0 + jb * 32 + 4 * half;
+          // wave-uniform: no element of this 32-row block of the tile is masked for any of the wave's owner rows (interior of the causal triangle,
+          // all rows real, no padded key): the mask arithmetic (4-5 of ~9 VALU operations per element) is skipped
+          const int blk0 = t0 + jb * 32;
+          const bool open_blk = __all(own_ok) && blk0 + 32 <= Nst && (!p.causal || (OWNER_Q ? blk0 + 31 <= wo0 : wo0 + 31 <= blk0)) &&
+                                (!OWNER_Q || __all((kmw & 0x0f0f0f0fu) == 0x0f0f0f0fu));      // the 16 mask bits this lane's registers use
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float lg[4] = {lse_o, lse_o, lse_o, lse_o}, dg[4] = {d_os, d_os, d_os, d_os};
+            if (!OWNER_Q) {
+              const float4 l4 = *reinterpret_cast<const float4*>(st_l + jb * 32 + 8 * g + 4 * half);
+              lg[0] = l4.x; lg[1] = l4.y; lg[2] = l4.z; lg[3] = l4.w;
+              if (MODE == MODE_DK) {
+                const float4 d4 = *reinterpret_cast<const float4*>(st_d + jb * 32 + 8 * g + 4 * half);
+                dg[0] = d4.x * p.scale; dg[1] = d4.y * p.scale; dg[2] = d4.z * p.scale; dg[3] = d4.w * p.scale;
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * g + e;
+              float pv = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, -lg[e]));
+              if (!open_blk) {
+                const int sr = sr0 + e + 8 * g;
+                bool ok = own_ok && sr < Nst;
+                if (p.causal) ok = ok && (OWNER_Q ? sr <= ow : ow <= sr);
+                if (OWNER_Q) ok = ok && ((kmw >> (e + 8 * g)) & 1u);
+                pv = ok ? pv : 0.f;
+              }
+              if (MODE == MODE_DV) s[r] = pv;
+              else s[r] = pv * fmaf(dp[r], p.scale, -dg[e]);        // dS = scale * P * (dP - D)
+            }
+          }
+        }
+        // out^T += Yt . (P | dS): k-steps of 16 staged rows; the B fragment of step ss = registers 8*(ss&1)..+7 of block ss>>1
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int ss = 2 * jb + s2, rb = 8 * s2;
+          const uint4 pu = make_uint4(pack2bf(s[rb + 0], s[rb + 1]), pack2bf(s[rb + 2], s[rb + 3]),
+                                      pack2bf(s[rb + 4], s[rb + 5]), pack2bf(s[rb + 6], s[rb + 7]));
+          const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
+#pragma unroll
+          for (int d = 0; d < DT; ++d) {
+            const char* vrow = Yt + (d * 32 + ql) * PV + (16 * ss + 4 * half) * 2;
+            const uint2 va = *reinterpret_cast<const uint2*>(vrow);
+            const uint2 vb = *reinterpret_cast<const uint2*>(vrow + 16);
+            const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(va.x, va.y, vb.x, vb.y));
+            acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc[d], 0, 0, 0);
+          }
         }
       }
-    // key-padding mask of the staged keys (mode dQ): one byte load per lane + a ballot per tile, pre-shifted by the lane half's 4
-    uint32_t km_lo = 0xffffffffu, km_hi = 0xffffffffu;
-    if (OWNER_Q && p.key_mask) {
-      const unsigned long long kb = __ballot(p.key_mask[(long)b * p.Nk + min(t0 + lane, p.Nk - 1)] != 0) >> (4 * half);
-      km_lo = (uint32_t)kb; km_hi = (uint32_t)(kb >> 32);
     }
-    // P (mode dV) or dS (modes dQ, dK), in place
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int loc = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int sr = t0 + loc;
-        bool ok = own_ok && sr < Nst;
-        if (p.causal) ok = ok && (OWNER_Q ? sr <= ow : ow <= sr);
-        if (OWNER_Q) ok = ok && (((jb ? km_hi : km_lo) >> ((r & 3) + 8 * (r >> 2))) & 1u);
-        const float lse = OWNER_Q ? lse_o : st_l[loc];
-        const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(s[jb][r], p.scale_log2, -lse)) : 0.f;
-        if (MODE == MODE_DV) {
-          s[jb][r] = pv;
-        } else {
-          const float dd = OWNER_Q ? d_o : st_d[loc];
-          s[jb][r] = pv * (dp[jb][r] - dd) * p.scale;
-        }
-      }
-    // out^T += Yt . (P | dS): k-steps of 16 staged rows; the B fragment of step ss = accumulator regs 8*(ss&1)..+7 of block ss>>1
-#pragma unroll
-    for (int ss = 0; ss < 4; ++ss) {
-      const int jb = ss >> 1, rb = 8 * (ss & 1);
-      const uint4 pu = make_uint4(pack2bf(s[jb][rb + 0], s[jb][rb + 1]), pack2bf(s[jb][rb + 2], s[jb][rb + 3]),
-                                  pack2bf(s[jb][rb + 4], s[jb][rb + 5]), pack2bf(s[jb][rb + 6], s[jb][rb + 7]));
-      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
-#pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        const char* vrow = Yt + (d * 32 + ql) * PV + (16 * ss + 4 * half) * 2;
-        const uint2 va = *reinterpret_cast<const uint2*>(vrow);
-        const uint2 vb = *reinterpret_cast<const uint2*>(vrow + 16);
-        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(va.x, va.y, vb.x, vb.y));
-        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc[d], 0, 0, 0);
-      }
-    }
+    BW_PIN
   }
+#undef BW_LOAD
+#undef BW_STORE
+#undef BW_PIN
+#undef BW_PIN4
 
   // ---- store: lane holds out[owner][d .. d+3] groups ----------------------------------------------------------------------
-  if (ow < Nown) {
+  // Optional rotation of the dQ / dK rows (round 6): the inverse RoPE of the gradient (`rope_cos`, `rope_sin` = the NEGATED sine table) at
+  // position = owner row, with llmseg_rope's arithmetic on the bf16-rounded values -- bit for bit what a separate llmseg_rope launch over
+  // the stored rows gives.  The two elements of a rotate-half pair (d, d + HD/2) sit in accumulators d and d + DT/2 of the same lane.
+  if (ow < Nown && (BWD_ABLATE != 2 || acc[0][0] == 12345.f)) {
     bf16_t* orow = MODE == MODE_DQ   ? p.dQ + (long)b * p.dqs[0] + (long)h * p.dqs[1] + (long)ow * p.dqs[2]
                    : MODE == MODE_DK ? p.dK + (long)b * p.dks[0] + (long)h * p.dks[1] + (long)ow * p.dks[2]
                                      : p.dV + (long)b * p.dvs[0] + (long)h * p.dvs[1] + (long)ow * p.dvs[2];
+    if (MODE != MODE_DV && p.rope_cos != nullptr) {
+      const float* cs = p.rope_cos + (long)ow * (HD / 2);
+      const float* sn = p.rope_sin + (long)ow * (HD / 2);
 #pragma unroll
-    for (int d = 0; d < DT; ++d)
+      for (int d = 0; d < DT / 2; ++d)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int dd = d * 32 + 8 * g + 4 * half;
-        *reinterpret_cast<uint2*>(orow + dd) = make_uint2(pack2bf(acc[d][4 * g], acc[d][4 * g + 1]), pack2bf(acc[d][4 * g + 2], acc[d][4 * g + 3]));
-      }
+        for (int g = 0; g < 4; ++g) {
+          const int dd = d * 32 + 8 * g + 4 * half;
+          const float4 c4 = *reinterpret_cast<const float4*>(cs + dd), s4 = *reinterpret_cast<const float4*>(sn + dd);
+          const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w};
+          float o1[4], o2[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a = round_bf(acc[d][4 * g + e]), bb = round_bf(acc[d + DT / 2][4 * g + e]);
+            o1[e] = rope_lo(a, bb, cv[e], sv[e]);
+            o2[e] = rope_hi(a, bb, cv[e], sv[e]);
+          }
+          *reinterpret_cast<uint2*>(orow + dd) = make_uint2(pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3]));
+          *reinterpret_cast<uint2*>(orow + dd + HD / 2) = make_uint2(pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3]));
+        }
+    } else {
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dd = d * 32 + 8 * g + 4 * half;
+          *reinterpret_cast<uint2*>(orow + dd) = make_uint2(pack2bf(acc[d][4 * g], acc[d][4 * g + 1]), pack2bf(acc[d][4 * g + 2], acc[d][4 * g + 3]));
+        }
+    }
   }
 }
 
 template <int HD, int MODE>
 __global__ __launch_bounds__(NT, 2) void attn_bwd_kernel(BwdP p) {
   __shared__ __attribute__((aligned(16))) char smem[bwd_smem_bytes<HD>(MODE != MODE_DV)];
-  attn_bwd_body<HD, MODE>(p, blockIdx.x, smem);
+  attn_bwd_body<HD, MODE>(p, blockIdx.x, blockIdx.z, blockIdx.y, smem);
 }
 
 // All three gradients in ONE launch: blockIdx.x = [dQ owner blocks | dK owner blocks | dV owner blocks].  At the Llama shape (T = 319,
@@ -253,10 +351,16 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_kernel(BwdP p) {
 template <int HD>
 __global__ __launch_bounds__(NT, 2) void attn_bwd_all_kernel(BwdP p, int nbq, int nbk) {
   __shared__ __attribute__((aligned(16))) char smem[bwd_smem_bytes<HD>(true)];
-  const int x = blockIdx.x;
-  if (x < nbq) attn_bwd_body<HD, MODE_DQ>(p, p.causal ? nbq - 1 - x : x, smem);
-  else if (x < nbq + nbk) attn_bwd_body<HD, MODE_DK>(p, x - nbq, smem);
-  else attn_bwd_body<HD, MODE_DV>(p, x - nbq - nbk, smem);
+  // 1-D grid, (batch, head) fastest: workgroup id -> (class, b, h), the classes ordered by their tile-chain length so that the workgroups the
+  // dispatcher starts LAST (the grid is 576 workgroups for 512 resident slots at the Llama shape) are the shortest ones.  Causal: a dQ block of
+  // late queries and a dK / dV block of early keys are the long chains -> class c walks [dq(n-1-c) | dk(c) | dv(c)].
+  const int bh = p.batch * p.heads;
+  const int cls = blockIdx.x / bh, r = blockIdx.x - cls * bh;
+  const int b = r / p.heads, h = r - b * p.heads;
+  const int lvl = cls / 3, mode = cls - lvl * 3;           // level 0 = the longest chains
+  if (mode == 0) { if (lvl < nbq) attn_bwd_body<HD, MODE_DQ>(p, p.causal ? nbq - 1 - lvl : lvl, b, h, smem); }
+  else if (mode == 1) { if (lvl < nbk) attn_bwd_body<HD, MODE_DK>(p, lvl, b, h, smem); }
+  else { if (lvl < nbk) attn_bwd_body<HD, MODE_DV>(p, lvl, b, h, smem); }
 }
 
 // delta[b][h][q] = sum_d dO[b][h][q][d] * O[b][h][q][d]: 16 lanes per row (one 16-byte load each per 128 d), 16 rows per workgroup
@@ -295,7 +399,7 @@ void launch_bwd(const BwdP& p, hipStream_t s) {
     LL_LAUNCH_KERNEL((attn_bwd_kernel<HD, MODE_DK>), gk, dim3(NT), 0, s, p);
     LL_LAUNCH_KERNEL((attn_bwd_kernel<HD, MODE_DV>), gk, dim3(NT), 0, s, p);
   } else {
-    LL_LAUNCH_KERNEL((attn_bwd_all_kernel<HD>), dim3(nbq + 2 * nbk, p.heads, p.batch), dim3(NT), 0, s, p, nbq, nbk);
+    LL_LAUNCH_KERNEL((attn_bwd_all_kernel<HD>), dim3((unsigned)(3 * std::max(nbq, nbk) * p.heads * p.batch)), dim3(NT), 0, s, p, nbq, nbk);
   }
 }
 
@@ -332,6 +436,10 @@ extern "C" int llmseg_attn_bwd(const llmseg_attn_bwd_args* a, void* stream) {
   p.batch = a->batch; p.heads = a->heads; p.Nq = a->Nq; p.Nk = a->Nk;
   p.scale = a->scale; p.scale_log2 = a->scale * LOG2E;
   p.causal = a->causal; p.key_mask = a->key_mask;
+  p.rope_cos = a->rope_cos; p.rope_sin = a->rope_sin;
+  LL_CHECK((a->rope_cos == nullptr) == (a->rope_sin == nullptr), "attn_bwd: rope_cos and rope_sin come together");
+  LL_CHECK(!a->rope_cos || (a->head_dim >= 64 && a->Nq == a->Nk && (((uintptr_t)a->rope_cos | (uintptr_t)a->rope_sin) & 15) == 0),
+           "attn_bwd: the fused rotation needs head_dim 64 or 128, Nq == Nk (self attention: position = row) and 16-byte aligned tables");
   hipStream_t s = (hipStream_t)stream;
   switch (a->head_dim) {
     case 32: launch_bwd<32>(p, s); break;

@@ -26,6 +26,13 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
+// fp32 -> bf16 -> fp32 (hardware RNE): what a value is after a bf16 store + load
+__device__ __forceinline__ float round_bf(float x) { return __uint_as_float(pack2bf(x, 0.f) << 16); }
+// rotate-half RoPE of the pair (a, b) = (x[d], x[d + head_dim/2]) with cos c, sin s: ONE explicit fma form, shared by llmseg_rope, the
+// decode-step kernels and the fused epilogues (attention backward store, q|k|v GEMM), so that the fused and unfused routes agree bit for bit
+__device__ __forceinline__ float rope_lo(float a, float b, float c, float s) { return fmaf(a, c, -(b * s)); }
+__device__ __forceinline__ float rope_hi(float a, float b, float c, float s) { return fmaf(b, c, a * s); }
+
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
   f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
   f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);

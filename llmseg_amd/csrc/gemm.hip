@@ -45,7 +45,7 @@ struct GemmP {
   int accum;                 // fp32 output only: C += result (gradient accumulation into an fp32 arena)
   int k_split_total;         // register-staging kernel as K-slices: total K (elements); blockIdx.y % batch1 = slice, p.K = elements per slice; 0 = off
   const bf16_t* a_norm_w; float a_norm_eps; int a_swiglu;     // skinny route: transform of the A rows while they are loaded (decode-step fusions)
-  int ablate;                // loader-wave experiment only (LLMSEG_LW_ABLATE; results are garbage): bit 0 = no MFMAs, bit 1 = no fragment reads, bit 2 = no DMA after the prologue
+  int ablate;                // loader-wave experiment only (LLMSEG_LW_ABLATE; results are garbage): bit 0 = no MFMAs, bit 1 = no fragment reads, bit 2 = no DMA after the prologue, bit 3 = no per-K-tile barrier
 };
 
 // exact-erf GELU on a pair (packed fp32 VALU: v_pk_fma / v_pk_mul).  Same Abramowitz-Stegun 7.1.26 erf as apply_act, rearranged:
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(NTL, 1) void gemm_bf16_tn_lw_kernel(GemmP p) {
     for (int t = 0; t < nt; ++t) {
       if (t + 1 < nt) G4_VM(12); else G4_VM(0);            // tile t has landed (tile t + 1 may still be in flight)
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
+      if (!(p.ablate & 8)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       if (t + 2 < nt && !(p.ablate & 4)) issue(t + 2, st2);
       st2 = st2 == NS - 1 ? 0 : st2 + 1;
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(NTL, 1) void gemm_bf16_tn_lw_kernel(GemmP p) {
   const int frow = lane & 15, fq = lane >> 4;
   int st = 0;
   for (int t = 0; t < nt; ++t) {
-    __builtin_amdgcn_s_barrier();
+    if (!(p.ablate & 8)) __builtin_amdgcn_s_barrier();      // (bit 3: no per-K-tile barrier -- with bits 1 + 2 the bare MFMA stream of this wave arrangement)
     __builtin_amdgcn_sched_barrier(0);
     const char* base = smem + ((p.ablate & 2) ? 0 : st) * BUF;
     bf16x8_t wf[4][2], af[4][2];

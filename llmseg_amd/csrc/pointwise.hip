@@ -177,8 +177,8 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ x, const
     const float* sp = sn + pos * (hd >> 1) + c * 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      o1[e] = a[e] * cp[e] - b[e] * sp[e];
-      o2[e] = b[e] * cp[e] + a[e] * sp[e];
+      o1[e] = rope_lo(a[e], b[e], cp[e], sp[e]);
+      o2[e] = rope_hi(a[e], b[e], cp[e], sp[e]);
     }
     *reinterpret_cast<uint4*>(p1) = pack8(o1);
     *reinterpret_cast<uint4*>(p2) = pack8(o2);
@@ -213,8 +213,8 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(bf16_t* __restrict_
     const float* sp = sn + pos * (hd >> 1) + c * 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      o1[e] = a[e] * cp[e] - b[e] * sp[e];
-      o2[e] = b[e] * cp[e] + a[e] * sp[e];
+      o1[e] = rope_lo(a[e], b[e], cp[e], sp[e]);
+      o2[e] = rope_hi(a[e], b[e], cp[e], sp[e]);
     }
     if (sec == 0) { *reinterpret_cast<uint4*>(p1) = pack8(o1); *reinterpret_cast<uint4*>(p2) = pack8(o2); }
     else { *reinterpret_cast<uint4*>(d1) = pack8(o1); *reinterpret_cast<uint4*>(d1 + (hd >> 1)) = pack8(o2); }

@@ -151,8 +151,9 @@ def attention_packed(qkv, batch, n_tok, heads, head_dim, out=None, **kw):
 
 
 def attention_bwd(q, k, v, o, do, dq, dk, dv, lse, *, batch, heads, Nq, Nk, head_dim, q_strides, k_strides, v_strides, o_strides, do_strides,
-                  dq_strides, dk_strides, dv_strides, scale=None, causal=False, key_mask=None):
-    """Fused attention backward (dq, dk, dv are written).  lse = the fp32 [batch, heads, Nq] row statistics the forward wrote."""
+                  dq_strides, dk_strides, dv_strides, scale=None, causal=False, key_mask=None, rope=None):
+    """Fused attention backward (dq, dk, dv are written).  lse = the fp32 [batch, heads, Nq] row statistics the forward wrote.
+    rope = (cos, sin) fp32 [Nq, head_dim/2]: every dq / dk row is rotated at its position before the store (pass -sin for the inverse)."""
     assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.numel() == batch * heads * Nq
     delta = torch.empty_like(lse)
     kw = {}
@@ -163,6 +164,9 @@ def attention_bwd(q, k, v, o, do, dq, dk, dv, lse, *, batch, heads, Nq, Nk, head
                     dV=dv.data_ptr(), batch=batch, heads=heads, Nq=Nq, Nk=Nk, head_dim=head_dim,
                     scale=(1.0 / math.sqrt(head_dim)) if scale is None else scale, causal=1 if causal else 0,
                     key_mask=None if key_mask is None else key_mask.data_ptr(), lse=lse.data_ptr(), delta=delta.data_ptr(), **kw)
+    if rope is not None:
+        assert all(t.dtype == torch.float32 and t.is_contiguous() and t.shape == (Nq, head_dim // 2) for t in rope)
+        a.rope_cos, a.rope_sin = rope[0].data_ptr(), rope[1].data_ptr()
     _lib.check(_lib.load().llmseg_attn_bwd(C.byref(a), _stream()), "attn_bwd")
 
 

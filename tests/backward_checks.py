@@ -161,6 +161,27 @@ def check_autograd_ops():
         return (p @ v).transpose(1, 2).reshape(N * T, nh * hd)
     rope_tabs = (cos.to(DEV), sin.to(DEV), (-sin).to(DEV))
     out += _grads(rope_attn_ref, lambda t: ag.rope_attention(t.clone(), rope_tabs, N, T, nh, hd, True, None), [qkv], ["rope+attn", "qkv"])
+    # round 6: the inverse rotation rides in the attention backward's dq / dk store == a separate llmseg_rope launch over the stored
+    # gradient, BIT FOR BIT (the benchmark's T = 319 with right padding; head_dim 128 and 64)
+    for hd2 in (128, 64):
+        T2, N2, nh2 = 319, 2, 2
+        qkv2 = rnd(N2 * T2, 3 * nh2 * hd2, seed=33 + hd2, scale=0.5).to(DEV)
+        go = rnd(N2 * T2, nh2 * hd2, seed=34, scale=0.1).to(DEV)
+        km2 = torch.ones(N2, T2, dtype=torch.uint8)
+        km2[1, 300:] = 0
+        ang2 = torch.outer(torch.arange(T2).float(), 1.0 / (10000 ** (torch.arange(0, hd2, 2).float() / hd2)))
+        tabs2 = (ang2.cos().contiguous().to(DEV), ang2.sin().contiguous().to(DEV), (-ang2.sin()).contiguous().to(DEV))
+        keep = ag.FUSE_ROPE_BWD
+        gs = []
+        try:
+            for fuse in (True, False):
+                ag.FUSE_ROPE_BWD = fuse
+                t = qkv2.clone().requires_grad_(True)
+                ag.rope_attention(t.clone(), tabs2, N2, T2, nh2, hd2, True, km2.to(DEV)).backward(go)
+                gs.append(t.grad.float().cpu())
+        finally:
+            ag.FUSE_ROPE_BWD = keep
+        out.append((f"rope inside attn-bwd store == rope launch, hd={hd2} (bits)", float((gs[0] - gs[1]).abs().max()), 0.0))
     # CE
     Nn, T, V = 2, 7, 1000
     logits = rnd(Nn, T, V, seed=15, scale=2.0)
