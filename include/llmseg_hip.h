@@ -96,7 +96,19 @@ typedef struct {
    * as K-slices (Llama o / down at M = 2 x 319) the reduce launch computes it on the row it has just summed (one launch and one pass over the row instead of
    * two); otherwise the library runs llmseg_norm behind the GEMM.  Same bits either way.  NULL = off. */
   const void* norm_w; float norm_eps; int reserved1; void* norm_out; int64_t ldn;
+  /* fused Llama-layer epilogues (ABI 8): the pointwise launch that used to follow the product runs inside the GEMM's store.  Plain bf16 product only
+   * (batch 1, alpha 1, no bias / activation / gamma / residual / norm_out / trans_*).  Same bits as the product followed by that launch: the library runs
+   * exactly that two-launch route on every shape its fused kernel (the 128 x 256 tile in one K-slice: the Llama layer at 2 x 319 rows) does not take.
+   *   LLMSEG_FX_ROPE        C = q|k|v [M][N]: the heads (width 128) of columns < fx_cols are rotated (rotate-half; fx_cos / fx_sin fp32 [fx_T][64], position
+   *                         = row % fx_T) as llmseg_rope(C, ...) would after the product (HF LlamaAttention: apply_rotary_pos_emb on q and k,
+   *                         call site llava_llama.py:93-102);
+   *   LLMSEG_FX_SWIGLU      N = 2 I, C = gate|up [M][2 I] as without fx AND fx_out[m][c] = silu(gate[m][c]) * up[m][c], bf16 [M][fx_ld] (HF LlamaMLP), as
+   *                         llmseg_swiglu would after the product;
+   *   LLMSEG_FX_SWIGLU_BWD  N = I: the product is d(silu(gate) * up) [M][I] (dX of down_proj); fx_in = the saved gate|up [M][fx_ld >= 2 I]; C = d(gate|up)
+   *                         bf16 [M][ldc >= 2 I], as llmseg_swiglu_bwd would compute from the stored product. */
+  int fx; int fx_T; int64_t fx_cols; const float* fx_cos; const float* fx_sin; void* fx_out; const void* fx_in; int64_t fx_ld;
 } llmseg_gemm_args;
+enum { LLMSEG_FX_NONE = 0, LLMSEG_FX_ROPE = 1, LLMSEG_FX_SWIGLU = 2, LLMSEG_FX_SWIGLU_BWD = 3 };
 int llmseg_gemm_bf16(const llmseg_gemm_args* args, void* stream);
 /* tuning knob (results are identical up to fp32 summation order of split-K; only speed differs):
  * bits 0-3: GEMM kernel for K % 64 == 0 shapes: 0 = register staging 128x128, 2 = LDS-DMA 128x128, 8 = LDS-DMA 256x256 ping-pong,

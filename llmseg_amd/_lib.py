@@ -34,7 +34,11 @@ class GemmArgs(_Sized):
                 ("A2", C.c_void_p), ("W2", C.c_void_p), ("lda2", C.c_int64), ("ldw2", C.c_int64),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("accumulate", C.c_int),
                 ("a_norm_w", C.c_void_p), ("a_norm_eps", C.c_float), ("a_swiglu", C.c_int),
-                ("norm_w", C.c_void_p), ("norm_eps", C.c_float), ("reserved1", C.c_int), ("norm_out", C.c_void_p), ("ldn", C.c_int64)]
+                ("norm_w", C.c_void_p), ("norm_eps", C.c_float), ("reserved1", C.c_int), ("norm_out", C.c_void_p), ("ldn", C.c_int64),
+                ("fx", C.c_int), ("fx_T", C.c_int), ("fx_cols", C.c_int64), ("fx_cos", C.c_void_p), ("fx_sin", C.c_void_p), ("fx_out", C.c_void_p),
+                ("fx_in", C.c_void_p), ("fx_ld", C.c_int64)]
+
+FX_NONE, FX_ROPE, FX_SWIGLU, FX_SWIGLU_BWD = 0, 1, 2, 3          # LLMSEG_FX_* of include/llmseg_hip.h
 
 
 class AttnArgs(_Sized):

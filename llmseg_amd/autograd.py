@@ -26,6 +26,8 @@ BIG_LINEAR = 1 << 34          # M*N*K above which LinearFn.backward transposes/p
 BIG_WEIGHT = 1 << 26          # N * K of a Linear whose dX / dW always take the transposed-operand route below (lm_head: 131 M)
 # A/B switches of the round-6 Llama-layer fusions (tests compare each fused route with the unfused one bit for bit)
 FUSE_ROPE_BWD = os.environ.get("LLMSEG_NO_FUSE_ROPE_BWD") is None      # inverse RoPE inside the attention backward's dq / dk store
+FUSE_ROPE_FWD = os.environ.get("LLMSEG_NO_FUSE_ROPE_FWD") is None      # RoPE inside the q|k|v GEMM's store (rank-8 LoRA route, head_dim 128)
+FUSE_MLP = os.environ.get("LLMSEG_NO_FUSE_MLP") is None                # swiglu / swiglu_bwd inside the gate|up and dX(down) GEMMs' stores (frozen MLP weights)
 
 
 class Leaves:
@@ -184,12 +186,13 @@ def linear_norm(x, w, residual, wt, norm_w, eps):
     return LinearNormFn.apply(x, w, None, ops.ACT_NONE, residual, wt, norm_w, eps)
 
 
-def lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, drop=None, want_bt=False):
+def lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, drop=None, want_bt=False, rope=None):
     """qkv = x Wqkv^T + s (drop_q(x) Aq^T) Bq^T on the q block + s (drop_v(x) Av^T) Bv^T on the v block, rank 8.  The two updates
     ride in the qkv GEMM as one extra 64-wide K-tile: A2 = [x Aq^T | x Av^T | 0], W2 rows of the q block = [s Bq | 0], rows of the
     v block = [0 | s Bv | 0] (no read-modify-write pass over q and v).  Both operands are rebuilt from the current LoRA matrices
     on every call (two small kernels): nothing is cached, so an in-place optimizer update or a load_state_dict cannot leave a
-    stale operand behind.  drop = (rng_state, layer, p[, seg_rows]) or None.  -> (qkv, A2, B^T | None)"""
+    stale operand behind.  drop = (rng_state, layer, p[, seg_rows]) or None.  rope = (cos, sin, T): the q | k heads (width 128) leave the GEMM
+    already rotated (`llmseg_gemm_args.fx`, round 6: `rope_` used to be a launch of its own).  -> (qkv, A2, B^T | None)"""
     H = wqkv.shape[1]
     M = x.shape[0]
     a2 = torch.empty((M, 64), device=x.device, dtype=BF16)
@@ -197,7 +200,7 @@ def lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, drop=None, want_bt=False):
     w2b = torch.empty((3 * H, 64), device=x.device, dtype=BF16)
     bt = torch.empty((16, H), device=x.device, dtype=BF16) if want_bt else None      # Bq^T | Bv^T for the backward's down projection
     ops.lora_pack(aq, bq, av, bv, s, w2b=w2b, bt=bt)
-    return ops.gemm(x, wqkv, a2=a2, w2=w2b), a2, bt
+    return ops.gemm(x, wqkv, a2=a2, w2=w2b, rope=None if rope is None else (rope[0], rope[1], rope[2], 2 * H)), a2, bt
 
 
 def _drops(drop):
@@ -214,17 +217,21 @@ class LoraQKVFn(Function):
     (peft 0.4.0 Linear: `lora_B(lora_A(lora_dropout(x))) * scaling`; base weight frozen).  PARITY UNPINNED (peft absent)."""
 
     @staticmethod
-    def forward(ctx, x, wqkv, aq, bq, av, bv, s, wqkv_t=None, drop=None):
+    def forward(ctx, x, wqkv, aq, bq, av, bv, s, wqkv_t=None, drop=None, rope=None):
+        """rope = (cos, sin, T) (rank-8 route only): the output's q | k heads are ROTATED inside the GEMM.  This node's backward still expects the
+        gradient w.r.t. the UNROTATED q|k|v -- which is what `PackedAttnFn(..., pre_rotated=True)` returns (its backward applies the inverse rotation
+        in the attention kernel's store): the two nodes are a pair, the rotated tensor must have no other consumer."""
         ctx.wqkv_t = wqkv_t
         H = wqkv.shape[1]
         ctx.fast = aq.shape[0] == 8                                      # rank-8 skinny kernels
         ctx.drop = drop if (drop is not None and drop[2] > 0.0) else None
         ctx.g = tuple(g32_of(t) for t in (aq, bq, av, bv))
         if ctx.fast:
-            qkv, a2, ctx.bt = lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, ctx.drop, want_bt=True)
+            qkv, a2, ctx.bt = lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, ctx.drop, want_bt=True, rope=rope)
             xaq, xav = a2[:, :8], a2[:, 8:16]
         else:
             assert ctx.drop is None, "LoRA dropout is implemented for rank 8"
+            assert rope is None, "the fused rotation rides on the rank-8 route"
             qkv = ops.gemm(x, wqkv)
             xaq, xav = ops.gemm(x, aq), ops.gemm(x, av)                   # [M, r]
             ops.gemm(xaq, bq, residual=qkv[:, :H], out=qkv[:, :H], alpha=s)
@@ -269,7 +276,7 @@ class LoraQKVFn(Function):
             else:
                 (dbq, dbv), (daq, dav) = wgrads()
             outs = [None if (g is not None or t is None) else t.to(BF16) for g, t in ((gaq, daq), (gbq, dbq), (gav, dav), (gbv, dbv))]
-            return dx, None, outs[0], outs[1], outs[2], outs[3], None, None, None
+            return dx, None, outs[0], outs[1], outs[2], outs[3], None, None, None, None
         tq = ops.gemm(dq, bq, trans_w=True, alpha=s)                      # [M, r] = s dq Bq
         tv = ops.gemm(dv, bv, trans_w=True, alpha=s)
         dx = ops.gemm(d, ctx.wqkv_t) if ctx.wqkv_t is not None else ops.gemm(d, wqkv, trans_w=True)
@@ -282,7 +289,7 @@ class LoraQKVFn(Function):
                 grads.append(None)
             else:
                 grads.append(ops.gemm(a_, b_, trans_a=True, trans_w=True, alpha=al))
-        return dx, None, grads[0], grads[1], grads[2], grads[3], None, None, None
+        return dx, None, grads[0], grads[1], grads[2], grads[3], None, None, None, None
 
 
 class NormFn(Function):
@@ -382,10 +389,11 @@ class PackedAttnFn(Function):
     buffer that is rotated in place)."""
 
     @staticmethod
-    def forward(ctx, qkv, batch, n, heads, hd, causal, key_mask, rope=None):
-        """rope = (cos, sin, -sin) fp32 [n, hd/2] tables or None."""
+    def forward(ctx, qkv, batch, n, heads, hd, causal, key_mask, rope=None, pre_rotated=False):
+        """rope = (cos, sin, -sin) fp32 [n, hd/2] tables or None.  pre_rotated: the q | k part of qkv was rotated by its producer (`LoraQKVFn(rope=)`:
+        inside the GEMM); the backward still applies the inverse rotation, i.e. returns the gradient w.r.t. the UNROTATED q|k|v that producer expects."""
         D = heads * hd
-        if rope is not None:
+        if rope is not None and not pre_rotated:
             ops.rope_(qkv, rope[0], rope[1], batch * n, n, 2 * heads, hd, qkv.stride(0))
             ctx.mark_dirty(qkv)
             ctx.set_materialize_grads(False)          # the rotated qkv output has no consumer: its gradient stays None
@@ -395,7 +403,7 @@ class PackedAttnFn(Function):
         ctx.args = (batch, n, heads, hd, causal)
         ctx.rope = rope
         ctx.save_for_backward(qkv, key_mask, out if fused else None, lse)
-        return (qkv, out) if rope is not None else out
+        return (qkv, out) if (rope is not None and not pre_rotated) else out
 
     @staticmethod
     def backward(ctx, *grads):
@@ -419,15 +427,16 @@ class PackedAttnFn(Function):
                                hd=hd, qs=st, ks=st, vs=st, dos=dst, dqs=st, dks=st, dvs=st, scale=1.0 / math.sqrt(hd), causal=causal,
                                key_mask=key_mask)
         if ctx.rope is not None:
-            assert grads[0] is None, "the rotated qkv buffer must not be consumed outside this node"
+            assert len(grads) == 1 or grads[0] is None, "the rotated qkv buffer must not be consumed outside this node"
             if not rope_in_bwd:
                 ops.rope_(dqkv, ctx.rope[0], ctx.rope[2], batch * n, n, 2 * heads, hd, ld)
-        return dqkv, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None
 
 
-def rope_attention(qkv, rope, batch, n, heads, hd, causal, key_mask):
-    """RoPE (in place on the q|k part of qkv) + attention as one autograd node -> attention output."""
-    return PackedAttnFn.apply(qkv, batch, n, heads, hd, causal, key_mask, rope)[1]
+def rope_attention(qkv, rope, batch, n, heads, hd, causal, key_mask, pre_rotated=False):
+    """RoPE (in place on the q|k part of qkv, unless its producer already rotated it) + attention as one autograd node -> attention output."""
+    r = PackedAttnFn.apply(qkv, batch, n, heads, hd, causal, key_mask, rope, pre_rotated)
+    return r[1] if isinstance(r, tuple) else r
 
 
 class CrossAttn1QFn(Function):
@@ -468,6 +477,42 @@ class SwigluFn(Function):
     def backward(ctx, d):
         (gu,) = ctx.saved_tensors
         return ops.swiglu_bwd(gu, d.contiguous(), ctx.inter), None
+
+
+class MlpFn(Function):
+    """HF LlamaMLP with FROZEN weights + the residual add (+ optionally the residual stream's next RMSNorm) as ONE node (round 6):
+        gate|up = x Wgu^T,  h = silu(gate) * up (inside that GEMM's store),  y = h Wd^T + residual (, pre = RMSNorm(y) * norm_w);
+    backward:  d(gate|up) = swiglu'(dy Wd) inside the dX GEMM's store,  dx = d(gate|up) Wgu,  d(residual) = dy.
+    `swiglu` and `swiglu_bwd` used to be launches of their own (8.8 + 13.4 us per layer at 2 images, each re-reading what a GEMM had just written);
+    h is not kept for the backward (no weight gradient needs it).  Same bits as linear -> SwigluFn -> linear_norm.  llava_llama.py:93-102 (HF LlamaMLP)."""
+
+    @staticmethod
+    def forward(ctx, x, wgu, wgu_t, wd, wd_t, residual, norm_w, eps):
+        M, inter = x.shape[0], wd.shape[1]
+        gu = torch.empty((M, 2 * inter), device=x.device, dtype=BF16)
+        h = torch.empty((M, inter), device=x.device, dtype=BF16)
+        ops.gemm(x, wgu, out=gu, swiglu_out=h)
+        ctx.wgu_t, ctx.wd_t = wgu_t, wd_t
+        ctx.save_for_backward(gu)
+        ctx.set_materialize_grads(False)
+        if norm_w is None:
+            return ops.gemm(h, wd, residual=residual), None
+        pre = torch.empty((M, wd.shape[0]), device=x.device, dtype=BF16)
+        y = ops.gemm(h, wd, residual=residual, norm_w=norm_w, norm_eps=eps, norm_out=pre)
+        ctx.mark_non_differentiable(pre)
+        return y, pre
+
+    @staticmethod
+    def backward(ctx, dy, _dpre):
+        (gu,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dgu = ops.gemm(dy, ctx.wd_t, swiglu_bwd_of=gu)          # [M, 2I] = swiglu_bwd(gu, dy Wd)
+        dx = ops.gemm(dgu, ctx.wgu_t) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, None, (dy if ctx.needs_input_grad[5] else None), None, None
+
+
+def mlp(x, wgu, wgu_t, wd, wd_t, residual, norm_w, eps):
+    return MlpFn.apply(x, wgu, wgu_t, wd, wd_t, residual, norm_w, eps)
 
 
 def embed_token_index(ids, P):

@@ -243,21 +243,19 @@ __global__ __launch_bounds__(256) void norm_dwdb_kernel(const bf16_t* __restrict
 }
 
 // d_gu[r][c] = d_out * up * silu'(gate), d_gu[r][I+c] = d_out * silu(gate)
-__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dout, bf16_t* __restrict__ dgu,
-                                                        long rows, long I) {
+// dout rows have stride ld_dout; dout may ALIAS the up half of dgu's rows (the two-launch route of the GEMM's fused swiglu-backward epilogue): every
+// thread reads its own 8 elements of dout before it overwrites them, so no restrict on those two
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* dout, bf16_t* dgu,
+                                                        long rows, long I, long ld_dout) {
   const long ich = I >> 3, total = rows * ich;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long row = i / ich, c = i % ich;
     float g[8], u[8], d[8], og[8], ou[8];
     unpack8(*reinterpret_cast<const uint4*>(gu + row * 2 * I + c * 8), g);
     unpack8(*reinterpret_cast<const uint4*>(gu + row * 2 * I + I + c * 8), u);
-    unpack8(*reinterpret_cast<const uint4*>(dout + row * I + c * 8), d);
+    unpack8(*reinterpret_cast<const uint4*>(dout + row * ld_dout + c * 8), d);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float sg = 1.f / (1.f + __expf(-g[e]));
-      ou[e] = d[e] * g[e] * sg;
-      og[e] = d[e] * u[e] * sg * (1.f + g[e] * (1.f - sg));
-    }
+    for (int e = 0; e < 8; ++e) swiglu_bwd1(d[e], g[e], u[e], og[e], ou[e]);
     *reinterpret_cast<uint4*>(dgu + row * 2 * I + c * 8) = pack8(og);
     *reinterpret_cast<uint4*>(dgu + row * 2 * I + I + c * 8) = pack8(ou);
   }
@@ -526,7 +524,16 @@ extern "C" int llmseg_norm_bwd_add(const void* dy, const void* x, const void* w,
 extern "C" int llmseg_swiglu_bwd(const void* gu, const void* dout, void* dgu, int64_t rows, int64_t I, void* stream) {
   LL_CHECK(gu && dout && dgu && rows > 0 && I > 0 && (I & 7) == 0 && AL16(gu) && AL16(dout) && AL16(dgu), "swiglu_bwd: bad arguments");
   LL_LAUNCH_KERNEL(swiglu_bwd_kernel, dim3(grid_for(rows * (I >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gu, (const bf16_t*)dout,
-                     (bf16_t*)dgu, (long)rows, (long)I);
+                     (bf16_t*)dgu, (long)rows, (long)I, (long)I);
+  LL_LAUNCH_CHECK("swiglu_bwd");
+  return LLMSEG_OK;
+}
+
+// library-internal (gemm.hip, the two-launch route of llmseg_gemm_args.fx = LLMSEG_FX_SWIGLU_BWD): d(out) rows of stride ld_dout, possibly inside dgu's own rows
+extern "C" __attribute__((visibility("hidden"))) int llmseg_swiglu_bwd_ld(const void* gu, const void* dout, void* dgu, int64_t rows, int64_t I, int64_t ld_dout, void* stream) {
+  LL_CHECK(gu && dout && dgu && rows > 0 && I > 0 && (I & 7) == 0 && (ld_dout & 7) == 0 && AL16(gu) && AL16(dout) && AL16(dgu), "swiglu_bwd: bad arguments");
+  LL_LAUNCH_KERNEL(swiglu_bwd_kernel, dim3(grid_for(rows * (I >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gu, (const bf16_t*)dout,
+                     (bf16_t*)dgu, (long)rows, (long)I, (long)ld_dout);
   LL_LAUNCH_CHECK("swiglu_bwd");
   return LLMSEG_OK;
 }

@@ -33,6 +33,15 @@ __device__ __forceinline__ float round_bf(float x) { return __uint_as_float(pack
 __device__ __forceinline__ float rope_lo(float a, float b, float c, float s) { return fmaf(a, c, -(b * s)); }
 __device__ __forceinline__ float rope_hi(float a, float b, float c, float s) { return fmaf(b, c, a * s); }
 
+// HF LlamaMLP act(gate) * up and its gradient, per element: ONE form shared by llmseg_swiglu / llmseg_swiglu_bwd and the GEMM's fused epilogues
+__device__ __forceinline__ float swiglu_fwd1(float g, float u) { return g / (1.f + __expf(-g)) * u; }
+// d(gate) = d * up * silu'(gate), d(up) = d * silu(gate)
+__device__ __forceinline__ void swiglu_bwd1(float d, float g, float u, float& og, float& ou) {
+  const float sg = 1.f / (1.f + __expf(-g));
+  ou = d * g * sg;
+  og = d * u * sg * (1.f + g * (1.f - sg));
+}
+
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
   f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
   f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);

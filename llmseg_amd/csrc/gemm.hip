@@ -45,6 +45,8 @@ struct GemmP {
   int accum;                 // fp32 output only: C += result (gradient accumulation into an fp32 arena)
   int k_split_total;         // register-staging kernel as K-slices: total K (elements); blockIdx.y % batch1 = slice, p.K = elements per slice; 0 = off
   const bf16_t* a_norm_w; float a_norm_eps; int a_swiglu;     // skinny route: transform of the A rows while they are loaded (decode-step fusions)
+  // fused Llama-layer epilogues of the 128 x 256 two-phase kernel (llmseg_gemm_args.fx, round 6): see epilogue_fx
+  int fx, fx_T, fx_cols, fx_I; const float* fx_cos; const float* fx_sin; bf16_t* fx_out; const bf16_t* fx_in; long fx_ld;
   int ablate;                // loader-wave experiment only (LLMSEG_LW_ABLATE; results are garbage): bit 0 = no MFMAs, bit 1 = no fragment reads, bit 2 = no DMA after the prologue, bit 3 = no per-K-tile barrier
 };
 
@@ -312,6 +314,95 @@ __device__ __forceinline__ void epilogue_lds(const GemmP& p, const ACC& acc, cha
     case LLMSEG_ACT_SILU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_SILU, ACC>(p, acc, slab, mw, nw, lane, bz); break;
     case LLMSEG_ACT_RELU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_RELU, ACC>(p, acc, slab, mw, nw, lane, bz); break;
     default: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_SIGMOID, ACC>(p, acc, slab, mw, nw, lane, bz); break;
+  }
+}
+
+// ---- fused Llama-layer epilogues of the 128 x 256 two-phase kernel (llmseg_gemm_args.fx; round 6) -------------------------------------------------
+// Each replaces a pointwise launch that used to re-read what the GEMM has just written, and reproduces that launch's bits: the product is rounded to
+// bf16 first (what the unfused route stores) and then goes through the pointwise kernel's own arithmetic (common.h: rope_lo / rope_hi, swiglu_*).
+//   FX_ROPE        q|k|v projection: every head (128 columns) of the columns < fx_cols is rotated (rotate-half, position = row % fx_T) before the store
+//   FX_SWIGLU      gate|up projection: C = gate|up as before AND fx_out = silu(gate) * up
+//   FX_SWIGLU_BWD  dX of down_proj: the product is d(silu(gate) * up); C = d(gate|up) computed from it and the saved gate|up (fx_in)
+// ROPE and SWIGLU need two columns a fixed distance apart (64 inside a head; gate column c and up column c) in ONE lane: the kernel then gives wave wn
+// the W-tile rows {b .. b + 31} and {b + PS .. b + PS + 31} (ROPE: b = 128 (wn / 2) + 32 (wn % 2), PS = 64; SWIGLU: b = 32 wn, PS = 128 and the tile's 256 W
+// rows are 128 gate rows + the 128 up rows of the same columns) instead of 64 consecutive ones, so that accumulator blocks nb and nb + 2 hold the two
+// elements of a pair, and after the LDS bounce lane (cc = lane % 8, r8 = lane / 8) reads slab chunks cc and cc + 8 of a row: 4 + 4 paired columns.
+enum { FX_NONE = 0, FX_ROPE = 1, FX_SWIGLU = 2, FX_SWIGLU_BWD = 3 };
+
+__device__ __forceinline__ void st4bf(bf16_t* p, const float* v) { *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3])); }
+__device__ __forceinline__ void ld4bf_v(const bf16_t* p, float* o) {
+  const uint2 r = *reinterpret_cast<const uint2*>(p);
+  o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u); o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+}
+
+template <int MI, int FX, class ACC>
+__device__ __forceinline__ void epilogue_fx(const GemmP& p, const ACC& acc, char* smem, int wave, int m0, int n0, int wm, int wn, int lane) {
+  float* slab = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+  bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+  const int mw = m0 + wm * 32 * MI;
+  if constexpr (FX == FX_SWIGLU_BWD) {
+    const int c = lane & 15, rsub = lane >> 4;
+    const int n = n0 + wn * 64 + c * 4;                     // column of d(out): 4 consecutive per lane
+    if (n >= p.N) return;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      acc.write(slab, lane, i);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + rsub, m = mw + i * 32 + row;
+        const float4 a4 = *reinterpret_cast<const float4*>(slab + row * 64 + ((c ^ (row & 15)) << 2));
+        if (m >= p.M) continue;
+        const float d[4] = {round_bf(a4.x), round_bf(a4.y), round_bf(a4.z), round_bf(a4.w)};
+        float g[4], u[4], og[4], ou[4];
+        ld4bf_v(p.fx_in + (long)m * p.fx_ld + n, g);
+        ld4bf_v(p.fx_in + (long)m * p.fx_ld + p.fx_I + n, u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) swiglu_bwd1(d[e], g[e], u[e], og[e], ou[e]);
+        st4bf(C + (long)m * p.ldc + n, og);
+        st4bf(C + (long)m * p.ldc + p.fx_I + n, ou);
+      }
+    }
+  } else {
+    const int cc = lane & 7, r8 = lane >> 3;
+    const int lcol = (FX == FX_ROPE ? (wn >> 1) * 128 + (wn & 1) * 32 : wn * 32) + cc * 4;      // tile-local column of the first element of the pair
+    const bool rot = FX == FX_ROPE && n0 < p.fx_cols;
+    const float inv_T = 1.f / (float)p.fx_T;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      acc.write(slab, lane, i);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + r8, m = mw + i * 32 + row;
+        const float4 x1 = *reinterpret_cast<const float4*>(slab + row * 64 + ((cc ^ (row & 15)) << 2));
+        const float4 x2 = *reinterpret_cast<const float4*>(slab + row * 64 + (((cc + 8) ^ (row & 15)) << 2));
+        if (m >= p.M) continue;
+        const float v1[4] = {round_bf(x1.x), round_bf(x1.y), round_bf(x1.z), round_bf(x1.w)};
+        const float v2[4] = {round_bf(x2.x), round_bf(x2.y), round_bf(x2.z), round_bf(x2.w)};
+        if constexpr (FX == FX_ROPE) {
+          float o1[4] = {v1[0], v1[1], v1[2], v1[3]}, o2[4] = {v2[0], v2[1], v2[2], v2[3]};
+          if (rot) {
+            int pos = m - __float2int_rz((float)m * inv_T) * p.fx_T;      // m % fx_T without an integer division (m < 2^22)
+            pos = pos < 0 ? pos + p.fx_T : (pos >= p.fx_T ? pos - p.fx_T : pos);
+            const int d = (wn & 1) * 32 + cc * 4;
+            const float4 c4 = *reinterpret_cast<const float4*>(p.fx_cos + (long)pos * 64 + d), s4 = *reinterpret_cast<const float4*>(p.fx_sin + (long)pos * 64 + d);
+            const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o1[e] = rope_lo(v1[e], v2[e], cv[e], sv[e]); o2[e] = rope_hi(v1[e], v2[e], cv[e], sv[e]); }
+          }
+          bf16_t* cp = C + (long)m * p.ldc + n0 + lcol;
+          st4bf(cp, o1);
+          st4bf(cp + 64, o2);
+        } else {
+          float h[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h[e] = swiglu_fwd1(v1[e], v2[e]);
+          bf16_t* cp = C + (long)m * p.ldc + n0 + lcol;        // n0 = 128 x the tile's column index: gate columns n0 .., up columns fx_I + n0 ..
+          st4bf(cp, v1);
+          st4bf(cp + p.fx_I, v2);
+          st4bf(p.fx_out + (long)m * p.fx_ld + n0 + lcol, h);
+        }
+      }
+    }
   }
 }
 
@@ -767,7 +858,7 @@ constexpr int NTB = 512;
 // 16x16x32 fragments: lane -> (row lane&15, 16-byte k chunk lane>>4) of a 16-row block, two k-steps of 32 per K-tile
 #define P16_READ_W(dst, j, base)                                                                                              \
   _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                         \
-      dst[nb][ks] = *reinterpret_cast<const bf16x8_t*>((base) + A_BYTES + lds_off(wn * 64 + (j) * 32 + nb * 16 + frow, ks * 4 + fq))
+      dst[nb][ks] = *reinterpret_cast<const bf16x8_t*>((base) + A_BYTES + lds_off(((j) ? wrow1 : wrow0) + nb * 16 + frow, ks * 4 + fq))
 #define P16_READ_A(mb0, base)                                                                                                 \
   _Pragma("unroll") for (int mb = 0; mb < MI; ++mb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                        \
       af[mb][ks] = *reinterpret_cast<const bf16x8_t*>((base) + lds_off(wm * (32 * MI) + ((mb0) + mb) * 16 + frow, ks * 4 + fq))
@@ -842,6 +933,7 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
     for (int mb = 0; mb < 2 * MI; ++mb) acc[nb][mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   bf16x8_t af[MI][2], wf0[2][2], wf1[2][2];
   const int frow = lane & 15, fq = lane >> 4;
+  const int wrow0 = wn * 64, wrow1 = wn * 64 + 32;      // first W-tile row of this wave's two 32-column halves
 
   // prologue: S[0..5] = A0(0) W0(0) W1(0) A1(0) A0(1) W0(1)
   if (EXT) { PP_ISSUE_AX(0, smem); PP_ISSUE_WX(0, smem); PP_ISSUE_WX(1, smem); PP_ISSUE_AX(1, smem); }
@@ -888,10 +980,11 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
 // in each phase (A: A0 + W0, B: W1 + A1 -- each region >= 2 phases after its last read, the lagging group's reads included), and one
 // counted wait per K-tile (phase B: vmcnt(6) = tile t + 2 may stay in flight, tile t + 1 is complete) retires what phase A of the next
 // tile reads, one barrier later.
-template <bool OUT_F32, bool EXT>
+template <bool OUT_F32, bool EXT, int FX = FX_NONE>
 __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp2_kernel(GemmP p) {
   constexpr int MI = 2;
   constexpr int BMB = 128, BNB = 256;
+  constexpr int BN_STEP = FX == FX_SWIGLU ? 128 : BNB;        // FX_SWIGLU: a tile is 128 gate columns + the 128 up columns of the same index
   constexpr int A_BYTES = BMB * BK * 2, W_BYTES = BNB * BK * 2, BUF = A_BYTES + W_BYTES;     // 48 KiB per buffer
   __shared__ __attribute__((aligned(16))) char smem[3 * BUF];
   int bid = blockIdx.x;
@@ -906,7 +999,7 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp2_kernel(GemmP p) {
   const int first_m = (bid / per_group) * p.group_m;
   const int gsz = min(p.tiles_m - first_m, p.group_m);
   const int m0 = (first_m + (bid % per_group) % gsz) * BMB;
-  const int n0 = ((bid % per_group) / gsz) * BNB;
+  const int n0 = ((bid % per_group) / gsz) * BN_STEP;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -928,7 +1021,9 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp2_kernel(GemmP p) {
       a_off[h][i] = (int)(((long)min(ra, p.M - 1 - m0) * p.lda + (((lane & 7) ^ ((ra >> 1) & 7)) << 3)) * 2);
       const int rw0 = PP_WROW0(h, i), rw = rw0 + (lane >> 3);
       w_lds[h][i] = A_BYTES + rw0 * 128;
-      w_off[h][i] = (int)(((long)min(rw, p.N - 1 - n0) * p.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) << 3)) * 2);
+      // FX_SWIGLU: tile rows 128 .. 255 are the up_proj rows fx_I + n0 .. of the gate|up weight (n0 = 128 x the tile's column index)
+      const int gw = (FX == FX_SWIGLU && rw >= 128) ? rw - 128 + p.fx_I : rw;
+      w_off[h][i] = (int)(((long)min(gw, p.N - 1 - n0) * p.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) << 3)) * 2);
     }
   }
   int nt_main = p.K / BK;
@@ -950,6 +1045,9 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp2_kernel(GemmP p) {
     for (int mb = 0; mb < 2 * MI; ++mb) acc[nb][mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   bf16x8_t af[MI][2], wf0[2][2], wf1[2][2];
   const int frow = lane & 15, fq = lane >> 4;
+  // first W-tile row of this wave's two 32-column halves: 64 consecutive columns, or (fused epilogues) two blocks a pair distance apart
+  const int wrow0 = FX == FX_ROPE ? (wn >> 1) * 128 + (wn & 1) * 32 : FX == FX_SWIGLU ? wn * 32 : wn * 64;
+  const int wrow1 = wrow0 + (FX == FX_ROPE ? 64 : FX == FX_SWIGLU ? 128 : 32);
 
   char* cur = smem;               // K-tile t
   char* nxt = smem + BUF;         // K-tile t + 1
@@ -982,7 +1080,8 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp2_kernel(GemmP p) {
 #undef PP2_MMA_A
 #undef PP2_MMA_B
   if (wm == 0) __builtin_amdgcn_s_barrier();            // re-join: every wave's reads and DMA are retired past this point
-  epilogue_lds<OUT_F32, MI>(p, Acc16<MI>{acc}, smem, wave, m0, n0, wm, wn, lane, bz);
+  if constexpr (FX != FX_NONE) epilogue_fx<MI, FX>(p, Acc16<MI>{acc}, smem, wave, m0, n0, wm, wn, lane);
+  else epilogue_lds<OUT_F32, MI>(p, Acc16<MI>{acc}, smem, wave, m0, n0, wm, wn, lane, bz);
 }
 
 // ---- variant V: skinny GEMM, M <= 8 rows (the decode step of generation: one token per sequence) ---------------------------------
@@ -1050,7 +1149,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int out_f32) 
       for (int e = 0; e < 8; ++e) o[e] = g[e] * f[e];
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = f[e] / (1.f + __expf(-f[e])) * g[e];
+      for (int e = 0; e < 8; ++e) o[e] = swiglu_fwd1(f[e], g[e]);
     }
     return pack8(o);
   };
@@ -1345,7 +1444,44 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
 extern "C" int llmseg_norm(const void* x, const void* w, const void* b, void* y, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy, float eps, int rms,
                            const int32_t* row_map, void* stream);
 
+extern "C" int llmseg_rope(void* x, const float* cos, const float* sin, int64_t rows, int64_t T, int32_t heads, int32_t head_dim, int64_t ld, void* stream);
+extern "C" int llmseg_swiglu(const void* gu, void* out, int64_t rows, int64_t I, int64_t ldgu, int64_t ldo, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int llmseg_swiglu_bwd_ld(const void* gu, const void* dout, void* dgu, int64_t rows, int64_t I, int64_t ld_dout, void* stream);
+
+static thread_local bool g_fx_done = false;        // set by gemm_dispatch when the fused-epilogue kernel ran for the call being dispatched on this thread
+static const bool g_fx_off = getenv("LLMSEG_GEMM_NO_FX") != nullptr;      // A/B switch: always the GEMM + pointwise launch
+
+// llmseg_gemm_args.fx: the fused kernel where the call takes the 128 x 256 two-phase kernel in one K-slice (the Llama layer at 2 images per micro-step),
+// the GEMM followed by the pointwise launch it replaces everywhere else.  Same bits either way.
+static int gemm_fx(const llmseg_gemm_args* a, void* stream) {
+  LL_CHECK(a->fx >= 1 && a->fx <= 3, "gemm: unknown fx %d", a->fx);
+  LL_CHECK(!a->out_f32 && a->batch <= 1 && a->batch2 <= 1 && a->alpha == 1.f && !a->bias && !a->gamma && !a->residual && a->act == LLMSEG_ACT_NONE && !a->norm_out &&
+               !a->trans_a && !a->trans_w && !a->accumulate, "gemm: fx needs a plain bf16 product (batch 1, alpha 1, no bias / activation / gamma / residual / norm_out)");
+  if (a->fx == LLMSEG_FX_ROPE) {
+    LL_CHECK(a->fx_cos && a->fx_sin && a->fx_T > 0 && a->fx_cols > 0 && (a->fx_cols % 128) == 0 && a->fx_cols <= a->N && (a->ldc & 3) == 0 &&
+                 ((((uintptr_t)a->fx_cos) | ((uintptr_t)a->fx_sin)) & 15) == 0 && (((uintptr_t)a->C) & 7) == 0,
+             "gemm: fx rope needs fp32 [fx_T][64] tables (16-byte aligned), fx_cols a multiple of 128 (heads of width 128) and <= N");
+  } else if (a->fx == LLMSEG_FX_SWIGLU) {
+    LL_CHECK(a->fx_out && (a->N & 15) == 0 && (a->fx_ld & 7) == 0 && a->fx_ld >= a->N / 2 && (a->ldc & 7) == 0 && !a->A2 && ((((uintptr_t)a->fx_out) | ((uintptr_t)a->C)) & 15) == 0,
+             "gemm: fx swiglu needs N = 2 I with I %% 8 == 0, fx_out bf16 [M][fx_ld >= I], 16-byte aligned rows, no extension operands");
+  } else {
+    LL_CHECK(a->fx_in && (a->N & 7) == 0 && (a->fx_ld & 7) == 0 && a->fx_ld >= 2 * a->N && a->ldc >= 2 * a->N && (a->ldc & 7) == 0 && !a->A2 &&
+                 ((((uintptr_t)a->fx_in) | ((uintptr_t)a->C)) & 15) == 0,
+             "gemm: fx swiglu_bwd needs N = I, fx_in = gate|up bf16 [M][fx_ld >= 2 I], C = d(gate|up) [M][ldc >= 2 I], 16-byte aligned rows");
+  }
+  g_fx_done = false;
+  llmseg_gemm_args g = *a;
+  if (a->fx == LLMSEG_FX_SWIGLU_BWD) g.C = (bf16_t*)a->C + a->N;      // unfused route: d(out) lands in the up half of C's rows, llmseg_swiglu_bwd then works in place
+  const int rc = gemm_dispatch(&g, stream, -1);
+  if (rc != LLMSEG_OK || g_fx_done) return rc;
+  if (a->fx == LLMSEG_FX_ROPE) return llmseg_rope(a->C, a->fx_cos, a->fx_sin, a->M, a->fx_T, (int32_t)(a->fx_cols / 128), 128, a->ldc, stream);
+  if (a->fx == LLMSEG_FX_SWIGLU) return llmseg_swiglu(a->C, a->fx_out, a->M, a->N / 2, a->ldc, a->fx_ld, stream);
+  LL_CHECK(a->fx_ld == 2 * a->N && a->ldc == 2 * a->N, "gemm: fx swiglu_bwd on this shape (two-launch route) needs dense gate|up and d(gate|up) rows");
+  return llmseg_swiglu_bwd_ld(a->fx_in, g.C, a->C, a->M, a->N, a->ldc, stream);
+}
+
 extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
+  if (a && a->struct_size == sizeof(*a) && a->fx) return gemm_fx(a, stream);
   if (!(a && a->struct_size == sizeof(*a) && a->norm_out)) return gemm_dispatch(a, stream, -1);
   // second output RMSNorm(C) * norm_w: the K-sliced route folds it into its reduce launch, every other route gets llmseg_norm behind the product
   LL_CHECK(a->norm_w && !a->out_f32 && a->batch <= 1 && a->batch2 <= 1 && (a->N & 7) == 0 && (a->ldn & 7) == 0 && a->ldn >= a->N && (a->ldc & 7) == 0 &&
@@ -1388,6 +1524,8 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
   p.sA2 = a->strideA2; p.sW2 = a->strideW2; p.sC2 = a->strideC2;
   p.alpha = a->alpha; p.act = a->act;
   p.kt_total = 0; p.k_split_total = 0; p.accum = a->accumulate ? 1 : 0;
+  p.fx = 0; p.fx_T = a->fx_T; p.fx_cols = (int)a->fx_cols; p.fx_I = a->fx == LLMSEG_FX_SWIGLU ? (int)(a->N / 2) : (int)a->N;
+  p.fx_cos = a->fx_cos; p.fx_sin = a->fx_sin; p.fx_out = (bf16_t*)a->fx_out; p.fx_in = (const bf16_t*)a->fx_in; p.fx_ld = a->fx_ld;
   { static const int abl = getenv("LLMSEG_LW_ABLATE") ? atoi(getenv("LLMSEG_LW_ABLATE")) : 0; p.ablate = abl; }
   // vector stores/loads need 4-element alignment of every row start; otherwise the kernel goes element-wise
   p.c_vec = ((((uintptr_t)a->C) % (4 * esz)) == 0 && (a->ldc & 3) == 0 && ((a->strideC | a->strideC2) & 3) == 0) ? 1 : 0;
@@ -1602,6 +1740,20 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
           break;
         }
         if (g_gemm_pp2) {
+          // fused Llama-layer epilogues (llmseg_gemm_args.fx): this kernel, one K-slice; shapes whose tiles hold whole pairs (gemm_fx runs the pointwise launch otherwise)
+          const bool fx_ok = a->fx && !g_fx_off && !f && batch == 1 &&
+                             (a->fx == LLMSEG_FX_ROPE ? (p.N % 256) == 0 && p.A2 != nullptr
+                              : a->fx == LLMSEG_FX_SWIGLU ? (p.fx_I % 128) == 0 : (p.N % 64) == 0);
+          if (fx_ok) {
+            GemmP q = p;
+            q.fx = a->fx;
+            if (a->fx == LLMSEG_FX_SWIGLU_BWD) q.C = (bf16_t*)a->C - a->N;      // gemm_fx pointed C at the up half for the two-launch route: back to the row start
+            if (a->fx == LLMSEG_FX_ROPE) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp2_kernel<false, true, FX_ROPE>), grid, dim3(NTB), 0, s, q);
+            else if (a->fx == LLMSEG_FX_SWIGLU) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp2_kernel<false, false, FX_SWIGLU>), grid, dim3(NTB), 0, s, q);
+            else LL_LAUNCH_KERNEL((gemm_bf16_tn_pp2_kernel<false, false, FX_SWIGLU_BWD>), grid, dim3(NTB), 0, s, q);
+            g_fx_done = true;
+            break;
+          }
           if (p.A2) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp2_kernel<false, true>), grid, dim3(NTB), 0, s, p);
           else if (f) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp2_kernel<true, false>), grid, dim3(NTB), 0, s, p);
           else LL_LAUNCH_KERNEL((gemm_bf16_tn_pp2_kernel<false, false>), grid, dim3(NTB), 0, s, p);

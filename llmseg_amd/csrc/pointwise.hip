@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ 
     unpack8(*reinterpret_cast<const uint4*>(gu + row * ldgu + c * 8), g);
     unpack8(*reinterpret_cast<const uint4*>(gu + row * ldgu + I + c * 8), u);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = g[e] / (1.f + __expf(-g[e])) * u[e];
+    for (int e = 0; e < 8; ++e) o[e] = swiglu_fwd1(g[e], u[e]);
     *reinterpret_cast<uint4*>(out + row * ldo + c * 8) = pack8(o);
   }
 }

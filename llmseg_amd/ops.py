@@ -55,12 +55,17 @@ def _reduce_ws(dev):
 
 
 def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alpha=1.0, out_f32=False, trans_a=False, trans_w=False,
-         a2=None, w2=None, accumulate=False, a_norm_w=None, a_norm_eps=1e-6, a_swiglu=False, norm_w=None, norm_eps=1e-6, norm_out=None):
+         a2=None, w2=None, accumulate=False, a_norm_w=None, a_norm_eps=1e-6, a_swiglu=False, norm_w=None, norm_eps=1e-6, norm_out=None,
+         rope=None, swiglu_out=None, swiglu_bwd_of=None):
     """out[M,N] = residual + gamma * act(alpha * A @ W^T + bias) with A = a [M,K] (or a^T when trans_a: a stored [K,M]) and
     W = w [N,K] (or w^T when trans_w: w stored [K,N]).  2-D bf16 operands, last dim contiguous.  a2 [M,64] / w2 [N,64]: optional
     extension of the contraction (A @ W^T + a2 @ w2^T), e.g. zero-padded low-rank updates.  accumulate (fp32 `out` only):
     out += result (gradient accumulation).  M <= 8 only (decode steps): a_norm_w -> A := RMSNorm(A) * a_norm_w on load; a_swiglu ->
-    a holds [gate | up] rows of width 2K and A := silu(gate) * up on load."""
+    a holds [gate | up] rows of width 2K and A := silu(gate) * up on load.
+    Fused Llama-layer epilogues (llmseg_gemm_args.fx; the same bits as the pointwise launch each replaces):
+      rope = (cos, sin, T, cols): the heads (width 128) of the first `cols` output columns are rotated, position = row % T (`rope_` after the product);
+      swiglu_out = h [M, N/2]: out = gate|up as usual and h = silu(gate) * up (`swiglu` after the product);
+      swiglu_bwd_of = gu [M, 2N]: the product is d(h) [M, N]; out [M, 2N] = d(gate|up) (`swiglu_bwd` of the stored product)."""
     _req(a); _req(w)
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
@@ -70,10 +75,10 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alp
     assert K == Kw, (a.shape, w.shape, trans_a, trans_w)
     if out is None:
         assert not accumulate
-        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else BF16)
+        out = torch.empty((M, 2 * N if swiglu_bwd_of is not None else N), device=a.device, dtype=torch.float32 if out_f32 else BF16)
     else:
         out_f32 = out.dtype == torch.float32
-    assert out.shape == (M, N) and out.stride(1) == 1 and (out_f32 or not accumulate)
+    assert out.shape == (M, 2 * N if swiglu_bwd_of is not None else N) and out.stride(1) == 1 and (out_f32 or not accumulate)
     stream = torch.cuda.current_stream().cuda_stream
     g = GemmArgs(A=a.data_ptr(), W=w.data_ptr(), C=out.data_ptr(),
                  bias=None if bias is None else _req(bias).data_ptr(),
@@ -86,6 +91,16 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alp
     if norm_out is not None:                                            # second output: RMSNorm(out) * norm_w (llmseg_gemm_args.norm_out, ABI 6)
         assert norm_w is not None and not out_f32 and norm_out.shape == out.shape and norm_out.stride(1) == 1 and norm_out.dtype == BF16
         g.norm_w, g.norm_eps, g.norm_out, g.ldn = _req(norm_w).data_ptr(), norm_eps, _req(norm_out).data_ptr(), norm_out.stride(0)
+    if rope is not None:
+        cos, sin, T, cols = rope
+        assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape == sin.shape == (T, 64)
+        g.fx, g.fx_T, g.fx_cols, g.fx_cos, g.fx_sin = _lib.FX_ROPE, T, cols, cos.data_ptr(), sin.data_ptr()
+    elif swiglu_out is not None:
+        assert _req(swiglu_out).shape == (M, N // 2) and swiglu_out.stride(1) == 1
+        g.fx, g.fx_out, g.fx_ld = _lib.FX_SWIGLU, swiglu_out.data_ptr(), swiglu_out.stride(0)
+    elif swiglu_bwd_of is not None:
+        assert _req(swiglu_bwd_of).shape == (M, 2 * N) and swiglu_bwd_of.stride(1) == 1
+        g.fx, g.fx_in, g.fx_ld = _lib.FX_SWIGLU_BWD, swiglu_bwd_of.data_ptr(), swiglu_bwd_of.stride(0)
     if a_norm_w is not None:
         g.a_norm_w, g.a_norm_eps = _req(a_norm_w).data_ptr(), a_norm_eps
     if a_swiglu:

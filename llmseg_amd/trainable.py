@@ -40,15 +40,28 @@ class _Direct:
     maskpool = staticmethod(lambda feat, segs, g, S: ops.upsample_maskpool(feat, segs, g, S))
 
     @staticmethod
-    def rope_attn(qkv, rope, batch, n, heads, hd, causal, key_mask):
-        ops.rope_(qkv, rope[0], rope[1], batch * n, n, 2 * heads, hd, qkv.stride(0))
+    def rope_attn(qkv, rope, batch, n, heads, hd, causal, key_mask, pre_rotated=False):
+        if not pre_rotated:
+            ops.rope_(qkv, rope[0], rope[1], batch * n, n, 2 * heads, hd, qkv.stride(0))
         return ops.attention_packed(qkv, batch, n, heads, hd, causal=causal, key_mask=key_mask)
 
     @staticmethod
-    def lora_qkv(x, wqkv, aq, bq, av, bv, s, wqkv_t=None, drop=None):
+    def mlp(x, wgu, wgu_t, wd, wd_t, residual, norm_w, eps):
+        M, inter = x.shape[0], wd.shape[1]
+        gu = torch.empty((M, 2 * inter), device=x.device, dtype=BF16)
+        h = torch.empty((M, inter), device=x.device, dtype=BF16)
+        ops.gemm(x, wgu, out=gu, swiglu_out=h)
+        if norm_w is None:
+            return ops.gemm(h, wd, residual=residual), None
+        pre = torch.empty((M, wd.shape[0]), device=x.device, dtype=BF16)
+        return ops.gemm(h, wd, residual=residual, norm_w=norm_w, norm_eps=eps, norm_out=pre), pre
+
+    @staticmethod
+    def lora_qkv(x, wqkv, aq, bq, av, bv, s, wqkv_t=None, drop=None, rope=None):
         H = wqkv.shape[1]
         if aq.shape[0] == 8:
-            return ag.lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, None)[0]
+            return ag.lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, None, rope=rope)[0]
+        assert rope is None
         qkv = ops.gemm(x, wqkv)
         ops.gemm(ops.gemm(x, aq), bq, residual=qkv[:, :H], out=qkv[:, :H], alpha=s)
         ops.gemm(ops.gemm(x, av), bv, residual=qkv[:, 2 * H:], out=qkv[:, 2 * H:], alpha=s)
@@ -92,8 +105,9 @@ class _Auto:
     embed_splice = staticmethod(lambda ids, emb, feats, P, fs, tok=None: ag.EmbedSpliceFn.apply(ids, emb, feats, P, fs, tok))
     gather_rows = staticmethod(lambda x, idx: ag.GatherRowsFn.apply(x, idx))
     maskpool = staticmethod(lambda feat, segs, g, S: ag.MaskPoolFn.apply(feat, segs, g, S))
-    lora_qkv = staticmethod(lambda x, wqkv, aq, bq, av, bv, s, wqkv_t=None, drop=None:
-                            ag.LoraQKVFn.apply(x, wqkv, aq, bq, av, bv, s, wqkv_t, drop))
+    lora_qkv = staticmethod(lambda x, wqkv, aq, bq, av, bv, s, wqkv_t=None, drop=None, rope=None:
+                            ag.LoraQKVFn.apply(x, wqkv, aq, bq, av, bv, s, wqkv_t, drop, rope))
+    mlp = staticmethod(ag.mlp)
     ce = staticmethod(lambda logits, labels: ag.CELossFn.apply(logits, labels))
     align_reg = staticmethod(lambda e, t, pred, gt_iou, gt_iop: ag.AlignRegFn.apply(e, t, pred, gt_iou, gt_iop))
     bcast_add = staticmethod(lambda s, add, Cn, K: ag.BcastAddFn.apply(s, add, Cn, K))
@@ -343,6 +357,8 @@ class TrainableMixin:
         rng = self.dropout_state() if p_drop > 0 else None
         pre = None           # RMSNorm of x under the NEXT pre-norm's weight, when the GEMM that produced x wrote it as its second output
         fuse = self.fuse_residual_norm
+        # RoPE inside the q|k|v GEMM's store (round 6): the rank-8 LoRA route at head_dim 128; kv_out (generation prefill) reads the rotated buffer either way
+        rope_in_gemm = ag.FUSE_ROPE_FWD and c.lora_r == 8 and c.head_dim == 128
         for i in range(c.layers):
             p = f"model.layers.{i}."
             h, x = F.norm_pass(x, self._w(p + "input_layernorm.weight", F), None, c.eps, True, pre)      # x: the residual branch of the same node
@@ -351,11 +367,12 @@ class TrainableMixin:
                 qkv = F.lora_qkv(h, self._w(p + "qkv", F), self._w(lp + "q_proj.lora_A.default.weight", F),
                                  self._w(lp + "q_proj.lora_B.default.weight", F), self._w(lp + "v_proj.lora_A.default.weight", F),
                                  self._w(lp + "v_proj.lora_B.default.weight", F), s, self._wT(p + "qkv", F),
-                                 ((rng, i, p_drop, drop_seg_rows) if drop_seg_rows else (rng, i, p_drop)) if p_drop > 0 else None)
+                                 ((rng, i, p_drop, drop_seg_rows) if drop_seg_rows else (rng, i, p_drop)) if p_drop > 0 else None,
+                                 (rope[0], rope[1], T) if rope_in_gemm else None)
             else:
                 mem = [p + f"self_attn.{n}_proj.weight" for n in "qkv"]
                 qkv = F.linear(h, self._wcat(p + "qkv", mem, F), None, ops.ACT_NONE, None, self._wT(p + "qkv", F) if self._frozen(mem) else None)
-            a = F.rope_attn(qkv, rope, N, T, c.heads, c.head_dim, True, key_mask_u8)
+            a = F.rope_attn(qkv, rope, N, T, c.heads, c.head_dim, True, key_mask_u8, rope_in_gemm)
             if kv_out is not None:                     # generation prefill (no-grad path): qkv now holds the rotated K and V
                 kv_out(i, qkv)
             pre = None
@@ -366,6 +383,12 @@ class TrainableMixin:
                 x = F.linear(a, self._w(p + "self_attn.o_proj.weight", F), None, ops.ACT_NONE, x, self._wT(p + "self_attn.o_proj.weight", F))
             h, x = F.norm_pass(x, self._w(p + "post_attention_layernorm.weight", F), None, c.eps, True, pre)
             mem = [p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"]
+            if ag.FUSE_MLP and self._frozen(mem + [p + "mlp.down_proj.weight"]) and c.inter % 8 == 0:
+                # frozen MLP (the reference's LoRA targets are q_proj / v_proj only): one node, swiglu and its backward inside the GEMMs' stores
+                nxt = self._w(f"model.layers.{i + 1}.input_layernorm.weight", F) if (fuse and i + 1 < c.layers) else None
+                x, pre = F.mlp(h, self._wcat(p + "gate_up", mem, F), self._wT(p + "gate_up", F), self._w(p + "mlp.down_proj.weight", F),
+                               self._wT(p + "mlp.down_proj.weight", F), x, nxt, c.eps)
+                continue
             gu = F.linear(h, self._wcat(p + "gate_up", mem, F), None, ops.ACT_NONE, None, self._wT(p + "gate_up", F) if self._frozen(mem) else None)
             pre = None
             if fuse and i + 1 < c.layers:      # down_proj + residual and the NEXT layer's input norm

@@ -261,6 +261,64 @@ def _attn_ref(q, k, v, scale, bias=None):
     return torch.softmax(s, -1) @ v.float()
 
 
+def check_gemm_fx():
+    """Round 6: the fused Llama-layer epilogues of llmseg_gemm_bf16 (fx = rope / swiglu / swiglu_bwd) against the product followed by the
+    pointwise launch each replaces -- BIT FOR BIT -- at the benchmark's shapes (the fused 128 x 256 kernel: one library launch) and at small
+    shapes (the library's own two-launch route), and against an fp32 reference."""
+    from llmseg_amd import _lib
+    lib = _lib.load()
+    out = []
+
+    def launches(fn):
+        torch.cuda.synchronize()
+        n0 = lib.llmseg_launch_count()
+        r = fn()
+        return r, lib.llmseg_launch_count() - n0
+
+    bits = lambda a, b: float((a.float() - b.float()).abs().max())
+    for (M, H, T, tag) in ((638, 4096, 319, "bench shape"), (50, 256, 25, "small")):
+        D = H
+        x, w = rnd(M, H, seed=1, scale=1.0).to(DEV), rnd(3 * D, H, seed=2, scale=H ** -0.5).to(DEV)
+        a2, w2 = rnd(M, 64, seed=3, scale=0.3).to(DEV), rnd(3 * D, 64, seed=4, scale=0.1).to(DEV)
+        ang = torch.outer(torch.arange(T).float(), 1.0 / (10000 ** (torch.arange(0, 128, 2).float() / 128)))
+        cos, sin = ang.cos().contiguous().to(DEV), ang.sin().contiguous().to(DEV)
+        ref = ops.gemm(x, w, a2=a2, w2=w2)
+        ops.rope_(ref, cos, sin, M, T, 2 * D // 128, 128, 3 * D)
+        got, n = launches(lambda: ops.gemm(x, w, a2=a2, w2=w2, rope=(cos, sin, T, 2 * D)))
+        out.append((f"gemm fx rope == gemm + rope ({tag}, {n} launch{'es' if n > 1 else ''}) (bits)", bits(got, ref), 0.0))
+        if M == 638:
+            out.append(("gemm fx rope ran as ONE launch at the bench shape", float(n), 1.0))
+            y = (x.float() @ w.float().t() + a2.float() @ w2.float().t()).cpu()
+            q = y.view(M, 3 * D // 128, 128).clone()
+            pos = torch.arange(M) % T
+            c, s_ = ang.cos()[pos][:, None, :], ang.sin()[pos][:, None, :]
+            nh = 2 * D // 128
+            a_, b_ = q[:, :nh, :64].clone(), q[:, :nh, 64:].clone()
+            q[:, :nh, :64], q[:, :nh, 64:] = a_ * c - b_ * s_, b_ * c + a_ * s_
+            out.append(("gemm fx rope vs fp32", err(got, q.reshape(M, 3 * D)), tol_bf16(q, 2.0)))
+        # gate|up + swiglu, and the backward of it on the dX product of down_proj
+        I = 11008 if M == 638 else 192
+        wg = rnd(2 * I, H, seed=5, scale=H ** -0.5).to(DEV)
+        gu_ref = ops.gemm(x, wg)
+        h_ref = ops.swiglu(gu_ref, I)
+        h = torch.empty(M, I, device=DEV, dtype=BF)
+        gu, n = launches(lambda: ops.gemm(x, wg, swiglu_out=h))
+        out.append((f"gemm fx swiglu: gate|up == gemm ({tag}, {n} launch{'es' if n > 1 else ''}) (bits)", bits(gu, gu_ref), 0.0))
+        out.append((f"gemm fx swiglu: h == swiglu(gemm) ({tag}) (bits)", bits(h, h_ref), 0.0))
+        if M == 638:
+            out.append(("gemm fx swiglu ran as ONE launch at the bench shape", float(n), 1.0))
+            yf = (x.float() @ wg.float().t()).cpu()
+            out.append(("gemm fx swiglu vs fp32", err(h, F.silu(yf[:, :I]) * yf[:, I:]), tol_bf16(yf, 2.0)))
+        dy, wd_t = rnd(M, H, seed=6, scale=0.5).to(DEV), rnd(I, H, seed=7, scale=H ** -0.5).to(DEV)      # dX = dY @ Wd with Wd^T stored [I, H]
+        dh_ref = ops.gemm(dy, wd_t)
+        dgu_ref = ops.swiglu_bwd(gu_ref, dh_ref, I)
+        dgu, n = launches(lambda: ops.gemm(dy, wd_t, swiglu_bwd_of=gu_ref))
+        out.append((f"gemm fx swiglu_bwd == swiglu_bwd(gemm) ({tag}, {n} launch{'es' if n > 1 else ''}) (bits)", bits(dgu, dgu_ref), 0.0))
+        if M == 638:
+            out.append(("gemm fx swiglu_bwd ran as ONE launch at the bench shape", float(n), 1.0))
+    return out
+
+
 def check_attention():
     out = []
     for hd, B, H, N in [(32, 2, 8, 256), (64, 1, 4, 257), (128, 2, 2, 319), (80, 3, 2, 196), (64, 1, 2, 1100)]:

@@ -284,6 +284,55 @@ def check_full_width_llama_layer():
              max(2e-2 * ref.abs().max().item(), 1.5 * lo_e))]
 
 
+def check_full_width_llama_fusions():
+    """Round 6: TWO Llama-7B decoder layers at full width, LoRA r = 8 with dropout on q / v, M = 2 x 319 rows, forward + backward, with the fused
+    epilogues (RoPE in the q|k|v GEMM's store, swiglu / swiglu_bwd in the gate|up / dX(down) GEMMs' stores, inverse RoPE in the attention backward's
+    store) against the same layers with every one of them switched OFF (the pointwise launches): output, input gradient and the LoRA gradients BIT FOR BIT."""
+    from llmseg_amd import autograd as ag
+    from llmseg_amd.trainable import _Auto
+    from oracle import llama as ol, seeded
+    lcfg = ol.LlamaCfg(layers=2, vocab=64, lora_r=8, lora_dropout=0.05)
+    cfg = cases.tiny_lisa_cfg("sam")
+    cfg.llama = lcfg
+    sd = {k: v.to(BF).float() for k, v in seeded.fill_state_dict(seeded.llama_shapes(lcfg), 7).items()}
+    m = hip_lisa.LISAForCausalLM(to_hip_cfg(cfg), device=DEV).init_random(seed=1)
+    m.load_state_dict(sd, strict=False)
+    m.set_trainable()
+    m.train()
+    N, T = 2, 319
+    x0 = (seeded.uniform((N, T, lcfg.hidden), 8, -1, 1) * 2).to(BF).to(DEV)
+    am = torch.ones(N, T, dtype=torch.uint8)
+    am[1, 300:] = 0
+    am = am.to(DEV).contiguous()
+    go = (seeded.uniform((N, T, lcfg.hidden), 9, -1, 1) * 0.1).to(BF).to(DEV)
+    lora = [(n, t) for n, t in m.params.flat.items() if "lora_" in n and isinstance(t, torch.nn.Parameter)]
+    keep = (ag.FUSE_ROPE_FWD, ag.FUSE_ROPE_BWD, ag.FUSE_MLP)
+    runs = []
+    try:
+        for on in (True, False):
+            ag.FUSE_ROPE_FWD = ag.FUSE_ROPE_BWD = ag.FUSE_MLP = on
+            m.reset_dropout(seed=5) if hasattr(m, "reset_dropout") else None
+            for _, t in lora:
+                t.grad = None
+            x = x0.clone().requires_grad_(True)
+            from llmseg_amd import _lib
+            torch.cuda.synchronize()
+            n0 = _lib.load().llmseg_launch_count()
+            y = m._llama(x, am, _Auto)
+            y.backward(go)
+            torch.cuda.synchronize()
+            runs.append((y.detach().float().cpu(), x.grad.float().cpu(), [t.grad.float().cpu() for _, t in lora], _lib.load().llmseg_launch_count() - n0))
+    finally:
+        ag.FUSE_ROPE_FWD, ag.FUSE_ROPE_BWD, ag.FUSE_MLP = keep
+    (yf, gxf, glf, nf), (yu, gxu, glu, nu) = runs
+    res = [(f"full-width Llama x2 + LoRA: fused epilogues == pointwise launches, output (bits; {nf} vs {nu} library launches fwd+bwd)", (yf - yu).abs().max().item(), 0.0),
+           ("full-width Llama x2 + LoRA: fused == unfused, d(input) (bits)", (gxf - gxu).abs().max().item(), 0.0),
+           ("full-width Llama x2 + LoRA: fused == unfused, LoRA gradients (bits)", max((a - b).abs().max().item() for a, b in zip(glf, glu)), 0.0),
+           ("full-width Llama x2 + LoRA: the fused route saves 4 launches per layer", float(nu - nf), float("inf"))]
+    assert nu - nf >= 8, (nu, nf)
+    return res
+
+
 def check_full_width_sam_blocks():
     """SAM ViT-H at full width (dim 1280, 16 heads x 80, 64 x 64 grid at 1024 x 1024) with ONE windowed and ONE global block: patch embed,
     14 x 14 windows with zero padding, decomposed rel-pos on both paths, neck -- against the fp32 oracle."""

@@ -33,6 +33,11 @@ def test_gemm_norm_out():
     _run(kc.check_gemm_norm_out)
 
 
+def test_gemm_fused_llama_epilogues():
+    from tests import kernel_checks as kc
+    _run(kc.check_gemm_fx)
+
+
 def test_attention():
     from tests import kernel_checks as kc
     _run(kc.check_attention)

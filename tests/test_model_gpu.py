@@ -79,6 +79,11 @@ def test_full_width_llama_layer():
     _assert(mc.check_full_width_llama_layer())
 
 
+def test_full_width_llama_fused_epilogues_equal_pointwise_launches():
+    from tests import model_checks as mc
+    _assert(mc.check_full_width_llama_fusions())
+
+
 def test_full_width_sam_blocks():
     from tests import model_checks as mc
     _assert(mc.check_full_width_sam_blocks())
