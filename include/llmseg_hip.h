@@ -107,6 +107,16 @@ typedef struct {
    *   LLMSEG_FX_SWIGLU_BWD  N = I: the product is d(silu(gate) * up) [M][I] (dX of down_proj); fx_in = the saved gate|up [M][fx_ld >= 2 I]; C = d(gate|up)
    *                         bf16 [M][ldc >= 2 I], as llmseg_swiglu_bwd would compute from the stored product. */
   int fx; int fx_T; int64_t fx_cols; const float* fx_cos; const float* fx_sin; void* fx_out; const void* fx_in; int64_t fx_ld;
+  /* norm-backward tail (ABI 8): the product is the gradient dy [M][N] of a pre-norm's OUTPUT (dX of q|k|v or of gate|up: HF LlamaDecoderLayer,
+   * hidden = residual + sublayer(norm(hidden))), and what the caller wants is the gradient of the norm's INPUT:
+   *   C = norm_backward(dy, nb_x, nb_w; nb_eps, nb_rms) + nb_dres          (llmseg_norm_bwd_add: frozen norm weight, nb_dres = the residual branch's gradient or NULL)
+   * with, optionally, the LoRA branches' dX added to dy first (llmseg_lora_apply with w_rn = 1: dy += nb_lora_alpha * mask_b * (nb_lora_t[:, 8 b ..] . nb_lora_w_b),
+   * nb_lora_t bf16 [M][nb_lora_ldt >= 16], nb_lora_w0 / nb_lora_w1 bf16 [8][N] (w1 NULL = one branch), nb_lora_drop = llmseg_dropout* or NULL).  A K-sliced product
+   * (the Llama dX products at 2 x 319 rows) does all of it in its reduce launch -- one pass over the gradient instead of three launches; otherwise the library
+   * runs the product into the tail of `workspace` (>= M N 2 bytes, required) followed by llmseg_lora_apply / llmseg_norm_bwd_add.  Same bits either way.
+   * Plain bf16 product, ldc == N, N % 8 == 0.  nb_x NULL = off. */
+  const void* nb_x; const void* nb_w; const void* nb_dres; float nb_eps; int nb_rms;
+  const void* nb_lora_t; int64_t nb_lora_ldt; const void* nb_lora_w0; const void* nb_lora_w1; float nb_lora_alpha; int reserved2; const void* nb_lora_drop;
 } llmseg_gemm_args;
 enum { LLMSEG_FX_NONE = 0, LLMSEG_FX_ROPE = 1, LLMSEG_FX_SWIGLU = 2, LLMSEG_FX_SWIGLU_BWD = 3 };
 int llmseg_gemm_bf16(const llmseg_gemm_args* args, void* stream);

@@ -36,7 +36,10 @@ class GemmArgs(_Sized):
                 ("a_norm_w", C.c_void_p), ("a_norm_eps", C.c_float), ("a_swiglu", C.c_int),
                 ("norm_w", C.c_void_p), ("norm_eps", C.c_float), ("reserved1", C.c_int), ("norm_out", C.c_void_p), ("ldn", C.c_int64),
                 ("fx", C.c_int), ("fx_T", C.c_int), ("fx_cols", C.c_int64), ("fx_cos", C.c_void_p), ("fx_sin", C.c_void_p), ("fx_out", C.c_void_p),
-                ("fx_in", C.c_void_p), ("fx_ld", C.c_int64)]
+                ("fx_in", C.c_void_p), ("fx_ld", C.c_int64),
+                ("nb_x", C.c_void_p), ("nb_w", C.c_void_p), ("nb_dres", C.c_void_p), ("nb_eps", C.c_float), ("nb_rms", C.c_int),
+                ("nb_lora_t", C.c_void_p), ("nb_lora_ldt", C.c_int64), ("nb_lora_w0", C.c_void_p), ("nb_lora_w1", C.c_void_p), ("nb_lora_alpha", C.c_float),
+                ("reserved2", C.c_int), ("nb_lora_drop", C.c_void_p)]
 
 FX_NONE, FX_ROPE, FX_SWIGLU, FX_SWIGLU_BWD = 0, 1, 2, 3          # LLMSEG_FX_* of include/llmseg_hip.h
 

@@ -27,6 +27,7 @@ BIG_WEIGHT = 1 << 26          # N * K of a Linear whose dX / dW always take the 
 # A/B switches of the round-6 Llama-layer fusions (tests compare each fused route with the unfused one bit for bit)
 FUSE_ROPE_BWD = os.environ.get("LLMSEG_NO_FUSE_ROPE_BWD") is None      # inverse RoPE inside the attention backward's dq / dk store
 FUSE_ROPE_FWD = os.environ.get("LLMSEG_NO_FUSE_ROPE_FWD") is None      # RoPE inside the q|k|v GEMM's store (rank-8 LoRA route, head_dim 128)
+FUSE_NORM_BWD = os.environ.get("LLMSEG_NO_FUSE_NORM_BWD") is None      # pre-norm backward (+ LoRA dX + residual gradient) inside the dX product's K-slice reduce launch
 FUSE_MLP = os.environ.get("LLMSEG_NO_FUSE_MLP") is None                # swiglu / swiglu_bwd inside the gate|up and dX(down) GEMMs' stores (frozen MLP weights)
 
 
@@ -290,6 +291,89 @@ class LoraQKVFn(Function):
             else:
                 grads.append(ops.gemm(a_, b_, trans_a=True, trans_w=True, alpha=al))
         return dx, None, grads[0], grads[1], grads[2], grads[3], None, None, None, None
+
+
+class NormLoraQKVFn(Function):
+    """RMSNorm pre-norm + the LoRA'd q|k|v projection of it as ONE node (round 6): (qkv, x) = (lora_qkv(norm(x) * w), x) -- `NormPassFn` followed by
+    `LoraQKVFn` (rank 8, frozen base weight, frozen norm weight).  What the merge buys is the backward: the dX product of q|k|v, the LoRA branches' dX
+    (`lora_apply_`), the norm backward and the residual branch's gradient are ONE GEMM call (`llmseg_gemm_args.nb_x`: all of it in the K-sliced product's
+    reduce launch) instead of a reduce, a lora_apply and a norm_bwd launch with two round trips of the [M, H] gradient.  Same bits as the two nodes."""
+
+    @staticmethod
+    def forward(ctx, x, norm_w, eps, pre, wqkv, aq, bq, av, bv, s, wqkv_t, drop, rope):
+        x = x.contiguous()
+        h = ops.norm(x, norm_w, None, eps=eps, rms=True) if pre is None else pre
+        ctx.drop = drop if (drop is not None and drop[2] > 0.0) else None
+        ctx.g = tuple(g32_of(t) for t in (aq, bq, av, bv))
+        qkv, a2, ctx.bt = lora_qkv_fused(h, wqkv, aq, bq, av, bv, s, ctx.drop, want_bt=True, rope=rope)
+        ctx.s, ctx.eps, ctx.wqkv_t = s, eps, wqkv_t
+        ctx.save_for_backward(x, norm_w, h, wqkv, aq, bq, av, bv, a2)
+        ctx.set_materialize_grads(False)
+        return qkv, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, d, dpass):
+        x, norm_w, h, wqkv, aq, bq, av, bv, a2 = ctx.saved_tensors
+        if d is None:
+            return (dpass,) + (None,) * 12
+        s, H = ctx.s, wqkv.shape[1]
+        d = d.contiguous()
+        M = d.shape[0]
+        gaq, gbq, gav, gbv = ctx.g
+        drq = _drops(ctx.drop)[0]
+        t2 = torch.empty((M, 64), device=d.device, dtype=BF16)       # [s dq Bq | s dv Bv | 0]
+        ops.lora_down(d[:, :H], ctx.bt[:8], alpha=s, out=t2, zero_cols=48, x2=d[:, 2 * H:], w2=ctx.bt[8:])
+        dres = None if dpass is None else dpass.contiguous()
+        dx = ops.gemm(d, ctx.wqkv_t, normbwd=(x, norm_w, ctx.eps, True, dres), nb_lora=(t2, aq, av, 1.0, drq))
+        if all(g is not None for g in ctx.g):                            # arena mode: the four gradients in ONE launch (+ one fold), off the main chain
+            Leaves.run(lambda: ops.lora_wgrads(d, H, h, a2, t2, gbq, gbv, gaq, gav, s, drop=drq), d, h, t2, a2)
+            outs = [None] * 4
+        else:
+            dbq, dbv = ops.lora_outer(d[:, :H], a2[:, :8], alpha=s, out=gbq, a2=d[:, 2 * H:], b2=a2[:, 8:16], out2=gbv)
+            daq, dav = ops.lora_outer(h, t2[:, :8], out_rn=True, out=gaq, drop=drq, a2=h, b2=t2[:, 8:16], out2=gav)
+            outs = [None if (g is not None or t is None) else t.to(BF16) for g, t in ((gaq, daq), (gbq, dbq), (gav, dav), (gbv, dbv))]
+        return dx, None, None, None, None, outs[0], outs[1], outs[2], outs[3], None, None, None, None
+
+
+def norm_lora_qkv(x, norm_w, eps, pre, wqkv, aq, bq, av, bv, s, wqkv_t, drop, rope):
+    return NormLoraQKVFn.apply(x, norm_w, eps, pre, wqkv, aq, bq, av, bv, s, wqkv_t, drop, rope)
+
+
+class NormMlpFn(Function):
+    """A whole pre-norm MLP block of HF LlamaDecoderLayer with frozen weights as ONE node (round 6):
+        y = x + down(silu(gate) * up),  gate|up = (RMSNorm(x) * norm_w) Wgu^T      (, pre = RMSNorm(y) * next_norm_w)
+    = `NormPassFn` + `MlpFn`.  Backward: d(gate|up) inside the dX(down) GEMM's store, then dX(gate|up) + the norm backward + the residual gradient (= dy) in
+    ONE GEMM call (`llmseg_gemm_args.nb_x`).  Same bits as the separate nodes.  llava_llama.py:93-102."""
+
+    @staticmethod
+    def forward(ctx, x, norm_w, eps, pre, wgu, wgu_t, wd, wd_t, next_norm_w):
+        x = x.contiguous()
+        h = ops.norm(x, norm_w, None, eps=eps, rms=True) if pre is None else pre
+        M, inter = x.shape[0], wd.shape[1]
+        gu = torch.empty((M, 2 * inter), device=x.device, dtype=BF16)
+        act = torch.empty((M, inter), device=x.device, dtype=BF16)
+        ops.gemm(h, wgu, out=gu, swiglu_out=act)
+        ctx.wgu_t, ctx.wd_t, ctx.eps = wgu_t, wd_t, eps
+        ctx.save_for_backward(x, norm_w, gu)
+        ctx.set_materialize_grads(False)
+        if next_norm_w is None:
+            return ops.gemm(act, wd, residual=x), None
+        nxt = torch.empty_like(x)
+        y = ops.gemm(act, wd, residual=x, norm_w=next_norm_w, norm_eps=eps, norm_out=nxt)
+        ctx.mark_non_differentiable(nxt)
+        return y, nxt
+
+    @staticmethod
+    def backward(ctx, dy, _dnxt):
+        x, norm_w, gu = ctx.saved_tensors
+        dy = dy.contiguous()
+        dgu = ops.gemm(dy, ctx.wd_t, swiglu_bwd_of=gu)
+        dx = ops.gemm(dgu, ctx.wgu_t, normbwd=(x, norm_w, ctx.eps, True, dy))
+        return dx, None, None, None, None, None, None, None, None
+
+
+def norm_mlp(x, norm_w, eps, pre, wgu, wgu_t, wd, wd_t, next_norm_w):
+    return NormMlpFn.apply(x, norm_w, eps, pre, wgu, wgu_t, wd, wd_t, next_norm_w)
 
 
 class NormFn(Function):

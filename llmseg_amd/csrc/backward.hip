@@ -156,23 +156,12 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16_t* __restri
 
 // Norm backward for a FROZEN weight (no dw / db) with a WORKGROUP per row: short, wide activations (Llama at two images per step: 638 rows x
 // 4096 columns) leave most of the chip idle with one wave per row (14 us for 21 MB); 4 waves per row keep 4 x the loads in flight.
+// the row arithmetic of norm_bwd_wg_kernel, shared with the fused split-K tail (reduce_lora_normbwd_kernel) so that both produce the same bits:
+// xc / gc / wc = this thread's 8-element chunks (c = thread + 256 i) of x, dy and the norm weight; writes dx = norm backward + dres
 template <int CPT>
-__global__ __launch_bounds__(256) void norm_bwd_wg_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                         bf16_t* __restrict__ dx, long rows, int cols, float eps, int rms, const bf16_t* __restrict__ dres) {
-  __shared__ float red[16];
-  const long row = blockIdx.x;
+__device__ __forceinline__ void normbwd_row(const uint4 (&xc)[CPT], const uint4 (&gc)[CPT], const uint4 (&wc)[CPT], float* red, bf16_t* __restrict__ dx, long row,
+                                            int cols, float eps, int rms, const bf16_t* __restrict__ dres) {
   const int nch = cols >> 3;
-  const bf16_t* xr = x + row * cols;
-  const bf16_t* gr = dy + row * cols;
-  uint4 xc[CPT], gc[CPT], wc[CPT];
-#pragma unroll
-  for (int i = 0; i < CPT; ++i) {
-    const int c = threadIdx.x + 256 * i;
-    const bool on = c < nch;
-    xc[i] = on ? *reinterpret_cast<const uint4*>(xr + c * 8) : make_uint4(0, 0, 0, 0);
-    gc[i] = on ? *reinterpret_cast<const uint4*>(gr + c * 8) : make_uint4(0, 0, 0, 0);
-    wc[i] = on ? *reinterpret_cast<const uint4*>(w + c * 8) : make_uint4(0, 0, 0, 0);
-  }
   float f[8], g[8], ww[8];
   float s = 0.f;
   if (!rms) {
@@ -214,6 +203,26 @@ __global__ __launch_bounds__(256) void norm_bwd_wg_kernel(const bf16_t* __restri
       *reinterpret_cast<uint4*>(dx + row * cols + c * 8) = pack8(o);
     }
   }
+}
+
+template <int CPT>
+__global__ __launch_bounds__(256) void norm_bwd_wg_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                         bf16_t* __restrict__ dx, long rows, int cols, float eps, int rms, const bf16_t* __restrict__ dres) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const int nch = cols >> 3;
+  const bf16_t* xr = x + row * cols;
+  const bf16_t* gr = dy + row * cols;
+  uint4 xc[CPT], gc[CPT], wc[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    const bool on = c < nch;
+    xc[i] = on ? *reinterpret_cast<const uint4*>(xr + c * 8) : make_uint4(0, 0, 0, 0);
+    gc[i] = on ? *reinterpret_cast<const uint4*>(gr + c * 8) : make_uint4(0, 0, 0, 0);
+    wc[i] = on ? *reinterpret_cast<const uint4*>(w + c * 8) : make_uint4(0, 0, 0, 0);
+  }
+  normbwd_row<CPT>(xc, gc, wc, red, dx, row, cols, eps, rms, dres);
 }
 
 // Column sums of a wide norm's backward from the stored row statistics: dw[c] = sum_r dy[r][c] (x[r][c] - mean_r) rstd_r, db[c] = sum_r dy[r][c].
@@ -937,6 +946,67 @@ __global__ __launch_bounds__(256) void lora_apply_kernel(bf16_t* __restrict__ y,
   }
 }
 
+// Split-K tail of a dX product that feeds a pre-norm's backward (llmseg_gemm_args.nb_x, round 6): a workgroup per row sums the row's S fp32 slab rows and
+// rounds to bf16 (splitk_reduce_kernel's arithmetic: alpha = 1, no bias / activation / residual), optionally adds the LoRA branches' dX to it with
+// lora_apply_kernel's arithmetic and rounds again (LORA: y += alpha * mask_b * (xa[:, 8b..] . W_b), W stored [8][N]), and -- holding that row as dy -- writes
+// the norm backward + dres with norm_bwd_wg_kernel's arithmetic and thread -> column mapping: three launches and two round trips of the [M][N] gradient
+// (reduce 6.9 + lora_apply 10.9 + norm_bwd 7.6 us per Llama layer at 2 images) in one pass.  Same bits as the three launches.
+template <int CPT, bool LORA>
+__global__ __launch_bounds__(256) void reduce_lora_normbwd_kernel(const float* __restrict__ slab, int S, long slab_sz, const bf16_t* __restrict__ x,
+                                                                 const bf16_t* __restrict__ w, bf16_t* __restrict__ dx, long rows, int cols, float eps, int rms,
+                                                                 const bf16_t* __restrict__ dres, const bf16_t* __restrict__ xa, long ldxa,
+                                                                 const bf16_t* __restrict__ w0, const bf16_t* __restrict__ w1, float alpha, int nb, DropP dp) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const int nch = cols >> 3;
+  const long N = cols;
+  uint4 xc[CPT], gc[CPT], wc[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    xc[i] = gc[i] = wc[i] = make_uint4(0, 0, 0, 0);
+    if (c < nch) {
+      xc[i] = *reinterpret_cast<const uint4*>(x + row * cols + c * 8);
+      wc[i] = *reinterpret_cast<const uint4*>(w + c * 8);
+      const float* sp = slab + row * N + c * 8;
+      float4 a0 = *reinterpret_cast<const float4*>(sp), a1 = *reinterpret_cast<const float4*>(sp + 4);
+      for (int s2 = 1; s2 < S; ++s2) {
+        const float4 b0 = *reinterpret_cast<const float4*>(sp + s2 * slab_sz), b1 = *reinterpret_cast<const float4*>(sp + s2 * slab_sz + 4);
+        a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+        a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+      }
+      const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      gc[i] = pack8(v);                                   // the bf16 product row the reduce launch would have stored
+      if (LORA) {
+        float yv[8], wv[8];
+        unpack8(gc[i], yv);
+        for (int b = 0; b < nb; ++b) {
+          const bf16_t* wl = b == 0 ? w0 : w1;
+          float xv[8], dv[8];
+          unpack8(*reinterpret_cast<const uint4*>(xa + row * ldxa + 8 * b), xv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dv[j] = 0.f;
+#pragma unroll
+          for (int r = 0; r < LR; ++r) {
+            unpack8(*reinterpret_cast<const uint4*>(wl + (long)r * N + c * 8), wv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dv[j] += xv[r] * wv[j];
+          }
+          if (dp.thr) {
+            uint32_t oa;
+            const unsigned long di = drop_index(dp, (unsigned long)row, (unsigned long)N, (unsigned long)(c * 8), oa);
+            dropout8(dv, di, dp.stream + b, dp.rng, dp.thr, dp.scale, oa);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) yv[j] += alpha * dv[j];
+        }
+        gc[i] = pack8(yv);                                // ... and the bf16 row lora_apply would have left
+      }
+    }
+  }
+  normbwd_row<CPT>(xc, gc, wc, red, dx, row, cols, eps, rms, dres);
+}
+
 // The two [*, 64] extension operands of a LoRA'd q|k|v projection (llmseg_gemm_args.A2 / W2), rebuilt from the CURRENT LoRA
 // matrices on every call (no cache to go stale when the optimizer updates them in place):
 //   w2b [3H][64]: rows of the q block = [s Bq | 0], k block = 0, v block = [0 | s Bv | 0]     (forward: qkv += [xAq | xAv | 0] . w2b^T)
@@ -1015,6 +1085,26 @@ static DropP make_drop(const llmseg_dropout* d) {
     dp.scale = 65536.f / (65536.f - (float)d->drop_thr);
   }
   return dp;
+}
+
+// library-internal (gemm.hip: the K-sliced route of llmseg_gemm_args.nb_x).  slab: fp32 [S][M][N]; la_t == NULL: no LoRA term.
+extern "C" __attribute__((visibility("hidden"))) int llmseg_reduce_lora_normbwd(const float* slab, int S, int64_t M, int64_t N, const void* x, const void* w, void* dx, float eps,
+                                                                                int rms, const void* dres, const void* la_t, int64_t la_ldt, const void* la_w0,
+                                                                                const void* la_w1, float la_alpha, const llmseg_dropout* la_drop, void* stream) {
+  LL_CHECK(slab && S >= 1 && M > 0 && N >= 2048 && N <= 8192 && (N & 7) == 0 && x && w && dx && AL16(x) && AL16(w) && AL16(dx) && AL16(dres) && AL16(slab),
+           "reduce_lora_normbwd: bad arguments");
+  LL_CHECK(!la_t || (la_w0 && AL16(la_t) && AL16(la_w0) && AL16(la_w1) && (la_ldt & 7) == 0), "reduce_lora_normbwd: bad LoRA operands");
+  const DropP dp = make_drop(la_drop);
+  const int cpt = (int)(((N >> 3) + 255) / 256), nb = la_w1 ? 2 : 1;
+#define LL_RLN(C, L)                                                                                                                                     \
+  LL_LAUNCH_KERNEL((reduce_lora_normbwd_kernel<C, L>), dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, slab, S, (long)(M * N), (const bf16_t*)x,    \
+                   (const bf16_t*)w, (bf16_t*)dx, (long)M, (int)N, eps, rms, (const bf16_t*)dres, (const bf16_t*)la_t, (long)la_ldt, (const bf16_t*)la_w0, \
+                   (const bf16_t*)la_w1, la_alpha, nb, dp)
+  if (la_t) { if (cpt <= 1) LL_RLN(1, true); else if (cpt <= 2) LL_RLN(2, true); else LL_RLN(4, true); }
+  else { if (cpt <= 1) LL_RLN(1, false); else if (cpt <= 2) LL_RLN(2, false); else LL_RLN(4, false); }
+#undef LL_RLN
+  LL_LAUNCH_CHECK("reduce_lora_normbwd");
+  return LLMSEG_OK;
 }
 #define LL_DROP_OK(d) (!(d) || (d)->drop_thr < 65536u)
 

@@ -1370,6 +1370,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_rmsnorm_kernel(GemmP p, con
 // a pending second output of the call being dispatched on this thread (llmseg_gemm_args.norm_out): the K-sliced ping-pong route consumes it in its reduce launch
 struct NormReq { const bf16_t* w; bf16_t* out; long ldn; float eps; bool active, done; };
 static thread_local NormReq g_norm_req = {nullptr, nullptr, 0, 0.f, false, false};
+// a pending norm-backward tail of the call being dispatched on this thread (llmseg_gemm_args.nb_x): the K-sliced ping-pong route consumes it in its reduce launch
+struct NbReq { const llmseg_gemm_args* a; void* out; bool active, done; };
+static thread_local NbReq g_nb_req = {nullptr, nullptr, false, false};
 
 template <bool OUT_F32, int MI, int NBUF>
 void launch_glds(const GemmP& p, dim3 grid, hipStream_t s) {
@@ -1480,8 +1483,46 @@ static int gemm_fx(const llmseg_gemm_args* a, void* stream) {
   return llmseg_swiglu_bwd_ld(a->fx_in, g.C, a->C, a->M, a->N, a->ldc, stream);
 }
 
+extern "C" __attribute__((visibility("hidden"))) int llmseg_reduce_lora_normbwd(const float* slab, int S, int64_t M, int64_t N, const void* x, const void* w, void* dx, float eps,
+                                                                                int rms, const void* dres, const void* la_t, int64_t la_ldt, const void* la_w0,
+                                                                                const void* la_w1, float la_alpha, const llmseg_dropout* la_drop, void* stream);
+extern "C" int llmseg_norm_bwd_add(const void* dy, const void* x, const void* w, const void* dres, void* dx, float* dw, float* db, int64_t rows, int64_t cols,
+                                   float eps, int rms, void* workspace, int64_t workspace_bytes, void* stream);
+extern "C" int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, int64_t ldxa, const void* w0, const void* w1, int64_t M, int64_t N, int32_t w_rn,
+                                 float alpha, const llmseg_dropout* drop, void* stream);
+static const bool g_nb_off = getenv("LLMSEG_GEMM_NO_NB") != nullptr;      // A/B switch: always the product + lora_apply + norm_bwd launches
+
+// llmseg_gemm_args.nb_x: C = norm_bwd(dy = the bf16 product [+ LoRA term], nb_x, nb_w) + nb_dres.  K-sliced products fold all of it into their reduce launch;
+// every other route writes the product to the tail of the caller's workspace and runs llmseg_lora_apply / llmseg_norm_bwd_add behind it.  Same bits.
+static int gemm_nb(const llmseg_gemm_args* a, void* stream) {
+  LL_CHECK(a->nb_w && !a->out_f32 && a->batch <= 1 && a->batch2 <= 1 && a->alpha == 1.f && !a->bias && !a->gamma && !a->residual && a->act == LLMSEG_ACT_NONE &&
+               !a->norm_out && !a->fx && !a->accumulate && (a->N & 7) == 0 && a->ldc == a->N,
+           "gemm: nb_x needs a plain bf16 product (batch 1, alpha 1, no bias / activation / gamma / residual / norm_out / fx) with dense C rows (ldc == N)");
+  LL_CHECK(((((uintptr_t)a->nb_x) | ((uintptr_t)a->nb_w) | ((uintptr_t)a->nb_dres) | ((uintptr_t)a->C)) & 15) == 0, "gemm: nb_x / nb_w / nb_dres / C must be 16-byte aligned");
+  LL_CHECK(!a->nb_lora_t || (a->nb_lora_w0 && (a->nb_lora_ldt & 7) == 0), "gemm: nb_lora_t needs nb_lora_w0 ([8][N]) and a row pitch that is a multiple of 8");
+  const int64_t tmp_bytes = ((a->M * a->N * 2 + 255) / 256) * 256;
+  LL_CHECK(a->workspace && a->workspace_bytes >= tmp_bytes && (((uintptr_t)a->workspace) & 255) == 0, "gemm: nb_x needs a workspace of >= M N 2 bytes (256-byte aligned)");
+  llmseg_gemm_args g = *a;
+  g.workspace_bytes = (a->workspace_bytes - tmp_bytes) & ~(int64_t)255;
+  void* tmp = (char*)a->workspace + g.workspace_bytes;
+  g.C = tmp;                                                  // the two-launch routes leave the bf16 product here; the fused tail writes a->C itself
+  g.nb_x = nullptr;
+  g_nb_req = NbReq{a, a->C, !g_nb_off, false};
+  const int rc = gemm_dispatch(&g, stream, -1);
+  const bool done = g_nb_req.done;
+  g_nb_req.active = false;
+  if (rc != LLMSEG_OK || done) return rc;
+  if (a->nb_lora_t) {
+    const int rc2 = llmseg_lora_apply(tmp, a->N, a->nb_lora_t, a->nb_lora_ldt, a->nb_lora_w0, a->nb_lora_w1, a->M, a->N, 1, a->nb_lora_alpha,
+                                      (const llmseg_dropout*)a->nb_lora_drop, stream);
+    if (rc2 != LLMSEG_OK) return rc2;
+  }
+  return llmseg_norm_bwd_add(tmp, a->nb_x, a->nb_w, a->nb_dres, a->C, nullptr, nullptr, a->M, a->N, a->nb_eps, a->nb_rms, nullptr, 0, stream);
+}
+
 extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   if (a && a->struct_size == sizeof(*a) && a->fx) return gemm_fx(a, stream);
+  if (a && a->struct_size == sizeof(*a) && a->nb_x) return gemm_nb(a, stream);
   if (!(a && a->struct_size == sizeof(*a) && a->norm_out)) return gemm_dispatch(a, stream, -1);
   // second output RMSNorm(C) * norm_w: the K-sliced route folds it into its reduce launch, every other route gets llmseg_norm behind the product
   LL_CHECK(a->norm_w && !a->out_f32 && a->batch <= 1 && a->batch2 <= 1 && (a->N & 7) == 0 && (a->ldn & 7) == 0 && a->ldn >= a->N && (a->ldc & 7) == 0 &&
@@ -1711,7 +1752,15 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
     const bool fuse_norm = g_norm_req.active && !no_fuse && !f && p.alpha == 1.f && !p.bias && !p.gamma && p.act == LLMSEG_ACT_NONE && p.M >= 64 && p.M < wg_max_rows &&
                            p.N >= 2048 && p.N <= 8192 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.res || (p.ldr & 7) == 0) && (g_norm_req.ldn & 7) == 0 &&
                            ((((uintptr_t)p.C) | ((uintptr_t)p.res) | ((uintptr_t)g_norm_req.w) | ((uintptr_t)g_norm_req.out)) & 15) == 0;
-    if (fuse_norm) {
+    const bool fuse_nb = g_nb_req.active && !f && p.alpha == 1.f && !p.bias && !p.gamma && !p.res && p.act == LLMSEG_ACT_NONE && p.M >= 64 && p.N >= 2048 && p.N <= 8192 &&
+                         (p.N & 7) == 0;       // == where llmseg_norm_bwd_add runs its workgroup-per-row kernel (same arithmetic, same bits)
+    if (fuse_nb) {
+      const llmseg_gemm_args* q = g_nb_req.a;
+      const int rc = llmseg_reduce_lora_normbwd((const float*)a->workspace, split + (p.A2 ? 1 : 0), p.M, p.N, q->nb_x, q->nb_w, g_nb_req.out, q->nb_eps, q->nb_rms, q->nb_dres,
+                                                q->nb_lora_t, q->nb_lora_ldt, q->nb_lora_w0, q->nb_lora_w1, q->nb_lora_alpha, (const llmseg_dropout*)q->nb_lora_drop, stream);
+      if (rc != LLMSEG_OK) return rc;
+      g_nb_req.done = true;
+    } else if (fuse_norm) {
       const int S2 = split + (p.A2 ? 1 : 0);
       const int cpt = ((p.N >> 3) + 255) / 256;
       if (cpt <= 1) LL_LAUNCH_KERNEL(splitk_reduce_rmsnorm_kernel<1>, dim3((unsigned)p.M), dim3(256), 0, s, p, (const float*)a->workspace, S2, g_norm_req.w, g_norm_req.eps, g_norm_req.out, g_norm_req.ldn);

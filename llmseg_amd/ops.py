@@ -56,7 +56,7 @@ def _reduce_ws(dev):
 
 def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alpha=1.0, out_f32=False, trans_a=False, trans_w=False,
          a2=None, w2=None, accumulate=False, a_norm_w=None, a_norm_eps=1e-6, a_swiglu=False, norm_w=None, norm_eps=1e-6, norm_out=None,
-         rope=None, swiglu_out=None, swiglu_bwd_of=None):
+         rope=None, swiglu_out=None, swiglu_bwd_of=None, normbwd=None, nb_lora=None):
     """out[M,N] = residual + gamma * act(alpha * A @ W^T + bias) with A = a [M,K] (or a^T when trans_a: a stored [K,M]) and
     W = w [N,K] (or w^T when trans_w: w stored [K,N]).  2-D bf16 operands, last dim contiguous.  a2 [M,64] / w2 [N,64]: optional
     extension of the contraction (A @ W^T + a2 @ w2^T), e.g. zero-padded low-rank updates.  accumulate (fp32 `out` only):
@@ -65,7 +65,10 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alp
     Fused Llama-layer epilogues (llmseg_gemm_args.fx; the same bits as the pointwise launch each replaces):
       rope = (cos, sin, T, cols): the heads (width 128) of the first `cols` output columns are rotated, position = row % T (`rope_` after the product);
       swiglu_out = h [M, N/2]: out = gate|up as usual and h = silu(gate) * up (`swiglu` after the product);
-      swiglu_bwd_of = gu [M, 2N]: the product is d(h) [M, N]; out [M, 2N] = d(gate|up) (`swiglu_bwd` of the stored product)."""
+      swiglu_bwd_of = gu [M, 2N]: the product is d(h) [M, N]; out [M, 2N] = d(gate|up) (`swiglu_bwd` of the stored product).
+    Norm-backward tail (llmseg_gemm_args.nb_x): normbwd = (x, w, eps, rms, dres | None): the product is the gradient of a pre-norm's output and
+    out = norm_bwd(product, x, w) + dres; nb_lora = (t [M, >=16], w0 [8, N], w1 [8, N] | None, alpha, drop | None) adds the LoRA branches' dX to the
+    product first (`lora_apply_` with w_rn).  One pass in the K-sliced route, the three launches otherwise; same bits."""
     _req(a); _req(w)
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
@@ -101,6 +104,25 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alp
     elif swiglu_bwd_of is not None:
         assert _req(swiglu_bwd_of).shape == (M, 2 * N) and swiglu_bwd_of.stride(1) == 1
         g.fx, g.fx_in, g.fx_ld = _lib.FX_SWIGLU_BWD, swiglu_bwd_of.data_ptr(), swiglu_bwd_of.stride(0)
+    keep = None
+    if normbwd is not None:
+        nx, nw, neps, nrms, ndres = normbwd
+        assert _req(nx).shape == (M, N) and nx.is_contiguous() and _req(nw).numel() == N and out.is_contiguous() and not out_f32
+        g.nb_x, g.nb_w, g.nb_eps, g.nb_rms = nx.data_ptr(), nw.data_ptr(), neps, 1 if nrms else 0
+        if ndres is not None:
+            assert _req(ndres).shape == (M, N) and ndres.is_contiguous()
+            g.nb_dres = ndres.data_ptr()
+        if nb_lora is not None:
+            lt, lw0, lw1, lalpha, ldrop = nb_lora
+            assert _req(lt).shape[0] == M and lt.stride(1) == 1 and _req(lw0).shape == (8, N) and lw0.is_contiguous() and (lw1 is None or (_req(lw1).shape == (8, N) and lw1.is_contiguous()))
+            g.nb_lora_t, g.nb_lora_ldt, g.nb_lora_w0, g.nb_lora_alpha = lt.data_ptr(), lt.stride(0), lw0.data_ptr(), lalpha
+            g.nb_lora_w1 = None if lw1 is None else lw1.data_ptr()
+            if ldrop is not None and ldrop[2] > 0.0:
+                rng, st, pd = ldrop[:3]
+                keep = _lib.Dropout(rng_state=rng.data_ptr(), stream=int(st), drop_thr=int(round(pd * 65536)), seg_rows=int(ldrop[3]) if len(ldrop) > 3 else 0, reserved0=0)
+                g.nb_lora_drop = C.addressof(keep)
+    else:
+        assert nb_lora is None
     if a_norm_w is not None:
         g.a_norm_w, g.a_norm_eps = _req(a_norm_w).data_ptr(), a_norm_eps
     if a_swiglu:
@@ -109,7 +131,7 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alp
         _req(a2); _req(w2)
         assert a2.shape == (M, 64) and w2.shape == (N, 64) and a2.stride(1) == 1 and w2.stride(1) == 1
         g.A2, g.W2, g.lda2, g.ldw2 = a2.data_ptr(), w2.data_ptr(), a2.stride(0), w2.stride(0)
-    if K >= 256:                                                        # split-K candidates: hand the scratch over
+    if K >= 256 or normbwd is not None:                                 # split-K candidates (and the two-launch route of the norm-backward tail): hand the scratch over
         ws = _workspace(a.device, stream)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
     if residual is not None:

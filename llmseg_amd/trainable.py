@@ -108,6 +108,8 @@ class _Auto:
     lora_qkv = staticmethod(lambda x, wqkv, aq, bq, av, bv, s, wqkv_t=None, drop=None, rope=None:
                             ag.LoraQKVFn.apply(x, wqkv, aq, bq, av, bv, s, wqkv_t, drop, rope))
     mlp = staticmethod(ag.mlp)
+    norm_lora_qkv = staticmethod(ag.norm_lora_qkv)
+    norm_mlp = staticmethod(ag.norm_mlp)
     ce = staticmethod(lambda logits, labels: ag.CELossFn.apply(logits, labels))
     align_reg = staticmethod(lambda e, t, pred, gt_iou, gt_iop: ag.AlignRegFn.apply(e, t, pred, gt_iou, gt_iop))
     bcast_add = staticmethod(lambda s, add, Cn, K: ag.BcastAddFn.apply(s, add, Cn, K))
@@ -361,13 +363,26 @@ class TrainableMixin:
         rope_in_gemm = ag.FUSE_ROPE_FWD and c.lora_r == 8 and c.head_dim == 128
         for i in range(c.layers):
             p = f"model.layers.{i}."
-            h, x = F.norm_pass(x, self._w(p + "input_layernorm.weight", F), None, c.eps, True, pre)      # x: the residual branch of the same node
-            if c.lora_r > 0:
+            drop_i = (((rng, i, p_drop, drop_seg_rows) if drop_seg_rows else (rng, i, p_drop)) if p_drop > 0 else None)
+            # round 6: pre-norm + projection as one node where the whole backward tail (dX product, LoRA dX, norm backward, residual gradient) is one GEMM call
+            norm_frozen = F.grad and not self.params.flat[p + "input_layernorm.weight"].requires_grad and not self.params.flat[p + "post_attention_layernorm.weight"].requires_grad
+            merged = F.grad and ag.FUSE_NORM_BWD and norm_frozen and c.hidden % 8 == 0
+            if merged and c.lora_r == 8 and self._wT(p + "qkv", F) is not None:
+                lp = p + "self_attn."
+                qkv, x = F.norm_lora_qkv(x, self._w(p + "input_layernorm.weight", F), c.eps, pre, self._w(p + "qkv", F), self._w(lp + "q_proj.lora_A.default.weight", F),
+                                         self._w(lp + "q_proj.lora_B.default.weight", F), self._w(lp + "v_proj.lora_A.default.weight", F),
+                                         self._w(lp + "v_proj.lora_B.default.weight", F), s, self._wT(p + "qkv", F), drop_i,
+                                         (rope[0], rope[1], T) if rope_in_gemm else None)
+                h = None
+            else:
+                h, x = F.norm_pass(x, self._w(p + "input_layernorm.weight", F), None, c.eps, True, pre)      # x: the residual branch of the same node
+            if h is None:
+                pass
+            elif c.lora_r > 0:
                 lp = p + "self_attn."
                 qkv = F.lora_qkv(h, self._w(p + "qkv", F), self._w(lp + "q_proj.lora_A.default.weight", F),
                                  self._w(lp + "q_proj.lora_B.default.weight", F), self._w(lp + "v_proj.lora_A.default.weight", F),
-                                 self._w(lp + "v_proj.lora_B.default.weight", F), s, self._wT(p + "qkv", F),
-                                 ((rng, i, p_drop, drop_seg_rows) if drop_seg_rows else (rng, i, p_drop)) if p_drop > 0 else None,
+                                 self._w(lp + "v_proj.lora_B.default.weight", F), s, self._wT(p + "qkv", F), drop_i,
                                  (rope[0], rope[1], T) if rope_in_gemm else None)
             else:
                 mem = [p + f"self_attn.{n}_proj.weight" for n in "qkv"]
@@ -381,8 +396,13 @@ class TrainableMixin:
                                        self._w(p + "post_attention_layernorm.weight", F), c.eps)
             else:
                 x = F.linear(a, self._w(p + "self_attn.o_proj.weight", F), None, ops.ACT_NONE, x, self._wT(p + "self_attn.o_proj.weight", F))
-            h, x = F.norm_pass(x, self._w(p + "post_attention_layernorm.weight", F), None, c.eps, True, pre)
             mem = [p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"]
+            if merged and ag.FUSE_MLP and self._frozen(mem + [p + "mlp.down_proj.weight"]) and c.inter % 8 == 0:
+                nxt = self._w(f"model.layers.{i + 1}.input_layernorm.weight", F) if (fuse and i + 1 < c.layers) else None
+                x, pre = F.norm_mlp(x, self._w(p + "post_attention_layernorm.weight", F), c.eps, pre, self._wcat(p + "gate_up", mem, F), self._wT(p + "gate_up", F),
+                                    self._w(p + "mlp.down_proj.weight", F), self._wT(p + "mlp.down_proj.weight", F), nxt)
+                continue
+            h, x = F.norm_pass(x, self._w(p + "post_attention_layernorm.weight", F), None, c.eps, True, pre)
             if ag.FUSE_MLP and self._frozen(mem + [p + "mlp.down_proj.weight"]) and c.inter % 8 == 0:
                 # frozen MLP (the reference's LoRA targets are q_proj / v_proj only): one node, swiglu and its backward inside the GEMMs' stores
                 nxt = self._w(f"model.layers.{i + 1}.input_layernorm.weight", F) if (fuse and i + 1 < c.layers) else None

@@ -319,6 +319,34 @@ def check_gemm_fx():
     return out
 
 
+def check_gemm_normbwd_tail():
+    """Round 6: llmseg_gemm_args.nb_x -- dX product + LoRA dX + pre-norm backward + residual gradient as ONE call -- against the product,
+    `lora_apply_` and `norm_bwd` launches it replaces, BIT FOR BIT: the K-sliced route at the benchmark's shapes (dX of q|k|v with the LoRA term and
+    dropout, dX of gate|up without), and a small shape on the library's own three-launch route."""
+    from llmseg_amd import _lib
+    lib = _lib.load()
+    out = []
+    bits = lambda a, b: float((a.float() - b.float()).abs().max())
+    rng = torch.tensor([1234, 7], device=DEV, dtype=torch.int64)
+    for (M, N, K, lora, tag) in ((638, 4096, 12288, True, "dX(q|k|v) + LoRA, dropout"), (638, 4096, 22016, False, "dX(gate|up)"), (50, 256, 512, True, "small")):
+        d, wt = rnd(M, K, seed=1, scale=0.3).to(DEV), rnd(N, K, seed=2, scale=K ** -0.5).to(DEV)
+        x, w, dres = rnd(M, N, seed=3).to(DEV), rnd(N, seed=4).to(DEV), rnd(M, N, seed=5, scale=0.2).to(DEV)
+        t2, a0, a1 = rnd(M, 64, seed=6, scale=0.3).to(DEV), rnd(8, N, seed=7, scale=0.1).to(DEV), rnd(8, N, seed=8, scale=0.1).to(DEV)
+        drop = (rng, 6, 0.05)
+        ref = ops.gemm(d, wt)
+        if lora:
+            ops.lora_apply_(ref, t2, a0, w_rn=True, drop=drop, w2=a1)
+        ref = ops.norm_bwd(ref, x, w, 1e-6, True, dres=dres)
+        torch.cuda.synchronize()
+        n0 = lib.llmseg_launch_count()
+        got = ops.gemm(d, wt, normbwd=(x, w, 1e-6, True, dres), nb_lora=(t2, a0, a1, 1.0, drop) if lora else None)
+        n = lib.llmseg_launch_count() - n0
+        out.append((f"gemm nb tail == gemm + lora_apply + norm_bwd: {tag} ({n} launches) (bits)", bits(got, ref), 0.0))
+        if M == 638:
+            out.append((f"gemm nb tail: {tag} ran as the K-sliced kernel + ONE tail launch", float(n), 2.0))
+    return out
+
+
 def check_attention():
     out = []
     for hd, B, H, N in [(32, 2, 8, 256), (64, 1, 4, 257), (128, 2, 2, 319), (80, 3, 2, 196), (64, 1, 2, 1100)]:

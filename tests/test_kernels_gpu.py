@@ -38,6 +38,11 @@ def test_gemm_fused_llama_epilogues():
     _run(kc.check_gemm_fx)
 
 
+def test_gemm_norm_backward_tail():
+    from tests import kernel_checks as kc
+    _run(kc.check_gemm_normbwd_tail)
+
+
 def test_attention():
     from tests import kernel_checks as kc
     _run(kc.check_attention)
