@@ -464,6 +464,11 @@ int llmseg_lora_wgrads(const void* dq, const void* dv, int64_t ldd, const void* 
 int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, int64_t ldxa, const void* w0, const void* w1, int64_t M, int64_t N, int32_t w_rn,
                       float alpha, const llmseg_dropout* drop, void* stream);
 int llmseg_lora_pack(const void* aq, const void* bq, const void* av, const void* bv, void* w2b, void* w2a, void* bt, int64_t H, float s, void* stream);
+/* llmseg_lora_down_ws followed by llmseg_lora_pack in one call (ABI 8): the two are independent (activations vs. weights), so where the down projection runs
+ * as K slices the pack rides in its finish launch -- one launch fewer per LoRA'd projection; the same bits as the two calls. */
+int llmseg_lora_down_pack(const void* x0, const void* x1, int64_t ldx, const void* w0, const void* w1, void* y, int64_t ldy, int64_t M, int64_t K,
+                          int32_t w_kr, float alpha, int32_t zero_cols, const llmseg_dropout* drop, void* scratch, int64_t scratch_bytes, const void* aq,
+                          const void* bq, const void* av, const void* bv, void* w2b, void* w2a, void* bt, int64_t H, float s, void* stream);
 /* out[c][r] = in[r][c] (bf16; in [rows][cols] with leading dimension ld_in, out [cols][ld_out]); rows r in [rows, rows_pad) of the
  * source are taken as zero.  Lets the weight / input gradients of a wide trainable Linear (lm_head: dX = dY.W, dW = dY^T.X) run on
  * the K-contiguous LDS-DMA GEMM kernels with the contraction dimension padded to a multiple of 64. */

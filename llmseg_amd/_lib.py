@@ -137,6 +137,7 @@ SIGNATURES = {
     "llmseg_lora_wgrads": [_p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _f32, _dp, _p, _i64, _p],
     "llmseg_lora_apply": [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i32, _f32, _dp, _p],
     "llmseg_lora_pack": [_p, _p, _p, _p, _p, _p, _p, _i64, _f32, _p],
+    "llmseg_lora_down_pack": [_p, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i32, _f32, _i32, _dp, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _f32, _p],
     "llmseg_transpose_pad": [_p, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "llmseg_sumsq": [_p, _i64, C.c_int, _p, _p, _i64, _p],
     "llmseg_adamw": [_p, _p, _p, C.c_int, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _p, _p],

@@ -197,10 +197,10 @@ def lora_qkv_fused(x, wqkv, aq, bq, av, bv, s, drop=None, want_bt=False, rope=No
     H = wqkv.shape[1]
     M = x.shape[0]
     a2 = torch.empty((M, 64), device=x.device, dtype=BF16)
-    ops.lora_down(x, aq, out=a2, zero_cols=48, drop=_drops(drop)[0], x2=x, w2=av)      # [x Aq^T | x Av^T | 0], x read once
     w2b = torch.empty((3 * H, 64), device=x.device, dtype=BF16)
     bt = torch.empty((16, H), device=x.device, dtype=BF16) if want_bt else None      # Bq^T | Bv^T for the backward's down projection
-    ops.lora_pack(aq, bq, av, bv, s, w2b=w2b, bt=bt)
+    ops.lora_down(x, aq, out=a2, zero_cols=48, drop=_drops(drop)[0], x2=x, w2=av,      # [x Aq^T | x Av^T | 0], x read once; the pack rides in its finish launch
+                  pack=(aq, bq, av, bv, s, w2b, None, bt))
     return ops.gemm(x, wqkv, a2=a2, w2=w2b, rope=None if rope is None else (rope[0], rope[1], rope[2], 2 * H)), a2, bt
 
 

@@ -775,11 +775,11 @@ __global__ __launch_bounds__(256) void lora_down_mfma_kernel(const bf16_t* __res
   }
 }
 
-__global__ __launch_bounds__(256) void lora_down_finish_kernel(const float* __restrict__ part, int S, bf16_t* __restrict__ y, long ldy, long M, float scale,
-                                                              int zero_cols, int nb) {
+__device__ __forceinline__ void lora_down_finish_body(const float* __restrict__ part, int S, bf16_t* __restrict__ y, long ldy, long M, float scale,
+                                                      int zero_cols, int nb, long bid, long nblocks) {
   const int nch = nb + zero_cols / 8;
   const long total = M * nch;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+  for (long t = bid * blockDim.x + threadIdx.x; t < total; t += nblocks * blockDim.x) {
     const long mm = t / nch;
     const int ch = (int)(t - mm * nch);
     uint4 o = make_uint4(0, 0, 0, 0);
@@ -798,6 +798,10 @@ __global__ __launch_bounds__(256) void lora_down_finish_kernel(const float* __re
     }
     *reinterpret_cast<uint4*>(y + mm * ldy + ch * 8) = o;
   }
+}
+__global__ __launch_bounds__(256) void lora_down_finish_kernel(const float* __restrict__ part, int S, bf16_t* __restrict__ y, long ldy, long M, float scale,
+                                                              int zero_cols, int nb) {
+  lora_down_finish_body(part, S, y, ldy, M, scale, zero_cols, nb, blockIdx.x, gridDim.x);
 }
 
 // out(n,r) += alpha * sum_m drop(a)[m][n] * b[m][r]  (the caller zero-fills `out` or accumulates into a gradient arena; no atomics:
@@ -1011,11 +1015,11 @@ __global__ __launch_bounds__(256) void reduce_lora_normbwd_kernel(const float* _
 // matrices on every call (no cache to go stale when the optimizer updates them in place):
 //   w2b [3H][64]: rows of the q block = [s Bq | 0], k block = 0, v block = [0 | s Bv | 0]     (forward: qkv += [xAq | xAv | 0] . w2b^T)
 //   w2a [H][64]:  row h = [Aq[:, h] | Av[:, h] | 0]                                             (backward: dx += [tq | tv | 0] . w2a^T)
-__global__ __launch_bounds__(256) void lora_pack_kernel(const bf16_t* __restrict__ aq, const bf16_t* __restrict__ bq, const bf16_t* __restrict__ av,
-                                                       const bf16_t* __restrict__ bv, bf16_t* __restrict__ w2b, bf16_t* __restrict__ w2a, bf16_t* __restrict__ bt,
-                                                       long H, float s) {
+__device__ __forceinline__ void lora_pack_body(const bf16_t* __restrict__ aq, const bf16_t* __restrict__ bq, const bf16_t* __restrict__ av,
+                                               const bf16_t* __restrict__ bv, bf16_t* __restrict__ w2b, bf16_t* __restrict__ w2a, bf16_t* __restrict__ bt,
+                                               long H, float s, long bid, long nblocks) {
   const long total = 4 * H * 8 + (bt ? 2 * H : 0);                   // (3H + H) rows x 8 chunks of 8 columns (+ the B^T copies: 16 rows x H / 8 chunks)
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i = bid * blockDim.x + threadIdx.x; i < total; i += nblocks * blockDim.x) {
     if (i >= 4 * H * 8) {                                            // bt [16][H]: rows 0..7 = Bq^T, 8..15 = Bv^T (the backward's rank-8 down projection wants K-contiguous rows)
       const long j = i - 4 * H * 8;
       const int row16 = (int)(j / (H >> 3));
@@ -1048,6 +1052,20 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const bf16_t* __restrict
       *reinterpret_cast<uint4*>(w2a + h * 64 + ch * 8) = pack8(v);
     }
   }
+}
+__global__ __launch_bounds__(256) void lora_pack_kernel(const bf16_t* __restrict__ aq, const bf16_t* __restrict__ bq, const bf16_t* __restrict__ av,
+                                                       const bf16_t* __restrict__ bv, bf16_t* __restrict__ w2b, bf16_t* __restrict__ w2a, bf16_t* __restrict__ bt,
+                                                       long H, float s) {
+  lora_pack_body(aq, bq, av, bv, w2b, w2a, bt, H, s, blockIdx.x, gridDim.x);
+}
+// lora_down's K-slice finish and lora_pack in ONE launch (round 6: the two are independent -- activations vs. weights -- and each is a ~4 us grid-stride pass):
+// workgroups [0, gf) add the slices, [gf, gridDim.x) build the extension operands.  Same arithmetic as the two kernels.
+__global__ __launch_bounds__(256) void lora_finish_pack_kernel(const float* __restrict__ part, int S, bf16_t* __restrict__ y, long ldy, long M, float scale, int zero_cols,
+                                                              int nb, int gf, const bf16_t* __restrict__ aq, const bf16_t* __restrict__ bq,
+                                                              const bf16_t* __restrict__ av, const bf16_t* __restrict__ bv, bf16_t* __restrict__ w2b,
+                                                              bf16_t* __restrict__ w2a, bf16_t* __restrict__ bt, long H, float s) {
+  if ((int)blockIdx.x < gf) lora_down_finish_body(part, S, y, ldy, M, scale, zero_cols, nb, blockIdx.x, gf);
+  else lora_pack_body(aq, bq, av, bv, w2b, w2a, bt, H, s, (long)blockIdx.x - gf, (long)gridDim.x - gf);
 }
 // out[c][r] = in[r][c] for r < rows (zero for rows <= r < rows_pad): 64 x 64 tiles through LDS, 16-byte global accesses both ways.
 __global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, long rows, long cols, long ld_in,
@@ -1113,6 +1131,10 @@ extern "C" int llmseg_lora_down(const void* x0, const void* x1, int64_t ldx, con
   return llmseg_lora_down_ws(x0, x1, ldx, w0, w1, y, ldy, M, K, w_kr, alpha, zero_cols, drop, nullptr, 0, stream);
 }
 
+// a lora_pack job waiting to ride in the finish launch of the lora_down call being issued on this thread (llmseg_lora_down_pack)
+struct PackReq { const bf16_t *aq, *bq, *av, *bv; bf16_t *w2b, *w2a, *bt; long H; float s; bool active, done; };
+static thread_local PackReq g_pack_req = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, false, false};
+
 extern "C" int llmseg_lora_down_ws(const void* x0, const void* x1, int64_t ldx, const void* w0, const void* w1, void* y, int64_t ldy, int64_t M, int64_t K,
                                    int32_t w_kr, float alpha, int32_t zero_cols, const llmseg_dropout* drop, void* scratch, int64_t scratch_bytes, void* stream) {
   const int nb = (x1 && w1) ? 2 : 1;
@@ -1131,7 +1153,13 @@ extern "C" int llmseg_lora_down_ws(const void* x0, const void* x1, int64_t ldx, 
     float* part = S > 1 ? (float*)scratch : nullptr;
     LL_LAUNCH_KERNEL(lora_down_mfma_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, (hipStream_t)stream, X0, X1, (long)ldx, W0, W1, (bf16_t*)y, (long)ldy,
                        (long)M, (int)K, alpha, zero_cols, nb, dp, part);
-    if (S > 1)
+    if (S > 1 && g_pack_req.active) {
+      const PackReq& q = g_pack_req;
+      const unsigned gf = grid_for(M * (nb + zero_cols / 8)), gp = grid_for(4 * q.H * 8 + 2 * q.H);
+      LL_LAUNCH_KERNEL(lora_finish_pack_kernel, dim3(gf + gp), dim3(256), 0, (hipStream_t)stream, (const float*)part, S, (bf16_t*)y, (long)ldy, (long)M,
+                         alpha * (dp.thr ? dp.scale : 1.f), zero_cols, nb, (int)gf, q.aq, q.bq, q.av, q.bv, q.w2b, q.w2a, q.bt, q.H, q.s);
+      g_pack_req.done = true;
+    } else if (S > 1)
       LL_LAUNCH_KERNEL(lora_down_finish_kernel, dim3(grid_for(M * (nb + zero_cols / 8))), dim3(256), 0, (hipStream_t)stream, (const float*)part, S, (bf16_t*)y,
                          (long)ldy, (long)M, alpha * (dp.thr ? dp.scale : 1.f), zero_cols, nb);
   } else if (M <= 2048)
@@ -1207,6 +1235,21 @@ extern "C" int llmseg_lora_pack(const void* aq, const void* bq, const void* av, 
                      (const bf16_t*)bv, (bf16_t*)w2b, (bf16_t*)w2a, (bf16_t*)bt, (long)H, s);
   LL_LAUNCH_CHECK("lora_pack");
   return LLMSEG_OK;
+}
+
+// llmseg_lora_down_ws followed by llmseg_lora_pack as one entry point: where the down projection runs as K slices, the pack rides in its finish launch (same bits)
+extern "C" int llmseg_lora_down_pack(const void* x0, const void* x1, int64_t ldx, const void* w0, const void* w1, void* y, int64_t ldy, int64_t M, int64_t K,
+                                     int32_t w_kr, float alpha, int32_t zero_cols, const llmseg_dropout* drop, void* scratch, int64_t scratch_bytes, const void* aq,
+                                     const void* bq, const void* av, const void* bv, void* w2b, void* w2a, void* bt, int64_t H, float s, void* stream) {
+  LL_CHECK(aq && bq && av && bv && (w2b || w2a || bt) && H > 0 && (H & 7) == 0 && AL16(aq) && AL16(bq) && AL16(av) && AL16(bv) && AL16(w2b) && AL16(w2a) && AL16(bt),
+           "lora_down_pack: bad pack arguments");
+  static const bool off = getenv("LLMSEG_NO_FINISH_PACK") != nullptr;      // A/B switch: always the two launches
+  g_pack_req = PackReq{(const bf16_t*)aq, (const bf16_t*)bq, (const bf16_t*)av, (const bf16_t*)bv, (bf16_t*)w2b, (bf16_t*)w2a, (bf16_t*)bt, (long)H, s, !off, false};
+  const int rc = llmseg_lora_down_ws(x0, x1, ldx, w0, w1, y, ldy, M, K, w_kr, alpha, zero_cols, drop, scratch, scratch_bytes, stream);
+  const bool done = g_pack_req.done;
+  g_pack_req.active = false;
+  if (rc != LLMSEG_OK || done) return rc;
+  return llmseg_lora_pack(aq, bq, av, bv, w2b, w2a, bt, H, s, stream);
 }
 
 extern "C" int llmseg_transpose_pad(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, int64_t rows_pad, void* stream) {

@@ -595,10 +595,11 @@ def _drop(drop):
     return C.byref(_lib.Dropout(rng_state=rng.data_ptr(), stream=int(stream), drop_thr=int(round(p * 65536)), seg_rows=seg, reserved0=0))
 
 
-def lora_down(x, w, w_kr=False, alpha=1.0, out=None, zero_cols=0, drop=None, x2=None, w2=None):
+def lora_down(x, w, w_kr=False, alpha=1.0, out=None, zero_cols=0, drop=None, x2=None, w2=None, pack=None):
     """y [M, 8] = alpha * drop(x) [M, K] @ W^T; W stored [8, K] (or [K, 8] when w_kr).  x may be a column view (row stride = ld).
     With (x2, w2) the second branch lands in columns 8..15 of the same rows (its dropout stream is drop's + 1; x2 may be x).  `out`
-    may be the leading columns of a wider row; `zero_cols` further columns of every row are zero-filled."""
+    may be the leading columns of a wider row; `zero_cols` further columns of every row are zero-filled.
+    pack = (aq, bq, av, bv, s, w2b, w2a, bt): `lora_pack` of the same layer in the same call (`llmseg_lora_down_pack`: it rides in the K-slice finish launch)."""
     M, K = x.shape
     nb = 1 if w2 is None else 2
     y = torch.empty((M, 8 * nb), device=x.device, dtype=BF16) if out is None else out
@@ -606,9 +607,17 @@ def lora_down(x, w, w_kr=False, alpha=1.0, out=None, zero_cols=0, drop=None, x2=
     scratch = None
     if not w_kr and (M + 15) // 16 < 256 and K % 256 == 0:       # short activations: K-sliced over several workgroups per row tile (fp32 partials)
         scratch = torch.empty((32 * 2 * M * 16,), device=x.device, dtype=torch.float32)
-    _lib.check(_lib.load().llmseg_lora_down_ws(_ptr(x), _ptr(x2 if w2 is not None and x2 is not None else (x if w2 is not None else None)), x.stride(0),
-                                               _ptr(w), _ptr(w2), _ptr(y), y.stride(0), M, K, 1 if w_kr else 0, alpha, zero_cols, _drop(drop),
-                                               _ptr(scratch), 0 if scratch is None else scratch.numel() * 4, _stream()), "lora_down")
+    args = (_ptr(x), _ptr(x2 if w2 is not None and x2 is not None else (x if w2 is not None else None)), x.stride(0),
+            _ptr(w), _ptr(w2), _ptr(y), y.stride(0), M, K, 1 if w_kr else 0, alpha, zero_cols, _drop(drop),
+            _ptr(scratch), 0 if scratch is None else scratch.numel() * 4)
+    if pack is None:
+        _lib.check(_lib.load().llmseg_lora_down_ws(*args, _stream()), "lora_down")
+    else:
+        aq, bq, av, bv, ps, w2b, w2a, bt = pack
+        for t in (aq, bq, av, bv):
+            assert t.is_contiguous()
+        _lib.check(_lib.load().llmseg_lora_down_pack(*args, _ptr(aq), _ptr(bq), _ptr(av), _ptr(bv), _ptr(w2b), _ptr(w2a), _ptr(bt), aq.shape[1], ps, _stream()),
+                   "lora_down_pack")
     return y
 
 
