@@ -867,9 +867,10 @@ constexpr int NTB = 512;
       _Pragma("unroll") for (int mb = 0; mb < MI; ++mb)                                                                       \
           acc[(nb0) + nb][(mb0) + mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfx[nb][ks], af[mb][ks], acc[(nb0) + nb][(mb0) + mb], 0, 0, 0)
 
-template <bool OUT_F32, bool EXT, int MI>
+template <bool OUT_F32, bool EXT, int MI, int FX = FX_NONE>
 __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
   constexpr int BMB = 64 * MI, BNB = 256;
+  constexpr int BN_STEP = FX == FX_SWIGLU ? 128 : BNB;        // FX_SWIGLU: a tile is 128 gate columns + the 128 up columns of the same index (see epilogue_fx)
   constexpr int A_BYTES = BMB * BK * 2, W_BYTES = BNB * BK * 2, BUF = A_BYTES + W_BYTES;     // 64 KiB (MI 4) / 48 KiB (MI 2) per buffer
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   int bid = blockIdx.x;
@@ -884,7 +885,7 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
   const int first_m = (bid / per_group) * p.group_m;
   const int gsz = min(p.tiles_m - first_m, p.group_m);
   const int m0 = (first_m + (bid % per_group) % gsz) * BMB;
-  const int n0 = ((bid % per_group) / gsz) * BNB;
+  const int n0 = ((bid % per_group) / gsz) * BN_STEP;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -907,9 +908,12 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
       const int ra0 = i < MI / 2 ? PP_AROW0(h, i) : 0, ra = ra0 + (lane >> 3);
       a_lds[h][i] = ra0 * 128;
       a_off[h][i] = (int)(((long)min(ra, p.M - 1 - m0) * p.lda + (((lane & 7) ^ ((ra >> 1) & 7)) << 3)) * 2);
-      const int rw0 = PP_WROW0(h, i), rw = rw0 + (lane >> 3);
+      // fused epilogues: a W half-tile is the set of rows the waves read as their FIRST / SECOND 32-column block (what phases p0 / p1 read), so with
+      // the paired wave -> row mapping half h = rows with (row % 128) / 64 == h (RoPE) or row / 128 == h (SwiGLU); the DMA ring's timing is unchanged
+      const int rw0 = FX == FX_ROPE ? i * 128 + h * 64 + wave * 8 : FX == FX_SWIGLU ? h * 128 + i * 64 + wave * 8 : PP_WROW0(h, i), rw = rw0 + (lane >> 3);
       w_lds[h][i] = A_BYTES + rw0 * 128;
-      w_off[h][i] = (int)(((long)min(rw, p.N - 1 - n0) * p.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) << 3)) * 2);
+      const int gw = (FX == FX_SWIGLU && rw >= 128) ? rw - 128 + p.fx_I : rw;
+      w_off[h][i] = (int)(((long)min(gw, p.N - 1 - n0) * p.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) << 3)) * 2);
     }
   }
   int nt_main = p.K / BK;
@@ -920,7 +924,7 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
     return p.A2 + (long)min(m0 + ra, p.M - 1) * p.lda2 + (((lane & 7) ^ ((ra >> 1) & 7)) << 3);
   };
   auto ext_w = [&](int h, int i) {
-    const int rw = PP_WROW0(h, i) + (lane >> 3);
+    const int rw = (FX == FX_ROPE ? i * 128 + h * 64 + wave * 8 : PP_WROW0(h, i)) + (lane >> 3);
     return p.W2 + (long)min(n0 + rw, p.N - 1) * p.ldw2 + (((lane & 7) ^ ((rw >> 1) & 7)) << 3);
   };
 
@@ -933,7 +937,9 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
     for (int mb = 0; mb < 2 * MI; ++mb) acc[nb][mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   bf16x8_t af[MI][2], wf0[2][2], wf1[2][2];
   const int frow = lane & 15, fq = lane >> 4;
-  const int wrow0 = wn * 64, wrow1 = wn * 64 + 32;      // first W-tile row of this wave's two 32-column halves
+  // first W-tile row of this wave's two 32-column halves: 64 consecutive columns, or (fused epilogues) two blocks a pair distance apart
+  const int wrow0 = FX == FX_ROPE ? (wn >> 1) * 128 + (wn & 1) * 32 : FX == FX_SWIGLU ? wn * 32 : wn * 64;
+  const int wrow1 = wrow0 + (FX == FX_ROPE ? 64 : FX == FX_SWIGLU ? 128 : 32);
 
   // prologue: S[0..5] = A0(0) W0(0) W1(0) A1(0) A0(1) W0(1)
   if (EXT) { PP_ISSUE_AX(0, smem); PP_ISSUE_WX(0, smem); PP_ISSUE_WX(1, smem); PP_ISSUE_AX(1, smem); }
@@ -967,7 +973,8 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
     PP_PHASE(PP_NOP, PP_NOP, PP_NOP, P16_MMA(wf0, 0, MI));
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();            // re-join: every wave's reads and DMA are retired past this point
-  epilogue_lds<OUT_F32, MI>(p, Acc16<MI>{acc}, smem, wave, m0, n0, wm, wn, lane, bz);
+  if constexpr (FX != FX_NONE) epilogue_fx<MI, FX>(p, Acc16<MI>{acc}, smem, wave, m0, n0, wm, wn, lane);
+  else epilogue_lds<OUT_F32, MI>(p, Acc16<MI>{acc}, smem, wave, m0, n0, wm, wn, lane, bz);
 }
 
 // ---- variant Q2: 128 x 256 tile, TWO phases per K-tile, THREE LDS buffers -------------------------------------------------------
@@ -1777,11 +1784,26 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
         if (f) LL_LAUNCH_KERNEL((gemm_bf16_tn_g4_kernel<true>), grid, dim3(NT), 0, s, p);
         else LL_LAUNCH_KERNEL((gemm_bf16_tn_g4_kernel<false>), grid, dim3(NT), 0, s, p);
         break;
-      case 8:
+      case 8: {
+        // fused Llama-layer epilogues at large M (the fused accumulation window, 24-image micro-batches): the 256 x 256 tile's FX forms
+        const bool fx_ok8 = a->fx && !g_fx_off && !f && batch == 1 &&
+                            (a->fx == LLMSEG_FX_ROPE ? (p.N % 256) == 0 && p.A2 != nullptr
+                             : a->fx == LLMSEG_FX_SWIGLU ? (p.fx_I % 128) == 0 : (p.N % 64) == 0);
+        if (fx_ok8) {
+          GemmP q = p;
+          q.fx = a->fx;
+          if (a->fx == LLMSEG_FX_SWIGLU_BWD) q.C = (bf16_t*)a->C - a->N;
+          if (a->fx == LLMSEG_FX_ROPE) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<false, true, 4, FX_ROPE>), grid, dim3(NTB), 0, s, q);
+          else if (a->fx == LLMSEG_FX_SWIGLU) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<false, false, 4, FX_SWIGLU>), grid, dim3(NTB), 0, s, q);
+          else LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<false, false, 4, FX_SWIGLU_BWD>), grid, dim3(NTB), 0, s, q);
+          g_fx_done = true;
+          break;
+        }
         if (p.A2) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<false, true, 4>), grid, dim3(NTB), 0, s, p);      // bf16 out only (checked above)
         else if (f) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<true, false, 4>), grid, dim3(NTB), 0, s, p);
         else LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<false, false, 4>), grid, dim3(NTB), 0, s, p);
         break;
+      }
       case 9:
         if (g_gemm_pp2 == 2 && !p.A2) {                     // loader-wave form (experiment; the LoRA extension tile keeps the two-phase kernel)
           if (f) LL_LAUNCH_KERNEL((gemm_bf16_tn_lw_kernel<true>), grid, dim3(NTL), 0, s, p);
