@@ -61,7 +61,7 @@ def pmc_traffic(kernel, B):
     total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in forms.values())
     sliced = lambda b: sum(v["launches"] for k, v in ks.items() if k.startswith(b) and k[len(b):].startswith("true"))
     others = [k.split("<")[0] + "<" for k in ks if k.startswith("gemm_bf16_tn_pp") and not k.startswith(base)]
-    reds = [v for k, v in ks.items() if k.startswith("splitk_reduce")]          # the plain reduce and its reduce + RMSNorm form (`norm_out` calls)
+    reds = [v for k, v in ks.items() if k.startswith("splitk_reduce") or k.startswith("reduce_lora_normbwd")]     # the plain reduce, its reduce + RMSNorm form (`norm_out`) and the reduce + LoRA dX + norm-backward tail (`nb_x`)
     if reds and sliced(base) >= max([sliced(o) for o in set(others)] + [0]):
         total += sum(r["hbm_bytes_per_launch"] * r["launches"] for r in reds)
     prov["forms"] = {k: {"launches": v["launches"], "hbm_bytes_per_launch": v["hbm_bytes_per_launch"]} for k, v in forms.items()}
@@ -228,11 +228,13 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
     composition = ("the class = every llmseg_gemm_bf16 CALL the dispatch sends to this tile kernel with bf16 output (a timed record spans the whole call): "
                    "%.0f calls per step, of which %.0f ran as K-slices (%.1f slices on average: ONE launch of the tile kernel's fp32-slab form -- rocprofv3 row "
                    "`...<true, ...>` -- with the slices as its batch index, + one `splitk_reduce_kernel` launch that applies the epilogue -- `splitk_reduce_rmsnorm_kernel` where the call also asks for the next RMSNorm, `norm_out`: that row's time is inside the call) and %.0f as a single "
-                   "launch of the bf16-out form (row `...<false, false>`) or its LoRA extension-tile form (`...<false, true>`); %.0f kernel launches per step in all"
+                   "launch of the bf16-out form (row `...<false, false, 0>`) or its LoRA extension-tile form (`...<false, true, ..>`); round 6: the timed calls also carry the "
+                   "pointwise work that used to be launches of its own -- RoPE / SwiGLU / SwiGLU-backward in the store of the `<.., 1|2|3>` forms, and the LoRA dX + pre-norm backward "
+                   "in the K-slice reduce launch `reduce_lora_normbwd_kernel` -- so the fraction prices those epilogues as GEMM time; %.0f kernel launches per step in all"
                    % (per("calls"), per("calls_as_k_slices"), di.get("k_slices", 0) / max(1, di.get("calls_as_k_slices", 0)),
                       per("calls") - per("calls_as_k_slices"), per("kernel_launches"))) if di else None
     res["roofline"] = {"bound": "mfma", "kernel": prof["dominant_kernel"], "class_composition": composition,
-                       "hottest_symbol": "by rocprofv3's per-symbol table (profiles/r06_b2_1stream_kernel_stats.md) the single hottest SYMBOL at 2 images is "
+                       "hottest_symbol": "by rocprofv3's per-symbol table (profiles/r06g_b2_1stream_kernel_stats.md) the single hottest SYMBOL at 2 images is "
                                          "gemm_bf16_tn_pp_kernel<false, false, 4> (the 256 x 256 tile: SAM products at M = 8192 / 9800; ~0.30 of peak): its calls are "
                                          "counted under `other_gemm_classes` below.  `kernel` above names the dominant CLASS by total time = the 128 x 256 tile's three "
                                          "symbols (bf16-out, fp32 K-slice slabs, LoRA extension tile) + their reduce launches (the Llama products at M = 638)",

@@ -30,7 +30,7 @@ def gemm(pmc_json, batch, traffic_json, note):
         tr = {}
     rec = {}
     for k, v in pmc.items():
-        if k.startswith("gemm_bf16") or k.startswith("attn_") or k.startswith("splitk"):
+        if k.startswith("gemm_bf16") or k.startswith("attn_") or k.startswith("splitk") or k.startswith("reduce_lora"):
             rec[k] = {"hbm_bytes_per_launch": v.get("FETCH_SIZE_KiB_mean", 0) * 2 * 1024 + v.get("WRITE_SIZE_KiB_mean", 0) * 1024,
                       "read_bytes": v.get("FETCH_SIZE_KiB_mean", 0) * 2 * 1024, "write_bytes": v.get("WRITE_SIZE_KiB_mean", 0) * 1024, "launches": v["launches"]}
     tr[f"batch_{batch}"] = {"source": note, "kernels": rec}

@@ -25,7 +25,10 @@ for _ in range(2):
     trainer.micro_step(batch)
 torch.cuda.synchronize()
 STACK = os.environ.get("STACK") is not None          # STACK=1: group by python source location instead of input shapes
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=STACK) as prof:
+kw = {}
+if STACK:
+    kw["experimental_config"] = torch._C._profiler._ExperimentalConfig(verbose=True)
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=STACK, **kw) as prof:
     trainer.micro_step(batch)
     torch.cuda.synchronize()
 rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.device_time_total > 0 and e.key.startswith("aten::")]
