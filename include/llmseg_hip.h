@@ -117,6 +117,10 @@ typedef struct {
    * Plain bf16 product, ldc == N, N % 8 == 0.  nb_x NULL = off. */
   const void* nb_x; const void* nb_w; const void* nb_dres; float nb_eps; int nb_rms;
   const void* nb_lora_t; int64_t nb_lora_ldt; const void* nb_lora_w0; const void* nb_lora_w1; float nb_lora_alpha; int reserved2; const void* nb_lora_drop;
+  /* delta tail (ABI 8): the product is dO [batch * dl_T][dl_heads * 128] of an attention (dX of o_proj; rows = b * dl_T + q) whose output was dl_o (bf16, row pitch
+   * dl_ldo); the call also writes dl_out[b][h][q] = sum_d dO * O (fp32 [batch][dl_heads][dl_T]) -- llmseg_attn_bwd's `delta`, which can then be passed with
+   * delta_ready = 1.  In the reduce launch of a K-sliced product, by the attention backward's delta kernel behind the product otherwise; same bits.  NULL = off. */
+  const void* dl_o; int64_t dl_ldo; float* dl_out; int32_t dl_heads; int32_t dl_T;
 } llmseg_gemm_args;
 enum { LLMSEG_FX_NONE = 0, LLMSEG_FX_ROPE = 1, LLMSEG_FX_SWIGLU = 2, LLMSEG_FX_SWIGLU_BWD = 3 };
 int llmseg_gemm_bf16(const llmseg_gemm_args* args, void* stream);
@@ -196,6 +200,8 @@ typedef struct {
    * stored dQ | dK gives.  The Llama layer passes (cos, -sin): the inverse rotation of HF apply_rotary_pos_emb's backward
    * (modeling_llama.py, transformers 4.29), which used to be a launch of its own per layer.  head_dim 64 or 128. */
   const float* rope_cos; const float* rope_sin;
+  /* 1: `delta` already holds rowsum(dO * O) (llmseg_gemm_args.dl_o wrote it): the delta launch is skipped (ABI 8) */
+  int32_t delta_ready; int32_t reserved1;
 } llmseg_attn_bwd_args;
 int llmseg_attn_bwd(const llmseg_attn_bwd_args* args, void* stream);
 

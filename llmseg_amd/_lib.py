@@ -39,7 +39,8 @@ class GemmArgs(_Sized):
                 ("fx_in", C.c_void_p), ("fx_ld", C.c_int64),
                 ("nb_x", C.c_void_p), ("nb_w", C.c_void_p), ("nb_dres", C.c_void_p), ("nb_eps", C.c_float), ("nb_rms", C.c_int),
                 ("nb_lora_t", C.c_void_p), ("nb_lora_ldt", C.c_int64), ("nb_lora_w0", C.c_void_p), ("nb_lora_w1", C.c_void_p), ("nb_lora_alpha", C.c_float),
-                ("reserved2", C.c_int), ("nb_lora_drop", C.c_void_p)]
+                ("reserved2", C.c_int), ("nb_lora_drop", C.c_void_p),
+                ("dl_o", C.c_void_p), ("dl_ldo", C.c_int64), ("dl_out", C.c_void_p), ("dl_heads", C.c_int32), ("dl_T", C.c_int32)]
 
 FX_NONE, FX_ROPE, FX_SWIGLU, FX_SWIGLU_BWD = 0, 1, 2, 3          # LLMSEG_FX_* of include/llmseg_hip.h
 
@@ -62,7 +63,7 @@ class AttnBwdArgs(_Sized):
                 [(f"{t}_stride_{s}", C.c_int64) for t in ("q", "k", "v", "o", "do", "dq", "dk", "dv") for s in ("b", "h", "row")] +
                 [("batch", C.c_int32), ("heads", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("head_dim", C.c_int32),
                  ("scale", C.c_float), ("causal", C.c_int32), ("key_mask", C.c_void_p), ("lse", C.c_void_p), ("delta", C.c_void_p),
-                 ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p)])
+                 ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("delta_ready", C.c_int32), ("reserved1", C.c_int32)])
 
 
 class Dropout(C.Structure):

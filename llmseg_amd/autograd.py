@@ -28,6 +28,7 @@ BIG_WEIGHT = 1 << 26          # N * K of a Linear whose dX / dW always take the 
 FUSE_ROPE_BWD = os.environ.get("LLMSEG_NO_FUSE_ROPE_BWD") is None      # inverse RoPE inside the attention backward's dq / dk store
 FUSE_ROPE_FWD = os.environ.get("LLMSEG_NO_FUSE_ROPE_FWD") is None      # RoPE inside the q|k|v GEMM's store (rank-8 LoRA route, head_dim 128)
 FUSE_NORM_BWD = os.environ.get("LLMSEG_NO_FUSE_NORM_BWD") is None      # pre-norm backward (+ LoRA dX + residual gradient) inside the dX product's K-slice reduce launch
+FUSE_DELTA = os.environ.get("LLMSEG_NO_FUSE_DELTA") is None            # the attention backward's delta inside the dX(o_proj) product's reduce launch
 FUSE_MLP = os.environ.get("LLMSEG_NO_FUSE_MLP") is None                # swiglu / swiglu_bwd inside the gate|up and dX(down) GEMMs' stores (frozen MLP weights)
 
 
@@ -515,6 +516,59 @@ class PackedAttnFn(Function):
             if not rope_in_bwd:
                 ops.rope_(dqkv, ctx.rope[0], ctx.rope[2], batch * n, n, 2 * heads, hd, ld)
         return dqkv, None, None, None, None, None, None, None, None
+
+
+class AttnOProjFn(Function):
+    """(RoPE +) causal attention on a packed q|k|v buffer and the o_proj + residual (+ the residual stream's next RMSNorm) behind it as ONE node (round 6; frozen
+    o_proj weight): `PackedAttnFn` followed by `LinearNormFn` / `LinearFn`.  What the merge buys is the backward: the K-sliced dX(o_proj) product's reduce launch also
+    writes the attention backward's row statistic delta = rowsum(dO * O) (`llmseg_gemm_args.dl_o`), so `llmseg_attn_bwd` skips its delta launch.  Same bits."""
+
+    @staticmethod
+    def forward(ctx, qkv, batch, n, heads, hd, causal, key_mask, rope, pre_rotated, wo, wo_t, residual, norm_w, eps):
+        if rope is not None and not pre_rotated:
+            ops.rope_(qkv, rope[0], rope[1], batch * n, n, 2 * heads, hd, qkv.stride(0))
+            ctx.mark_dirty(qkv)
+        lse = torch.empty((batch, heads, n), device=qkv.device, dtype=torch.float32)
+        out = ops.attention_packed(qkv, batch, n, heads, hd, causal=causal, key_mask=key_mask, lse=lse)
+        ctx.args = (batch, n, heads, hd, causal)
+        ctx.rope, ctx.wo_t = rope, wo_t
+        ctx.save_for_backward(qkv, key_mask, out, lse)
+        ctx.set_materialize_grads(False)
+        rot = rope is not None and not pre_rotated
+        if norm_w is None:
+            y = ops.gemm(out, wo, residual=residual)
+            return (qkv, y, None) if rot else (y, None)
+        pre = torch.empty((out.shape[0], wo.shape[0]), device=qkv.device, dtype=BF16)
+        y = ops.gemm(out, wo, residual=residual, norm_w=norm_w, norm_eps=eps, norm_out=pre)
+        ctx.mark_non_differentiable(pre)
+        return (qkv, y, pre) if rot else (y, pre)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        dy = grads[-2]
+        qkv, key_mask, out, lse = ctx.saved_tensors
+        batch, n, heads, hd, causal = ctx.args
+        D = heads * hd
+        dy = dy.contiguous()
+        do = torch.empty_like(out)
+        delta = torch.empty_like(lse) if hd == 128 else None
+        ops.gemm(dy, ctx.wo_t, out=do, delta_of=None if delta is None else (out, delta, heads, n))
+        dqkv = torch.empty_like(qkv)
+        ld = qkv.stride(0)
+        st, dst = (n * ld, hd, ld), (n * D, hd, D)
+        fuse_rope = ctx.rope is not None and hd in (64, 128) and FUSE_ROPE_BWD
+        ops.attention_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], out, do, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], lse, batch=batch, heads=heads, Nq=n, Nk=n, head_dim=hd,
+                          q_strides=st, k_strides=st, v_strides=st, o_strides=(n * out.stride(0), hd, out.stride(0)), do_strides=dst, dq_strides=st,
+                          dk_strides=st, dv_strides=st, causal=causal, key_mask=key_mask, rope=(ctx.rope[0], ctx.rope[2]) if fuse_rope else None, delta=delta)
+        if ctx.rope is not None and not fuse_rope:
+            ops.rope_(dqkv, ctx.rope[0], ctx.rope[2], batch * n, n, 2 * heads, hd, ld)
+        return (dqkv,) + (None,) * 10 + (dy if ctx.needs_input_grad[11] else None, None, None)
+
+
+def attn_oproj(qkv, rope, batch, n, heads, hd, causal, key_mask, pre_rotated, wo, wo_t, residual, norm_w, eps):
+    """-> (o_proj(attention) + residual, RMSNorm of that * norm_w | None)"""
+    r = AttnOProjFn.apply(qkv, batch, n, heads, hd, causal, key_mask, rope, pre_rotated, wo, wo_t, residual, norm_w, eps)
+    return r[-2], r[-1]
 
 
 def rope_attention(qkv, rope, batch, n, heads, hd, causal, key_mask, pre_rotated=False):

@@ -389,10 +389,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(BwdP p) {
 static const bool g_bwd_split = getenv("LLMSEG_ATTN_BWD_SPLIT") != nullptr;       // A/B: the three passes as three launches
 
 template <int HD>
-void launch_bwd(const BwdP& p, hipStream_t s) {
+void launch_bwd(const BwdP& p, hipStream_t s, bool delta_ready) {
   const int nbq = (p.Nq + BO - 1) / BO, nbk = (p.Nk + BO - 1) / BO;
   const long rows = (long)p.batch * p.heads * p.Nq;
-  LL_LAUNCH_KERNEL((attn_delta_kernel<HD>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, p);
+  if (!delta_ready) LL_LAUNCH_KERNEL((attn_delta_kernel<HD>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, p);
   if (g_bwd_split) {
     const dim3 gq(nbq, p.heads, p.batch), gk(nbk, p.heads, p.batch);
     LL_LAUNCH_KERNEL((attn_bwd_kernel<HD, MODE_DQ>), gq, dim3(NT), 0, s, p);
@@ -404,6 +404,20 @@ void launch_bwd(const BwdP& p, hipStream_t s) {
 }
 
 }  // namespace
+
+// library-internal (gemm.hip: the two-launch route of llmseg_gemm_args.dl_o): delta[b][h][q] of packed [batch * T][heads * 128] O / dO rows
+extern "C" __attribute__((visibility("hidden"))) int llmseg_attn_delta128(const void* O, int64_t ldo, const void* dO, int64_t lddo, float* delta, int64_t batch, int32_t heads,
+                                                                          int64_t T, void* stream) {
+  BwdP p{};
+  p.O = (const bf16_t*)O; p.dO = (const bf16_t*)dO; p.delta = delta;
+  p.os[0] = T * ldo; p.os[1] = 128; p.os[2] = ldo;
+  p.dos[0] = T * lddo; p.dos[1] = 128; p.dos[2] = lddo;
+  p.batch = (int)batch; p.heads = heads; p.Nq = (int)T; p.Nk = (int)T;
+  const long rows = (long)batch * heads * T;
+  LL_LAUNCH_KERNEL((attn_delta_kernel<128>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, p);
+  LL_LAUNCH_CHECK("attn_delta");
+  return LLMSEG_OK;
+}
 
 extern "C" int llmseg_attn_bwd(const llmseg_attn_bwd_args* a, void* stream) {
   LL_CHECK(a && a->struct_size == sizeof(*a), "%s: ABI mismatch: caller's struct_size %u != %zu (bind against include/llmseg_hip.h version %d)",
@@ -442,9 +456,9 @@ extern "C" int llmseg_attn_bwd(const llmseg_attn_bwd_args* a, void* stream) {
            "attn_bwd: the fused rotation needs head_dim 64 or 128, Nq == Nk (self attention: position = row) and 16-byte aligned tables");
   hipStream_t s = (hipStream_t)stream;
   switch (a->head_dim) {
-    case 32: launch_bwd<32>(p, s); break;
-    case 64: launch_bwd<64>(p, s); break;
-    default: launch_bwd<128>(p, s); break;
+    case 32: launch_bwd<32>(p, s, a->delta_ready != 0); break;
+    case 64: launch_bwd<64>(p, s, a->delta_ready != 0); break;
+    default: launch_bwd<128>(p, s, a->delta_ready != 0); break;
   }
   LL_LAUNCH_CHECK("attn_bwd");
   return LLMSEG_OK;

@@ -1374,12 +1374,54 @@ __global__ __launch_bounds__(256) void splitk_reduce_rmsnorm_kernel(GemmP p, con
   }
 }
 
+// Split-K tail of dX(o_proj) with the attention backward's row statistic (llmseg_gemm_args.dl_o, round 6): a workgroup per row sums the row's S slab rows and
+// stores the bf16 row dO (splitk_reduce_kernel's arithmetic, no bias / activation / residual) and, holding it, writes delta[b][h][q] = sum_d dO[q][h][d] O[q][h][d]
+// for every head of width 128 with attn_delta_kernel's arithmetic (16 lanes per head, one 8-element chunk each, fma in element order, xor-8/4/2/1 butterfly):
+// the bits `llmseg_attn_bwd`'s own delta launch would produce -- which it then skips (`delta_ready`).  Row m = b T + q.
+template <int CPT>
+__global__ __launch_bounds__(256) void splitk_reduce_delta_kernel(GemmP p, const float* __restrict__ slab, int S, const bf16_t* __restrict__ O, long ldo,
+                                                                 float* __restrict__ delta, int heads, int T) {
+  const long m = blockIdx.x;
+  const int nch = p.N >> 3;
+  const long slab_sz = (long)p.M * p.N;
+  const long b = m / T, q = m - b * T;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    if (c < nch) {                                              // (nch is a multiple of 16: whole 16-lane groups are in or out together)
+      const int n = c * 8;
+      const float* sp = slab + m * p.N + n;
+      float4 a0 = *reinterpret_cast<const float4*>(sp), a1 = *reinterpret_cast<const float4*>(sp + 4);
+      for (int s2 = 1; s2 < S; ++s2) {
+        const float4 b0 = *reinterpret_cast<const float4*>(sp + s2 * slab_sz), b1 = *reinterpret_cast<const float4*>(sp + s2 * slab_sz + 4);
+        a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+        a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+      }
+      const float v[8] = {a0.x * p.alpha, a0.y * p.alpha, a0.z * p.alpha, a0.w * p.alpha, a1.x * p.alpha, a1.y * p.alpha, a1.z * p.alpha, a1.w * p.alpha};
+      const uint4 g = pack8(v);
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n) = g;
+      float of[8], df[8];
+      unpack8(*reinterpret_cast<const uint4*>(O + m * ldo + n), of);
+      unpack8(g, df);
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part = fmaf(of[e], df[e], part);
+#pragma unroll
+      for (int mm = 8; mm >= 1; mm >>= 1) part += __shfl_xor(part, mm, 64);
+      if ((c & 15) == 0) delta[(b * heads + (c >> 4)) * T + q] = part;
+    }
+  }
+}
+
 // a pending second output of the call being dispatched on this thread (llmseg_gemm_args.norm_out): the K-sliced ping-pong route consumes it in its reduce launch
 struct NormReq { const bf16_t* w; bf16_t* out; long ldn; float eps; bool active, done; };
 static thread_local NormReq g_norm_req = {nullptr, nullptr, 0, 0.f, false, false};
 // a pending norm-backward tail of the call being dispatched on this thread (llmseg_gemm_args.nb_x): the K-sliced ping-pong route consumes it in its reduce launch
 struct NbReq { const llmseg_gemm_args* a; void* out; bool active, done; };
 static thread_local NbReq g_nb_req = {nullptr, nullptr, false, false};
+// a pending delta tail (llmseg_gemm_args.dl_o) of the call being dispatched on this thread
+struct DlReq { const llmseg_gemm_args* a; bool active, done; };
+static thread_local DlReq g_dl_req = {nullptr, false, false};
 
 template <bool OUT_F32, int MI, int NBUF>
 void launch_glds(const GemmP& p, dim3 grid, hipStream_t s) {
@@ -1527,9 +1569,31 @@ static int gemm_nb(const llmseg_gemm_args* a, void* stream) {
   return llmseg_norm_bwd_add(tmp, a->nb_x, a->nb_w, a->nb_dres, a->C, nullptr, nullptr, a->M, a->N, a->nb_eps, a->nb_rms, nullptr, 0, stream);
 }
 
+extern "C" __attribute__((visibility("hidden"))) int llmseg_attn_delta128(const void* O, int64_t ldo, const void* dO, int64_t lddo, float* delta, int64_t batch, int32_t heads,
+                                                                          int64_t T, void* stream);
+
+// llmseg_gemm_args.dl_o: the product is dO of an attention (dX of o_proj) and the call also returns delta = rowsum_d(dO * O) per head: inside the reduce launch of
+// a K-sliced product, by the attention backward's own delta kernel behind the product otherwise.  Same bits.
+static int gemm_dl(const llmseg_gemm_args* a, void* stream) {
+  LL_CHECK(a->dl_out && a->dl_heads > 0 && a->dl_T > 0 && !a->out_f32 && a->batch <= 1 && a->batch2 <= 1 && !a->bias && !a->gamma && !a->residual && a->act == LLMSEG_ACT_NONE &&
+               !a->norm_out && !a->fx && !a->nb_x && !a->accumulate && a->N == (int64_t)a->dl_heads * 128 && (a->M % a->dl_T) == 0 && (a->ldc & 7) == 0 && (a->dl_ldo & 7) == 0 &&
+               ((((uintptr_t)a->dl_o) | ((uintptr_t)a->C)) & 15) == 0,
+           "gemm: dl_o needs a plain bf16 product of width heads x 128 over batch x T rows, 16-byte aligned rows");
+  static const bool off = getenv("LLMSEG_GEMM_NO_DL") != nullptr;      // A/B switch
+  g_dl_req = DlReq{a, !off, false};
+  llmseg_gemm_args g = *a;
+  g.dl_o = nullptr;
+  const int rc = gemm_dispatch(&g, stream, -1);
+  const bool done = g_dl_req.done;
+  g_dl_req.active = false;
+  if (rc != LLMSEG_OK || done) return rc;
+  return llmseg_attn_delta128(a->dl_o, a->dl_ldo, a->C, a->ldc, a->dl_out, a->M / a->dl_T, a->dl_heads, a->dl_T, stream);
+}
+
 extern "C" int llmseg_gemm_bf16(const llmseg_gemm_args* a, void* stream) {
   if (a && a->struct_size == sizeof(*a) && a->fx) return gemm_fx(a, stream);
   if (a && a->struct_size == sizeof(*a) && a->nb_x) return gemm_nb(a, stream);
+  if (a && a->struct_size == sizeof(*a) && a->dl_o) return gemm_dl(a, stream);
   if (!(a && a->struct_size == sizeof(*a) && a->norm_out)) return gemm_dispatch(a, stream, -1);
   // second output RMSNorm(C) * norm_w: the K-sliced route folds it into its reduce launch, every other route gets llmseg_norm behind the product
   LL_CHECK(a->norm_w && !a->out_f32 && a->batch <= 1 && a->batch2 <= 1 && (a->N & 7) == 0 && (a->ldn & 7) == 0 && a->ldn >= a->N && (a->ldc & 7) == 0 &&
@@ -1761,7 +1825,17 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
                            ((((uintptr_t)p.C) | ((uintptr_t)p.res) | ((uintptr_t)g_norm_req.w) | ((uintptr_t)g_norm_req.out)) & 15) == 0;
     const bool fuse_nb = g_nb_req.active && !f && p.alpha == 1.f && !p.bias && !p.gamma && !p.res && p.act == LLMSEG_ACT_NONE && p.M >= 64 && p.N >= 2048 && p.N <= 8192 &&
                          (p.N & 7) == 0;       // == where llmseg_norm_bwd_add runs its workgroup-per-row kernel (same arithmetic, same bits)
-    if (fuse_nb) {
+    const bool fuse_dl = g_dl_req.active && !f && !p.bias && !p.gamma && !p.res && p.act == LLMSEG_ACT_NONE && p.N <= 8192 && (p.N & 127) == 0 && (p.ldc & 7) == 0;
+    if (fuse_dl) {
+      const llmseg_gemm_args* q = g_dl_req.a;
+      const int S2 = split + (p.A2 ? 1 : 0);
+      const int cpt = ((p.N >> 3) + 255) / 256;
+#define LL_RDL(C) LL_LAUNCH_KERNEL(splitk_reduce_delta_kernel<C>, dim3((unsigned)p.M), dim3(256), 0, s, p, (const float*)a->workspace, S2, (const bf16_t*)q->dl_o, \
+                                   (long)q->dl_ldo, q->dl_out, (int)q->dl_heads, (int)q->dl_T)
+      if (cpt <= 1) LL_RDL(1); else if (cpt <= 2) LL_RDL(2); else LL_RDL(4);
+#undef LL_RDL
+      g_dl_req.done = true;
+    } else if (fuse_nb) {
       const llmseg_gemm_args* q = g_nb_req.a;
       const int rc = llmseg_reduce_lora_normbwd((const float*)a->workspace, split + (p.A2 ? 1 : 0), p.M, p.N, q->nb_x, q->nb_w, g_nb_req.out, q->nb_eps, q->nb_rms, q->nb_dres,
                                                 q->nb_lora_t, q->nb_lora_ldt, q->nb_lora_w0, q->nb_lora_w1, q->nb_lora_alpha, (const llmseg_dropout*)q->nb_lora_drop, stream);

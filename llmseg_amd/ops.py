@@ -56,7 +56,7 @@ def _reduce_ws(dev):
 
 def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alpha=1.0, out_f32=False, trans_a=False, trans_w=False,
          a2=None, w2=None, accumulate=False, a_norm_w=None, a_norm_eps=1e-6, a_swiglu=False, norm_w=None, norm_eps=1e-6, norm_out=None,
-         rope=None, swiglu_out=None, swiglu_bwd_of=None, normbwd=None, nb_lora=None):
+         rope=None, swiglu_out=None, swiglu_bwd_of=None, normbwd=None, nb_lora=None, delta_of=None):
     """out[M,N] = residual + gamma * act(alpha * A @ W^T + bias) with A = a [M,K] (or a^T when trans_a: a stored [K,M]) and
     W = w [N,K] (or w^T when trans_w: w stored [K,N]).  2-D bf16 operands, last dim contiguous.  a2 [M,64] / w2 [N,64]: optional
     extension of the contraction (A @ W^T + a2 @ w2^T), e.g. zero-padded low-rank updates.  accumulate (fp32 `out` only):
@@ -68,7 +68,9 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alp
       swiglu_bwd_of = gu [M, 2N]: the product is d(h) [M, N]; out [M, 2N] = d(gate|up) (`swiglu_bwd` of the stored product).
     Norm-backward tail (llmseg_gemm_args.nb_x): normbwd = (x, w, eps, rms, dres | None): the product is the gradient of a pre-norm's output and
     out = norm_bwd(product, x, w) + dres; nb_lora = (t [M, >=16], w0 [8, N], w1 [8, N] | None, alpha, drop | None) adds the LoRA branches' dX to the
-    product first (`lora_apply_` with w_rn).  One pass in the K-sliced route, the three launches otherwise; same bits."""
+    product first (`lora_apply_` with w_rn).  One pass in the K-sliced route, the three launches otherwise; same bits.
+    Delta tail (llmseg_gemm_args.dl_o): delta_of = (o [M, N], delta fp32 [batch, heads, T], heads, T): the product is dO of an attention with output o and
+    the call also writes delta = rowsum_d(dO * o) per head (width 128) -- pass it to `attention_bwd(..., delta=)`."""
     _req(a); _req(w)
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
@@ -123,6 +125,10 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alp
                 g.nb_lora_drop = C.addressof(keep)
     else:
         assert nb_lora is None
+    if delta_of is not None:
+        do_, dl, dh, dT = delta_of
+        assert _req(do_).shape == (M, N) and do_.stride(1) == 1 and N == dh * 128 and M % dT == 0 and dl.dtype == torch.float32 and dl.is_contiguous() and dl.numel() == (M // dT) * dh * dT
+        g.dl_o, g.dl_ldo, g.dl_out, g.dl_heads, g.dl_T = do_.data_ptr(), do_.stride(0), dl.data_ptr(), dh, dT
     if a_norm_w is not None:
         g.a_norm_w, g.a_norm_eps = _req(a_norm_w).data_ptr(), a_norm_eps
     if a_swiglu:
@@ -188,11 +194,16 @@ def attention_packed(qkv, batch, n_tok, heads, head_dim, out=None, **kw):
 
 
 def attention_bwd(q, k, v, o, do, dq, dk, dv, lse, *, batch, heads, Nq, Nk, head_dim, q_strides, k_strides, v_strides, o_strides, do_strides,
-                  dq_strides, dk_strides, dv_strides, scale=None, causal=False, key_mask=None, rope=None):
+                  dq_strides, dk_strides, dv_strides, scale=None, causal=False, key_mask=None, rope=None, delta=None):
     """Fused attention backward (dq, dk, dv are written).  lse = the fp32 [batch, heads, Nq] row statistics the forward wrote.
-    rope = (cos, sin) fp32 [Nq, head_dim/2]: every dq / dk row is rotated at its position before the store (pass -sin for the inverse)."""
+    rope = (cos, sin) fp32 [Nq, head_dim/2]: every dq / dk row is rotated at its position before the store (pass -sin for the inverse).
+    delta: fp32 [batch, heads, Nq] = rowsum(dO * O) already computed (`gemm(..., delta_of=)`): the kernel's own delta launch is skipped."""
     assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.numel() == batch * heads * Nq
-    delta = torch.empty_like(lse)
+    ready = delta is not None
+    if ready:
+        assert delta.dtype == torch.float32 and delta.is_contiguous() and delta.numel() == lse.numel()
+    else:
+        delta = torch.empty_like(lse)
     kw = {}
     for name, st in (("q", q_strides), ("k", k_strides), ("v", v_strides), ("o", o_strides), ("do", do_strides), ("dq", dq_strides),
                      ("dk", dk_strides), ("dv", dv_strides)):
@@ -201,6 +212,7 @@ def attention_bwd(q, k, v, o, do, dq, dk, dv, lse, *, batch, heads, Nq, Nk, head
                     dV=dv.data_ptr(), batch=batch, heads=heads, Nq=Nq, Nk=Nk, head_dim=head_dim,
                     scale=(1.0 / math.sqrt(head_dim)) if scale is None else scale, causal=1 if causal else 0,
                     key_mask=None if key_mask is None else key_mask.data_ptr(), lse=lse.data_ptr(), delta=delta.data_ptr(), **kw)
+    a.delta_ready = 1 if ready else 0
     if rope is not None:
         assert all(t.dtype == torch.float32 and t.is_contiguous() and t.shape == (Nq, head_dim // 2) for t in rope)
         a.rope_cos, a.rope_sin = rope[0].data_ptr(), rope[1].data_ptr()

@@ -110,6 +110,7 @@ class _Auto:
     mlp = staticmethod(ag.mlp)
     norm_lora_qkv = staticmethod(ag.norm_lora_qkv)
     norm_mlp = staticmethod(ag.norm_mlp)
+    attn_oproj = staticmethod(ag.attn_oproj)
     ce = staticmethod(lambda logits, labels: ag.CELossFn.apply(logits, labels))
     align_reg = staticmethod(lambda e, t, pred, gt_iou, gt_iop: ag.AlignRegFn.apply(e, t, pred, gt_iou, gt_iop))
     bcast_add = staticmethod(lambda s, add, Cn, K: ag.BcastAddFn.apply(s, add, Cn, K))
@@ -387,11 +388,20 @@ class TrainableMixin:
             else:
                 mem = [p + f"self_attn.{n}_proj.weight" for n in "qkv"]
                 qkv = F.linear(h, self._wcat(p + "qkv", mem, F), None, ops.ACT_NONE, None, self._wT(p + "qkv", F) if self._frozen(mem) else None)
-            a = F.rope_attn(qkv, rope, N, T, c.heads, c.head_dim, True, key_mask_u8, rope_in_gemm)
+            if F.grad and ag.FUSE_DELTA and c.head_dim == 128 and self._wT(p + "self_attn.o_proj.weight", F) is not None:
+                # attention + o_proj as one node: dX(o_proj)'s reduce launch also writes the attention backward's delta
+                x, pre = F.attn_oproj(qkv, rope, N, T, c.heads, c.head_dim, True, key_mask_u8, rope_in_gemm, self._w(p + "self_attn.o_proj.weight", F),
+                                      self._wT(p + "self_attn.o_proj.weight", F), x, self._w(p + "post_attention_layernorm.weight", F) if fuse else None, c.eps)
+                a = None
+            else:
+                a = F.rope_attn(qkv, rope, N, T, c.heads, c.head_dim, True, key_mask_u8, rope_in_gemm)
             if kv_out is not None:                     # generation prefill (no-grad path): qkv now holds the rotated K and V
                 kv_out(i, qkv)
-            pre = None
-            if fuse:         # o_proj + residual and the post-attention norm of the sum: one GEMM call (its K-slice reduce launch writes both)
+            if a is not None:
+                pre = None
+            if a is None:
+                pass
+            elif fuse:         # o_proj + residual and the post-attention norm of the sum: one GEMM call (its K-slice reduce launch writes both)
                 x, pre = F.linear_norm(a, self._w(p + "self_attn.o_proj.weight", F), x, self._wT(p + "self_attn.o_proj.weight", F),
                                        self._w(p + "post_attention_layernorm.weight", F), c.eps)
             else:

@@ -347,6 +347,45 @@ def check_gemm_normbwd_tail():
     return out
 
 
+def check_gemm_delta_tail():
+    """Round 6: llmseg_gemm_args.dl_o -- dX(o_proj) with the attention backward's delta = rowsum(dO * O) written by the K-sliced product's reduce launch --
+    against the product followed by llmseg_attn_bwd's own delta launch: dO, delta and therefore dq | dk | dv BIT FOR BIT (2 x 319 rows, 32 heads x 128)."""
+    from llmseg_amd import _lib
+    lib = _lib.load()
+    out = []
+    bits = lambda a, b: float((a.float() - b.float()).abs().max())
+    N, T, H, hd = 2, 319, 32, 128
+    D, M = H * hd, N * T
+    dy, wt = rnd(M, D, seed=1, scale=0.3).to(DEV), rnd(D, D, seed=2, scale=D ** -0.5).to(DEV)
+    qkv = rnd(M, 3 * D, seed=3, scale=0.5).to(DEV)
+    km = torch.ones(N, T, dtype=torch.uint8)
+    km[1, 300:] = 0
+    km = km.to(DEV)
+    lse = torch.empty(N, H, T, device=DEV)
+    o = ops.attention_packed(qkv, N, T, H, hd, causal=True, key_mask=km, lse=lse)
+    ld, st, dst = 3 * D, (T * 3 * D, hd, 3 * D), (T * D, hd, D)
+
+    def bwd(do, delta):
+        dqkv = torch.empty_like(qkv)
+        ops.attention_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, do, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], lse, batch=N, heads=H, Nq=T, Nk=T, head_dim=hd, q_strides=st,
+                          k_strides=st, v_strides=st, o_strides=dst, do_strides=dst, dq_strides=st, dk_strides=st, dv_strides=st, causal=True, key_mask=km, delta=delta)
+        return dqkv
+    do_ref = ops.gemm(dy, wt)
+    g_ref = bwd(do_ref, None)
+    delta = torch.empty(N, H, T, device=DEV)
+    torch.cuda.synchronize()
+    n0 = lib.llmseg_launch_count()
+    do = ops.gemm(dy, wt, delta_of=(o, delta, H, T))
+    n = lib.llmseg_launch_count() - n0
+    g = bwd(do, delta)
+    dref = (do_ref.float().view(N, T, H, hd) * o.float().view(N, T, H, hd)).sum(-1).permute(0, 2, 1)
+    out.append((f"gemm delta tail: dO == gemm ({n} launches) (bits)", bits(do, do_ref), 0.0))
+    out.append(("gemm delta tail: delta vs fp32 rowsum(dO * O)", float((delta - dref).abs().max()), 1e-4 * max(1.0, float(dref.abs().max()))))
+    out.append(("gemm delta tail: attention backward with the precomputed delta == with its own delta launch (bits)", bits(g, g_ref), 0.0))
+    out.append(("gemm delta tail ran as the K-sliced kernel + ONE tail launch", float(n), 2.0))
+    return out
+
+
 def check_attention():
     out = []
     for hd, B, H, N in [(32, 2, 8, 256), (64, 1, 4, 257), (128, 2, 2, 319), (80, 3, 2, 196), (64, 1, 2, 1100)]:

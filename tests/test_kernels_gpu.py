@@ -43,6 +43,11 @@ def test_gemm_norm_backward_tail():
     _run(kc.check_gemm_normbwd_tail)
 
 
+def test_gemm_delta_tail():
+    from tests import kernel_checks as kc
+    _run(kc.check_gemm_delta_tail)
+
+
 def test_attention():
     from tests import kernel_checks as kc
     _run(kc.check_attention)
