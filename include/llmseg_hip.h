@@ -121,6 +121,10 @@ typedef struct {
    * dl_ldo); the call also writes dl_out[b][h][q] = sum_d dO * O (fp32 [batch][dl_heads][dl_T]) -- llmseg_attn_bwd's `delta`, which can then be passed with
    * delta_ready = 1.  In the reduce launch of a K-sliced product, by the attention backward's delta kernel behind the product otherwise; same bits.  NULL = off. */
   const void* dl_o; int64_t dl_ldo; float* dl_out; int32_t dl_heads; int32_t dl_T;
+  /* with nb_lora_t (ABI 8): the LoRA operand still as the K-slice partials llmseg_lora_down_parts left (fp32 [nb_lora_S][M][16]); the tail adds them in order, scales by
+   * nb_lora_scale, rounds to bf16 (llmseg_lora_down's finish arithmetic), uses the result AND stores it to nb_lora_t[:, 0:16] (+ nb_lora_zero zero columns) for
+   * llmseg_lora_wgrads: the finish launch of the backward's rank-8 down projection rides in the reduce launch.  NULL = nb_lora_t is an input. */
+  const float* nb_lora_part; int32_t nb_lora_S; float nb_lora_scale; int32_t nb_lora_zero; int32_t reserved3;
 } llmseg_gemm_args;
 enum { LLMSEG_FX_NONE = 0, LLMSEG_FX_ROPE = 1, LLMSEG_FX_SWIGLU = 2, LLMSEG_FX_SWIGLU_BWD = 3 };
 int llmseg_gemm_bf16(const llmseg_gemm_args* args, void* stream);
@@ -470,6 +474,11 @@ int llmseg_lora_wgrads(const void* dq, const void* dv, int64_t ldd, const void* 
 int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, int64_t ldxa, const void* w0, const void* w1, int64_t M, int64_t N, int32_t w_rn,
                       float alpha, const llmseg_dropout* drop, void* stream);
 int llmseg_lora_pack(const void* aq, const void* bq, const void* av, const void* bv, void* w2b, void* w2a, void* bt, int64_t H, float s, void* stream);
+/* llmseg_lora_down_ws that leaves a K-sliced product UNFINISHED (ABI 8): *S_out = slice count with the fp32 partials [S][M][16] in `scratch` and y untouched (hand them
+ * to llmseg_gemm_args.nb_lora_part), or 0 when the shape took no slices and y is complete; *scale_out = alpha * dropout scale (the finish factor). */
+int llmseg_lora_down_parts(const void* x0, const void* x1, int64_t ldx, const void* w0, const void* w1, void* y, int64_t ldy, int64_t M, int64_t K,
+                           int32_t w_kr, float alpha, int32_t zero_cols, const llmseg_dropout* drop, void* scratch, int64_t scratch_bytes, int32_t* S_out,
+                           float* scale_out, void* stream);
 /* llmseg_lora_down_ws followed by llmseg_lora_pack in one call (ABI 8): the two are independent (activations vs. weights), so where the down projection runs
  * as K slices the pack rides in its finish launch -- one launch fewer per LoRA'd projection; the same bits as the two calls. */
 int llmseg_lora_down_pack(const void* x0, const void* x1, int64_t ldx, const void* w0, const void* w1, void* y, int64_t ldy, int64_t M, int64_t K,

@@ -40,7 +40,8 @@ class GemmArgs(_Sized):
                 ("nb_x", C.c_void_p), ("nb_w", C.c_void_p), ("nb_dres", C.c_void_p), ("nb_eps", C.c_float), ("nb_rms", C.c_int),
                 ("nb_lora_t", C.c_void_p), ("nb_lora_ldt", C.c_int64), ("nb_lora_w0", C.c_void_p), ("nb_lora_w1", C.c_void_p), ("nb_lora_alpha", C.c_float),
                 ("reserved2", C.c_int), ("nb_lora_drop", C.c_void_p),
-                ("dl_o", C.c_void_p), ("dl_ldo", C.c_int64), ("dl_out", C.c_void_p), ("dl_heads", C.c_int32), ("dl_T", C.c_int32)]
+                ("dl_o", C.c_void_p), ("dl_ldo", C.c_int64), ("dl_out", C.c_void_p), ("dl_heads", C.c_int32), ("dl_T", C.c_int32),
+                ("nb_lora_part", C.c_void_p), ("nb_lora_S", C.c_int32), ("nb_lora_scale", C.c_float), ("nb_lora_zero", C.c_int32), ("reserved3", C.c_int32)]
 
 FX_NONE, FX_ROPE, FX_SWIGLU, FX_SWIGLU_BWD = 0, 1, 2, 3          # LLMSEG_FX_* of include/llmseg_hip.h
 
@@ -138,6 +139,7 @@ SIGNATURES = {
     "llmseg_lora_wgrads": [_p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _f32, _dp, _p, _i64, _p],
     "llmseg_lora_apply": [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i32, _f32, _dp, _p],
     "llmseg_lora_pack": [_p, _p, _p, _p, _p, _p, _p, _i64, _f32, _p],
+    "llmseg_lora_down_parts": [_p, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i32, _f32, _i32, _dp, _p, _i64, C.POINTER(C.c_int32), C.POINTER(C.c_float), _p],
     "llmseg_lora_down_pack": [_p, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i32, _f32, _i32, _dp, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _f32, _p],
     "llmseg_transpose_pad": [_p, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "llmseg_sumsq": [_p, _i64, C.c_int, _p, _p, _i64, _p],

@@ -28,6 +28,7 @@ BIG_WEIGHT = 1 << 26          # N * K of a Linear whose dX / dW always take the 
 FUSE_ROPE_BWD = os.environ.get("LLMSEG_NO_FUSE_ROPE_BWD") is None      # inverse RoPE inside the attention backward's dq / dk store
 FUSE_ROPE_FWD = os.environ.get("LLMSEG_NO_FUSE_ROPE_FWD") is None      # RoPE inside the q|k|v GEMM's store (rank-8 LoRA route, head_dim 128)
 FUSE_NORM_BWD = os.environ.get("LLMSEG_NO_FUSE_NORM_BWD") is None      # pre-norm backward (+ LoRA dX + residual gradient) inside the dX product's K-slice reduce launch
+FUSE_LORA_PARTS = os.environ.get("LLMSEG_NO_FUSE_LORA_PARTS") is None  # the backward's rank-8 down projection is finished inside the dX(q|k|v) product's tail
 FUSE_DELTA = os.environ.get("LLMSEG_NO_FUSE_DELTA") is None            # the attention backward's delta inside the dX(o_proj) product's reduce launch
 FUSE_MLP = os.environ.get("LLMSEG_NO_FUSE_MLP") is None                # swiglu / swiglu_bwd inside the gate|up and dX(down) GEMMs' stores (frozen MLP weights)
 
@@ -323,9 +324,14 @@ class NormLoraQKVFn(Function):
         gaq, gbq, gav, gbv = ctx.g
         drq = _drops(ctx.drop)[0]
         t2 = torch.empty((M, 64), device=d.device, dtype=BF16)       # [s dq Bq | s dv Bv | 0]
-        ops.lora_down(d[:, :H], ctx.bt[:8], alpha=s, out=t2, zero_cols=48, x2=d[:, 2 * H:], w2=ctx.bt[8:])
+        # the rank-8 down projection leaves its K-slice partials: the dX product's tail finishes them (and writes t2 for the weight gradients below)
+        part, pS, pscale = None, 0, 0.0
+        if FUSE_LORA_PARTS:
+            _, part, pS, pscale = ops.lora_down(d[:, :H], ctx.bt[:8], alpha=s, out=t2, zero_cols=48, x2=d[:, 2 * H:], w2=ctx.bt[8:], parts=True)
+        else:
+            ops.lora_down(d[:, :H], ctx.bt[:8], alpha=s, out=t2, zero_cols=48, x2=d[:, 2 * H:], w2=ctx.bt[8:])
         dres = None if dpass is None else dpass.contiguous()
-        dx = ops.gemm(d, ctx.wqkv_t, normbwd=(x, norm_w, ctx.eps, True, dres), nb_lora=(t2, aq, av, 1.0, drq))
+        dx = ops.gemm(d, ctx.wqkv_t, normbwd=(x, norm_w, ctx.eps, True, dres), nb_lora=(t2, aq, av, 1.0, drq, part, pS, pscale, 48))
         if all(g is not None for g in ctx.g):                            # arena mode: the four gradients in ONE launch (+ one fold), off the main chain
             Leaves.run(lambda: ops.lora_wgrads(d, H, h, a2, t2, gbq, gbv, gaq, gav, s, drop=drq), d, h, t2, a2)
             outs = [None] * 4

@@ -955,15 +955,33 @@ __global__ __launch_bounds__(256) void lora_apply_kernel(bf16_t* __restrict__ y,
 // lora_apply_kernel's arithmetic and rounds again (LORA: y += alpha * mask_b * (xa[:, 8b..] . W_b), W stored [8][N]), and -- holding that row as dy -- writes
 // the norm backward + dres with norm_bwd_wg_kernel's arithmetic and thread -> column mapping: three launches and two round trips of the [M][N] gradient
 // (reduce 6.9 + lora_apply 10.9 + norm_bwd 7.6 us per Llama layer at 2 images) in one pass.  Same bits as the three launches.
+// lp != NULL (LORA only): the LoRA operand t = [s dq Bq | s dv Bv] arrives as the K-slice PARTIALS of llmseg_lora_down (fp32 [lS][rows][16]): threads 0..15 add
+// the row's slices in order, scale and round to bf16 (lora_down_finish_kernel's arithmetic), hand the 16 values to the workgroup through LDS and store them (+ zero
+// columns) into xa for the weight-gradient kernel -- the finish launch of the backward's rank-8 down projection rides here.
 template <int CPT, bool LORA>
 __global__ __launch_bounds__(256) void reduce_lora_normbwd_kernel(const float* __restrict__ slab, int S, long slab_sz, const bf16_t* __restrict__ x,
                                                                  const bf16_t* __restrict__ w, bf16_t* __restrict__ dx, long rows, int cols, float eps, int rms,
-                                                                 const bf16_t* __restrict__ dres, const bf16_t* __restrict__ xa, long ldxa,
-                                                                 const bf16_t* __restrict__ w0, const bf16_t* __restrict__ w1, float alpha, int nb, DropP dp) {
+                                                                 const bf16_t* __restrict__ dres, bf16_t* __restrict__ xa, long ldxa,
+                                                                 const bf16_t* __restrict__ w0, const bf16_t* __restrict__ w1, float alpha, int nb, DropP dp,
+                                                                 const float* __restrict__ lp, int lS, float lscale, int lzero) {
   __shared__ float red[16];
+  __shared__ float tl[16];
   const long row = blockIdx.x;
   const int nch = cols >> 3;
   const long N = cols;
+  if (LORA && lp != nullptr) {
+    if (threadIdx.x < 16) {
+      float v = 0.f;
+      if ((int)threadIdx.x < 8 * nb) {
+        for (int s2 = 0; s2 < lS; ++s2) v += lp[((long)s2 * rows + row) * 16 + threadIdx.x];
+        v *= lscale;
+      }
+      const bf16_t vb = f2bf(v);
+      tl[threadIdx.x] = bf2f(vb);
+      xa[row * ldxa + threadIdx.x] = vb;
+    } else if ((int)threadIdx.x < 16 + lzero) xa[row * ldxa + threadIdx.x] = 0;
+    __syncthreads();
+  }
   uint4 xc[CPT], gc[CPT], wc[CPT];
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
@@ -987,7 +1005,10 @@ __global__ __launch_bounds__(256) void reduce_lora_normbwd_kernel(const float* _
         for (int b = 0; b < nb; ++b) {
           const bf16_t* wl = b == 0 ? w0 : w1;
           float xv[8], dv[8];
-          unpack8(*reinterpret_cast<const uint4*>(xa + row * ldxa + 8 * b), xv);
+          if (lp != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) xv[r] = tl[8 * b + r];
+          } else unpack8(*reinterpret_cast<const uint4*>(xa + row * ldxa + 8 * b), xv);
 #pragma unroll
           for (int j = 0; j < 8; ++j) dv[j] = 0.f;
 #pragma unroll
@@ -1107,17 +1128,19 @@ static DropP make_drop(const llmseg_dropout* d) {
 
 // library-internal (gemm.hip: the K-sliced route of llmseg_gemm_args.nb_x).  slab: fp32 [S][M][N]; la_t == NULL: no LoRA term.
 extern "C" __attribute__((visibility("hidden"))) int llmseg_reduce_lora_normbwd(const float* slab, int S, int64_t M, int64_t N, const void* x, const void* w, void* dx, float eps,
-                                                                                int rms, const void* dres, const void* la_t, int64_t la_ldt, const void* la_w0,
-                                                                                const void* la_w1, float la_alpha, const llmseg_dropout* la_drop, void* stream) {
+                                                                                int rms, const void* dres, void* la_t, int64_t la_ldt, const void* la_w0,
+                                                                                const void* la_w1, float la_alpha, const llmseg_dropout* la_drop, const float* la_part,
+                                                                                int la_S, float la_scale, int la_zero, void* stream) {
   LL_CHECK(slab && S >= 1 && M > 0 && N >= 2048 && N <= 8192 && (N & 7) == 0 && x && w && dx && AL16(x) && AL16(w) && AL16(dx) && AL16(dres) && AL16(slab),
            "reduce_lora_normbwd: bad arguments");
   LL_CHECK(!la_t || (la_w0 && AL16(la_t) && AL16(la_w0) && AL16(la_w1) && (la_ldt & 7) == 0), "reduce_lora_normbwd: bad LoRA operands");
+  LL_CHECK(!la_part || (la_t && la_S >= 1 && la_zero >= 0 && la_zero <= 240 && la_ldt >= 16 + la_zero), "reduce_lora_normbwd: bad LoRA partials");
   const DropP dp = make_drop(la_drop);
   const int cpt = (int)(((N >> 3) + 255) / 256), nb = la_w1 ? 2 : 1;
 #define LL_RLN(C, L)                                                                                                                                     \
   LL_LAUNCH_KERNEL((reduce_lora_normbwd_kernel<C, L>), dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, slab, S, (long)(M * N), (const bf16_t*)x,    \
-                   (const bf16_t*)w, (bf16_t*)dx, (long)M, (int)N, eps, rms, (const bf16_t*)dres, (const bf16_t*)la_t, (long)la_ldt, (const bf16_t*)la_w0, \
-                   (const bf16_t*)la_w1, la_alpha, nb, dp)
+                   (const bf16_t*)w, (bf16_t*)dx, (long)M, (int)N, eps, rms, (const bf16_t*)dres, (bf16_t*)la_t, (long)la_ldt, (const bf16_t*)la_w0, \
+                   (const bf16_t*)la_w1, la_alpha, nb, dp, la_part, la_S, la_scale, la_zero)
   if (la_t) { if (cpt <= 1) LL_RLN(1, true); else if (cpt <= 2) LL_RLN(2, true); else LL_RLN(4, true); }
   else { if (cpt <= 1) LL_RLN(1, false); else if (cpt <= 2) LL_RLN(2, false); else LL_RLN(4, false); }
 #undef LL_RLN
@@ -1132,6 +1155,9 @@ extern "C" int llmseg_lora_down(const void* x0, const void* x1, int64_t ldx, con
 }
 
 // a lora_pack job waiting to ride in the finish launch of the lora_down call being issued on this thread (llmseg_lora_down_pack)
+// llmseg_lora_down_parts: the K-sliced route leaves its fp32 partials for the consumer (no finish launch) and reports the slice count and the finish scale
+struct PartsReq { bool active, done; int S; float scale; };
+static thread_local PartsReq g_parts_req = {false, false, 0, 0.f};
 struct PackReq { const bf16_t *aq, *bq, *av, *bv; bf16_t *w2b, *w2a, *bt; long H; float s; bool active, done; };
 static thread_local PackReq g_pack_req = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, false, false};
 
@@ -1153,7 +1179,9 @@ extern "C" int llmseg_lora_down_ws(const void* x0, const void* x1, int64_t ldx, 
     float* part = S > 1 ? (float*)scratch : nullptr;
     LL_LAUNCH_KERNEL(lora_down_mfma_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, (hipStream_t)stream, X0, X1, (long)ldx, W0, W1, (bf16_t*)y, (long)ldy,
                        (long)M, (int)K, alpha, zero_cols, nb, dp, part);
-    if (S > 1 && g_pack_req.active) {
+    if (S > 1 && g_parts_req.active) {
+      g_parts_req.done = true; g_parts_req.S = S; g_parts_req.scale = alpha * (dp.thr ? dp.scale : 1.f);
+    } else if (S > 1 && g_pack_req.active) {
       const PackReq& q = g_pack_req;
       const unsigned gf = grid_for(M * (nb + zero_cols / 8)), gp = grid_for(4 * q.H * 8 + 2 * q.H);
       LL_LAUNCH_KERNEL(lora_finish_pack_kernel, dim3(gf + gp), dim3(256), 0, (hipStream_t)stream, (const float*)part, S, (bf16_t*)y, (long)ldy, (long)M,
@@ -1234,6 +1262,28 @@ extern "C" int llmseg_lora_pack(const void* aq, const void* bq, const void* av, 
   LL_LAUNCH_KERNEL(lora_pack_kernel, dim3(grid_for(4 * H * 8 + 2 * H)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)aq, (const bf16_t*)bq, (const bf16_t*)av,
                      (const bf16_t*)bv, (bf16_t*)w2b, (bf16_t*)w2a, (bf16_t*)bt, (long)H, s);
   LL_LAUNCH_CHECK("lora_pack");
+  return LLMSEG_OK;
+}
+
+// llmseg_lora_down_ws WITHOUT its finish launch where it runs as K slices: *S_out = slice count (the fp32 partials [S][M][16] are then in `scratch` and y is NOT
+// written: llmseg_gemm_args.nb_lora_part finishes them), *S_out = 0 when the call completed y itself (no slices on this shape).  *scale_out = the finish scale.
+extern "C" int llmseg_lora_down_parts(const void* x0, const void* x1, int64_t ldx, const void* w0, const void* w1, void* y, int64_t ldy, int64_t M, int64_t K,
+                                      int32_t w_kr, float alpha, int32_t zero_cols, const llmseg_dropout* drop, void* scratch, int64_t scratch_bytes, int32_t* S_out,
+                                      float* scale_out, void* stream) {
+  LL_CHECK(S_out && scale_out, "lora_down_parts: S_out / scale_out");
+  static const bool off = getenv("LLMSEG_NO_LORA_PARTS") != nullptr;      // A/B switch: always finish here
+  g_parts_req = PartsReq{!off, false, 0, 0.f};
+  const int rc = llmseg_lora_down_ws(x0, x1, ldx, w0, w1, y, ldy, M, K, w_kr, alpha, zero_cols, drop, scratch, scratch_bytes, stream);
+  *S_out = g_parts_req.done ? g_parts_req.S : 0;
+  *scale_out = g_parts_req.scale;
+  g_parts_req.active = false;
+  return rc;
+}
+// library-internal (gemm.hip: the two-launch route of llmseg_gemm_args.nb_lora_part)
+extern "C" __attribute__((visibility("hidden"))) int llmseg_lora_down_finish(const float* part, int S, void* y, int64_t ldy, int64_t M, float scale, int zero_cols, int nb, void* stream) {
+  LL_LAUNCH_KERNEL(lora_down_finish_kernel, dim3(grid_for(M * (nb + zero_cols / 8))), dim3(256), 0, (hipStream_t)stream, part, S, (bf16_t*)y, (long)ldy, (long)M, scale,
+                     zero_cols, nb);
+  LL_LAUNCH_CHECK("lora_down_finish");
   return LLMSEG_OK;
 }
 

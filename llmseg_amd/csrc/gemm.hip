@@ -1533,8 +1533,10 @@ static int gemm_fx(const llmseg_gemm_args* a, void* stream) {
 }
 
 extern "C" __attribute__((visibility("hidden"))) int llmseg_reduce_lora_normbwd(const float* slab, int S, int64_t M, int64_t N, const void* x, const void* w, void* dx, float eps,
-                                                                                int rms, const void* dres, const void* la_t, int64_t la_ldt, const void* la_w0,
-                                                                                const void* la_w1, float la_alpha, const llmseg_dropout* la_drop, void* stream);
+                                                                                int rms, const void* dres, void* la_t, int64_t la_ldt, const void* la_w0,
+                                                                                const void* la_w1, float la_alpha, const llmseg_dropout* la_drop, const float* la_part,
+                                                                                int la_S, float la_scale, int la_zero, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int llmseg_lora_down_finish(const float* part, int S, void* y, int64_t ldy, int64_t M, float scale, int zero_cols, int nb, void* stream);
 extern "C" int llmseg_norm_bwd_add(const void* dy, const void* x, const void* w, const void* dres, void* dx, float* dw, float* db, int64_t rows, int64_t cols,
                                    float eps, int rms, void* workspace, int64_t workspace_bytes, void* stream);
 extern "C" int llmseg_lora_apply(void* y, int64_t ldy, const void* xa, int64_t ldxa, const void* w0, const void* w1, int64_t M, int64_t N, int32_t w_rn,
@@ -1549,6 +1551,8 @@ static int gemm_nb(const llmseg_gemm_args* a, void* stream) {
            "gemm: nb_x needs a plain bf16 product (batch 1, alpha 1, no bias / activation / gamma / residual / norm_out / fx) with dense C rows (ldc == N)");
   LL_CHECK(((((uintptr_t)a->nb_x) | ((uintptr_t)a->nb_w) | ((uintptr_t)a->nb_dres) | ((uintptr_t)a->C)) & 15) == 0, "gemm: nb_x / nb_w / nb_dres / C must be 16-byte aligned");
   LL_CHECK(!a->nb_lora_t || (a->nb_lora_w0 && (a->nb_lora_ldt & 7) == 0), "gemm: nb_lora_t needs nb_lora_w0 ([8][N]) and a row pitch that is a multiple of 8");
+  LL_CHECK(!a->nb_lora_part || (a->nb_lora_t && a->nb_lora_S >= 1 && a->nb_lora_zero >= 0 && (a->nb_lora_zero & 7) == 0 && a->nb_lora_ldt >= 16 + a->nb_lora_zero),
+           "gemm: nb_lora_part needs nb_lora_t (the bf16 [M][>= 16 + zero] buffer the finished operand is written to), the slice count and the zero-column count");
   const int64_t tmp_bytes = ((a->M * a->N * 2 + 255) / 256) * 256;
   LL_CHECK(a->workspace && a->workspace_bytes >= tmp_bytes && (((uintptr_t)a->workspace) & 255) == 0, "gemm: nb_x needs a workspace of >= M N 2 bytes (256-byte aligned)");
   llmseg_gemm_args g = *a;
@@ -1561,6 +1565,10 @@ static int gemm_nb(const llmseg_gemm_args* a, void* stream) {
   const bool done = g_nb_req.done;
   g_nb_req.active = false;
   if (rc != LLMSEG_OK || done) return rc;
+  if (a->nb_lora_t && a->nb_lora_part) {          // the LoRA operand is still K-slice partials: finish them first (what the fused tail does in its own launch)
+    const int rc0 = llmseg_lora_down_finish(a->nb_lora_part, a->nb_lora_S, (void*)a->nb_lora_t, a->nb_lora_ldt, a->M, a->nb_lora_scale, a->nb_lora_zero, a->nb_lora_w1 ? 2 : 1, stream);
+    if (rc0 != LLMSEG_OK) return rc0;
+  }
   if (a->nb_lora_t) {
     const int rc2 = llmseg_lora_apply(tmp, a->N, a->nb_lora_t, a->nb_lora_ldt, a->nb_lora_w0, a->nb_lora_w1, a->M, a->N, 1, a->nb_lora_alpha,
                                       (const llmseg_dropout*)a->nb_lora_drop, stream);
@@ -1838,7 +1846,8 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
     } else if (fuse_nb) {
       const llmseg_gemm_args* q = g_nb_req.a;
       const int rc = llmseg_reduce_lora_normbwd((const float*)a->workspace, split + (p.A2 ? 1 : 0), p.M, p.N, q->nb_x, q->nb_w, g_nb_req.out, q->nb_eps, q->nb_rms, q->nb_dres,
-                                                q->nb_lora_t, q->nb_lora_ldt, q->nb_lora_w0, q->nb_lora_w1, q->nb_lora_alpha, (const llmseg_dropout*)q->nb_lora_drop, stream);
+                                                (void*)q->nb_lora_t, q->nb_lora_ldt, q->nb_lora_w0, q->nb_lora_w1, q->nb_lora_alpha, (const llmseg_dropout*)q->nb_lora_drop,
+                                                q->nb_lora_part, q->nb_lora_S, q->nb_lora_scale, q->nb_lora_zero, stream);
       if (rc != LLMSEG_OK) return rc;
       g_nb_req.done = true;
     } else if (fuse_norm) {

@@ -115,7 +115,11 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, gamma=None, out=None, alp
             assert _req(ndres).shape == (M, N) and ndres.is_contiguous()
             g.nb_dres = ndres.data_ptr()
         if nb_lora is not None:
-            lt, lw0, lw1, lalpha, ldrop = nb_lora
+            lt, lw0, lw1, lalpha, ldrop = nb_lora[:5]
+            if len(nb_lora) > 5 and nb_lora[5] is not None:                       # t still as lora_down's K-slice partials: (..., partials, S, scale, zero_cols)
+                lpart, lS, lscale, lzero = nb_lora[5:9]
+                assert lpart.dtype == torch.float32 and lpart.numel() >= lS * M * 16 and lt.shape[1] >= 16 + lzero
+                g.nb_lora_part, g.nb_lora_S, g.nb_lora_scale, g.nb_lora_zero = lpart.data_ptr(), lS, lscale, lzero
             assert _req(lt).shape[0] == M and lt.stride(1) == 1 and _req(lw0).shape == (8, N) and lw0.is_contiguous() and (lw1 is None or (_req(lw1).shape == (8, N) and lw1.is_contiguous()))
             g.nb_lora_t, g.nb_lora_ldt, g.nb_lora_w0, g.nb_lora_alpha = lt.data_ptr(), lt.stride(0), lw0.data_ptr(), lalpha
             g.nb_lora_w1 = None if lw1 is None else lw1.data_ptr()
@@ -607,11 +611,13 @@ def _drop(drop):
     return C.byref(_lib.Dropout(rng_state=rng.data_ptr(), stream=int(stream), drop_thr=int(round(p * 65536)), seg_rows=seg, reserved0=0))
 
 
-def lora_down(x, w, w_kr=False, alpha=1.0, out=None, zero_cols=0, drop=None, x2=None, w2=None, pack=None):
+def lora_down(x, w, w_kr=False, alpha=1.0, out=None, zero_cols=0, drop=None, x2=None, w2=None, pack=None, parts=False):
     """y [M, 8] = alpha * drop(x) [M, K] @ W^T; W stored [8, K] (or [K, 8] when w_kr).  x may be a column view (row stride = ld).
     With (x2, w2) the second branch lands in columns 8..15 of the same rows (its dropout stream is drop's + 1; x2 may be x).  `out`
     may be the leading columns of a wider row; `zero_cols` further columns of every row are zero-filled.
-    pack = (aq, bq, av, bv, s, w2b, w2a, bt): `lora_pack` of the same layer in the same call (`llmseg_lora_down_pack`: it rides in the K-slice finish launch)."""
+    pack = (aq, bq, av, bv, s, w2b, w2a, bt): `lora_pack` of the same layer in the same call (`llmseg_lora_down_pack`: it rides in the K-slice finish launch).
+    parts=True (`llmseg_lora_down_parts`): -> (y, partials | None, S, scale): where the product runs as K slices it is left UNFINISHED (y not written; hand
+    (partials, S, scale, zero_cols) to `gemm(..., nb_lora=)`, whose tail finishes it and writes y); S = 0: y is complete."""
     M, K = x.shape
     nb = 1 if w2 is None else 2
     y = torch.empty((M, 8 * nb), device=x.device, dtype=BF16) if out is None else out
@@ -622,6 +628,11 @@ def lora_down(x, w, w_kr=False, alpha=1.0, out=None, zero_cols=0, drop=None, x2=
     args = (_ptr(x), _ptr(x2 if w2 is not None and x2 is not None else (x if w2 is not None else None)), x.stride(0),
             _ptr(w), _ptr(w2), _ptr(y), y.stride(0), M, K, 1 if w_kr else 0, alpha, zero_cols, _drop(drop),
             _ptr(scratch), 0 if scratch is None else scratch.numel() * 4)
+    if parts:
+        assert pack is None
+        S_out, sc_out = C.c_int32(0), C.c_float(0.0)
+        _lib.check(_lib.load().llmseg_lora_down_parts(*args, C.byref(S_out), C.byref(sc_out), _stream()), "lora_down_parts")
+        return y, (scratch if S_out.value > 0 else None), S_out.value, sc_out.value
     if pack is None:
         _lib.check(_lib.load().llmseg_lora_down_ws(*args, _stream()), "lora_down")
     else:

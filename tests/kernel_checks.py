@@ -342,6 +342,19 @@ def check_gemm_normbwd_tail():
         got = ops.gemm(d, wt, normbwd=(x, w, 1e-6, True, dres), nb_lora=(t2, a0, a1, 1.0, drop) if lora else None)
         n = lib.llmseg_launch_count() - n0
         out.append((f"gemm nb tail == gemm + lora_apply + norm_bwd: {tag} ({n} launches) (bits)", bits(got, ref), 0.0))
+        if lora:
+            # the LoRA operand as lora_down's UNFINISHED K-slice partials: the tail finishes them, uses them and writes t (for the weight gradients)
+            dq, bt = rnd(M, 2 * N, seed=9, scale=0.3).to(DEV), rnd(16, N, seed=10, scale=0.1).to(DEV)
+            t_ref = torch.empty(M, 64, device=DEV, dtype=BF)
+            ops.lora_down(dq[:, :N], bt[:8], alpha=2.0, out=t_ref, zero_cols=48, x2=dq[:, N:], w2=bt[8:])
+            ref2 = ops.gemm(d, wt)
+            ops.lora_apply_(ref2, t_ref, a0, w_rn=True, drop=drop, w2=a1)
+            ref2 = ops.norm_bwd(ref2, x, w, 1e-6, True, dres=dres)
+            t_out = torch.full((M, 64), 7.0, device=DEV, dtype=BF)
+            _, part, pS, pscale = ops.lora_down(dq[:, :N], bt[:8], alpha=2.0, out=t_out, zero_cols=48, x2=dq[:, N:], w2=bt[8:], parts=True)
+            got2 = ops.gemm(d, wt, normbwd=(x, w, 1e-6, True, dres), nb_lora=(t_out, a0, a1, 1.0, drop, part, pS, pscale, 48))
+            out.append((f"gemm nb tail fed lora_down's K-slice partials (S = {pS}): dx == finished route, {tag} (bits)", bits(got2, ref2), 0.0))
+            out.append((f"gemm nb tail fed partials: the t operand it writes == lora_down's finish, {tag} (bits)", bits(t_out, t_ref), 0.0))
         if M == 638:
             out.append((f"gemm nb tail: {tag} ran as the K-sliced kernel + ONE tail launch", float(n), 2.0))
     return out

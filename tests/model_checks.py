@@ -306,11 +306,11 @@ def check_full_width_llama_fusions():
     am = am.to(DEV).contiguous()
     go = (seeded.uniform((N, T, lcfg.hidden), 9, -1, 1) * 0.1).to(BF).to(DEV)
     lora = [(n, t) for n, t in m.params.flat.items() if "lora_" in n and isinstance(t, torch.nn.Parameter)]
-    keep = (ag.FUSE_ROPE_FWD, ag.FUSE_ROPE_BWD, ag.FUSE_MLP, ag.FUSE_NORM_BWD, ag.FUSE_DELTA)
+    keep = (ag.FUSE_ROPE_FWD, ag.FUSE_ROPE_BWD, ag.FUSE_MLP, ag.FUSE_NORM_BWD, ag.FUSE_DELTA, ag.FUSE_LORA_PARTS)
     runs = []
     try:
         for on in (True, False):
-            ag.FUSE_ROPE_FWD = ag.FUSE_ROPE_BWD = ag.FUSE_MLP = ag.FUSE_NORM_BWD = ag.FUSE_DELTA = on
+            ag.FUSE_ROPE_FWD = ag.FUSE_ROPE_BWD = ag.FUSE_MLP = ag.FUSE_NORM_BWD = ag.FUSE_DELTA = ag.FUSE_LORA_PARTS = on
             m.reset_dropout(seed=5) if hasattr(m, "reset_dropout") else None
             for _, t in lora:
                 t.grad = None
@@ -323,13 +323,13 @@ def check_full_width_llama_fusions():
             torch.cuda.synchronize()
             runs.append((y.detach().float().cpu(), x.grad.float().cpu(), [t.grad.float().cpu() for _, t in lora], _lib.load().llmseg_launch_count() - n0))
     finally:
-        ag.FUSE_ROPE_FWD, ag.FUSE_ROPE_BWD, ag.FUSE_MLP, ag.FUSE_NORM_BWD, ag.FUSE_DELTA = keep
+        ag.FUSE_ROPE_FWD, ag.FUSE_ROPE_BWD, ag.FUSE_MLP, ag.FUSE_NORM_BWD, ag.FUSE_DELTA, ag.FUSE_LORA_PARTS = keep
     (yf, gxf, glf, nf), (yu, gxu, glu, nu) = runs
     res = [(f"full-width Llama x2 + LoRA: fused epilogues == pointwise launches, output (bits; {nf} vs {nu} library launches fwd+bwd)", (yf - yu).abs().max().item(), 0.0),
            ("full-width Llama x2 + LoRA: fused == unfused, d(input) (bits)", (gxf - gxu).abs().max().item(), 0.0),
            ("full-width Llama x2 + LoRA: fused == unfused, LoRA gradients (bits)", max((a - b).abs().max().item() for a, b in zip(glf, glu)), 0.0),
-           ("full-width Llama x2 + LoRA: the fused route saves 8 launches per layer", float(nu - nf), float("inf"))]
-    assert nu - nf >= 16, (nu, nf)
+           ("full-width Llama x2 + LoRA: the fused route saves 9 launches per layer", float(nu - nf), float("inf"))]
+    assert nu - nf >= 18, (nu, nf)
     return res
 
 
