@@ -5,7 +5,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out; mkdir -p $OUT/r06g; cd $R
 COMMON="--no-cpu-baseline --no-neighbours --no-k512 --no-loader --no-accum-fused --no-mix --no-window-towers"
 ( time python bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/r06g/bench_driver_cmd.json 2> $OUT/r06g/bench_driver_cmd.err; tail -3 $OUT/r06g/bench_driver_cmd.err
-OFF="LLMSEG_GEMM_NO_FX=1 LLMSEG_GEMM_NO_NB=1 LLMSEG_NO_FINISH_PACK=1 LLMSEG_NO_FUSE_ROPE_BWD=1 LLMSEG_NO_FUSE_ROPE_FWD=1 LLMSEG_NO_FUSE_MLP=1 LLMSEG_NO_FUSE_NORM_BWD=1"
+OFF="LLMSEG_GEMM_NO_FX=1 LLMSEG_GEMM_NO_NB=1 LLMSEG_NO_FINISH_PACK=1 LLMSEG_NO_FUSE_ROPE_BWD=1 LLMSEG_NO_FUSE_ROPE_FWD=1 LLMSEG_NO_FUSE_MLP=1 LLMSEG_NO_FUSE_NORM_BWD=1 LLMSEG_NO_FUSE_DELTA=1 LLMSEG_NO_FUSE_LORA_PARTS=1 LLMSEG_GEMM_NO_DL=1 LLMSEG_NO_LORA_PARTS=1"
 echo "# alternating A/B on one box: python bench.py $COMMON --batch 2 --extra-batch 0 --steps 20 --warmup 5  (fused = default; unfused = $OFF)" > $OUT/r06g/ab_fusions.txt
 for i in 1 2 3; do
   for mode in fused unfused; do
