@@ -1140,8 +1140,18 @@ int launch_hd(const AttnP& p, hipStream_t s) {
   px.xcd_nqb = g_attn_xcd ? (int)grid.x : 0;
   const dim3 xgrid = g_attn_xcd ? dim3((unsigned)(8 * ((p.batch * p.heads + 7) / 8) * (int)grid.x)) : grid;
   constexpr int NT4 = 256, NT8 = 512;
-  if (p.rtab_h != nullptr && HD == 80 && g_attn_win_new == 2 && p.lse == nullptr && p.ksr == p.vsr)
-    LL_LAUNCH_KERNEL(attn_win14_dma_kernel, dim3((unsigned)std::min(p.batch * p.heads, g_attn_win_wgs)), dim3(NT8), 0, s, p);
+  if (p.rtab_h != nullptr && HD == 80 && g_attn_win_new == 2 && p.lse == nullptr && p.ksr == p.vsr) {
+    // persistent workgroups walk (window, head) items: with 800 items (2 images) 256 workgroups need 4 rounds with the last one 12 % full; the same 4 rounds on 200
+    // workgroups finish at the same time and leave 56 CUs to the other stream (CLIP -> Llama run beside the frozen SAM encoder) for the whole launch
+    static const bool balance = getenv("LLMSEG_WIN_NO_BALANCE") == nullptr;      // A/B switch
+    const int items = p.batch * p.heads;
+    int wgs = std::min(items, g_attn_win_wgs);
+    if (balance && wgs > 0) {
+      const int rounds = (items + wgs - 1) / wgs;
+      wgs = std::min(wgs, ((items + rounds - 1) / rounds + 7) & ~7);       // a multiple of 8 keeps the kernel's XCD grouping of the heads of a window
+    }
+    LL_LAUNCH_KERNEL(attn_win14_dma_kernel, dim3((unsigned)wgs), dim3(NT8), 0, s, p);
+  }
   else if (p.rtab_h != nullptr && HD == 80 && g_attn_win_new && p.lse == nullptr) LL_LAUNCH_KERNEL(attn_win14_kernel, dim3((unsigned)std::min(p.batch * p.heads, g_attn_win_wgs)), dim3(NT8), 0, s, p);
   else if (p.rtab_h != nullptr) LL_LAUNCH_KERNEL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 4 : 0>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
   else if (p.rel_h == nullptr) {
