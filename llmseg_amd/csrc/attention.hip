@@ -188,7 +188,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnP p) {
   uint4 kreg0 = make_uint4(0, 0, 0, 0), kreg1 = kreg0, kreg2 = kreg0, kreg3 = kreg0;
   uint4 vreg0 = kreg0, vreg1 = kreg0, vreg2 = kreg0, vreg3 = kreg0;
   const int v_kq = tid & 15, v_c = tid >> 4;
-  const bool v_on = (16 * CH >= NT) || tid < 16 * CH;     // head_dim 128 with 4 waves: every thread stages V (no branch around the prefetch)
+  const bool v_on = (16 * CH >= NT) || tid < 16 * CH;     // head_dim 128 with 4 waves: every thread stages V
+  const int v_cl = (16 * CH >= NT) ? v_c : v_c % CH;      // the LOADS are unconditional (threads past 16 CH re-read a valid chunk, only the LDS stores are predicated):
+                                                          // a branch around the prefetch costs register copies at its join that wait for the loads in front of the MFMAs
 
 #define LL_K_LOAD(IT, REG)                                                                          \
   if constexpr (KIT > IT) {                                                                         \
@@ -210,8 +212,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnP p) {
   {                                                                                                 \
     const int k0s = (T) * BKV;                                                                      \
     LL_K_LOAD(0, kreg0) LL_K_LOAD(1, kreg1) LL_K_LOAD(2, kreg2) LL_K_LOAD(3, kreg3)                 \
-    if (v_on) {                                                                                     \
-      const bf16_t* vp = Vg + v_c * 8;                                                              \
+    {                                                                                               \
+      const bf16_t* vp = Vg + v_cl * 8;                                                             \
       vreg0 = *reinterpret_cast<const uint4*>(vp + (long)min(k0s + 4 * v_kq + 0, p.Nk - 1) * p.vsr); \
       vreg1 = *reinterpret_cast<const uint4*>(vp + (long)min(k0s + 4 * v_kq + 1, p.Nk - 1) * p.vsr); \
       vreg2 = *reinterpret_cast<const uint4*>(vp + (long)min(k0s + 4 * v_kq + 2, p.Nk - 1) * p.vsr); \
