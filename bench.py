@@ -308,9 +308,11 @@ def window_towers(model, cfg, args, B, dev, dist, rank, world, local, trainer_cl
     trainer = trainer_cls(model, lr=3e-4, grad_accum=k, device_ids=[local], use_graph=True)
     pending = [trainer.encode_window(batches, prefetch=True)]
 
+    chain_only = os.environ.get("LLMSEG_BENCH_CHAIN_ONLY") is not None      # profiling aid: no tower pass at all (one stale result reused) = the trainable chain alone
+
     def window():
         tw = pending.pop()
-        pending.append(trainer.encode_window(batches, prefetch=True))     # the next window's towers: beside this window's micro-steps
+        pending.append(tw if chain_only else trainer.encode_window(batches, prefetch=True))     # the next window's towers: beside this window's micro-steps
         return trainer.window_step(batches, plans, towers=tw)[-1]
     windows = max(2, args.steps // k)
     dt, out = timed(window, windows, 3, dist, dev)

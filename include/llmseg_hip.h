@@ -31,9 +31,9 @@ enum { LLMSEG_ACT_NONE = 0, LLMSEG_ACT_RELU = 1, LLMSEG_ACT_GELU = 2, LLMSEG_ACT
  * so a binding written against an older header (fields were appended in every round) fails loudly instead of having the library read
  * past the caller's struct.  llmseg_struct_size(which) returns the library's sizeof (0 = llmseg_gemm_args, 1 = llmseg_attn_args,
  * 2 = llmseg_attn_bwd_args, 3 = llmseg_dropout; -1 for an unknown index) so a binding can assert at load time;
- * llmseg_version() is bumped whenever a struct or a signature changes (7: the fp32-activation head entry points; 4: the reduction entry points take a workspace; 5 = this header:
+ * llmseg_version() is bumped whenever a struct or a signature changes (9: llmseg_attn_args.win_grid / win_nw / pad_q / pad_k / pad_v; 7: the fp32-activation head entry points; 4: the reduction entry points take a workspace; 5 = this header:
  * llmseg_dropout.seg_rows; 6: llmseg_gemm_args.norm_w / norm_eps / norm_out / ldn). */
-#define LLMSEG_ABI_VERSION 8
+#define LLMSEG_ABI_VERSION 9
 
 /* Determinism (round 4).  No kernel adds floating-point numbers with atomics: every sum whose terms come from several workgroups is
  * written as per-workgroup partials into CALLER-OWNED scratch (`workspace`, `workspace_bytes`; any device memory, 256-byte aligned, not
@@ -167,6 +167,13 @@ typedef struct {
   /* optional device int32: the number of keys present NOW (<= Nk, which is then the capacity of K / V); read by the kernel, so that a
    * decode step captured in a hipGraph can be replayed while the KV cache grows (llava_llama.py:137-163 prepare_inputs_for_generation) */
   const int32_t* nk_dev;
+  /* window gather (ABI 9; only with rel_tab_h / rel_tab_w): the kernel applies SAM's window_partition + zero padding (image_encoder.py:263-289) and window_unpartition +
+   * crop (:291-318) itself.  Q / K / V / O rows are then the UNPARTITIONED token rows of images on a win_grid x win_grid grid (row = image * win_grid^2 + y * win_grid + x,
+   * *_stride_row apart; *_stride_b and o_row_map are ignored), batch = images * win_nw^2 windows (win_nw = ceil(win_grid / 14)); row (iy, ix) of window (wy, wx) is token
+   * (14 wy + iy, 14 wx + ix) or, outside the grid, the row pad_q / pad_k / pad_v (bf16, head h at + h * *_stride_h): the reference pads AFTER norm1 (:178-183), so a padded
+   * token's q|k|v row is the projection's bias -- the q|k|v product then runs on the real tokens only (4096 instead of 4900 rows per 1024^2 image).  win_grid = 0: off. */
+  int32_t win_grid; int32_t win_nw;
+  const void* pad_q; const void* pad_k; const void* pad_v;
 } llmseg_attn_args;
 int llmseg_attn_fwd(const llmseg_attn_args* args, void* stream);
 /* tuning knob (identical results up to fp32 summation order): bit 0 = 1 [default]: SAM 14x14 windows on the resident-window kernel

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LLMSEG_LIB") or os.path.join(_HERE, "libllmseg_hip.so")     # LLMSEG_LIB: side builds of the same ABI (tools/ experiments)
 
-ABI_VERSION = 8          # == LLMSEG_ABI_VERSION of include/llmseg_hip.h
+ABI_VERSION = 9          # == LLMSEG_ABI_VERSION of include/llmseg_hip.h
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SILU, ACT_SIGMOID = range(6)
 
@@ -56,7 +56,8 @@ class AttnArgs(_Sized):
                 ("scale", C.c_float), ("causal", C.c_int32),
                 ("key_mask", C.c_void_p), ("rel_h", C.c_void_p), ("rel_w", C.c_void_p),
                 ("rel_ld", C.c_int32), ("grid_h", C.c_int32), ("grid_w", C.c_int32),
-                ("o_row_map", C.c_void_p), ("rel_tab_h", C.c_void_p), ("rel_tab_w", C.c_void_p), ("lse", C.c_void_p), ("nk_dev", C.c_void_p)]
+                ("o_row_map", C.c_void_p), ("rel_tab_h", C.c_void_p), ("rel_tab_w", C.c_void_p), ("lse", C.c_void_p), ("nk_dev", C.c_void_p),
+                ("win_grid", C.c_int32), ("win_nw", C.c_int32), ("pad_q", C.c_void_p), ("pad_k", C.c_void_p), ("pad_v", C.c_void_p)]
 
 
 class AttnBwdArgs(_Sized):

@@ -51,6 +51,10 @@ struct AttnP {
   const bf16_t* rtab_h; const bf16_t* rtab_w;   // REL == 4: bf16 [32][head_dim] relative-position tables (rows >= 2*14-1 are zero)
   const int32_t* nk_dev;                        // optional: the key count is read from device memory (decode steps replayed from a hipGraph)
   int xcd_nqb;                                  // > 0: 1-D grid, XCD-grouped (see attn_fwd_kernel); = query blocks per (batch, head)
+  // window gather (attn_win14_dma_kernel<true>): Q / K / V / O rows are UNPARTITIONED token rows of images on a win_grid x win_grid grid; window (wy, wx) of image i
+  // (batch index i * win_nw^2 + wy * win_nw + wx) reads token (14 wy + iy, 14 wx + ix) or, outside the grid, the pad rows (the q|k|v projection of a zero row = its bias)
+  int win_grid, win_nw;
+  const bf16_t* pad_q; const bf16_t* pad_k; const bf16_t* pad_v;
 };
 
 typedef short short4v __attribute__((ext_vector_type(4)));
@@ -706,6 +710,10 @@ __global__ __launch_bounds__(512, 2) void attn_win14_kernel(AttnP p) {
 //   * the rel-pos tables' MFMA fragments stay in registers for the whole kernel; G^T = R . Q^T is bounced through ONE per-wave slab (table h,
 //     then table w) with 16-byte stores; the bias enters the score accumulators as their INITIAL value (one add per score instead of two
 //     after the MFMAs).
+// GATHER (round 6): the kernel applies window_partition (+ its zero padding) itself -- Q / K / V are the q|k|v rows of the UNPARTITIONED tokens, a window row outside the
+// image reads the projection's bias (what the reference's padded zero token projects to: it pads AFTER norm1, image_encoder.py:178-183), the output goes to the token's own row.
+// The q|k|v GEMM of a windowed block then runs on the 4096 real tokens of an image instead of the 4900 rows of its 25 padded windows (-16.4 % of that product, same bits).
+template <bool GATHER>
 __global__ __launch_bounds__(512, 2) void attn_win14_dma_kernel(AttnP p) {
   constexpr int HD = 80, KS = HD / 16, DT = 3, NKB = 7, NKEY = 196, ROWB = HD * 2;
   constexpr int KBYTES = NKEY * ROWB;                    // 31360: rows >= 196 of the last key block are never real keys (masked below)
@@ -733,15 +741,24 @@ __global__ __launch_bounds__(512, 2) void attn_win14_dma_kernel(AttnP p) {
   for (int k = 0; k < 5; ++k) {
     const int j = wave + 8 * k, L = j * 1024 + lane * 16;
     const int row = L / ROWB, slot = (L - row * ROWB) >> 4;
+    const int rc = min(row, NKEY - 1);
     if (k < 4) {
       int c = slot - ((row >> 3) & 1);                   // LDS slot `slot` of a rotated row holds global chunk slot - 1 (mod 10)
       if (c < 0) c += HD / 8;
-      kvoff[k] = (min(row, NKEY - 1) * (int)p.ksr + c * 8) * 2;
+      kvoff[k] = GATHER ? ((rc / 14) | ((rc % 14) << 8) | (c * 16) << 16) : (rc * (int)p.ksr + c * 8) * 2;       // GATHER: (iy, ix, byte offset in the row), packed
       kval[k] = j < K_DMA && L < KBYTES;
     }
-    vvoff[k] = (min(row, NKEY - 1) * (int)p.vsr + slot * 8) * 2;
+    vvoff[k] = GATHER ? ((rc / 14) | ((rc % 14) << 8) | (slot * 16) << 16) : (rc * (int)p.vsr + slot * 8) * 2;
     vval[k] = j < V_DMA && L < VBYTES;
   }
+  // GATHER: source of window row (iy, ix) [packed in pk] of the window whose first token is (y0, x0); img = the operand's first row of that image and head (wave-uniform),
+  // pad = the pad row at that head; rs2 = row pitch in bytes.  Branch-free: the offset inside an image fits 32 bits (g^2 rows x pitch), only the two selects depend on `in`.
+  auto gsrc = [&](const char* img, const char* pad, int rs2, int pk, int y0, int x0) -> const char* {
+    const int ty = y0 + (pk & 255), tx = x0 + ((pk >> 8) & 255);
+    const bool in = (ty < p.win_grid) & (tx < p.win_grid);
+    const unsigned off = (unsigned)((ty * p.win_grid + tx) * rs2);
+    return (in ? img : pad) + ((in ? off : 0u) + (unsigned)(pk >> 16));
+  };
   // fragment read offsets: K row ql of a key block, chunk 2 ks + half at its (rotated) slot; V^T through the transposing read
   int koff[KS];
 #pragma unroll
@@ -771,16 +788,34 @@ __global__ __launch_bounds__(512, 2) void attn_win14_dma_kernel(AttnP p) {
   }
 #define WIND_ISSUE(KD, VD)                                                                                          \
   {                                                                                                                 \
-    const char* Kg = reinterpret_cast<const char*>(p.K + (long)b * p.ksb + (long)h * p.ksh);                        \
-    const char* Vg = reinterpret_cast<const char*>(p.V + (long)b * p.vsb + (long)h * p.vsh);                        \
-    const bf16_t* Qg = p.Q + (long)b * p.qsb + (long)h * p.qsh;                                                     \
     const unsigned kd_ = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_p)(KD)) + wave * 1024;           \
     const unsigned vd_ = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_p)(VD)) + wave * 1024;           \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                                   \
-      if (kval[k]) WIND_DMA16(kd_ + 8192 * k, Kg + kvoff[k])                                                        \
-    _Pragma("unroll") for (int k = 0; k < 5; ++k)                                                                   \
-      if (vval[k]) WIND_DMA16(vd_ + 8192 * k, Vg + vvoff[k])                                                        \
-    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) qn[ks] = *reinterpret_cast<const bf16x8_t*>(Qg + (qoff + ks * 16)); \
+    if constexpr (GATHER) {                                                                                         \
+      const int nw2_ = p.win_nw * p.win_nw, im_ = b / nw2_, w_ = b - im_ * nw2_, wy_ = w_ / p.win_nw;               \
+      const int y0_ = wy_ * 14, x0_ = (w_ - wy_ * p.win_nw) * 14;                                                   \
+      const long r0_ = (long)im_ * p.win_grid * p.win_grid;                                                         \
+      const char* ki_ = reinterpret_cast<const char*>(p.K + r0_ * p.ksr + (long)h * p.ksh);                         \
+      const char* vi_ = reinterpret_cast<const char*>(p.V + r0_ * p.vsr + (long)h * p.vsh);                         \
+      const char* qi_ = reinterpret_cast<const char*>(p.Q + r0_ * p.qsr + (long)h * p.qsh);                         \
+      const char* kp_ = reinterpret_cast<const char*>(p.pad_k + (long)h * p.ksh);                                   \
+      const char* vp_ = reinterpret_cast<const char*>(p.pad_v + (long)h * p.vsh);                                   \
+      const char* qp_ = reinterpret_cast<const char*>(p.pad_q + (long)h * p.qsh);                                   \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                                 \
+        if (kval[k]) WIND_DMA16(kd_ + 8192 * k, gsrc(ki_, kp_, (int)p.ksr * 2, kvoff[k], y0_, x0_))                 \
+      _Pragma("unroll") for (int k = 0; k < 5; ++k)                                                                 \
+        if (vval[k]) WIND_DMA16(vd_ + 8192 * k, gsrc(vi_, vp_, (int)p.vsr * 2, vvoff[k], y0_, x0_))                 \
+      const bf16_t* Qg = reinterpret_cast<const bf16_t*>(gsrc(qi_, qp_, (int)p.qsr * 2, qh | (qw << 8), y0_, x0_)) + half * 8; \
+      _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) qn[ks] = *reinterpret_cast<const bf16x8_t*>(Qg + ks * 16);  \
+    } else {                                                                                                        \
+      const char* Kg = reinterpret_cast<const char*>(p.K + (long)b * p.ksb + (long)h * p.ksh);                      \
+      const char* Vg = reinterpret_cast<const char*>(p.V + (long)b * p.vsb + (long)h * p.vsh);                      \
+      const bf16_t* Qg = p.Q + (long)b * p.qsb + (long)h * p.qsh;                                                   \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                                 \
+        if (kval[k]) WIND_DMA16(kd_ + 8192 * k, Kg + kvoff[k])                                                      \
+      _Pragma("unroll") for (int k = 0; k < 5; ++k)                                                                 \
+        if (vval[k]) WIND_DMA16(vd_ + 8192 * k, Vg + vvoff[k])                                                      \
+      _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) qn[ks] = *reinterpret_cast<const bf16x8_t*>(Qg + (qoff + ks * 16)); \
+    }                                                                                                               \
   }
 
   char* Kc = smem;                                   // buffers of the item being computed
@@ -905,7 +940,12 @@ __global__ __launch_bounds__(512, 2) void attn_win14_dma_kernel(AttnP p) {
     if (q < NKEY) {
       bf16_t* orow;
       bool skip = false;
-      if (p.o_row_map) {
+      if constexpr (GATHER) {                        // window_unpartition + crop: the query's own token row, padding queries store nothing
+        const int nw2 = p.win_nw * p.win_nw, im = cb / nw2, w = cb - im * nw2, wy = w / p.win_nw;
+        const int ty = wy * 14 + qh, tx = (w - wy * p.win_nw) * 14 + qw;
+        skip = ty >= p.win_grid || tx >= p.win_grid;
+        orow = p.O + (long)chd * p.osh + (skip ? 0 : ((long)im * p.win_grid + ty) * p.win_grid + tx) * p.osr;
+      } else if (p.o_row_map) {
         const int row = p.o_row_map[(long)cb * p.Nq + q];
         skip = row < 0;
         orow = p.O + (long)chd * p.osh + (long)(skip ? 0 : row) * p.osr;
@@ -1152,7 +1192,8 @@ int launch_hd(const AttnP& p, hipStream_t s) {
       const int rounds = (items + wgs - 1) / wgs;
       wgs = std::min(wgs, ((items + rounds - 1) / rounds + 7) & ~7);       // a multiple of 8 keeps the kernel's XCD grouping of the heads of a window
     }
-    LL_LAUNCH_KERNEL(attn_win14_dma_kernel, dim3((unsigned)wgs), dim3(NT8), 0, s, p);
+    if (p.win_grid > 0) LL_LAUNCH_KERNEL(attn_win14_dma_kernel<true>, dim3((unsigned)wgs), dim3(NT8), 0, s, p);
+    else LL_LAUNCH_KERNEL(attn_win14_dma_kernel<false>, dim3((unsigned)wgs), dim3(NT8), 0, s, p);
   }
   else if (p.rtab_h != nullptr && HD == 80 && g_attn_win_new && p.lse == nullptr) LL_LAUNCH_KERNEL(attn_win14_kernel, dim3((unsigned)std::min(p.batch * p.heads, g_attn_win_wgs)), dim3(NT8), 0, s, p);
   else if (p.rtab_h != nullptr) LL_LAUNCH_KERNEL((attn_fwd_kernel<HD == 80 ? 80 : HD, HD == 80 ? 4 : 0>), dim3((p.Nq + 127) / 128, p.heads, p.batch), dim3(NT4), 0, s, p);
@@ -1368,6 +1409,13 @@ extern "C" int llmseg_attn_fwd(const llmseg_attn_args* a, void* stream) {
   p.rtab_h = (const bf16_t*)a->rel_tab_h; p.rtab_w = (const bf16_t*)a->rel_tab_w;
   p.nk_dev = a->nk_dev;
   p.xcd_nqb = 0;
+  p.win_grid = a->win_grid; p.win_nw = a->win_nw;
+  p.pad_q = (const bf16_t*)a->pad_q; p.pad_k = (const bf16_t*)a->pad_k; p.pad_v = (const bf16_t*)a->pad_v;
+  if (a->win_grid != 0) {
+    LL_CHECK(a->rel_tab_h && g_attn_win_new == 2 && !a->lse && a->k_stride_row == a->v_stride_row, "attn: the window-gather form needs the LDS-DMA window kernel (rel_tab_*, no lse)");
+    LL_CHECK(a->win_grid > 0 && a->win_nw == (a->win_grid + 13) / 14 && a->win_nw < 19 && a->batch % (a->win_nw * a->win_nw) == 0, "attn: bad window-gather grid");
+    LL_CHECK(a->pad_q && a->pad_k && a->pad_v && (((uintptr_t)a->pad_q | (uintptr_t)a->pad_k | (uintptr_t)a->pad_v) & 15) == 0, "attn: window-gather pad rows missing / misaligned");
+  }
   LL_CHECK(!a->nk_dev || (!a->rel_tab_h && !a->rel_h && !a->causal), "attn: nk_dev is for plain (decode-step) attention");
   hipStream_t s = (hipStream_t)stream;
   switch (a->head_dim) {

@@ -809,16 +809,23 @@ __global__ __launch_bounds__(NTL, 1) void gemm_bf16_tn_lw_kernel(GemmP p) {
 #define PP_WROW0(h, i) (((i) * 2 + (wave >> 2)) * 64 + (h) * 32 + (wave & 3) * 8)
 // NB: the LDS address handed to the DMA builtins must not be a value-dependent expression of a template parameter (hipcc 7.2 then
 // silently drops the kernel's host stub): the per-wave LDS offsets live in the runtime tables a_lds / w_lds.
-#define PP_BL(rs, dst, voff, tt) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst), 16, voff, PP_KOFF(tt), 0, 0)
+// cache-policy bits of the DMA loads (experiment switch, side builds only: -DPP_AUX_A=n -DPP_AUX_W=n; bit 0 sc0, bit 1 nt, bit 4 sc1)
+#ifndef PP_AUX_A
+#define PP_AUX_A 0
+#endif
+#ifndef PP_AUX_W
+#define PP_AUX_W 0
+#endif
+#define PP_BL(rs, dst, voff, tt, aux) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst), 16, voff, PP_KOFF(tt), 0, aux)
 #define PP_ISSUE_A(h, tt, base)                                                  \
   do {                                                                           \
-    PP_BL(rsrc_a, (base) + a_lds[h][0], a_off[h][0], tt);                        \
-    if constexpr (MI == 4) PP_BL(rsrc_a, (base) + a_lds[h][1], a_off[h][1], tt); \
+    PP_BL(rsrc_a, (base) + a_lds[h][0], a_off[h][0], tt, PP_AUX_A);                        \
+    if constexpr (MI == 4) PP_BL(rsrc_a, (base) + a_lds[h][1], a_off[h][1], tt, PP_AUX_A); \
   } while (0)
 #define PP_ISSUE_W(h, tt, base)                                                  \
   do {                                                                           \
-    PP_BL(rsrc_w, (base) + w_lds[h][0], w_off[h][0], tt);                        \
-    PP_BL(rsrc_w, (base) + w_lds[h][1], w_off[h][1], tt);                        \
+    PP_BL(rsrc_w, (base) + w_lds[h][0], w_off[h][0], tt, PP_AUX_W);                        \
+    PP_BL(rsrc_w, (base) + w_lds[h][1], w_off[h][1], tt, PP_AUX_W);                        \
   } while (0)
 // the optional extension tile (A2, W2) is K-tile 0, fetched in the prologue with the same lane -> (row, chunk) mapping
 #define PP_ISSUE_AX(h, base)                                                     \

@@ -17,6 +17,7 @@ Layout choices (MI355X-first, differ from the reference's eager code on purpose)
   * `text_hidden_fcs` runs on the gathered [SEG] rows only (identical result, ~300x fewer rows -- LISA.py:318-323).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -32,6 +33,7 @@ from .trainable import TrainableMixin
 IMAGE_TOKEN_INDEX = -200
 IGNORE_INDEX = -100
 BF16 = torch.bfloat16
+WIN_GATHER = os.environ.get("LLMSEG_WIN_NO_GATHER") is None      # A/B switch: SAM windows partitioned by the norm1 launch (row map) + q|k|v over the padded windows
 
 
 def _pad_rows(t, rows):
@@ -303,6 +305,7 @@ class LISAForCausalLM(TrainableMixin, GenerateMixin, SamDecoderMixin, AmgMixin, 
         x = ops.add_rows(x, d["sam.pos"])
         part, unpart, n_win, per_img = self._window_maps(B, g, s.window)
         winbuf = None
+        gather = hd == 80 and s.window == 14 and WIN_GATHER and P[sp + "blocks.0.attn.qkv.bias"].dtype == BF16
         for i in range(s.depth):
             p = f"{sp}blocks.{i}."
             glob = i in s.global_idx
@@ -311,6 +314,11 @@ class LISAForCausalLM(TrainableMixin, GenerateMixin, SamDecoderMixin, AmgMixin, 
             if glob:
                 h = ops.norm(x, P[p + "norm1.weight"], P[p + "norm1.bias"], eps=s.eps)
                 batch, n_tok = B, g * g
+            elif gather:
+                # window_partition, its zero padding and window_unpartition happen inside the attention kernel (llmseg_attn_args.win_grid): q|k|v of the real tokens only --
+                # the reference pads AFTER norm1 (image_encoder.py:178-183), so a padded token's q|k|v row is the projection's bias, which the kernel reads instead
+                h = ops.norm(x, P[p + "norm1.weight"], P[p + "norm1.bias"], eps=s.eps)
+                batch, n_tok = B * n_win, s.window * s.window
             else:
                 if winbuf is None:
                     winbuf = torch.zeros((B * per_img, D), device=x.device, dtype=BF16)   # padding rows stay zero
@@ -319,7 +327,10 @@ class LISAForCausalLM(TrainableMixin, GenerateMixin, SamDecoderMixin, AmgMixin, 
             qkv = ops.gemm(h, P[p + "attn.qkv.weight"], bias=P[p + "attn.qkv.bias"])
             rows = batch * n_tok
             a = torch.empty((B * g * g, D), device=x.device, dtype=BF16)
-            if (not glob) and hd == 80 and sz == 14:
+            if (not glob) and gather:
+                ops.attention_packed(qkv, batch, n_tok, nh, hd, out=a, rel_tab_h=d[f"sam.relh.{i}"], rel_tab_w=d[f"sam.relw.{i}"],
+                                     grid_hw=(sz, sz), win_pad=(g, P[p + "attn.qkv.bias"]))
+            elif (not glob) and hd == 80 and sz == 14:
                 # fused: q.R^T is computed inside the attention kernel from the (32-row padded) tables
                 ops.attention_packed(qkv, batch, n_tok, nh, hd, out=a, rel_tab_h=d[f"sam.relh.{i}"], rel_tab_w=d[f"sam.relw.{i}"],
                                      grid_hw=(sz, sz), o_row_map=unpart)

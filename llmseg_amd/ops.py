@@ -166,8 +166,9 @@ def gemm_batched(a, w, out, M, N, K, lda, ldw, ldc, batch, sA, sW, sC, out_f32=T
 
 def attention(q, k, v, out, *, batch, heads, Nq, Nk, head_dim, q_strides, k_strides, v_strides, o_strides, scale=None,
               causal=False, key_mask=None, rel_h=None, rel_w=None, rel_ld=0, grid_hw=(0, 0), o_row_map=None, rel_tab_h=None, rel_tab_w=None, lse=None,
-              nk_dev=None):
-    """Strided fused attention.  *_strides = (batch, head, row) in elements relative to the given tensors' data_ptr."""
+              nk_dev=None, win_gather=None):
+    """Strided fused attention.  *_strides = (batch, head, row) in elements relative to the given tensors' data_ptr.
+    win_gather = (grid, pad_q, pad_k, pad_v): SAM 14x14 windows gathered from / scattered to UNPARTITIONED token rows inside the kernel (see llmseg_attn_args.win_grid)."""
     a = AttnArgs(Q=q.data_ptr(), K=k.data_ptr(), V=v.data_ptr(), O=out.data_ptr(),
                  q_stride_b=q_strides[0], q_stride_h=q_strides[1], q_stride_row=q_strides[2],
                  k_stride_b=k_strides[0], k_stride_h=k_strides[1], k_stride_row=k_strides[2],
@@ -181,17 +182,28 @@ def attention(q, k, v, out, *, batch, heads, Nq, Nk, head_dim, q_strides, k_stri
                  o_row_map=None if o_row_map is None else o_row_map.data_ptr(),
                  rel_tab_h=None if rel_tab_h is None else rel_tab_h.data_ptr(), rel_tab_w=None if rel_tab_w is None else rel_tab_w.data_ptr(),
                  lse=None if lse is None else lse.data_ptr(), nk_dev=None if nk_dev is None else nk_dev.data_ptr())
+    if win_gather is not None:
+        g, pq, pk, pv = win_gather
+        a.win_grid, a.win_nw, a.pad_q, a.pad_k, a.pad_v = g, (g + 13) // 14, pq.data_ptr(), pk.data_ptr(), pv.data_ptr()
     _lib.check(_lib.load().llmseg_attn_fwd(C.byref(a), _stream()), "attn_fwd")
     return out
 
 
-def attention_packed(qkv, batch, n_tok, heads, head_dim, out=None, **kw):
-    """qkv [batch*n_tok, 3*heads*head_dim] (q|k|v, heads-major inside each) -> out [batch*n_tok, heads*head_dim]."""
+def attention_packed(qkv, batch, n_tok, heads, head_dim, out=None, win_pad=None, **kw):
+    """qkv [batch*n_tok, 3*heads*head_dim] (q|k|v, heads-major inside each) -> out [batch*n_tok, heads*head_dim].
+    win_pad = (grid, pad [3*heads*head_dim] bf16): qkv / out hold the rows of the unpartitioned tokens of images on a grid x grid grid, `batch` counts the 14x14 windows
+    (window gather, see `attention`); pad = the q|k|v row of a padded token (the projection's bias)."""
     D = heads * head_dim
-    assert qkv.shape == (batch * n_tok, 3 * D) and qkv.stride(1) == 1
+    if win_pad is not None:
+        g, pad = win_pad
+        nw = (g + 13) // 14
+        assert qkv.shape == (batch // (nw * nw) * g * g, 3 * D) and qkv.stride(1) == 1 and pad.shape == (3 * D,) and pad.dtype == BF16 and pad.is_contiguous()
+        kw["win_gather"] = (g, pad, pad[D:], pad[2 * D:])
+    else:
+        assert qkv.shape == (batch * n_tok, 3 * D) and qkv.stride(1) == 1
     ld = qkv.stride(0)
     if out is None:
-        out = torch.empty((batch * n_tok, D), device=qkv.device, dtype=BF16)
+        out = torch.empty((qkv.shape[0], D), device=qkv.device, dtype=BF16)
     st = (n_tok * ld, head_dim, ld)
     return attention(qkv, qkv[:, D:], qkv[:, 2 * D:], out, batch=batch, heads=heads, Nq=n_tok, Nk=n_tok, head_dim=head_dim,
                      q_strides=st, k_strides=st, v_strides=st, o_strides=(n_tok * out.stride(0), head_dim, out.stride(0)), **kw)

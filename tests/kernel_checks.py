@@ -472,6 +472,39 @@ def check_attention():
     keep = rm >= 0
     ref[rm[keep].long()] = full[keep]
     out.append(("attn o_row_map", err(od, ref), tol_bf16(ref, 2.0)))
+    # window gather (llmseg_attn_args.win_grid): partition + zero padding + un-partition inside the kernel == the row-map route over padded windows, bit for bit,
+    # and against the fp32 computation of the padded windows (image_encoder.py:178-183, 263-318); grid 30 -> 3 x 3 windows (12 padded rows / columns), grid 64 -> SAM's 5 x 5
+    for g, Bi, H in [(30, 2, 2), (64, 1, 3), (14, 3, 1)]:
+        hd, ws = 80, 14
+        D, nw = H * hd, (g + 13) // 14
+        tok = rnd(Bi * g * g, 3 * D, seed=900 + g, scale=0.7)
+        pad = rnd(3 * D, seed=901 + g, scale=0.7)
+        th, tw = torch.zeros(32, hd, dtype=BF), torch.zeros(32, hd, dtype=BF)
+        th[:27], tw[:27] = rnd(27, hd, seed=902 + g, scale=0.3), rnd(27, hd, seed=903 + g, scale=0.3)
+        yy, xx = torch.meshgrid(torch.arange(g), torch.arange(g), indexing="ij")
+        part1 = (((yy // ws) * nw + xx // ws) * ws * ws + (yy % ws) * ws + xx % ws).reshape(-1)
+        per_img = nw * nw * ws * ws
+        part = torch.cat([part1 + b * per_img for b in range(Bi)])
+        unpart = torch.full((Bi * per_img,), -1, dtype=torch.int32)
+        unpart[part] = torch.arange(Bi * g * g, dtype=torch.int32)
+        win = pad[None].repeat(Bi * per_img, 1)
+        win[part] = tok
+        kw = dict(rel_tab_h=th.to(DEV), rel_tab_w=tw.to(DEV), grid_hw=(14, 14))
+        o_map = torch.zeros(Bi * g * g, D, device=DEV, dtype=BF)
+        ops.attention_packed(win.to(DEV), Bi * nw * nw, ws * ws, H, hd, out=o_map, o_row_map=unpart.to(DEV), **kw)
+        o_gat = torch.zeros(Bi * g * g, D, device=DEV, dtype=BF)
+        ops.attention_packed(tok.to(DEV), Bi * nw * nw, ws * ws, H, hd, out=o_gat, win_pad=(g, pad.to(DEV)), **kw)
+        out.append((f"attn window gather grid {g}: differing elements vs the row-map route", float((o_gat != o_map).sum()), 0.0))
+        Bw, N = Bi * nw * nw, ws * ws
+        x = win.view(Bw, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+        qi = torch.arange(N)
+        qh_, qw_ = qi // ws, qi % ws
+        Gh, Gw = x[0].float() @ th[:27].float().t(), x[0].float() @ tw[:27].float().t()
+        ih = (qh_[:, None] - qh_[None, :] + ws - 1)[None, None].expand(Bw, H, N, N)
+        iw = (qw_[:, None] - qw_[None, :] + ws - 1)[None, None].expand(Bw, H, N, N)
+        full = _attn_ref(x[0], x[1], x[2], hd ** -0.5, torch.gather(Gh, 3, ih) + torch.gather(Gw, 3, iw)).transpose(1, 2).reshape(Bw * N, D)
+        ref = full[part]
+        out.append((f"attn window gather grid {g} vs fp32", err(o_gat, ref), tol_bf16(ref, 2.0)))
     # cross attention shape of the head: Nq != Nk (1 query over K keys), separate tensors
     hd, H, Nq, Nk = 32, 8, 1, 256
     q, k, v = rnd(Nq, H * hd, seed=1), rnd(Nk, H * hd, seed=2), rnd(Nk, H * hd, seed=3)
