@@ -1169,271 +1169,8 @@ __global__ __launch_bounds__(512, 2) void attn_glob80_dma_kernel(AttnP p) {
   }
 }
 
-// ---- the LDS-DMA window kernel as TWO workgroups of four waves per CU (round 6) -------------------------------------------------------------
-// attn_win14_dma_kernel runs ~8.5k VALU + ~5.6k matrix-pipe cycles per item and SIMD one after the other: its two waves of a SIMD leave the item barrier
-// together and execute the same sequence in phase (MFMA-pipe occupancy 15.6 %, profiles/r05_b2_mfma.md).  Here a workgroup is 4 waves (one per SIMD) that take an
-// item's 196 queries in two passes of 128 over the SAME resident K / V image (single-buffered: 78,976 B of LDS, so two workgroups fit a CU); the two workgroups of a
-// CU walk different items and share nothing, so on every SIMD one wave's softmax VALU runs under the other's MFMAs, and one workgroup's DMA wait under the other's
-// compute.  Per-query arithmetic, operand layouts and DMA addressing are those of attn_win14_dma_kernel: bit-identical results.
-template <bool GATHER>
-__global__ __launch_bounds__(256, 2) void attn_win14_w4_kernel(AttnP p) {
-  constexpr int HD = 80, KS = HD / 16, DT = 3, NKB = 7, NKEY = 196, ROWB = HD * 2;
-  constexpr int KBYTES = NKEY * ROWB;
-  constexpr int VROWS = 208, VBYTES = VROWS * ROWB;
-  constexpr int K_DMA = (KBYTES + 1023) / 1024, V_DMA = (VBYTES + 1023) / 1024;      // 31 / 33 one-KiB pieces: 8 / 9 per wave
-  constexpr int SPITCH = 28, SLAB = 32 * SPITCH;
-  __shared__ __attribute__((aligned(16))) char smem[KBYTES + VBYTES + 4 * SLAB * 4];               // 78,976 B
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ql = lane & 31, half = lane >> 5;
-  const int nitems = p.batch * p.heads;
-  const int wg = (int)blockIdx.x, nwg = (int)gridDim.x;
-  const int vwg = (nwg % 8 == 0) ? (wg % 8) * (nwg / 8) + wg / 8 : wg;
-  int item = vwg;
-  if (item >= nitems) return;
-  int b = item / p.heads, h = item - b * p.heads;
-
-  // per-lane DMA sources: piece j = wave + 4 k fills LDS bytes [1024 j, 1024 j + 1024)
-  int kvoff[8], vvoff[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    const int j = wave + 4 * k, L = j * 1024 + lane * 16;
-    const int row = L / ROWB, slot = (L - row * ROWB) >> 4;
-    const int rc = min(row, NKEY - 1);
-    if (k < 8) {
-      int c = slot - ((row >> 3) & 1);
-      if (c < 0) c += HD / 8;
-      const int v = GATHER ? ((rc / 14) | ((rc % 14) << 8) | (c * 16) << 16) : (rc * (int)p.ksr + c * 8) * 2;
-      kvoff[k] = (j < K_DMA && L < KBYTES) ? v : -1;             // -1: no piece / past the buffer
-    }
-    const int v = GATHER ? ((rc / 14) | ((rc % 14) << 8) | (slot * 16) << 16) : (rc * (int)p.vsr + slot * 8) * 2;
-    vvoff[k] = (j < V_DMA && L < VBYTES) ? v : -1;
-  }
-  auto gsrc = [&](const char* img, const char* pad, int rs2, int pk, int y0, int x0) -> const char* {
-    const int ty = y0 + (pk & 255), tx = x0 + ((pk >> 8) & 255);
-    const bool in = (ty < p.win_grid) & (tx < p.win_grid);
-    const unsigned off = (unsigned)((ty * p.win_grid + tx) * rs2);
-    return (in ? img : pad) + ((in ? off : 0u) + (unsigned)(pk >> 16));
-  };
-  int koff[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) koff[ks] = ql * ROWB + (((2 * ks + half + ((ql >> 3) & 1)) % (HD / 8)) << 4);
-  const int voff = (4 * half + ((lane & 15) >> 2)) * ROWB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-  bf16x8_t rth[KS], rtw[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    rth[ks] = *reinterpret_cast<const bf16x8_t*>(p.rtab_h + ql * HD + ks * 16 + half * 8);
-    rtw[ks] = *reinterpret_cast<const bf16x8_t*>(p.rtab_w + ql * HD + ks * 16 + half * 8);
-  }
-  bf16x8_t qn[KS];
-  typedef __attribute__((address_space(3))) void* lds_p;
-  typedef __attribute__((address_space(3))) short4v* lds_tr;
-#define W4_DMA16(LDS_BYTE_ADDR, GSRC)                                                                               \
-  {                                                                                                                 \
-    unsigned keep_;                                                                                                 \
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"        \
-                 : "=&s"(keep_) : "v"(GSRC), "s"(LDS_BYTE_ADDR) : "memory");                                        \
-  }
-  // Q rows of pass `pass` (queries 128 pass + 32 wave + ql) of item (bb, hh) -> dst
-  auto load_q = [&](int bb, int hh, int pass, bf16x8_t* dst) {
-    const int qc_ = min(pass * 128 + wave * 32 + ql, NKEY - 1);
-    const bf16_t* Qg;
-    if constexpr (GATHER) {
-      const int nw2_ = p.win_nw * p.win_nw, im_ = bb / nw2_, w_ = bb - im_ * nw2_, wy_ = w_ / p.win_nw;
-      const char* qi_ = reinterpret_cast<const char*>(p.Q + (long)im_ * p.win_grid * p.win_grid * p.qsr + (long)hh * p.qsh);
-      const char* qp_ = reinterpret_cast<const char*>(p.pad_q + (long)hh * p.qsh);
-      const int qh_ = qc_ / 14;
-      Qg = reinterpret_cast<const bf16_t*>(gsrc(qi_, qp_, (int)p.qsr * 2, qh_ | ((qc_ - qh_ * 14) << 8), wy_ * 14, (w_ - wy_ * p.win_nw) * 14)) + half * 8;
-    } else {
-      Qg = p.Q + (long)bb * p.qsb + (long)hh * p.qsh + qc_ * (int)p.qsr + half * 8;
-    }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) dst[ks] = *reinterpret_cast<const bf16x8_t*>(Qg + ks * 16);
-  };
-  char* const Kb = smem;
-  char* const Vb = smem + KBYTES;
-  float* const gs = reinterpret_cast<float*>(smem + KBYTES + VBYTES) + wave * SLAB;
-  const unsigned kd_ = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_p)(Kb)) + wave * 1024;
-  const unsigned vd_ = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_p)(Vb)) + wave * 1024;
-
-  while (true) {
-    __syncthreads();                                           // every wave is done with the previous item's K / V image
-    if constexpr (GATHER) {
-      const int nw2_ = p.win_nw * p.win_nw, im_ = b / nw2_, w_ = b - im_ * nw2_, wy_ = w_ / p.win_nw;
-      const int y0_ = wy_ * 14, x0_ = (w_ - wy_ * p.win_nw) * 14;
-      const long r0_ = (long)im_ * p.win_grid * p.win_grid;
-      const char* ki_ = reinterpret_cast<const char*>(p.K + r0_ * p.ksr + (long)h * p.ksh);
-      const char* vi_ = reinterpret_cast<const char*>(p.V + r0_ * p.vsr + (long)h * p.vsh);
-      const char* kp_ = reinterpret_cast<const char*>(p.pad_k + (long)h * p.ksh);
-      const char* vp_ = reinterpret_cast<const char*>(p.pad_v + (long)h * p.vsh);
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (kvoff[k] >= 0) W4_DMA16(kd_ + 4096 * k, gsrc(ki_, kp_, (int)p.ksr * 2, kvoff[k], y0_, x0_))
-#pragma unroll
-      for (int k = 0; k < 9; ++k)
-        if (vvoff[k] >= 0) W4_DMA16(vd_ + 4096 * k, gsrc(vi_, vp_, (int)p.vsr * 2, vvoff[k], y0_, x0_))
-    } else {
-      const char* Kg = reinterpret_cast<const char*>(p.K + (long)b * p.ksb + (long)h * p.ksh);
-      const char* Vg = reinterpret_cast<const char*>(p.V + (long)b * p.vsb + (long)h * p.vsh);
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (kvoff[k] >= 0) W4_DMA16(kd_ + 4096 * k, Kg + kvoff[k])
-#pragma unroll
-      for (int k = 0; k < 9; ++k)
-        if (vvoff[k] >= 0) W4_DMA16(vd_ + 4096 * k, Vg + vvoff[k])
-    }
-    load_q(b, h, 0, qn);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of the item (and its pass-0 Q rows) have arrived
-    __syncthreads();                                           // ... everyone's have
-    const int cb = b, chd = h;
-    item += nwg;
-    const bool more = item < nitems;
-    if (more) { b = item / p.heads; h = item - b * p.heads; }
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-      if (pass == 1 && wave == 3) break;                         // queries 224..255 do not exist
-      bf16x8_t qf[KS];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
-      if (pass == 0 && wave < 3) load_q(cb, chd, 1, qn);         // the second pass's Q rows fly behind the first pass
-      const int q = pass * 128 + wave * 32 + ql;
-      const int qc = min(q, NKEY - 1);
-      const int qh = qc / 14, qw = qc - qh * 14;
-
-      // ---- decomposed rel-pos: G^T = R . Q^T per table, bounced through the per-wave slab; lane-half folded into the LOAD index ----
-      float bh_s[14], bh_x[13];
-      f32x2_t bw_y2[7];                                             // key-column bias as register PAIRS (columns 2j, 2j + 1): one v_pk_add_f32 per two accumulator slots
-  #pragma unroll
-      for (int tb = 0; tb < 2; ++tb) {
-        f32x16_t g;
-  #pragma unroll
-        for (int e = 0; e < 16; ++e) g[e] = 0.f;
-  #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tb == 0 ? rth[ks] : rtw[ks], qf[ks], g, 0, 0, 0);
-  #pragma unroll
-        for (int gq = 0; gq < 4; ++gq)                              // regs 4 gq .. + 3 = table rows 8 gq + 4 half + 0..3 of query ql
-          if (!(gq == 3 && half == 1))
-            *reinterpret_cast<float4*>(gs + ql * SPITCH + 8 * gq + 4 * half) = make_float4(g[4 * gq], g[4 * gq + 1], g[4 * gq + 2], g[4 * gq + 3]);
-        if (tb == 0) {
-          const float* gh = gs + ql * SPITCH + qh;
-  #pragma unroll
-          for (int j = 0; j < 14; ++j) bh_s[j] = gh[13 - j] * p.inv_scale;
-  #pragma unroll
-          for (int j = 0; j < 13; ++j) bh_x[j] = gh[13 - j - half] * p.inv_scale;
-        } else {
-          const float* gw = gs + ql * SPITCH + qw + 13;
-  #pragma unroll
-          for (int j = 0; j < 7; ++j) bw_y2[j] = f32x2_t{gw[-((2 * j + 4 * half) % 14)], gw[-((2 * j + 1 + 4 * half) % 14)]} * p.inv_scale;
-        }
-      }
-
-      // ---- scores: accumulators start at the bias, then 35 MFMAs (7 independent accumulators between dependent ones) ----
-      f32x16_t s[NKB];
-  #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-  #pragma unroll
-        for (int r = 0; r < 16; r += 2) {                             // slots r, r + 1 = keys key0, key0 + 1: same key row (key0 and 14 are even)
-          const int key0 = kb * 32 + (r & 3) + 8 * (r >> 2);            // this register's key for half 0; half 1: + 4
-          const int kh0 = key0 / 14 > 13 ? 13 : key0 / 14, kw0 = key0 % 14;
-          const bool cross = kw0 >= 10 && kh0 < 13;                    // key0 + 4 falls into the next key row
-          const f32x2_t v = bw_y2[kw0 >> 1] + (cross ? bh_x[kh0 > 12 ? 12 : kh0] : bh_s[kh0]);
-          s[kb][r] = v.x; s[kb][r + 1] = v.y;
-        }
-  #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-  #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-          const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Kb + kb * (32 * ROWB) + koff[ks]);
-          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
-        }
-      // keys >= 196 live in block 6 only: key = 192 + (r&3) + 8 (r>>2) + 4 half is valid for half 0, r < 4
-  #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (half != 0 || r >= 4) s[NKB - 1][r] = NEG;
-      float mx = NEG;
-  #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-  #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float nmc = -mx * p.scale_log2;
-      f32x2_t lsum2 = {0.f, 0.f};
-      const f32x2_t sc2 = {p.scale_log2, p.scale_log2}, nmc2 = {nmc, nmc};
-      uint32_t pk[NKB][8];
-  #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-  #pragma unroll
-        for (int r = 0; r < 16; r += 2) {                             // packed fp32: one v_pk_fma / v_pk_add per two scores
-          const f32x2_t t2 = __builtin_elementwise_fma(f32x2_t{s[kb][r], s[kb][r + 1]}, sc2, nmc2);
-          const f32x2_t e2 = {__builtin_amdgcn_exp2f(t2.x), __builtin_amdgcn_exp2f(t2.y)};
-          lsum2 += e2;
-          pk[kb][r >> 1] = pack2bf(e2.x, e2.y);
-        }
-      const float lsum = lsum2.x + lsum2.y;
-
-      // ---- O^T = V^T . P^T: k-steps of 16 keys; V^T fragments = two transposing reads of the row-major V image ----
-      f32x16_t o[DT];
-  #pragma unroll
-      for (int d = 0; d < DT; ++d)
-  #pragma unroll
-        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
-  #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-  #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          if (kb == NKB - 1 && u == 1) continue;                         // keys 208..223: all padding
-          const int rb = 8 * u, ss = 2 * kb + u;
-          const uint4 pu = make_uint4(pk[kb][rb / 2 + 0], pk[kb][rb / 2 + 1], pk[kb][rb / 2 + 2], pk[kb][rb / 2 + 3]);
-          const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
-  #pragma unroll
-          for (int d = 0; d < DT; ++d) {
-            const char* va = Vb + ss * (16 * ROWB) + voff + d * 64;     // keys 16 ss + 4 half + 0..3 | + 8: the P fragment's k-slot order
-            const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)va);
-            const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(va + 8 * ROWB));
-            const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
-            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
-          }
-        }
-
-      // ---- normalise and store through the window un-partition map ----
-      const float l_tot = lsum + __shfl_xor(lsum, 32, 64);
-      const float inv = 1.f / l_tot;
-      if (q < NKEY) {
-        bf16_t* orow;
-        bool skip = false;
-        if constexpr (GATHER) {                        // window_unpartition + crop: the query's own token row, padding queries store nothing
-          const int nw2 = p.win_nw * p.win_nw, im = cb / nw2, w = cb - im * nw2, wy = w / p.win_nw;
-          const int ty = wy * 14 + qh, tx = (w - wy * p.win_nw) * 14 + qw;
-          skip = ty >= p.win_grid || tx >= p.win_grid;
-          orow = p.O + (long)chd * p.osh + (skip ? 0 : ((long)im * p.win_grid + ty) * p.win_grid + tx) * p.osr;
-        } else if (p.o_row_map) {
-          const int row = p.o_row_map[(long)cb * p.Nq + q];
-          skip = row < 0;
-          orow = p.O + (long)chd * p.osh + (long)(skip ? 0 : row) * p.osr;
-        } else {
-          orow = p.O + (long)cb * p.osb + (long)chd * p.osh + (long)q * p.osr;
-        }
-        if (!skip) {
-  #pragma unroll
-          for (int d = 0; d < DT; ++d)
-  #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int dd = d * 32 + 8 * g + 4 * half;
-              if (dd < HD)
-                *reinterpret_cast<uint2*>(orow + dd) =
-                    make_uint2(pack2bf(o[d][4 * g] * inv, o[d][4 * g + 1] * inv), pack2bf(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv));
-            }
-        }
-      }
-    }
-    if (!more) break;
-  }
-#undef W4_DMA16
-}
-
 static const int g_attn_xcd = getenv("LLMSEG_ATTN_NO_XCD") ? 0 : 1;
 static const int g_attn_glob_dma = getenv("LLMSEG_ATTN_NO_GLOB_DMA") ? 0 : 1;      // LDS-DMA form of SAM global attention (A/B switch)
-static int g_attn_win_w4 = getenv("LLMSEG_WIN_W4") ? atoi(getenv("LLMSEG_WIN_W4")) : 0;      // A/B switch: the 2 x 4-wave form of the LDS-DMA window kernel
 static int g_attn_win_wgs = 256;    // persistent workgroups of the window kernel: one per CU      // tuning knob (tools): 0 = the general tiled kernel on the window shape
 
 template <int HD>
@@ -1455,13 +1192,7 @@ int launch_hd(const AttnP& p, hipStream_t s) {
       const int rounds = (items + wgs - 1) / wgs;
       wgs = std::min(wgs, ((items + rounds - 1) / rounds + 7) & ~7);       // a multiple of 8 keeps the kernel's XCD grouping of the heads of a window
     }
-    if (g_attn_win_w4) {                            // two workgroups of four waves per CU (see attn_win14_w4_kernel)
-      int w4 = std::min(items, 2 * g_attn_win_wgs);
-      if (balance && w4 > 0) { const int rounds = (items + w4 - 1) / w4; w4 = std::min(w4, ((items + rounds - 1) / rounds + 7) & ~7); }
-      if (p.win_grid > 0) LL_LAUNCH_KERNEL(attn_win14_w4_kernel<true>, dim3((unsigned)w4), dim3(NT4), 0, s, p);
-      else LL_LAUNCH_KERNEL(attn_win14_w4_kernel<false>, dim3((unsigned)w4), dim3(NT4), 0, s, p);
-    }
-    else if (p.win_grid > 0) LL_LAUNCH_KERNEL(attn_win14_dma_kernel<true>, dim3((unsigned)wgs), dim3(NT8), 0, s, p);
+    if (p.win_grid > 0) LL_LAUNCH_KERNEL(attn_win14_dma_kernel<true>, dim3((unsigned)wgs), dim3(NT8), 0, s, p);
     else LL_LAUNCH_KERNEL(attn_win14_dma_kernel<false>, dim3((unsigned)wgs), dim3(NT8), 0, s, p);
   }
   else if (p.rtab_h != nullptr && HD == 80 && g_attn_win_new && p.lse == nullptr) LL_LAUNCH_KERNEL(attn_win14_kernel, dim3((unsigned)std::min(p.batch * p.heads, g_attn_win_wgs)), dim3(NT8), 0, s, p);
