@@ -234,9 +234,9 @@ def measure(model, cfg, args, B, dev, dist, rank, world, local, use_graph, train
                    % (per("calls"), per("calls_as_k_slices"), di.get("k_slices", 0) / max(1, di.get("calls_as_k_slices", 0)),
                       per("calls") - per("calls_as_k_slices"), per("kernel_launches"))) if di else None
     res["roofline"] = {"bound": "mfma", "kernel": prof["dominant_kernel"], "class_composition": composition,
-                       "hottest_symbol": "by rocprofv3's per-symbol table (profiles/r06g_b2_1stream_kernel_stats.md) the single hottest SYMBOL at 2 images is "
-                                         "gemm_bf16_tn_pp_kernel<false, false, 4> (the 256 x 256 tile: SAM products at M = 8192 / 9800; ~0.30 of peak): its calls are "
-                                         "counted under `other_gemm_classes` below.  `kernel` above names the dominant CLASS by total time = the 128 x 256 tile's three "
+                       "hottest_symbol": "by rocprofv3's per-symbol tables (profiles/r06p_b2_kernel_stats.md, r06p_b2_1stream_kernel_stats.md) the hottest single SYMBOL of the replayed step at 2 images is "
+                                         "gemm_bf16_tn_pp_kernel<false, false, 4> (the 256 x 256 tile: the SAM products at M = 8192; ~0.35 of peak; 22-28 % of the kernel time), level with "
+                                         "the K-slice form of the class below (`...pp2_kernel<true, false, 0>`, 21-22 %): its calls are counted under `other_gemm_classes` below.  `kernel` above names the dominant CLASS by total time = the 128 x 256 tile's three "
                                          "symbols (bf16-out, fp32 K-slice slabs, LoRA extension tile) + their reduce launches (the Llama products at M = 638)",
                        "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                        "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
