@@ -159,11 +159,9 @@ struct Acc16 {                       // v_mfma_f32_16x16x32: a[nb][mb][e] = C[n 
 // hold one output row's 64 consecutive columns: residual loads and C stores become full 128-byte lines instead of 8-byte
 // pieces scattered over 32 rows (measured on 32768x1280x1280 + bias + residual: 480 -> see profiles).  LDS ops of one wave
 // execute in order, so no barrier is needed; the slab aliases the (finished) operand tiles.
-struct NoPre { __device__ __forceinline__ void operator()() const {} };     // epilogue hook (persistent kernel: the next tile's first K-tile is issued from inside the epilogue)
-template <bool OUT_F32, int MI, class ACC, class PRE = NoPre>
+template <bool OUT_F32, int MI, class ACC>
 __device__ __forceinline__ void epilogue_lds_edge(const GemmP& p, const ACC& acc, char* smem, int wave, int m0, int n0, int wm, int wn,
-                                               int lane, long bz, PRE pre = PRE{}) {
-  pre();
+                                               int lane, long bz) {
   float* slab = reinterpret_cast<float*>(smem) + wave * (32 * 64);
   const int frow = lane & 31, fhalf = lane >> 5;
   const int c = lane & 15, rsub = lane >> 4;
@@ -241,21 +239,14 @@ __device__ __forceinline__ void epilogue_lds_edge(const GemmP& p, const ACC& acc
 // straight-line code - no per-lane bounds or alignment branches, the activation resolved once per tile (ACT is a template
 // argument of the body), LDS offsets hoisted out of the pass loop, running 64-bit row pointers instead of a 64-bit multiply per
 // row.  The branchy edge version above costs ~10-18 us per 256 x 256 tile (instruction-bound with 2 waves/SIMD).
-template <bool OUT_F32, int MI, int ACT, class ACC, class PRE = NoPre>
-__device__ __forceinline__ void epilogue_lds_body(const GemmP& p, const ACC& acc, float* slab, int mw, int nw, int lane, long bz, PRE pre = PRE{}) {
+template <bool OUT_F32, int MI, int ACT, class ACC>
+__device__ __forceinline__ void epilogue_lds_body(const GemmP& p, const ACC& acc, float* slab, int mw, int nw, int lane, long bz) {
   const int frow = lane & 31, fhalf = lane >> 5;
   const int c = lane & 15, rsub = lane >> 4;
   const int n = nw + c * 4;
   float bs[4] = {0.f, 0.f, 0.f, 0.f}, gm[4] = {1.f, 1.f, 1.f, 1.f};
   if (p.bias) ld4bf(p.bias + n, true, 4, bs);
   if (p.gamma) ld4bf(p.gamma + n, true, 4, gm);
-  if constexpr (!__is_same(PRE, NoPre)) {
-    // the hook issues loads the compiler does not see: every load of this epilogue that is waited for by a compiler-placed vmcnt must have RETURNED before them
-    // (an in-order vmcnt wait placed behind the hook would also wait for the hook's loads)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { asm volatile("" : "+v"(bs[e])); asm volatile("" : "+v"(gm[e])); }
-    pre();
-  }
   int roff[4];
 #pragma unroll
   for (int it = 0; it < 4; ++it) roff[it] = (it * 4 + rsub) * 64 + ((c ^ ((it * 4 + rsub) & 15)) << 2);
@@ -306,23 +297,23 @@ __device__ __forceinline__ void epilogue_lds_body(const GemmP& p, const ACC& acc
   }
 }
 
-template <bool OUT_F32, int MI, class ACC, class PRE = NoPre>
+template <bool OUT_F32, int MI, class ACC>
 __device__ __forceinline__ void epilogue_lds(const GemmP& p, const ACC& acc, char* smem, int wave, int m0, int n0, int wm, int wn,
-                                             int lane, long bz, PRE pre = PRE{}) {
+                                             int lane, long bz) {
   const int mw = m0 + wm * 32 * MI, nw = n0 + wn * 64;
   const bool interior = mw + 32 * MI <= p.M && nw + 64 <= p.N && p.c_vec && p.b_vec && (!p.res || p.r_vec);
   if (!interior) {
-    epilogue_lds_edge<OUT_F32, MI, ACC, PRE>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz, pre);
+    epilogue_lds_edge<OUT_F32, MI, ACC>(p, acc, smem, wave, m0, n0, wm, wn, lane, bz);
     return;
   }
   float* slab = reinterpret_cast<float*>(smem) + wave * (32 * 64);
   switch (p.act) {
-    case LLMSEG_ACT_NONE: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_NONE, ACC, PRE>(p, acc, slab, mw, nw, lane, bz, pre); break;
-    case LLMSEG_ACT_GELU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_GELU, ACC, PRE>(p, acc, slab, mw, nw, lane, bz, pre); break;
-    case LLMSEG_ACT_QUICKGELU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_QUICKGELU, ACC, PRE>(p, acc, slab, mw, nw, lane, bz, pre); break;
-    case LLMSEG_ACT_SILU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_SILU, ACC, PRE>(p, acc, slab, mw, nw, lane, bz, pre); break;
-    case LLMSEG_ACT_RELU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_RELU, ACC, PRE>(p, acc, slab, mw, nw, lane, bz, pre); break;
-    default: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_SIGMOID, ACC, PRE>(p, acc, slab, mw, nw, lane, bz, pre); break;
+    case LLMSEG_ACT_NONE: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_NONE, ACC>(p, acc, slab, mw, nw, lane, bz); break;
+    case LLMSEG_ACT_GELU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_GELU, ACC>(p, acc, slab, mw, nw, lane, bz); break;
+    case LLMSEG_ACT_QUICKGELU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_QUICKGELU, ACC>(p, acc, slab, mw, nw, lane, bz); break;
+    case LLMSEG_ACT_SILU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_SILU, ACC>(p, acc, slab, mw, nw, lane, bz); break;
+    case LLMSEG_ACT_RELU: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_RELU, ACC>(p, acc, slab, mw, nw, lane, bz); break;
+    default: epilogue_lds_body<OUT_F32, MI, LLMSEG_ACT_SIGMOID, ACC>(p, acc, slab, mw, nw, lane, bz); break;
   }
 }
 
@@ -993,136 +984,6 @@ __global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_pp_kernel(GemmP p) {
   else epilogue_lds<OUT_F32, MI>(p, Acc16<MI>{acc}, smem, wave, m0, n0, wm, wn, lane, bz);
 }
 
-// ---- variant Q persistent (round 6, experiment): the 256 x 256 ping-pong kernel walking SEVERAL tiles per workgroup ---------------------------------------
-// tools/gemm_ksweep.py: a round of 256 tiles costs F + k n with F ~ 10 us fixed (dispatch of the next workgroup on the CU, its prologue burst -- every CU fetching its
-// first 96 KB at once --, the epilogue's store burst): 27 % of a K = 1280 product.  Here gridDim.x workgroups (one per CU) walk tiles bid, bid + G, ...; while tile i
-// is in its epilogue (the LDS bounce uses the first 64 KiB = buffer 0 only) K-tile 0 of tile i + 1 is already flying into buffer 1: issued from INSIDE the epilogue,
-// after its bias loads have returned, as asm statements the compiler cannot see (so that none of its own waits drains them); after the epilogue K-tile 1's first two
-// half-tiles go to buffer 0 and the main loop runs with the buffer parity flipped.  bf16 output, no extension tile, no K-slices, one batch; same arithmetic and
-// summation order as gemm_bf16_tn_pp_kernel<false, false, 4>: bit-identical.
-#define PPP_DMA16(LDS_BYTE_ADDR, GSRC)                                                                              \
-  {                                                                                                                 \
-    unsigned keep_;                                                                                                 \
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"        \
-                 : "=&s"(keep_) : "v"(GSRC), "s"(LDS_BYTE_ADDR) : "memory");                                        \
-  }
-__global__ __launch_bounds__(NTB, 2) void gemm_bf16_tn_ppp_kernel(GemmP p) {
-  constexpr int MI = 4;
-  constexpr bool EXT = false;
-  constexpr int BMB = 64 * MI, BNB = 256;
-  constexpr int A_BYTES = BMB * BK * 2, W_BYTES = BNB * BK * 2, BUF = A_BYTES + W_BYTES;
-  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const bf16_t* __restrict__ Ag = p.A;
-  const bf16_t* __restrict__ Wg = p.W;
-  typedef __attribute__((address_space(3))) void* lds_p;
-
-  int m0, n0;
-  __amdgpu_buffer_rsrc_t rsrc_a, rsrc_w;
-  int a_off[2][2], w_off[2][2];
-  int a_lds[2][2], w_lds[2][2];
-  auto setup = [&](int vb) {                               // tile of virtual block id vb (the XCD-aware walk of gemm_bf16_tn_pp_kernel; gridDim.x % 8 == 0 keeps vb's XCD)
-    int bid = vb;
-    {
-      const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-      const int len = q + (xcd < r ? 1 : 0);
-      const int idx = ((bid >> 3) + xcd * p.skew) % len;
-      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int per_group = p.group_m * p.tiles_n;
-    const int first_m = (bid / per_group) * p.group_m;
-    const int gsz = min(p.tiles_m - first_m, p.group_m);
-    m0 = (first_m + (bid % per_group) % gsz) * BMB;
-    n0 = ((bid % per_group) / gsz) * BNB;
-    rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ag + (long)m0 * p.lda), 0, 0x7fffffff, 0x00020000);
-    rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Wg + (long)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ra0 = PP_AROW0(h, i), ra = ra0 + (lane >> 3);
-        a_lds[h][i] = ra0 * 128;
-        a_off[h][i] = (int)(((long)min(ra, p.M - 1 - m0) * p.lda + (((lane & 7) ^ ((ra >> 1) & 7)) << 3)) * 2);
-        const int rw0 = PP_WROW0(h, i), rw = rw0 + (lane >> 3);
-        w_lds[h][i] = A_BYTES + rw0 * 128;
-        w_off[h][i] = (int)(((long)min(rw, p.N - 1 - n0) * p.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) << 3)) * 2);
-      }
-  };
-  const int nt = p.K / BK;
-  const int frow = lane & 15, fq = lane >> 4;
-  const int wrow0 = wn * 64, wrow1 = wrow0 + 32;
-  const unsigned lds1 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_p)(smem + BUF));      // physical buffer 1
-
-  int vb = blockIdx.x;
-  setup(vb);
-  int flip = 0;
-  // first tile: the prologue of gemm_bf16_tn_pp_kernel
-  PP_ISSUE_A(0, 0, smem); PP_ISSUE_W(0, 0, smem); PP_ISSUE_W(1, 0, smem); PP_ISSUE_A(1, 0, smem);
-  PP_ISSUE_A(0, 1, smem + BUF); PP_ISSUE_W(0, 1, smem + BUF);
-  while (true) {
-    PP_VM_FULL;
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();            // the stagger
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4_t acc[4][2 * MI];
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-      for (int mb = 0; mb < 2 * MI; ++mb) acc[nb][mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    bf16x8_t af[MI][2], wf0[2][2], wf1[2][2];
-    int t = 0;
-    for (; t < nt - 2; ++t) {
-      char* cur = smem + ((t & 1) ^ flip) * BUF;
-      char* oth = smem + (((t + 1) & 1) ^ flip) * BUF;
-      PP_PHASE(P16_READ_W(wf0, 0, cur); P16_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM_FULL, P16_MMA(wf0, 0, 0));
-      PP_PHASE(P16_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM_FULL, P16_MMA(wf1, 2, 0));
-      PP_PHASE(P16_READ_A(MI, cur), PP_ISSUE_A(0, t + 2, cur), PP_NOP, P16_MMA(wf1, 2, MI));
-      PP_PHASE(PP_NOP, PP_ISSUE_W(0, t + 2, cur), PP_VM_FULL, P16_MMA(wf0, 0, MI));
-    }
-    {
-      char* cur = smem + ((t & 1) ^ flip) * BUF;
-      char* oth = smem + (((t + 1) & 1) ^ flip) * BUF;
-      PP_PHASE(P16_READ_W(wf0, 0, cur); P16_READ_A(0, cur), PP_ISSUE_W(1, t + 1, oth), PP_VM_FULL, P16_MMA(wf0, 0, 0));
-      PP_PHASE(P16_READ_W(wf1, 1, cur), PP_ISSUE_A(1, t + 1, oth), PP_VM_FULL, P16_MMA(wf1, 2, 0));
-      PP_PHASE(P16_READ_A(MI, cur), PP_NOP, PP_NOP, P16_MMA(wf1, 2, MI));
-      PP_PHASE(PP_NOP, PP_NOP, PP_VM_WA, P16_MMA(wf0, 0, MI));
-      cur = oth;
-      PP_PHASE(P16_READ_W(wf0, 0, cur); P16_READ_A(0, cur), PP_NOP, PP_VM_A, P16_MMA(wf0, 0, 0));
-      PP_PHASE(P16_READ_W(wf1, 1, cur), PP_NOP, PP_VM_0, P16_MMA(wf1, 2, 0));
-      PP_PHASE(P16_READ_A(MI, cur), PP_NOP, PP_NOP, P16_MMA(wf1, 2, MI));
-      PP_PHASE(PP_NOP, PP_NOP, PP_NOP, P16_MMA(wf0, 0, MI));
-    }
-    if (wm == 0) __builtin_amdgcn_s_barrier();            // re-join: every wave's reads and DMA are retired past this point
-    const int cm0 = m0, cn0 = n0;
-    const int nvb = vb + (int)gridDim.x;
-    const bool more = nvb < nwg;
-    if (more) setup(nvb);                                  // the operand offsets of this tile are dead: the next tile's take their registers
-    const char* ab = reinterpret_cast<const char*>(Ag + (long)m0 * p.lda);
-    const char* wb = reinterpret_cast<const char*>(Wg + (long)n0 * p.ldw);
-    auto pre = [&]() {                                     // K-tile 0 of the next tile -> physical buffer 1 (the epilogue's bounce lives in buffer 0)
-      if (more) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            PPP_DMA16(lds1 + a_lds[h][i], ab + a_off[h][i])
-            PPP_DMA16(lds1 + w_lds[h][i], wb + w_off[h][i])
-          }
-      }
-    };
-    epilogue_lds<false, MI>(p, Acc16<MI>{acc}, smem, wave, cm0, cn0, wm, wn, lane, 0L, pre);
-    if (!more) break;
-    vb = nvb;
-    flip = 1;
-    __builtin_amdgcn_s_barrier();                          // every wave is done with its bounce slab: buffer 0 is free for K-tile 1
-    __builtin_amdgcn_sched_barrier(0);
-    PP_ISSUE_A(0, 1, smem); PP_ISSUE_W(0, 1, smem);
-  }
-}
-
 // ---- variant Q2: 128 x 256 tile, TWO phases per K-tile, THREE LDS buffers -------------------------------------------------------
 // The 128 x 256 form of the ping-pong kernel above spends four phases of 8 MFMAs (128 matrix-pipe cycles per wave) per K-tile; a phase's
 // fixed cost (two barriers, the LDS-DMA issue, the exposed part of the fragment-read latency: ~130-190 cycles measured per phase on both
@@ -1585,7 +1446,6 @@ void llmseg_prof_tag(long a, long b, long c, long d);
 // 256x256 / 128x256; 5 (default) = cost model), bits 4-7 = XCD skew + 1, bits 8-12 = forced split-K slice count for 8 / 9.
 static int g_gemm_variant = 5, g_gemm_skew = 13, g_gemm_split = 0, g_gemm_pp2 = getenv("LLMSEG_GEMM_PP2") ? atoi(getenv("LLMSEG_GEMM_PP2")) : 1;
 static const int g_gemm_rsplit = getenv("LLMSEG_GEMM_NO_RSPLIT") ? 0 : 1;      // K-slices for the register-staging kernel (A/B switch)
-static int g_gemm_persist = getenv("LLMSEG_GEMM_PERSIST") ? atoi(getenv("LLMSEG_GEMM_PERSIST")) : 0;      // n > 0: the persistent 256 x 256 form for launches of more than n rounds of tiles
 static int num_cus() {
   static int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
   return n;
@@ -1594,7 +1454,6 @@ extern "C" int llmseg_gemm_set_variant(int v) {
   g_gemm_variant = v & 15;
   if ((v >> 4) & 15) g_gemm_skew = ((v >> 4) & 15) - 1;
   g_gemm_split = (v >> 8) & 31;
-  if ((v >> 15) & 3) g_gemm_persist = ((v >> 15) & 3) - 1;             // bits 15-16: persistent 256 x 256 form + 1 (1 = off, 2 = for launches of more than one round of tiles)
   g_gemm_pp2 = (v >> 13) & 3 ? ((v >> 13) & 3) - 1 : g_gemm_pp2;     // bits 13-14: 128 x 256 kernel form + 1 (1 = four phases / two buffers, 2 = two phases / three buffers, 3 = loader waves)
   return LLMSEG_OK;
 }
@@ -2032,8 +1891,6 @@ static int gemm_dispatch(const llmseg_gemm_args* a, void* stream, int force_vari
         }
         if (p.A2) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<false, true, 4>), grid, dim3(NTB), 0, s, p);      // bf16 out only (checked above)
         else if (f) LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<true, false, 4>), grid, dim3(NTB), 0, s, p);
-        else if (g_gemm_persist && batch == 1 && p.K / BK >= 3 && (long)grid.x > g_gemm_persist * (num_cus() & ~7))      // experiment: persistent workgroups, the next tile's prologue under the epilogue
-          LL_LAUNCH_KERNEL(gemm_bf16_tn_ppp_kernel, dim3((unsigned)(num_cus() & ~7)), dim3(NTB), 0, s, p);
         else LL_LAUNCH_KERNEL((gemm_bf16_tn_pp_kernel<false, false, 4>), grid, dim3(NTB), 0, s, p);
         break;
       }
