@@ -1,4 +1,5 @@
-"""Experiment (GPU box): the persistent form of the 256 x 256 GEMM kernel (gemm_bf16_tn_ppp_kernel: several tiles per workgroup, the next tile's first K-tile issued from inside
+"""(Historical: needs the library of commit 721598e -- the persistent kernel and the variant bits 15-16 were removed again, profiles/r06r.)
+Experiment (GPU box): the persistent form of the 256 x 256 GEMM kernel (gemm_bf16_tn_ppp_kernel: several tiles per workgroup, the next tile's first K-tile issued from inside
 the epilogue) against the shipped kernel: bit equality, a race screen (repeated runs must reproduce the bits) and time.  tools/gemm_persist.py [set]"""
 import os
 import sys
