@@ -41,6 +41,8 @@ g1, g2 = torch.zeros(H, 8, device=dev), torch.zeros(H, 8, device=dev)
 t("lora_outer dB (2 products)", lambda: ops.lora_outer(d[:, :H], a2[:, :8], alpha=2.0, out=g1, a2=d[:, 2 * H:], b2=a2[:, 8:16], out2=g2))
 g3, g4 = torch.zeros(8, H, device=dev), torch.zeros(8, H, device=dev)
 t("lora_outer dA (2 products, dropout)", lambda: ops.lora_outer(x, t2[:, :8], out_rn=True, out=g3, drop=(rng, 0, 0.05), a2=x, b2=t2[:, 8:16], out2=g4))
+gq, gv, ga, gb = torch.zeros(H, 8, device=dev), torch.zeros(H, 8, device=dev), torch.zeros(8, H, device=dev), torch.zeros(8, H, device=dev)
+t("lora_wgrads (4 products, dropout; LLMSEG_LORA_OUTER_GY=%s)" % os.environ.get("LLMSEG_LORA_OUTER_GY", "-"), lambda: ops.lora_wgrads(d, H, x, a2, t2, gq, gv, ga, gb, 2.0, drop=(rng, 0, 0.05)))
 t("lora_outer dA (2 products, no dropout)", lambda: ops.lora_outer(x, t2[:, :8], out_rn=True, out=g3, a2=x, b2=t2[:, 8:16], out2=g4))
 dx = r(M, H)
 t("lora_apply (2 branches, dropout)", lambda: ops.lora_apply_(dx, t2, aq, w_rn=True, drop=(rng, 0, 0.05), w2=av))
